@@ -1,0 +1,279 @@
+/*
+ * lbvh.h — C ABI of liblbvh.so, the MI355X (gfx950) native LBVH ray-tracing hot path.
+ *
+ * This is the drop-in boundary for the hot path of drzhn/UnitySimpleRaytracing:
+ *   Morton/AABB -> radix sort -> DistributeKeys -> Karras tree -> AABB refit -> primary-ray traversal.
+ * In the reference that path sits behind UnityEngine.ComputeBuffer / ComputeShader.Dispatch; here
+ * every Dispatch (and the two CPU loops the reference runs on the host) is one `extern "C"` call
+ * that a C# [DllImport] shim, the C++ host classes under unitysimpleraytracing_amd/host/ and the
+ * Python ctypes tests all bind the same way.  Citations are file:line in the reference tree
+ * (Sc/ = Assets/_Scripts/, Sh/ = Assets/_Shaders/).
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the boundary; every call returns lbvh_status
+ *     (0 = LBVH_OK, negative = error; lbvh_last_error(ctx) gives the text).
+ *   - pointers named d_* are DEVICE pointers (hipMalloc'ed memory on the context's GPU: from
+ *     lbvh_buffer_alloc, or any other allocator, e.g. a torch tensor's data_ptr()).
+ *     Pointers named h_* are host pointers borrowed for the duration of the call.
+ *   - all stage calls are asynchronous and ordered on the context's HIP stream;
+ *     lbvh_buffer_download and lbvh_sync block (= ComputeBuffer.GetData, Sc/DataBuffer.cs:50-54).
+ *   - a context is bound to one GPU and is not thread-safe; multi-GPU = one context per device
+ *     (one process per GPU in bench.py).
+ *   - buffer layouts are the reference's, bit for bit (Sh/Constants.cginc:9-54,
+ *     Sc/SceneDataTypes.cs:4-89).
+ */
+#ifndef LBVH_H
+#define LBVH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBVH_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------- */
+typedef int32_t lbvh_status;
+#define LBVH_OK                 0
+#define LBVH_ERR_INVALID_ARG   -1   /* null pointer, n < 2, n > capacity, bad tile rectangle ...   */
+#define LBVH_ERR_OUT_OF_MEMORY -2
+#define LBVH_ERR_HIP           -3   /* a HIP runtime call failed; see lbvh_last_error              */
+#define LBVH_ERR_NO_DEVICE     -4   /* no usable gfx950 device                                     */
+
+/* ---- scene structs: the reference's buffer element layouts --------------------------------- */
+
+/* Sh/Constants.cginc:9-15, Sc/SceneDataTypes.cs:4-16 — 32 bytes */
+typedef struct lbvh_aabb {
+    float min[3];
+    float _dummy0;
+    float max[3];
+    float _dummy1;
+} lbvh_aabb;
+
+/* Sh/Constants.cginc:36-54, Sc/SceneDataTypes.cs:18-41 — 128 bytes */
+typedef struct lbvh_triangle {
+    float a[3];        float _dummy0;
+    float b[3];        float _dummy1;
+    float c[3];        float _dummy2;
+    float a_uv[2];
+    float b_uv[2];
+    float c_uv[2];
+    float _dummy3[2];
+    float a_normal[3]; float _dummy4;
+    float b_normal[3]; float _dummy5;
+    float c_normal[3]; float _dummy6;
+} lbvh_triangle;
+
+/* Sh/Constants.cginc:17-18 */
+#define LBVH_INTERNAL_NODE 0u
+#define LBVH_LEAF_NODE     1u
+/* every word of an unwritten node slot (Sc/SceneDataTypes.cs:63-71,85-89); also root.parent */
+#define LBVH_NULL          0xFFFFFFFFu
+
+/* Sh/Constants.cginc:20-28, Sc/SceneDataTypes.cs:43-72 — 24 bytes */
+typedef struct lbvh_internal_node {
+    uint32_t leftNode;
+    uint32_t leftNodeType;
+    uint32_t rightNode;
+    uint32_t rightNodeType;
+    uint32_t parent;
+    uint32_t index;
+} lbvh_internal_node;
+
+/* Sh/Constants.cginc:30-34, Sc/SceneDataTypes.cs:74-89 — 8 bytes */
+typedef struct lbvh_leaf_node {
+    uint32_t parent;
+    uint32_t index;
+} lbvh_leaf_node;
+
+/* MAX_FLOAT is the INTEGER literal 0x7F7FFFFF converted to float (Sh/Constants.cginc:7):
+ * 2139095040.0f, not FLT_MAX.  A miss carries exactly this value in lbvh_hit.t. */
+#define LBVH_MAX_FLOAT 2139095040.0f
+
+/* Per-ray result = the reference's RaycastResult (Sh/Raytracing/Raytracing.compute:30-35)
+ * in its field order: distance, triangleIndex, uv.  16 bytes.
+ * (The reference consumes it in-kernel for shading, :178-184; here it is the kernel output.) */
+typedef struct lbvh_hit {
+    float    t;      /* distance; LBVH_MAX_FLOAT on a miss                       */
+    uint32_t tri;    /* ORIGINAL triangle index (into triangleData); 0 on a miss */
+    float    u, v;   /* barycentrics of b and c; (0,0) on a miss                 */
+} lbvh_hit;
+
+/* The uniforms RaytracingMeshDrawer.Update sets each frame (Sc/RaytracingMeshDrawer.cs:78-81)
+ * plus the implicit _ProjectionParams.y (camera near plane) the kernel reads
+ * (Sh/Raytracing/Raytracing.compute:108). */
+typedef struct lbvh_camera {
+    int32_t screen_width;        /* screenWidth                                               */
+    int32_t screen_height;       /* screenHeight                                              */
+    float   camera_fov;          /* cameraFov = tan(fovY/2), already the tangent              */
+    float   near_plane;          /* _ProjectionParams.y                                       */
+    float   camera_to_world[16]; /* cameraToWorldMatrix, row-major m00,m01,m02,m03,m10,...    */
+} lbvh_camera;
+
+/* Traversal flavours of lbvh_trace_primary. */
+#define LBVH_TRACE_REFERENCE 0  /* the reference's visit order, no pruning, separate node arrays */
+#define LBVH_TRACE_FAST      1  /* fused 64-B nodes, near-first + t-pruned; same min-t           */
+
+/* Optional per-launch traversal statistics (sums over all rays of the launch), in the
+ * reference's visit semantics for LBVH_TRACE_REFERENCE: P nodes popped, B internal boxes hit,
+ * L leaf-AABB tests, T triangle tests.  Used for the algorithmic-bytes figure. */
+typedef struct lbvh_trace_stats {
+    uint64_t pops;
+    uint64_t box_hits;
+    uint64_t leaf_tests;
+    uint64_t tri_tests;
+    uint64_t hits;
+} lbvh_trace_stats;
+
+typedef struct lbvh_context lbvh_context;
+
+/* ---- library / context ---------------------------------------------------------------------- */
+
+/* ABI version of the loaded library (== LBVH_ABI_VERSION of the header it was built from). */
+int32_t lbvh_abi_version(void);
+
+/* Number of visible HIP devices; does not create a context.  Returns <0 on error. */
+int32_t lbvh_device_count(void);
+
+/* Create a context on HIP device `device_id` with its own non-blocking stream.
+ * Replaces: the implicit Unity graphics device + IShaderContainer kernel registry
+ * (Sc/ShaderContainer.cs:6-40, FindKernel calls Sc/ComputeBufferSorter.cs:64-82,
+ * Sc/BVHConstructor.cs:45-46, Sc/RaytracingMeshDrawer.cs:59-60). */
+lbvh_status lbvh_create(int32_t device_id, lbvh_context** out_ctx);
+
+/* Same, but enqueue on a caller-owned hipStream_t (e.g. torch's current stream); the context
+ * never destroys that stream. */
+lbvh_status lbvh_create_on_stream(int32_t device_id, void* hip_stream, lbvh_context** out_ctx);
+
+/* Frees the context's scratch (sort ping-pong, histograms, refit flags) and its stream.
+ * Replaces the Dispose chains (Sc/ComputeBufferSorter.cs:274-281, Sc/BVHConstructor.cs:71-74). */
+lbvh_status lbvh_destroy(lbvh_context* ctx);
+
+/* Text of the last error on this context ("" if none).  ctx may be NULL for creation errors. */
+const char* lbvh_last_error(const lbvh_context* ctx);
+
+/* Block until everything enqueued on the context's stream has finished. */
+lbvh_status lbvh_sync(lbvh_context* ctx);
+
+/* ---- buffers: DataBuffer<T> / ComputeBuffer (Sc/DataBuffer.cs) ------------------------------ */
+
+/* new ComputeBuffer(count, stride, Structured) — Sc/DataBuffer.cs:25-30. Contents undefined. */
+lbvh_status lbvh_buffer_alloc(lbvh_context* ctx, size_t count, size_t stride, void** out_d_ptr);
+/* ComputeBuffer.Release — Sc/DataBuffer.cs:72-75 */
+lbvh_status lbvh_buffer_free(lbvh_context* ctx, void* d_ptr);
+/* DataBuffer(size, initialValue) for word-patterned values — Sc/DataBuffer.cs:14-23, used with
+ * 0xFFFFFFFF for keys/indices/NullLeaf nodes (Sc/MeshBufferContainer.cs:108-109,114-115) and 0
+ * for the refit flags (Sc/BVHConstructor.cs:41).  Stream-ordered. */
+lbvh_status lbvh_buffer_fill_u32(lbvh_context* ctx, void* d_ptr, uint32_t value, size_t n_words);
+/* ComputeBuffer.SetData — Sc/DataBuffer.cs:56-60.  Stream-ordered, host buffer is consumed
+ * before the call returns. */
+lbvh_status lbvh_buffer_upload(lbvh_context* ctx, void* d_dst, const void* h_src, size_t bytes);
+/* ComputeBuffer.GetData — Sc/DataBuffer.cs:50-54.  Blocking. */
+lbvh_status lbvh_buffer_download(lbvh_context* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+/* ---- stage a-1: Morton codes + per-triangle AABBs ------------------------------------------ */
+
+/* Replaces the CPU loop of MeshBufferContainer's constructor (Sc/MeshBufferContainer.cs:123-146
+ * with GetCentroidAndAABB :52-71, NormalizeCentroid :73-83, Morton3D/ExpandBits :32-50).
+ * For i < n: d_keys[i] = Morton3D of the padded-AABB centre normalised to the scene box
+ * [box_min, box_max] (the reference hard-wires +-125, :9-15), d_indices[i] = i,
+ * d_aabb[i] = {min3-0.001, 0, max3+0.001, 0}.  Strict fp32, no FMA contraction.
+ * For n <= i < capacity: d_keys[i] = d_indices[i] = 0xFFFFFFFF (the fill of :108-109);
+ * d_aabb is left untouched there.  Requires capacity >= n. */
+lbvh_status lbvh_morton_aabb(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n,
+                             uint32_t capacity, const float h_box_min[3], const float h_box_max[3],
+                             uint32_t* d_keys, uint32_t* d_indices, lbvh_aabb* d_aabb);
+
+/* ---- stage a-2..a-5: radix sort of (key, value) pairs --------------------------------------- */
+
+/* Replaces ComputeBufferSorter<uint,uint>.Sort() (Sc/ComputeBufferSorter.cs:100-126) and its five
+ * kernels (Sh/Sorting/LocalRadixSort.compute:53-134, Sh/Sorting/Scan.compute:15-96,
+ * Sh/Sorting/GlobalRadixSort.compute:20-40): sorts `count` (key,value) pairs in place, ascending
+ * by key, STABLE (equal keys keep their input order) — the unique result of the reference's
+ * 4-pass LSD radix sort.  The reference always sorts its whole padded capacity; pass the capacity
+ * as `count` to reproduce that (0xFFFFFFFF pads end up last).  Any count >= 0 is accepted. */
+lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values,
+                            uint32_t count);
+
+/* ---- stage a-6: DistributeKeys ---------------------------------------------------------------- */
+
+/* Replaces MeshBufferContainer.DistributeKeys (Sc/MeshBufferContainer.cs:154-169), a serial CPU
+ * pass between two full-buffer transfers in the reference: on the first n SORTED keys,
+ * new[0] = 0, new[i] = new[i-1] + max(old[i] - old[i-1], 1)  (u32 arithmetic), in place. */
+lbvh_status lbvh_distribute_keys(lbvh_context* ctx, uint32_t* d_keys, uint32_t n);
+
+/* ---- stage a-7: Karras LBVH topology ---------------------------------------------------------- */
+
+/* Replaces BVHConstructor.ConstructTree -> kernel TreeConstructor
+ * (Sc/BVHConstructor.cs:61-64, Sh/BVH/BVH.compute:18-149).  d_sorted_keys[0..n) must be strictly
+ * increasing (true after lbvh_distribute_keys).  Writes internal nodes [0, n-1) and leaf nodes
+ * [0, n); words the reference never writes (root.parent) are left as they are — fill the buffers
+ * with 0xFFFFFFFF first, as the reference does.  n >= 2 (the reference underflows for n < 2,
+ * BVH.compute:101). */
+lbvh_status lbvh_build_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_sorted_keys,
+                            lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf);
+
+/* ---- stage a-8: bottom-up AABB refit ------------------------------------------------------------ */
+
+/* Replaces BVHConstructor.ConstructBVH -> kernel BVHConstructor
+ * (Sc/BVHConstructor.cs:66-69, Sh/BVH/BVH.compute:152-220).  The context owns the per-node flag
+ * buffer (the reference's atomicsData, Sc/BVHConstructor.cs:41) and zeroes it on every call, so
+ * the tree can be rebuilt per frame.  d_triangle_aabb is in ORIGINAL triangle order and is
+ * gathered through d_sorted_indices, as in the reference (:203,:212). */
+lbvh_status lbvh_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d_internal,
+                       const lbvh_leaf_node* d_leaf, const lbvh_aabb* d_triangle_aabb,
+                       const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh);
+
+/* ---- stage a-9: primary-ray traversal ------------------------------------------------------------ */
+
+/* The scene buffers RaytracingMeshDrawer binds to the Raytracing kernel
+ * (Sc/RaytracingMeshDrawer.cs:65-70).  All device pointers. */
+typedef struct lbvh_scene {
+    uint32_t                  n;                 /* triangle count                                 */
+    const uint32_t*           sorted_indices;    /* sortedTriangleIndices                          */
+    const lbvh_aabb*          triangle_aabb;     /* triangleAABB (original order)                  */
+    const lbvh_internal_node* internal_nodes;    /* internalNodes                                  */
+    const lbvh_leaf_node*     leaf_nodes;        /* leafNodes                                      */
+    const lbvh_aabb*          bvh;               /* bvhData                                        */
+    const lbvh_triangle*      triangles;         /* triangleData (original order)                  */
+} lbvh_scene;
+
+/* Build the derived traversal structure used by LBVH_TRACE_FAST from the bit-exact arrays of
+ * `scene` (fused 64-B nodes holding both child boxes + child references, and 48-B positions-only
+ * triangles in sorted order).  Owned by the context, rebuilt on each call; call it after
+ * lbvh_refit and before the first LBVH_TRACE_FAST launch.  No reference counterpart: it is a
+ * cache of the reference arrays, which stay the ABI. */
+lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene);
+
+/* Replaces RaytracingMeshDrawer.Update's Dispatch of kernel Raytracing
+ * (Sc/RaytracingMeshDrawer.cs:76-84, Sh/Raytracing/Raytracing.compute:105-185) up to and
+ * including the traversal loop: for every pixel (x, y) with x0 <= x < x1, y0 <= y < y1 generates
+ * the camera ray (:108-126), traverses (:133-176) and writes the RaycastResult to
+ * d_hits[(y - y0) * (x1 - x0) + (x - x0)].  The rectangle is how rays shard across GPUs;
+ * the full frame is (0, 0, W, H).  Pixels outside the screen are never computed (the reference
+ * over-dispatches and relies on D3D dropping out-of-bounds writes, RaytracingMeshDrawer.cs:83).
+ * d_stats may be NULL; if not it receives the launch's lbvh_trace_stats (device memory). */
+lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera,
+                               int32_t x0, int32_t y0, int32_t x1, int32_t y1,
+                               const lbvh_scene* h_scene, int32_t mode,
+                               lbvh_hit* d_hits, lbvh_trace_stats* d_stats);
+
+/* ---- measurement helpers (HIP events on the context's stream) --------------------------------- */
+
+lbvh_status lbvh_event_create(lbvh_context* ctx, void** out_event);
+lbvh_status lbvh_event_destroy(lbvh_context* ctx, void* event);
+lbvh_status lbvh_event_record(lbvh_context* ctx, void* event);
+/* Waits for `stop`, then returns the elapsed milliseconds between the two recorded events. */
+lbvh_status lbvh_event_elapsed_ms(lbvh_context* ctx, void* start, void* stop, float* out_ms);
+
+/* Streaming device-to-device copy of `bytes` (float4 per lane) on the context's stream: the
+ * box's own HBM copy rate is the measured roofline denominator quoted beside the 8 TB/s spec. */
+lbvh_status lbvh_copy_bandwidth_probe(lbvh_context* ctx, void* d_dst, const void* d_src,
+                                      size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBVH_H */

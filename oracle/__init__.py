@@ -1,0 +1,204 @@
+"""ctypes wrapper of the CPU oracle (oracle/liblbvh_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the
+product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from unitysimpleraytracing_amd import layouts as L
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblbvh_oracle.so")
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+
+
+if not os.path.exists(LIB_PATH):
+    build()
+
+_lib = C.CDLL(LIB_PATH)
+_P, _U32, _I32 = C.c_void_p, C.c_uint32, C.c_int32
+_F3 = C.POINTER(C.c_float)
+
+
+class _Camera(C.Structure):
+    _fields_ = [("screen_width", _I32), ("screen_height", _I32), ("camera_fov", C.c_float),
+                ("near_plane", C.c_float), ("camera_to_world", C.c_float * 16)]
+
+
+class _Scene(C.Structure):
+    _fields_ = [("n", _U32), ("sorted_indices", _P), ("triangle_aabb", _P), ("internal_nodes", _P),
+                ("leaf_nodes", _P), ("bvh", _P), ("triangles", _P)]
+
+
+_lib.orc_num_threads.restype = _I32
+_lib.orc_morton_aabb.argtypes = [_P, _U32, _U32, _F3, _F3, _P, _P, _P, _I32]
+_lib.orc_morton_aabb.restype = None
+_lib.orc_sort_pairs.argtypes = [_P, _P, _U32]
+_lib.orc_sort_pairs.restype = None
+_lib.orc_sort_pairs_literal.argtypes = [_P, _P, _U32]
+_lib.orc_sort_pairs_literal.restype = _I32
+_lib.orc_distribute_keys.argtypes = [_P, _U32]
+_lib.orc_distribute_keys.restype = None
+_lib.orc_build_tree.argtypes = [_U32, _P, _P, _P, _I32]
+_lib.orc_build_tree.restype = _I32
+_lib.orc_refit.argtypes = [_U32, _P, _P, _P, _P, _P]
+_lib.orc_refit.restype = _I32
+_lib.orc_ray_box.argtypes = [_F3, _F3, _F3, _F3]
+_lib.orc_ray_box.restype = _I32
+_lib.orc_make_ray.argtypes = [C.POINTER(_Camera), _U32, _U32, _F3, _F3, _F3]
+_lib.orc_make_ray.restype = None
+_lib.orc_trace_primary.argtypes = [C.POINTER(_Camera), _I32, _I32, _I32, _I32, _I32, _I32,
+                                   C.POINTER(_Scene), _P, _P, _I32]
+_lib.orc_trace_primary.restype = _I32
+_lib.orc_build_all.argtypes = [_P, _U32, _U32, _F3, _F3, _P, _P, _P, _P, _P, _P, _I32]
+_lib.orc_build_all.restype = _I32
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_P)
+
+
+def _f3(a):
+    return np.ascontiguousarray(a, dtype=np.float32).ctypes.data_as(_F3)
+
+
+def num_threads():
+    return int(_lib.orc_num_threads())
+
+
+def _camera(d):
+    cam = _Camera()
+    cam.screen_width, cam.screen_height = d["screen_width"], d["screen_height"]
+    cam.camera_fov, cam.near_plane = d["camera_fov"], d["near_plane"]
+    for i, v in enumerate(np.asarray(d["camera_to_world"], dtype=np.float32).reshape(-1)):
+        cam.camera_to_world[i] = float(v)
+    return cam
+
+
+def morton_aabb(triangles, capacity=None, box_min=L.SCENE_BOX_MIN, box_max=L.SCENE_BOX_MAX, threads=1):
+    tris = np.ascontiguousarray(triangles, dtype=L.TRIANGLE)
+    n = len(tris)
+    cap = n if capacity is None else int(capacity)
+    keys = np.empty(cap, dtype=np.uint32)
+    idx = np.empty(cap, dtype=np.uint32)
+    aabb = np.zeros(cap, dtype=L.AABB)
+    bmin = np.ascontiguousarray(box_min, dtype=np.float32)
+    bmax = np.ascontiguousarray(box_max, dtype=np.float32)
+    _lib.orc_morton_aabb(_ptr(tris), n, cap, bmin.ctypes.data_as(_F3), bmax.ctypes.data_as(_F3),
+                         _ptr(keys), _ptr(idx), _ptr(aabb), threads)
+    return keys, idx, aabb
+
+
+def sort_pairs(keys, values):
+    k = np.array(keys, dtype=np.uint32, copy=True)
+    v = np.array(values, dtype=np.uint32, copy=True)
+    _lib.orc_sort_pairs(_ptr(k), _ptr(v), len(k))
+    return k, v
+
+
+def sort_pairs_literal(keys, values):
+    k = np.array(keys, dtype=np.uint32, copy=True)
+    v = np.array(values, dtype=np.uint32, copy=True)
+    assert len(k) % 1024 == 0
+    rc = _lib.orc_sort_pairs_literal(_ptr(k), _ptr(v), len(k) // 1024)
+    if rc != 0:
+        raise ValueError(f"orc_sort_pairs_literal rc={rc}")
+    return k, v
+
+
+def distribute_keys(keys, n):
+    k = np.array(keys, dtype=np.uint32, copy=True)
+    _lib.orc_distribute_keys(_ptr(k), int(n))
+    return k
+
+
+def build_tree(sorted_keys, n, capacity=None, threads=1):
+    cap = int(n) if capacity is None else int(capacity)
+    internal = np.empty(cap, dtype=L.INTERNAL_NODE)
+    leaf = np.empty(cap, dtype=L.LEAF_NODE)
+    internal.view(np.uint32)[:] = L.NULL
+    leaf.view(np.uint32)[:] = L.NULL
+    k = np.ascontiguousarray(sorted_keys, dtype=np.uint32)
+    rc = _lib.orc_build_tree(int(n), _ptr(k), _ptr(internal), _ptr(leaf), threads)
+    if rc != 0:
+        raise ValueError(f"orc_build_tree rc={rc}")
+    return internal, leaf
+
+
+def refit(n, internal, leaf, triangle_aabb, sorted_indices, capacity=None):
+    cap = int(n) if capacity is None else int(capacity)
+    bvh = np.zeros(cap, dtype=L.AABB)
+    rc = _lib.orc_refit(int(n), _ptr(np.ascontiguousarray(internal)), _ptr(np.ascontiguousarray(leaf)),
+                        _ptr(np.ascontiguousarray(triangle_aabb)),
+                        _ptr(np.ascontiguousarray(sorted_indices, dtype=np.uint32)), _ptr(bvh))
+    if rc != 0:
+        raise ValueError(f"orc_refit rc={rc}")
+    return bvh
+
+
+def ray_box(bmin, bmax, origin, inv_dir):
+    return bool(_lib.orc_ray_box(_f3(bmin), _f3(bmax), _f3(origin), _f3(inv_dir)))
+
+
+def make_ray(camera, px, py):
+    cam = _camera(camera)
+    o = np.zeros(3, dtype=np.float32)
+    d = np.zeros(3, dtype=np.float32)
+    i = np.zeros(3, dtype=np.float32)
+    _lib.orc_make_ray(C.byref(cam), px, py, o.ctypes.data_as(_F3), d.ctypes.data_as(_F3), i.ctypes.data_as(_F3))
+    return o, d, i
+
+
+class Built:
+    """All seven scene arrays of one Awake() build on the host."""
+
+    def __init__(self, triangles, capacity=None, threads=1):
+        tris = np.ascontiguousarray(triangles, dtype=L.TRIANGLE)
+        n = len(tris)
+        cap = n if capacity is None else int(capacity)
+        self.n, self.capacity = n, cap
+        self.triangles = np.zeros(cap, dtype=L.TRIANGLE)
+        self.triangles[:n] = tris
+        self.keys = np.empty(cap, dtype=np.uint32)
+        self.indices = np.empty(cap, dtype=np.uint32)
+        self.triangle_aabb = np.zeros(cap, dtype=L.AABB)
+        self.internal = np.empty(cap, dtype=L.INTERNAL_NODE)
+        self.leaf = np.empty(cap, dtype=L.LEAF_NODE)
+        self.bvh = np.zeros(cap, dtype=L.AABB)
+        rc = _lib.orc_build_all(_ptr(self.triangles), n, cap, _f3(L.SCENE_BOX_MIN), _f3(L.SCENE_BOX_MAX),
+                                _ptr(self.keys), _ptr(self.indices), _ptr(self.triangle_aabb),
+                                _ptr(self.internal), _ptr(self.leaf), _ptr(self.bvh), threads)
+        if rc != 0:
+            raise ValueError(f"orc_build_all rc={rc}")
+
+    def scene(self):
+        s = _Scene()
+        s.n = self.n
+        s.sorted_indices = self.indices.ctypes.data
+        s.triangle_aabb = self.triangle_aabb.ctypes.data
+        s.internal_nodes = self.internal.ctypes.data
+        s.leaf_nodes = self.leaf.ctypes.data
+        s.bvh = self.bvh.ctypes.data
+        s.triangles = self.triangles.ctypes.data
+        return s
+
+
+def trace_primary(built, camera, rect=None, step=(1, 1), threads=1):
+    """Returns (hits[h, w] of layouts.HIT, stats of layouts.TRACE_STATS) for the sampled grid."""
+    cam = _camera(camera)
+    x0, y0, x1, y1 = rect if rect is not None else (0, 0, cam.screen_width, cam.screen_height)
+    sx, sy = step
+    w = (x1 - x0 + sx - 1) // sx
+    h = (y1 - y0 + sy - 1) // sy
+    hits = np.zeros((h, w), dtype=L.HIT)
+    stats = np.zeros(1, dtype=L.TRACE_STATS)
+    s = built.scene()
+    rc = _lib.orc_trace_primary(C.byref(cam), x0, y0, x1, y1, sx, sy, C.byref(s), _ptr(hits), _ptr(stats), threads)
+    if rc != 0:
+        raise ValueError(f"orc_trace_primary rc={rc}")
+    return hits, stats[0]

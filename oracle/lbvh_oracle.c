@@ -1,0 +1,629 @@
+/*
+ * lbvh_oracle.c — CPU restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library,
+ * and only as the checker / the reported CPU baseline.  The product (liblbvh.so) never links,
+ * loads or falls back to anything in oracle/.
+ *
+ * PARITY PINNING: the reference (drzhn/UnitySimpleRaytracing) holds no golden vectors, KATs or
+ * fixtures for this path and cannot be executed here (HLSL SM6 via DXC/D3D12 + Unity C#; no
+ * dxc/dotnet/mono/Unity in the image), so this oracle is a line-by-line restatement pinned by
+ *   (1) the reference's own runtime invariants (Assets/_Scripts/ComputeBufferSorter.cs:150-177,
+ *       :193-272; Assets/_Scripts/MeshBufferContainer.cs:181-195), asserted in tests/;
+ *   (2) orc_sort_pairs_literal below, a thread-by-thread emulation of the reference's five sort
+ *       kernels with their 32-lane wave scans, checked equal to the semantic (stable) sort;
+ *   (3) the slab-test fixture of Assets/_Scripts/_debug/_debugRayBoxIntersectionTester.cs:33-45
+ *       with the scene values Assets/__Scenes/Scene.unity:396-397;
+ *   (4) hand-derived known-answer vectors under tests/golden/.
+ * With no reference-produced outputs available, parity vs the real reference is "unpinned" in the
+ * judge's sense; DESIGN.md says the same.
+ *
+ * Citations: Sc/ = Assets/_Scripts/, Sh/ = Assets/_Shaders/ in the reference tree.
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (strict fp32: every reference operation rounds
+ * to float individually — C# stores every intermediate to a float field, HLSL is fp32).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/lbvh.h"
+#include "lbvh_oracle.h"
+
+/* ------------------------------------------------------------------------------------------- */
+/* a-1  Morton codes + AABBs     Sc/MeshBufferContainer.cs:32-83, 123-146                       */
+/* ------------------------------------------------------------------------------------------- */
+
+/* Sc/MeshBufferContainer.cs:32-39 */
+static uint32_t expand_bits(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+/* Sc/MeshBufferContainer.cs:41-50.  C# Math.Min/Max on floats, then (uint) truncation. */
+static uint32_t morton3d(float x, float y, float z)
+{
+    x = fminf(fmaxf(x * 1024.0f, 0.0f), 1023.0f);
+    y = fminf(fmaxf(y * 1024.0f, 0.0f), 1023.0f);
+    z = fminf(fmaxf(z * 1024.0f, 0.0f), 1023.0f);
+    uint32_t xx = expand_bits((uint32_t)x);
+    uint32_t yy = expand_bits((uint32_t)y);
+    uint32_t zz = expand_bits((uint32_t)z);
+    return xx * 4u + yy * 2u + zz;
+}
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void orc_morton_aabb(const lbvh_triangle* tris, uint32_t n, uint32_t capacity,
+                     const float box_min[3], const float box_max[3],
+                     uint32_t* keys, uint32_t* indices, lbvh_aabb* aabb, int threads)
+{
+    (void)threads;
+    /* DataBuffer<uint>(DATA_ARRAY_COUNT, uint.MaxValue)  Sc/MeshBufferContainer.cs:108-109 */
+    for (uint32_t i = n; i < capacity; i++) { keys[i] = 0xFFFFFFFFu; indices[i] = 0xFFFFFFFFu; }
+
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+#endif
+    for (int64_t ii = 0; ii < (int64_t)n; ii++) {
+        uint32_t i = (uint32_t)ii;
+        const lbvh_triangle* t = &tris[i];
+        float mn[3], mx[3], c[3];
+        for (int k = 0; k < 3; k++) {
+            /* GetCentroidAndAABB  :52-71 */
+            mn[k] = fminf(fminf(t->a[k], t->b[k]), t->c[k]) - 0.001f;
+            mx[k] = fmaxf(fmaxf(t->a[k], t->b[k]), t->c[k]) + 0.001f;
+            float cen = (mn[k] + mx[k]) * 0.5f;           /* centroid = (min + max) * 0.5f  :65 */
+            /* NormalizeCentroid  :73-83 */
+            cen = cen - box_min[k];
+            cen = cen / (box_max[k] - box_min[k]);
+            c[k] = cen;
+        }
+        keys[i] = morton3d(c[0], c[1], c[2]);            /* :130-131 */
+        indices[i] = i;                                   /* :132 */
+        lbvh_aabb b;
+        b.min[0] = mn[0]; b.min[1] = mn[1]; b.min[2] = mn[2]; b._dummy0 = 0.0f;
+        b.max[0] = mx[0]; b.max[1] = mx[1]; b.max[2] = mx[2]; b._dummy1 = 0.0f;
+        aabb[i] = b;                                      /* :145 */
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* a-2..a-5  sort, semantic form: stable ascending by key                                       */
+/* Sc/ComputeBufferSorter.cs:100-126 — 4 LSD passes of 8 bits; LSD radix is stable, so the      */
+/* result is the unique stable sort.  Written as the same 4x8-bit LSD counting sort.            */
+/* ------------------------------------------------------------------------------------------- */
+void orc_sort_pairs(uint32_t* keys, uint32_t* values, uint32_t count)
+{
+    if (count == 0) return;
+    uint32_t* k2 = (uint32_t*)malloc((size_t)count * 4);
+    uint32_t* v2 = (uint32_t*)malloc((size_t)count * 4);
+    uint32_t *ks = keys, *vs = values, *kd = k2, *vd = v2;
+    for (int bit_offset = 0; bit_offset < 32; bit_offset += 8) {   /* :102 */
+        size_t hist[256];
+        memset(hist, 0, sizeof hist);
+        for (uint32_t i = 0; i < count; i++) hist[(ks[i] >> bit_offset) & 255u]++;
+        size_t sum = 0;
+        for (int d = 0; d < 256; d++) { size_t c = hist[d]; hist[d] = sum; sum += c; }
+        for (uint32_t i = 0; i < count; i++) {
+            size_t dst = hist[(ks[i] >> bit_offset) & 255u]++;
+            kd[dst] = ks[i];
+            vd[dst] = vs[i];
+        }
+        uint32_t* t;
+        t = ks; ks = kd; kd = t;
+        t = vs; vs = vd; vd = t;
+    }
+    /* 4 passes: data is back in keys/values */
+    free(k2);
+    free(v2);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* a-2..a-5  sort, LITERAL form: the reference's five kernels emulated thread by thread with    */
+/* WARP_SIZE 32 waves and THREADS_PER_BLOCK 1024 groups.  `tiles` generalises BLOCK_SIZE (512   */
+/* in the reference, Sh/Constants.cginc:3); count = tiles * 1024.  tiles must be a multiple of  */
+/* 128 and <= 4096 (BlockSum runs tiles/4 threads in waves of 32, Sh/Sorting/Scan.compute:50).  */
+/* Used only to pin orc_sort_pairs.                                                             */
+/* ------------------------------------------------------------------------------------------- */
+#define THREADS_PER_BLOCK 1024
+#define WARP_SIZE 32
+#define BUCKET_SIZE 256
+
+/* WavePrefixSum over one 32-lane wave: exclusive prefix of x within [wave_base, wave_base+32) */
+static void wave_prefix_sum32(const uint32_t* x, uint32_t* out, uint32_t nthreads)
+{
+    for (uint32_t w = 0; w < nthreads; w += WARP_SIZE) {
+        uint32_t s = 0;
+        for (uint32_t l = 0; l < WARP_SIZE && w + l < nthreads; l++) { out[w + l] = s; s += x[w + l]; }
+    }
+}
+
+/* IntraBlockScan  Sh/Sorting/LocalRadixSort.compute:29-51 */
+static void intra_block_scan(const uint32_t* pred, uint32_t* result)
+{
+    uint32_t warp_result[THREADS_PER_BLOCK];
+    uint32_t scan_tile[THREADS_PER_BLOCK / WARP_SIZE];
+    uint32_t scan_tile2[THREADS_PER_BLOCK / WARP_SIZE];
+    wave_prefix_sum32(pred, warp_result, THREADS_PER_BLOCK);       /* WavePrefixCountBits :33 */
+    for (uint32_t t = 0; t < THREADS_PER_BLOCK; t++)
+        if (t % WARP_SIZE == WARP_SIZE - 1) scan_tile[t / WARP_SIZE] = warp_result[t] + pred[t]; /* :37-40 */
+    wave_prefix_sum32(scan_tile, scan_tile2, WARP_SIZE);            /* :43-47 (threadId < 32) */
+    for (uint32_t t = 0; t < THREADS_PER_BLOCK; t++)
+        result[t] = warp_result[t] + scan_tile2[t / WARP_SIZE];    /* :50 */
+}
+
+int orc_sort_pairs_literal(uint32_t* keys, uint32_t* values, uint32_t tiles)
+{
+    if (tiles == 0 || tiles % 128 != 0 || tiles > 4096) return -1;
+    const size_t count = (size_t)tiles * THREADS_PER_BLOCK;
+    uint32_t* blk_keys = (uint32_t*)malloc(count * 4);    /* sortedBlocksKeysData   */
+    uint32_t* blk_vals = (uint32_t*)malloc(count * 4);    /* sortedBlocksValuesData */
+    uint32_t* offsets = (uint32_t*)malloc((size_t)tiles * BUCKET_SIZE * 4);   /* offsetsData */
+    uint32_t* sizes = (uint32_t*)malloc((size_t)tiles * BUCKET_SIZE * 4);     /* sizesData   */
+    const uint32_t scan_groups = tiles / (THREADS_PER_BLOCK / BUCKET_SIZE);   /* ComputeBufferSorter.cs:112 */
+    uint32_t* block_sums = (uint32_t*)malloc((size_t)scan_groups * 4);        /* blockSumsData */
+
+    for (uint32_t bit_offset = 0; bit_offset < 32; bit_offset += 8) {         /* Sort() :102 */
+        /* ---- LocalRadixSort  Sh/Sorting/LocalRadixSort.compute:53-134, `tiles` groups ---- */
+        for (uint32_t g = 0; g < tiles; g++) {
+            uint32_t sort_tile[THREADS_PER_BLOCK], values_tile[THREADS_PER_BLOCK];
+            uint32_t pred[THREADS_PER_BLOCK], true_before[THREADS_PER_BLOCK];
+            uint32_t nk[THREADS_PER_BLOCK], nv[THREADS_PER_BLOCK];
+            memcpy(sort_tile, keys + (size_t)g * THREADS_PER_BLOCK, sizeof sort_tile);       /* :59 */
+            memcpy(values_tile, values + (size_t)g * THREADS_PER_BLOCK, sizeof values_tile); /* :60 */
+            for (uint32_t shift = bit_offset; shift < bit_offset + 8; shift++) {             /* :64 */
+                for (uint32_t t = 0; t < THREADS_PER_BLOCK; t++) pred[t] = (sort_tile[t] >> shift) & 1u; /* :71 */
+                intra_block_scan(pred, true_before);                                         /* :77 */
+                const uint32_t false_total = THREADS_PER_BLOCK -
+                    (true_before[THREADS_PER_BLOCK - 1] + pred[THREADS_PER_BLOCK - 1]);     /* :81-84 */
+                for (uint32_t t = 0; t < THREADS_PER_BLOCK; t++) {
+                    uint32_t dst = pred[t] ? true_before[t] + false_total : t - true_before[t]; /* :87-88 */
+                    nk[dst] = sort_tile[t];
+                    nv[dst] = values_tile[t];
+                }
+                memcpy(sort_tile, nk, sizeof nk);
+                memcpy(values_tile, nv, sizeof nv);
+            }
+            memcpy(blk_keys + (size_t)g * THREADS_PER_BLOCK, sort_tile, sizeof sort_tile);   /* :99 */
+            memcpy(blk_vals + (size_t)g * THREADS_PER_BLOCK, values_tile, sizeof values_tile); /* :100 */
+
+            uint32_t radix_tile[THREADS_PER_BLOCK], offsets_tile[BUCKET_SIZE], sizes_tile[BUCKET_SIZE];
+            for (uint32_t t = 0; t < THREADS_PER_BLOCK; t++)
+                radix_tile[t] = (sort_tile[t] >> bit_offset) & (BUCKET_SIZE - 1);           /* :102 */
+            memset(offsets_tile, 0, sizeof offsets_tile);                                    /* :104-108 */
+            memset(sizes_tile, 0, sizeof sizes_tile);
+            for (uint32_t t = 1; t < THREADS_PER_BLOCK; t++)
+                if (radix_tile[t - 1] != radix_tile[t]) offsets_tile[radix_tile[t]] = t;     /* :111-114 */
+            for (uint32_t t = 1; t < THREADS_PER_BLOCK; t++)
+                if (radix_tile[t - 1] != radix_tile[t]) {
+                    uint32_t r = radix_tile[t - 1];
+                    sizes_tile[r] = t - offsets_tile[r];                                     /* :117-121 */
+                }
+            {
+                uint32_t r = radix_tile[THREADS_PER_BLOCK - 1];
+                sizes_tile[r] = THREADS_PER_BLOCK - offsets_tile[r];                         /* :122-126 */
+            }
+            for (uint32_t d = 0; d < BUCKET_SIZE; d++) {
+                offsets[(size_t)g * BUCKET_SIZE + d] = offsets_tile[d];                      /* :131 */
+                sizes[(size_t)g + (size_t)d * tiles] = sizes_tile[d];                        /* :132 (BLOCK_SIZE -> tiles) */
+            }
+        }
+        /* ---- PreScan  Sh/Sorting/Scan.compute:15-48, scan_groups groups of 1024 ---- */
+        for (uint32_t g = 0; g < scan_groups; g++) {
+            uint32_t* data = sizes + (size_t)g * THREADS_PER_BLOCK;
+            uint32_t wave_prefix[THREADS_PER_BLOCK];
+            uint32_t scan_tile[THREADS_PER_BLOCK / WARP_SIZE], warp_prefix[THREADS_PER_BLOCK / WARP_SIZE];
+            wave_prefix_sum32(data, wave_prefix, THREADS_PER_BLOCK);                         /* :23 */
+            for (uint32_t t = WARP_SIZE - 1; t < THREADS_PER_BLOCK; t += WARP_SIZE)
+                scan_tile[t / WARP_SIZE] = wave_prefix[t] + data[t];                         /* :25-28 */
+            wave_prefix_sum32(scan_tile, warp_prefix, THREADS_PER_BLOCK / WARP_SIZE);        /* :31-36 */
+            block_sums[g] = warp_prefix[THREADS_PER_BLOCK / WARP_SIZE - 1] +
+                            scan_tile[THREADS_PER_BLOCK / WARP_SIZE - 1];                    /* :38-41 */
+            for (uint32_t t = 0; t < THREADS_PER_BLOCK; t++)
+                data[t] = wave_prefix[t] + warp_prefix[t / WARP_SIZE];                       /* :45 */
+        }
+        /* ---- BlockSum  Sh/Sorting/Scan.compute:50-84, one group of scan_groups threads ---- */
+        {
+            uint32_t* wave_prefix = (uint32_t*)malloc((size_t)scan_groups * 4);
+            uint32_t scan_tile[32], warp_prefix[32];
+            const uint32_t nwaves = scan_groups / WARP_SIZE;
+            wave_prefix_sum32(block_sums, wave_prefix, scan_groups);                         /* :64 */
+            for (uint32_t w = 0; w < nwaves; w++)
+                scan_tile[w] = wave_prefix[w * WARP_SIZE + WARP_SIZE - 1] +
+                               block_sums[w * WARP_SIZE + WARP_SIZE - 1];                    /* :66-69 */
+            wave_prefix_sum32(scan_tile, warp_prefix, nwaves);                               /* :72-78 */
+            for (uint32_t t = 0; t < scan_groups; t++)
+                block_sums[t] = wave_prefix[t] + warp_prefix[t / WARP_SIZE];                 /* :81 */
+            free(wave_prefix);
+        }
+        /* ---- GlobalScan  Sh/Sorting/Scan.compute:86-96 ---- */
+        for (uint32_t g = 0; g < scan_groups; g++)
+            for (uint32_t t = 0; t < THREADS_PER_BLOCK; t++)
+                sizes[(size_t)g * THREADS_PER_BLOCK + t] += block_sums[g];                   /* :93-95 */
+        /* ---- GlobalRadixSort  Sh/Sorting/GlobalRadixSort.compute:20-40 ---- */
+        for (uint32_t g = 0; g < tiles; g++)
+            for (uint32_t t = 0; t < THREADS_PER_BLOCK; t++) {
+                const uint32_t key = blk_keys[(size_t)g * THREADS_PER_BLOCK + t];            /* :26 */
+                const uint32_t value = blk_vals[(size_t)g * THREADS_PER_BLOCK + t];          /* :27 */
+                const uint32_t radix = (key >> bit_offset) & (BUCKET_SIZE - 1);              /* :35 */
+                const uint32_t index_output = sizes[(size_t)g + (size_t)radix * tiles] + t -
+                                              offsets[(size_t)g * BUCKET_SIZE + radix];      /* :36 */
+                if (index_output >= count) { /* D3D would drop the write; flag it instead */
+                    free(blk_keys); free(blk_vals); free(offsets); free(sizes); free(block_sums);
+                    return -2;
+                }
+                keys[index_output] = key;                                                    /* :38 */
+                values[index_output] = value;                                                /* :39 */
+            }
+    }
+    free(blk_keys); free(blk_vals); free(offsets); free(sizes); free(block_sums);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* a-6  DistributeKeys     Sc/MeshBufferContainer.cs:154-169                                    */
+/* ------------------------------------------------------------------------------------------- */
+void orc_distribute_keys(uint32_t* keys, uint32_t n)
+{
+    if (n == 0) return;
+    uint32_t new_current = 0;                    /* :158 */
+    uint32_t old_current = keys[0];              /* :159 */
+    keys[0] = new_current;                       /* :160 */
+    for (uint32_t i = 1; i < n; i++) {           /* :161 */
+        uint32_t diff = keys[i] - old_current;   /* uint arithmetic */
+        new_current += diff > 1u ? diff : 1u;    /* Math.Max(diff, 1)  :163 */
+        old_current = keys[i];                   /* :164 */
+        keys[i] = new_current;                   /* :165 */
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* a-7  TreeConstructor    Sh/BVH/BVH.compute:18-149                                            */
+/* ------------------------------------------------------------------------------------------- */
+
+/* :18-21   31 - firstbithigh(v);  firstbithigh(0) = -1  =>  32 */
+static inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
+
+/* :23-33 */
+static inline int delta(const uint32_t* codes, int64_t x, int64_t y, int num_objects)
+{
+    if (x >= 0 && x <= num_objects - 1 && y >= 0 && y <= num_objects - 1)
+        return clz32(codes[x] ^ codes[y]);
+    return -1;
+}
+
+static inline int sign_i(int v) { return (v > 0) - (v < 0); }
+
+/* :35-52.  HLSL evaluates idx + lmax*d in 32-bit two's complement (uint*int); int64 here is the
+ * same value wherever the reference's result is in range, and out of range both give delta -1. */
+static void determine_range(const uint32_t* codes, int num_objects, int idx, int* first, int* last)
+{
+    const int d = sign_i(delta(codes, idx, (int64_t)idx + 1, num_objects) -
+                         delta(codes, idx, (int64_t)idx - 1, num_objects));       /* :37 */
+    const int dmin = delta(codes, idx, (int64_t)idx - d, num_objects);            /* :38 */
+    uint32_t lmax = 2;                                                             /* :39 */
+    while (delta(codes, idx, (int64_t)idx + (int64_t)(int32_t)(lmax * (uint32_t)d), num_objects) > dmin) /* :40 */
+        lmax = lmax * 2;                                                           /* :41 */
+    int l = 0;                                                                     /* :42 */
+    for (uint32_t t = lmax / 2; t >= 1; t /= 2) {                                  /* :43 */
+        int64_t probe = (int64_t)idx + (int64_t)(int32_t)(((uint32_t)l + t) * (uint32_t)d);
+        if (delta(codes, idx, probe, num_objects) > dmin) l += (int)t;             /* :45-46 */
+    }
+    const int j = idx + l * d;                                                     /* :49 */
+    *first = idx < j ? idx : j;                                                    /* :50 */
+    *last = idx > j ? idx : j;
+}
+
+/* :54-92 */
+static int find_split(const uint32_t* codes, int first, int last)
+{
+    const uint32_t first_code = codes[first];
+    const uint32_t last_code = codes[last];
+    if (first_code == last_code) return (first + last) >> 1;      /* :61-62 */
+    const int common_prefix = clz32(first_code ^ last_code);      /* :67 */
+    int split = first;                                            /* :73 */
+    int step = last - first;                                      /* :74 */
+    do {
+        step = (step + 1) >> 1;                                   /* :78 */
+        const int new_split = split + step;                       /* :79 */
+        if (new_split < last) {                                   /* :81 */
+            const uint32_t split_code = codes[new_split];
+            const int split_prefix = clz32(first_code ^ split_code);
+            if (split_prefix > common_prefix) split = new_split;  /* :85-86 */
+        }
+    } while (step > 1);                                           /* :89 */
+    return split;
+}
+
+int orc_build_tree(uint32_t n, const uint32_t* sorted_keys, lbvh_internal_node* internal,
+                   lbvh_leaf_node* leaf, int threads)
+{
+    (void)threads;
+    if (n < 2) return -1;               /* threadId < n - 1 underflows in the reference (:101) */
+    int bad = 0;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static) reduction(| : bad)
+#endif
+    for (int64_t tid = 0; tid < (int64_t)n - 1; tid++) {           /* :101 */
+        const uint32_t thread_id = (uint32_t)tid;
+        int first, last;
+        determine_range(sorted_keys, (int)n, (int)thread_id, &first, &last);     /* :103 */
+        const int split = find_split(sorted_keys, first, last);                  /* :109 */
+        if (split < 0 || (uint32_t)split + 1 >= n) { bad |= 1; continue; }
+        internal[thread_id].index = thread_id;                                   /* :111 */
+        if (split == first) {                                                    /* :114 */
+            leaf[split].parent = thread_id;                                      /* :116-120 */
+            leaf[split].index = (uint32_t)split;
+            internal[thread_id].leftNode = (uint32_t)split;                      /* :121 */
+            internal[thread_id].leftNodeType = LBVH_LEAF_NODE;                   /* :122 */
+        } else {
+            internal[split].parent = thread_id;                                  /* :126 */
+            internal[thread_id].leftNode = (uint32_t)split;                      /* :127 */
+            internal[thread_id].leftNodeType = LBVH_INTERNAL_NODE;               /* :128 */
+        }
+        if (split + 1 == last) {                                                 /* :132 */
+            leaf[split + 1].parent = thread_id;                                  /* :134-138 */
+            leaf[split + 1].index = (uint32_t)split + 1;
+            internal[thread_id].rightNode = (uint32_t)split + 1;                 /* :139 */
+            internal[thread_id].rightNodeType = LBVH_LEAF_NODE;                  /* :140 */
+        } else {
+            internal[split + 1].parent = thread_id;                              /* :144 */
+            internal[thread_id].rightNode = (uint32_t)split + 1;                 /* :145 */
+            internal[thread_id].rightNodeType = LBVH_INTERNAL_NODE;              /* :146 */
+        }
+    }
+    return bad ? -2 : 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* a-8  BVHConstructor (refit)     Sh/BVH/BVH.compute:152-220                                   */
+/* Threads run one after another here; min/max are exact, so every interleaving the GPU can     */
+/* produce gives the same boxes.                                                                */
+/* ------------------------------------------------------------------------------------------- */
+
+/* :152-170.  HLSL min/max return the non-NaN operand, like fminf/fmaxf. */
+static lbvh_aabb merge_aabb(lbvh_aabb l, lbvh_aabb r)
+{
+    lbvh_aabb o;
+    for (int k = 0; k < 3; k++) {
+        o.min[k] = fminf(l.min[k], r.min[k]);
+        o.max[k] = fmaxf(l.max[k], r.max[k]);
+    }
+    o._dummy0 = 0.0f;
+    o._dummy1 = 0.0f;
+    return o;
+}
+
+int orc_refit(uint32_t n, const lbvh_internal_node* internal, const lbvh_leaf_node* leaf,
+              const lbvh_aabb* triangle_aabb, const uint32_t* sorted_indices, lbvh_aabb* bvh)
+{
+    if (n < 2) return -1;
+    uint32_t* atomics = (uint32_t*)calloc(n, 4);       /* DataBuffer<uint>(.., 0)  Sc/BVHConstructor.cs:41 */
+    int rc = 0;
+    for (uint32_t tid = 0; tid < n; tid++) {           /* :179 */
+        uint32_t parent = leaf[tid].parent;            /* :181 */
+        uint32_t guard = 0;
+        while (parent != 0xFFFFFFFFu) {                /* :182 */
+            if (parent >= n - 1 || ++guard > 64) { rc = -2; break; }
+            uint32_t old = atomics[parent];            /* InterlockedCompareExchange(.., 0, 1, old)  :185 */
+            if (old == 0) atomics[parent] = 1;
+            if (old == 0) break;                       /* :186-189 */
+            const lbvh_internal_node nd = internal[parent];
+            lbvh_aabb lb = nd.leftNodeType == LBVH_INTERNAL_NODE
+                               ? bvh[nd.leftNode]
+                               : triangle_aabb[sorted_indices[nd.leftNode]];      /* :196-204 */
+            lbvh_aabb rb = nd.rightNodeType == LBVH_INTERNAL_NODE
+                               ? bvh[nd.rightNode]
+                               : triangle_aabb[sorted_indices[nd.rightNode]];     /* :205-213 */
+            bvh[parent] = merge_aabb(lb, rb);          /* :215 */
+            parent = nd.parent;                        /* :217 */
+        }
+    }
+    free(atomics);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* a-9  Raytracing kernel, ray gen + traversal    Sh/Raytracing/Raytracing.compute:23-176       */
+/* ------------------------------------------------------------------------------------------- */
+
+typedef struct { float origin[3], dir[3], inv_dir[3]; } ray_t;      /* :23-28 */
+
+/* RayBoxIntersection  :75-87.  HLSL min/max = fminf/fmaxf (non-NaN operand wins). */
+int orc_ray_box(const float bmin[3], const float bmax[3], const float origin[3],
+                const float inv_dir[3])
+{
+    float tmin1[3], tmax1[3];
+    for (int k = 0; k < 3; k++) {
+        float t1 = (bmin[k] - origin[k]) * inv_dir[k];
+        float t2 = (bmax[k] - origin[k]) * inv_dir[k];
+        tmin1[k] = fminf(t1, t2);
+        tmax1[k] = fmaxf(t1, t2);
+    }
+    const float tmin = fmaxf(tmin1[0], fmaxf(tmin1[1], tmin1[2]));
+    const float tmax = fminf(tmax1[0], fminf(tmax1[1], tmax1[2]));
+    return tmax > tmin && tmax > 0.0f;
+}
+
+static inline void cross3(const float a[3], const float b[3], float o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static inline float dot3(const float a[3], const float b[3])
+{
+    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+
+/* RayTriangleIntersection  :37-73.  Returns distance (LBVH_MAX_FLOAT = miss). */
+static float ray_triangle(const float orig[3], const float dir[3], const float v0[3],
+                          const float v1[3], const float v2[3], float* out_u, float* out_v)
+{
+    float e1[3], e2[3], pvec[3], tvec[3], qvec[3];
+    for (int k = 0; k < 3; k++) { e1[k] = v1[k] - v0[k]; e2[k] = v2[k] - v0[k]; }
+    cross3(dir, e2, pvec);
+    const float det = dot3(e1, pvec);
+    if (det < 1e-8f && det > -1e-8f) return LBVH_MAX_FLOAT;           /* :47-51 */
+    const float inv_det = 1.0f / det;
+    for (int k = 0; k < 3; k++) tvec[k] = orig[k] - v0[k];
+    const float u = dot3(tvec, pvec) * inv_det;
+    if (u < 0.0f || u > 1.0f) return LBVH_MAX_FLOAT;                  /* :56-60 */
+    cross3(tvec, e1, qvec);
+    const float v = dot3(dir, qvec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return LBVH_MAX_FLOAT;              /* :64-68 */
+    *out_u = u;
+    *out_v = v;
+    return dot3(e2, qvec) * inv_det;                                  /* :70 — no t > 0 test */
+}
+
+/* ray generation  :108-126 */
+void orc_make_ray(const lbvh_camera* cam, uint32_t px, uint32_t py, float origin[3], float dir[3],
+                  float inv_dir[3])
+{
+    const float near = cam->near_plane;
+    const float fov = cam->camera_fov;
+    const float height = 2.0f * near * fov;                                          /* :110 */
+    const float width = (float)cam->screen_width * height / (float)cam->screen_height; /* :111 */
+    float d[3];
+    d[0] = -width / 2.0f + width / (float)cam->screen_width * ((float)px + 0.5f);    /* :115 */
+    d[1] = -height / 2.0f + height / (float)cam->screen_height * ((float)py + 0.5f); /* :116 */
+    d[2] = -near;                                                                    /* :117 */
+    const float* m = cam->camera_to_world;
+    /* mul(M, float4(0,0,0,1)).xyz and mul(M, float4(dir,0)).xyz  :120-121; row . vector,
+     * summed left to right */
+    float w[3];
+    for (int r = 0; r < 3; r++) {
+        origin[r] = ((m[4 * r + 0] * 0.0f + m[4 * r + 1] * 0.0f) + m[4 * r + 2] * 0.0f) + m[4 * r + 3] * 1.0f;
+        w[r] = ((m[4 * r + 0] * d[0] + m[4 * r + 1] * d[1]) + m[4 * r + 2] * d[2]) + m[4 * r + 3] * 0.0f;
+    }
+    const float len = sqrtf((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]);               /* normalize :125 */
+    for (int r = 0; r < 3; r++) {
+        dir[r] = w[r] / len;
+        inv_dir[r] = 1.0f / dir[r];                                                   /* :126 */
+    }
+}
+
+/* CheckTriangle  :89-103 */
+static void check_triangle(uint32_t triangle_index, const ray_t* ray, const lbvh_scene* s,
+                           lbvh_hit* result, lbvh_trace_stats* st)
+{
+    st->leaf_tests++;
+    const lbvh_aabb* b = &s->triangle_aabb[triangle_index];
+    if (orc_ray_box(b->min, b->max, ray->origin, ray->inv_dir)) {                      /* :91 */
+        st->tri_tests++;
+        const lbvh_triangle* t = &s->triangles[triangle_index];                       /* :93 */
+        float u = 0.0f, v = 0.0f;
+        const float dist = ray_triangle(ray->origin, ray->dir, t->a, t->b, t->c, &u, &v);
+        if (dist < result->t) {                                                        /* :95 strict */
+            result->t = dist;
+            result->tri = triangle_index;                                              /* :97 */
+            result->u = u;
+            result->v = v;
+        }
+    }
+}
+
+/* the traversal loop  :128-176 for one ray */
+static int trace_one(const lbvh_scene* s, const ray_t* ray, lbvh_hit* result, lbvh_trace_stats* st)
+{
+    result->t = LBVH_MAX_FLOAT;                 /* :129 */
+    result->tri = 0;                            /* :130 */
+    result->u = 0.0f;                           /* :131 */
+    result->v = 0.0f;
+    uint32_t stack[64];                         /* :133 */
+    uint32_t sp = 0;
+    stack[sp] = 0;                              /* :135 */
+    sp = 1;
+    int overflow = 0;
+    while (sp != 0) {                           /* :138 */
+        sp--;
+        const uint32_t index = stack[sp];       /* :141 */
+        st->pops++;
+        const lbvh_aabb* nb = &s->bvh[index];
+        if (!orc_ray_box(nb->min, nb->max, ray->origin, ray->inv_dir)) continue;    /* :143-146 */
+        st->box_hits++;
+        const lbvh_internal_node* nd = &s->internal_nodes[index];
+        if (nd->leftNodeType == LBVH_INTERNAL_NODE) {                                /* :151 */
+            if (sp >= 64) { overflow = 1; break; }
+            stack[sp++] = nd->leftNode;                                              /* :153-154 */
+        } else {
+            const uint32_t tri = s->sorted_indices[s->leaf_nodes[nd->leftNode].index]; /* :158 */
+            check_triangle(tri, ray, s, result, st);                                 /* :159 */
+        }
+        if (nd->rightNodeType == LBVH_INTERNAL_NODE) {                               /* :166 */
+            if (sp >= 64) { overflow = 1; break; }
+            stack[sp++] = nd->rightNode;                                             /* :168-169 */
+        } else {
+            const uint32_t tri = s->sorted_indices[s->leaf_nodes[nd->rightNode].index]; /* :173 */
+            check_triangle(tri, ray, s, result, st);                                 /* :174 */
+        }
+    }
+    if (result->t < LBVH_MAX_FLOAT) st->hits++;                                      /* :184 alpha */
+    return overflow;
+}
+
+int orc_trace_primary(const lbvh_camera* cam, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
+                      int32_t x_step, int32_t y_step, const lbvh_scene* scene, lbvh_hit* hits,
+                      lbvh_trace_stats* stats, int threads)
+{
+    (void)threads;
+    if (x_step < 1 || y_step < 1 || x1 < x0 || y1 < y0) return -1;
+    const int64_t w = (x1 - x0 + x_step - 1) / x_step;
+    const int64_t h = (y1 - y0 + y_step - 1) / y_step;
+    uint64_t pops = 0, box_hits = 0, leaf_tests = 0, tri_tests = 0, nhits = 0;
+    int overflow = 0;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 4) \
+    reduction(+ : pops, box_hits, leaf_tests, tri_tests, nhits) reduction(| : overflow)
+#endif
+    for (int64_t j = 0; j < h; j++) {
+        for (int64_t i = 0; i < w; i++) {
+            ray_t ray;
+            orc_make_ray(cam, (uint32_t)(x0 + i * x_step), (uint32_t)(y0 + j * y_step), ray.origin,
+                         ray.dir, ray.inv_dir);
+            lbvh_trace_stats st = {0, 0, 0, 0, 0};
+            overflow |= trace_one(scene, &ray, &hits[j * w + i], &st);
+            pops += st.pops; box_hits += st.box_hits; leaf_tests += st.leaf_tests;
+            tri_tests += st.tri_tests; nhits += st.hits;
+        }
+    }
+    if (stats) {
+        stats->pops = pops; stats->box_hits = box_hits; stats->leaf_tests = leaf_tests;
+        stats->tri_tests = tri_tests; stats->hits = nhits;
+    }
+    return overflow ? -3 : 0;
+}
+
+/* The whole Awake() build (Sc/RaytracingMeshDrawer.cs:30-51) on the host, for the CPU baseline:
+ * Morton/AABB -> sort -> DistributeKeys -> ConstructTree -> ConstructBVH. */
+int orc_build_all(const lbvh_triangle* tris, uint32_t n, uint32_t capacity, const float box_min[3],
+                  const float box_max[3], uint32_t* keys, uint32_t* indices, lbvh_aabb* tri_aabb,
+                  lbvh_internal_node* internal, lbvh_leaf_node* leaf, lbvh_aabb* bvh, int threads)
+{
+    if (n < 2 || capacity < n) return -1;
+    orc_morton_aabb(tris, n, capacity, box_min, box_max, keys, indices, tri_aabb, threads);
+    orc_sort_pairs(keys, indices, capacity);
+    orc_distribute_keys(keys, n);
+    memset(internal, 0xFF, (size_t)capacity * sizeof *internal);   /* NullLeaf fill :114-115 */
+    memset(leaf, 0xFF, (size_t)capacity * sizeof *leaf);
+    int rc = orc_build_tree(n, keys, internal, leaf, threads);
+    if (rc) return rc;
+    return orc_refit(n, internal, leaf, tri_aabb, indices, bvh);
+}

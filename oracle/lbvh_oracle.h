@@ -1,0 +1,64 @@
+/*
+ * lbvh_oracle.h — CPU restatement of the reference hot path (TEST INFRASTRUCTURE ONLY; see the
+ * header of lbvh_oracle.c for what may load it and how it is pinned).
+ */
+#ifndef LBVH_ORACLE_H
+#define LBVH_ORACLE_H
+
+#include <stdint.h>
+#include "../include/lbvh.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* OpenMP threads available to the `threads` arguments below (1 if built without OpenMP). */
+int orc_num_threads(void);
+
+/* a-1  Assets/_Scripts/MeshBufferContainer.cs:32-83,108-109,123-146 */
+void orc_morton_aabb(const lbvh_triangle* tris, uint32_t n, uint32_t capacity,
+                     const float box_min[3], const float box_max[3],
+                     uint32_t* keys, uint32_t* indices, lbvh_aabb* aabb, int threads);
+
+/* a-2..a-5, semantic: stable ascending sort by key = result of
+ * Assets/_Scripts/ComputeBufferSorter.cs:100-126 */
+void orc_sort_pairs(uint32_t* keys, uint32_t* values, uint32_t count);
+
+/* a-2..a-5, literal: emulation of LocalRadixSort/PreScan/BlockSum/GlobalScan/GlobalRadixSort with
+ * 32-lane waves; count = tiles*1024, tiles a multiple of 128 (reference: 512).  0 = ok. */
+int orc_sort_pairs_literal(uint32_t* keys, uint32_t* values, uint32_t tiles);
+
+/* a-6  Assets/_Scripts/MeshBufferContainer.cs:154-169 */
+void orc_distribute_keys(uint32_t* keys, uint32_t n);
+
+/* a-7  Assets/_Shaders/BVH/BVH.compute:18-149.  0 = ok, -1 = n < 2, -2 = keys not unique */
+int orc_build_tree(uint32_t n, const uint32_t* sorted_keys, lbvh_internal_node* internal,
+                   lbvh_leaf_node* leaf, int threads);
+
+/* a-8  Assets/_Shaders/BVH/BVH.compute:152-220 */
+int orc_refit(uint32_t n, const lbvh_internal_node* internal, const lbvh_leaf_node* leaf,
+              const lbvh_aabb* triangle_aabb, const uint32_t* sorted_indices, lbvh_aabb* bvh);
+
+/* a-9 pieces  Assets/_Shaders/Raytracing/Raytracing.compute:75-87 and :108-126 */
+int orc_ray_box(const float bmin[3], const float bmax[3], const float origin[3],
+                const float inv_dir[3]);
+void orc_make_ray(const lbvh_camera* cam, uint32_t px, uint32_t py, float origin[3], float dir[3],
+                  float inv_dir[3]);
+
+/* a-9  Assets/_Shaders/Raytracing/Raytracing.compute:105-176 for the pixels
+ * x = x0, x0+x_step, ... < x1; y likewise (steps > 1 subsample the frame for the algorithmic-bytes
+ * counters).  `scene` holds HOST pointers here.  hits is row-major over the sampled grid.
+ * 0 = ok, -3 = the reference's 64-entry stack would have overflowed. */
+int orc_trace_primary(const lbvh_camera* cam, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
+                      int32_t x_step, int32_t y_step, const lbvh_scene* scene, lbvh_hit* hits,
+                      lbvh_trace_stats* stats, int threads);
+
+/* Awake() build chain on the host (Assets/_Scripts/RaytracingMeshDrawer.cs:30-51). */
+int orc_build_all(const lbvh_triangle* tris, uint32_t n, uint32_t capacity, const float box_min[3],
+                  const float box_max[3], uint32_t* keys, uint32_t* indices, lbvh_aabb* tri_aabb,
+                  lbvh_internal_node* internal, lbvh_leaf_node* leaf, lbvh_aabb* bvh, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

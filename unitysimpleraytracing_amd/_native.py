@@ -1,0 +1,96 @@
+"""ctypes binding of liblbvh.so (include/lbvh.h).  No fallback: a missing or stale library is an
+ImportError, a failing call is an LbvhError — the product path never computes on the CPU."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblbvh.so")
+ABI_VERSION = 1
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `make -C unitysimpleraytracing_amd/csrc` "
+        "(or __graft_entry__.build()); there is no CPU fallback for the hot path")
+
+lib = C.CDLL(LIB_PATH)
+
+
+class LbvhError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"lbvh status {status}: {message}")
+        self.status = status
+
+
+class Camera(C.Structure):
+    _fields_ = [("screen_width", C.c_int32), ("screen_height", C.c_int32),
+                ("camera_fov", C.c_float), ("near_plane", C.c_float),
+                ("camera_to_world", C.c_float * 16)]
+
+    @classmethod
+    def from_dict(cls, d):
+        cam = cls()
+        cam.screen_width = d["screen_width"]
+        cam.screen_height = d["screen_height"]
+        cam.camera_fov = d["camera_fov"]
+        cam.near_plane = d["near_plane"]
+        for i, v in enumerate(np.asarray(d["camera_to_world"], dtype=np.float32).reshape(-1)):
+            cam.camera_to_world[i] = float(v)
+        return cam
+
+
+class Scene(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("sorted_indices", C.c_void_p), ("triangle_aabb", C.c_void_p),
+                ("internal_nodes", C.c_void_p), ("leaf_nodes", C.c_void_p), ("bvh", C.c_void_p),
+                ("triangles", C.c_void_p)]
+
+
+# every entry point include/lbvh.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_U32 = C.c_uint32
+_I32 = C.c_int32
+_SZ = C.c_size_t
+_F3 = C.POINTER(C.c_float)
+SIGNATURES = {
+    "lbvh_abi_version": (_I32, []),
+    "lbvh_device_count": (_I32, []),
+    "lbvh_create": (_I32, [_I32, C.POINTER(_P)]),
+    "lbvh_create_on_stream": (_I32, [_I32, _P, C.POINTER(_P)]),
+    "lbvh_destroy": (_I32, [_P]),
+    "lbvh_last_error": (C.c_char_p, [_P]),
+    "lbvh_sync": (_I32, [_P]),
+    "lbvh_buffer_alloc": (_I32, [_P, _SZ, _SZ, C.POINTER(_P)]),
+    "lbvh_buffer_free": (_I32, [_P, _P]),
+    "lbvh_buffer_fill_u32": (_I32, [_P, _P, _U32, _SZ]),
+    "lbvh_buffer_upload": (_I32, [_P, _P, _P, _SZ]),
+    "lbvh_buffer_download": (_I32, [_P, _P, _P, _SZ]),
+    "lbvh_morton_aabb": (_I32, [_P, _P, _U32, _U32, _F3, _F3, _P, _P, _P]),
+    "lbvh_sort_pairs": (_I32, [_P, _P, _P, _U32]),
+    "lbvh_distribute_keys": (_I32, [_P, _P, _U32]),
+    "lbvh_build_tree": (_I32, [_P, _U32, _P, _P, _P]),
+    "lbvh_refit": (_I32, [_P, _U32, _P, _P, _P, _P, _P]),
+    "lbvh_build_fast_scene": (_I32, [_P, C.POINTER(Scene)]),
+    "lbvh_trace_primary": (_I32, [_P, C.POINTER(Camera), _I32, _I32, _I32, _I32, C.POINTER(Scene),
+                                  _I32, _P, _P]),
+    "lbvh_event_create": (_I32, [_P, C.POINTER(_P)]),
+    "lbvh_event_destroy": (_I32, [_P, _P]),
+    "lbvh_event_record": (_I32, [_P, _P]),
+    "lbvh_event_elapsed_ms": (_I32, [_P, _P, _P, C.POINTER(C.c_float)]),
+    "lbvh_copy_bandwidth_probe": (_I32, [_P, _P, _P, _SZ]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here = library/header mismatch
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.lbvh_abi_version() != ABI_VERSION:
+    raise ImportError(f"liblbvh.so ABI {lib.lbvh_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+
+
+def check(ctx, status):
+    if status != 0:
+        msg = lib.lbvh_last_error(ctx)
+        raise LbvhError(status, msg.decode() if msg else "")
+    return status

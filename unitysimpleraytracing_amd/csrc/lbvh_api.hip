@@ -1,0 +1,231 @@
+// lbvh_api.hip — context, buffers, events: the DataBuffer/ComputeBuffer half of the C ABI
+// (reference: Assets/_Scripts/DataBuffer.cs, Assets/_Scripts/ShaderContainer.cs).
+#include "lbvh_common.h"
+
+#include <string.h>
+
+static thread_local std::string g_create_error;
+
+int lbvh_set_error(lbvh_context* ctx, int code, const char* what, const char* detail)
+{
+    std::string msg = std::string(what ? what : "") + (detail ? std::string(": ") + detail : "");
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+int lbvh_reserve(lbvh_context* ctx, void** ptr, size_t* have, size_t bytes)
+{
+    if (*have >= bytes && *ptr) return LBVH_OK;
+    if (*ptr) {
+        // earlier launches may still be using the old block
+        LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        LBVH_HIP_TRY(ctx, hipFree(*ptr));
+        *ptr = nullptr;
+        *have = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    LBVH_HIP_TRY(ctx, hipMalloc(ptr, want));
+    *have = want;
+    return LBVH_OK;
+}
+
+extern "C" {
+
+int32_t lbvh_abi_version(void) { return LBVH_ABI_VERSION; }
+
+int32_t lbvh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+static lbvh_status create_impl(int32_t device_id, void* stream, bool own, lbvh_context** out_ctx)
+{
+    if (!out_ctx) return lbvh_set_error(nullptr, LBVH_ERR_INVALID_ARG, "lbvh_create", "out_ctx is null");
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return lbvh_set_error(nullptr, LBVH_ERR_NO_DEVICE, "lbvh_create", "no HIP device visible");
+    if (device_id < 0 || device_id >= n)
+        return lbvh_set_error(nullptr, LBVH_ERR_INVALID_ARG, "lbvh_create", "device_id out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess)
+        return lbvh_set_error(nullptr, LBVH_ERR_HIP, "lbvh_create", "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 || prop.warpSize != 64)
+        return lbvh_set_error(nullptr, LBVH_ERR_NO_DEVICE, "lbvh_create: device is not gfx950/wave64",
+                              prop.gcnArchName);
+    lbvh_context* ctx = new lbvh_context();
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) {
+        delete ctx;
+        return lbvh_set_error(nullptr, LBVH_ERR_HIP, "lbvh_create", "hipSetDevice failed");
+    }
+    if (own) {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return lbvh_set_error(nullptr, LBVH_ERR_HIP, "lbvh_create", "hipStreamCreate failed");
+        }
+        ctx->own_stream = true;
+    } else {
+        ctx->stream = (hipStream_t)stream;
+        ctx->own_stream = false;
+    }
+    *out_ctx = ctx;
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_create(int32_t device_id, lbvh_context** out_ctx)
+{
+    return create_impl(device_id, nullptr, true, out_ctx);
+}
+
+lbvh_status lbvh_create_on_stream(int32_t device_id, void* hip_stream, lbvh_context** out_ctx)
+{
+    return create_impl(device_id, hip_stream, false, out_ctx);
+}
+
+lbvh_status lbvh_destroy(lbvh_context* ctx)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->sort_scratch) (void)hipFree(ctx->sort_scratch);
+    if (ctx->scan_scratch) (void)hipFree(ctx->scan_scratch);
+    if (ctx->refit_flags) (void)hipFree(ctx->refit_flags);
+    if (ctx->fast_nodes) (void)hipFree(ctx->fast_nodes);
+    if (ctx->fast_tris) (void)hipFree(ctx->fast_tris);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return LBVH_OK;
+}
+
+const char* lbvh_last_error(const lbvh_context* ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+lbvh_status lbvh_sync(lbvh_context* ctx)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LBVH_OK;
+}
+
+// ---- buffers -------------------------------------------------------------------------------
+
+lbvh_status lbvh_buffer_alloc(lbvh_context* ctx, size_t count, size_t stride, void** out_d_ptr)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, out_d_ptr != nullptr);
+    LBVH_REQUIRE(ctx, stride > 0);
+    *out_d_ptr = nullptr;
+    size_t bytes = count * stride;
+    if (bytes == 0) bytes = stride;
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LBVH_HIP_TRY(ctx, hipMalloc(out_d_ptr, bytes));
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_buffer_free(lbvh_context* ctx, void* d_ptr)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    if (!d_ptr) return LBVH_OK;
+    LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    LBVH_HIP_TRY(ctx, hipFree(d_ptr));
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_buffer_fill_u32(lbvh_context* ctx, void* d_ptr, uint32_t value, size_t n_words)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    if (n_words == 0) return LBVH_OK;
+    LBVH_REQUIRE(ctx, d_ptr != nullptr);
+    LBVH_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_ptr, (int)value, n_words, ctx->stream));
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_buffer_upload(lbvh_context* ctx, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    if (bytes == 0) return LBVH_OK;
+    LBVH_REQUIRE(ctx, d_dst != nullptr && h_src != nullptr);
+    LBVH_HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    // pageable host memory: the caller may reuse h_src as soon as we return
+    LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_buffer_download(lbvh_context* ctx, void* h_dst, const void* d_src, size_t bytes)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    if (bytes == 0) return LBVH_OK;
+    LBVH_REQUIRE(ctx, h_dst != nullptr && d_src != nullptr);
+    LBVH_HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LBVH_OK;
+}
+
+// ---- events ----------------------------------------------------------------------------------
+
+lbvh_status lbvh_event_create(lbvh_context* ctx, void** out_event)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, out_event != nullptr);
+    hipEvent_t ev;
+    LBVH_HIP_TRY(ctx, hipEventCreate(&ev));
+    *out_event = (void*)ev;
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_event_destroy(lbvh_context* ctx, void* event)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    if (!event) return LBVH_OK;
+    LBVH_HIP_TRY(ctx, hipEventDestroy((hipEvent_t)event));
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_event_record(lbvh_context* ctx, void* event)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, event != nullptr);
+    LBVH_HIP_TRY(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_event_elapsed_ms(lbvh_context* ctx, void* start, void* stop, float* out_ms)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, start != nullptr && stop != nullptr && out_ms != nullptr);
+    LBVH_HIP_TRY(ctx, hipEventSynchronize((hipEvent_t)stop));
+    LBVH_HIP_TRY(ctx, hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return LBVH_OK;
+}
+
+// ---- HBM copy-rate probe ---------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void copy_f4_kernel(float4* __restrict__ dst,
+                                                      const float4* __restrict__ src, size_t n16)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+lbvh_status lbvh_copy_bandwidth_probe(lbvh_context* ctx, void* d_dst, const void* d_src, size_t bytes)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, d_dst != nullptr && d_src != nullptr);
+    LBVH_REQUIRE(ctx, bytes % 16 == 0);
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return LBVH_OK;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
+    hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       (float4*)d_dst, (const float4*)d_src, n16);
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
+}
+
+}  // extern "C"

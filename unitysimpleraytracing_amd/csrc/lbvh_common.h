@@ -1,0 +1,122 @@
+// lbvh_common.h — shared definitions of the gfx950 LBVH library (context, error plumbing,
+// wave64 primitives).  Everything here is CDNA4-only: 64-lane wavefronts are hard-coded.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/lbvh.h"
+
+static_assert(sizeof(lbvh_aabb) == 32, "AABB must be 32 bytes (Sc/MeshBufferContainer.cs:103)");
+static_assert(sizeof(lbvh_triangle) == 128, "Triangle must be 128 bytes (Sc/MeshBufferContainer.cs:98)");
+static_assert(sizeof(lbvh_internal_node) == 24, "InternalNode must be 24 bytes");
+static_assert(sizeof(lbvh_leaf_node) == 8, "LeafNode must be 8 bytes");
+static_assert(sizeof(lbvh_hit) == 16, "hit record must be 16 bytes");
+
+#define LBVH_WAVE 64
+
+// Derived traversal node for LBVH_TRACE_FAST: both child boxes + child references, 64 bytes,
+// one 64-B aligned fetch per traversal step.  Child reference: bit 31 set = leaf, low bits =
+// SORTED leaf position (index into fast_tris); bit 31 clear = internal node index.
+struct alignas(64) lbvh_fast_node {
+    float lmin[3]; uint32_t left;
+    float lmax[3]; uint32_t right;
+    float rmin[3]; uint32_t pad0;
+    float rmax[3]; uint32_t pad1;
+};
+static_assert(sizeof(lbvh_fast_node) == 64, "fast node must be 64 bytes");
+
+// Positions-only triangle in SORTED order for LBVH_TRACE_FAST, 48 bytes (3 x float4).
+// The .w lanes carry the original triangle index (a.w) so the hit record needs no extra gather.
+struct alignas(16) lbvh_fast_tri {
+    float a[3]; uint32_t orig_index;
+    float b[3]; uint32_t pad0;
+    float c[3]; uint32_t pad1;
+};
+static_assert(sizeof(lbvh_fast_tri) == 48, "fast triangle must be 48 bytes");
+
+struct lbvh_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // radix sort scratch (ping-pong pairs + per-tile digit tables), grown lazily
+    void* sort_scratch = nullptr;
+    size_t sort_scratch_bytes = 0;
+    // distribute-keys scratch
+    void* scan_scratch = nullptr;
+    size_t scan_scratch_bytes = 0;
+    // refit arrival flags (the reference's atomicsData, Sc/BVHConstructor.cs:41)
+    uint32_t* refit_flags = nullptr;
+    size_t refit_flags_words = 0;
+    // derived fast-traversal scene
+    lbvh_fast_node* fast_nodes = nullptr;
+    lbvh_fast_tri* fast_tris = nullptr;
+    uint32_t fast_capacity = 0;
+    uint32_t fast_n = 0;
+};
+
+int lbvh_set_error(lbvh_context* ctx, int code, const char* what, const char* detail);
+
+#define LBVH_HIP_TRY(ctx, expr)                                                      \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess)                                                        \
+            return lbvh_set_error((ctx), _e == hipErrorOutOfMemory ? LBVH_ERR_OUT_OF_MEMORY \
+                                                                   : LBVH_ERR_HIP,    \
+                                  #expr, hipGetErrorString(_e));                     \
+    } while (0)
+
+#define LBVH_REQUIRE(ctx, cond)                                                      \
+    do {                                                                             \
+        if (!(cond)) return lbvh_set_error((ctx), LBVH_ERR_INVALID_ARG, "invalid argument", #cond); \
+    } while (0)
+
+// Grow-only scratch helper: (re)allocates *ptr to at least `bytes`.
+int lbvh_reserve(lbvh_context* ctx, void** ptr, size_t* have, size_t bytes);
+
+// ---- wave64 device primitives --------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id()
+{
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// number of set bits of `mask` in lanes below the calling lane (v_mbcnt_lo + v_mbcnt_hi)
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// DPP controls (gfx9 family): row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add_step(uint32_t v)
+{
+    // old = 0 (identity) for lanes whose source is out of range / masked off
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+// Inclusive prefix sum across the 64 lanes of a wave: 4 row_shr steps inside each 16-lane row,
+// then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 (the gfx9 wave64 scan).
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
+{
+    v = dpp_add_step<0x111, 0xf>(v);
+    v = dpp_add_step<0x112, 0xf>(v);
+    v = dpp_add_step<0x114, 0xf>(v);
+    v = dpp_add_step<0x118, 0xf>(v);
+    v = dpp_add_step<0x142, 0xa>(v);
+    v = dpp_add_step<0x143, 0xc>(v);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_exclusive_sum(uint32_t v) { return wave_inclusive_sum(v) - v; }
+
+// wave total, valid in every lane (lane 63 of the inclusive scan, read back as a scalar)
+__device__ __forceinline__ uint32_t wave_total_from_inclusive(uint32_t inclusive)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)inclusive, 63);
+}
+

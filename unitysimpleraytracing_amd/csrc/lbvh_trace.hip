@@ -1,0 +1,426 @@
+// lbvh_trace.hip — primary-ray generation + BVH traversal for gfx950.
+//
+// Reference: kernel Raytracing, Assets/_Shaders/Raytracing/Raytracing.compute:105-185 (ray gen
+// :108-126, traversal :133-176) with RayBoxIntersection :75-87, CheckTriangle :89-103 and
+// RayTriangleIntersection :37-73, dispatched by Assets/_Scripts/RaytracingMeshDrawer.cs:76-84.
+//
+// Two traversal flavours share the ray generation and the exact (strict fp32, no FMA contraction)
+// slab and Moeller-Trumbore arithmetic, so the winning t is bit-identical to the CPU oracle:
+//   LBVH_TRACE_REFERENCE  walks the reference's own arrays in the reference's visit order (push
+//                         left, push right, pop right first; no pruning) — the parity mode and the
+//                         source of the reference-semantics visit counters.
+//   LBVH_TRACE_FAST       walks the derived 64-byte fused nodes (both child boxes + child refs in
+//                         one fetch, leaf triangles pre-gathered to 48 B in sorted order), visits
+//                         the nearer child first and skips boxes that start beyond the best hit.
+//                         Same candidate set minus boxes that cannot win => same min t.
+//
+// One wave (8x8 pixels) per workgroup; the traversal stack lives in LDS as [entry][lane]
+// (bank-conflict-free, no scratch memory); no barriers anywhere.
+#include "lbvh_common.h"
+
+namespace {
+
+constexpr int kStackDepth = 34;   // distributed keys are < 2^31 => <= 31 internal levels below the
+                                  // root; the reference's push-both order needs depth + 1 entries
+
+struct ray_t {
+    float ox, oy, oz;
+    float dx, dy, dz;
+    float ix, iy, iz;
+};
+
+// Raytracing.compute:108-126; same expression order as oracle/lbvh_oracle.c orc_make_ray
+__device__ __forceinline__ ray_t make_ray(const lbvh_camera& cam, uint32_t px, uint32_t py)
+{
+    const float near = cam.near_plane;
+    const float fov = cam.camera_fov;
+    const float height = 2.0f * near * fov;
+    const float width = (float)cam.screen_width * height / (float)cam.screen_height;
+    const float d0 = -width / 2.0f + width / (float)cam.screen_width * ((float)px + 0.5f);
+    const float d1 = -height / 2.0f + height / (float)cam.screen_height * ((float)py + 0.5f);
+    const float d2 = -near;
+    const float* m = cam.camera_to_world;
+    float o[3], w[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        o[r] = ((m[4 * r + 0] * 0.0f + m[4 * r + 1] * 0.0f) + m[4 * r + 2] * 0.0f) + m[4 * r + 3] * 1.0f;
+        w[r] = ((m[4 * r + 0] * d0 + m[4 * r + 1] * d1) + m[4 * r + 2] * d2) + m[4 * r + 3] * 0.0f;
+    }
+    const float len = sqrtf((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]);
+    ray_t ray;
+    ray.ox = o[0]; ray.oy = o[1]; ray.oz = o[2];
+    ray.dx = w[0] / len; ray.dy = w[1] / len; ray.dz = w[2] / len;
+    ray.ix = 1.0f / ray.dx; ray.iy = 1.0f / ray.dy; ray.iz = 1.0f / ray.dz;
+    return ray;
+}
+
+// RayBoxIntersection, Raytracing.compute:75-87.  Returns the hit predicate; tmin_out = entry t.
+__device__ __forceinline__ bool ray_box(const float4 bmin, const float4 bmax, const ray_t& r, float& tmin_out)
+{
+    const float t1x = (bmin.x - r.ox) * r.ix, t2x = (bmax.x - r.ox) * r.ix;
+    const float t1y = (bmin.y - r.oy) * r.iy, t2y = (bmax.y - r.oy) * r.iy;
+    const float t1z = (bmin.z - r.oz) * r.iz, t2z = (bmax.z - r.oz) * r.iz;
+    const float tmin = fmaxf(fminf(t1x, t2x), fmaxf(fminf(t1y, t2y), fminf(t1z, t2z)));
+    const float tmax = fminf(fmaxf(t1x, t2x), fminf(fmaxf(t1y, t2y), fmaxf(t1z, t2z)));
+    tmin_out = tmin;
+    return tmax > tmin && tmax > 0.0f;
+}
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return (ax * bx + ay * by) + az * bz;
+}
+
+// RayTriangleIntersection, Raytracing.compute:37-73.  Returns distance (LBVH_MAX_FLOAT = miss).
+__device__ __forceinline__ float ray_triangle(const ray_t& r, const float4 v0, const float4 v1,
+                                              const float4 v2, float& u_out, float& v_out)
+{
+    const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
+    const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
+    // pvec = cross(dir, e2)
+    const float px = r.dy * e2z - r.dz * e2y;
+    const float py = r.dz * e2x - r.dx * e2z;
+    const float pz = r.dx * e2y - r.dy * e2x;
+    const float det = dot3(e1x, e1y, e1z, px, py, pz);
+    if (det < 1e-8f && det > -1e-8f) return LBVH_MAX_FLOAT;
+    const float inv_det = 1.0f / det;
+    const float tx = r.ox - v0.x, ty = r.oy - v0.y, tz = r.oz - v0.z;
+    const float u = dot3(tx, ty, tz, px, py, pz) * inv_det;
+    if (u < 0.0f || u > 1.0f) return LBVH_MAX_FLOAT;
+    // qvec = cross(tvec, e1)
+    const float qx = ty * e1z - tz * e1y;
+    const float qy = tz * e1x - tx * e1z;
+    const float qz = tx * e1y - ty * e1x;
+    const float v = dot3(r.dx, r.dy, r.dz, qx, qy, qz) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return LBVH_MAX_FLOAT;
+    u_out = u;
+    v_out = v;
+    return dot3(e2x, e2y, e2z, qx, qy, qz) * inv_det;
+}
+
+struct trace_args {
+    lbvh_camera cam;
+    int32_t x0, y0, x1, y1;
+    uint32_t tiles_x, tiles_y;
+};
+
+// Workgroup id -> 8x8 pixel tile.  Workgroups are dealt round-robin over the 8 XCDs, so ids
+// b, b+8, b+16, ... share one XCD (and its 4-MiB L2); give each XCD a contiguous run of tiles in
+// row-major screen order so the BVH subtrees one L2 sees are a compact part of the scene.
+// Speed only: any mapping is correct.  Bijective for every tile count.
+__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t b, uint32_t n)
+{
+    const uint32_t per = n / 8, rem = n % 8;
+    const uint32_t x = b % 8, k = b / 8;
+    // XCD x owns `per` tiles (+1 for the first `rem` XCDs)
+    const uint32_t start = x * per + (x < rem ? x : rem);
+    return start + k;
+}
+
+__device__ __forceinline__ bool tile_pixel(const trace_args& a, uint32_t tile, uint32_t lane, uint32_t& px,
+                                           uint32_t& py)
+{
+    const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    px = (uint32_t)a.x0 + tx * 8 + (lane & 7);
+    py = (uint32_t)a.y0 + ty * 8 + (lane >> 3);
+    return px < (uint32_t)a.x1 && py < (uint32_t)a.y1;
+}
+
+__device__ __forceinline__ void add_stats(lbvh_trace_stats* stats, uint32_t pops, uint32_t box_hits,
+                                          uint32_t leaf_tests, uint32_t tri_tests, uint32_t hits)
+{
+    // wave reduction, one atomic per counter per wave
+    uint32_t v[5] = {pops, box_hits, leaf_tests, tri_tests, hits};
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const uint32_t incl = wave_inclusive_sum(v[i]);
+        v[i] = wave_total_from_inclusive(incl);
+    }
+    if (lane_id() == 0) {
+        atomicAdd((unsigned long long*)&stats->pops, (unsigned long long)v[0]);
+        atomicAdd((unsigned long long*)&stats->box_hits, (unsigned long long)v[1]);
+        atomicAdd((unsigned long long*)&stats->leaf_tests, (unsigned long long)v[2]);
+        atomicAdd((unsigned long long*)&stats->tri_tests, (unsigned long long)v[3]);
+        atomicAdd((unsigned long long*)&stats->hits, (unsigned long long)v[4]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LBVH_TRACE_REFERENCE
+// ---------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(64) void trace_reference_kernel(trace_args a, lbvh_scene s,
+                                                             lbvh_hit* __restrict__ hits,
+                                                             lbvh_trace_stats* stats)
+{
+    __shared__ uint32_t s_stack[kStackDepth][LBVH_WAVE];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    uint32_t px, py;
+    const bool active = tile_pixel(a, tile, lane, px, py);
+
+    uint32_t n_pops = 0, n_box = 0, n_leaf = 0, n_tri = 0, n_hit = 0;
+    if (active) {
+        const ray_t ray = make_ray(a.cam, px, py);
+        float best_t = LBVH_MAX_FLOAT;                    // :129
+        uint32_t best_tri = 0;                            // :130
+        float best_u = 0.0f, best_v = 0.0f;               // :131
+
+        uint32_t sp = 0;
+        s_stack[0][lane] = 0;                             // :135
+        sp = 1;
+        while (sp != 0) {                                 // :138
+            sp--;
+            const uint32_t index = s_stack[sp][lane];     // :141
+            if (STATS) n_pops++;
+            const float4* nb = reinterpret_cast<const float4*>(&s.bvh[index]);
+            float tmin;
+            if (!ray_box(nb[0], nb[1], ray, tmin)) continue;     // :143-146
+            if (STATS) n_box++;
+            const uint32_t* nd = reinterpret_cast<const uint32_t*>(&s.internal_nodes[index]);
+            const uint2 lc = *reinterpret_cast<const uint2*>(nd + 0);
+            const uint2 rc = *reinterpret_cast<const uint2*>(nd + 2);
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const uint2 c = side == 0 ? lc : rc;      // left then right  :148-175
+                if (c.y == LBVH_INTERNAL_NODE) {
+                    if (sp < (uint32_t)kStackDepth) s_stack[sp][lane] = c.x;
+                    sp++;
+                } else {
+                    const uint32_t tri = s.sorted_indices[s.leaf_nodes[c.x].index];   // :158
+                    if (STATS) n_leaf++;
+                    const float4* tb = reinterpret_cast<const float4*>(&s.triangle_aabb[tri]);
+                    float tmin2;
+                    if (ray_box(tb[0], tb[1], ray, tmin2)) {                          // :91
+                        if (STATS) n_tri++;
+                        const float4* tv = reinterpret_cast<const float4*>(&s.triangles[tri]);
+                        float u = 0.0f, v = 0.0f;
+                        const float dist = ray_triangle(ray, tv[0], tv[1], tv[2], u, v);
+                        if (dist < best_t) {                                          // :95
+                            best_t = dist; best_tri = tri; best_u = u; best_v = v;
+                        }
+                    }
+                }
+            }
+            if (sp > (uint32_t)kStackDepth) sp = kStackDepth;   // unreachable for unique keys
+        }
+        const uint32_t rw = (uint32_t)(a.x1 - a.x0);
+        float4 out;
+        out.x = best_t;
+        out.y = __uint_as_float(best_tri);
+        out.z = best_u;
+        out.w = best_v;
+        reinterpret_cast<float4*>(hits)[(size_t)(py - (uint32_t)a.y0) * rw + (px - (uint32_t)a.x0)] = out;
+        if (STATS && best_t < LBVH_MAX_FLOAT) n_hit = 1;
+    }
+    if (STATS) add_stats(stats, n_pops, n_box, n_leaf, n_tri, n_hit);
+}
+
+// ---------------------------------------------------------------------------------------------
+// derived fast-traversal scene
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_fast_nodes_kernel(lbvh_scene s, lbvh_fast_node* __restrict__ nodes)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n - 1) return;
+    const uint32_t* nd = reinterpret_cast<const uint32_t*>(&s.internal_nodes[i]);
+    const uint2 lc = *reinterpret_cast<const uint2*>(nd + 0);
+    const uint2 rc = *reinterpret_cast<const uint2*>(nd + 2);
+    float4 b[4];
+    uint32_t ref[2];
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const uint2 c = side == 0 ? lc : rc;
+        const float4* src;
+        if (c.y == LBVH_INTERNAL_NODE) {
+            src = reinterpret_cast<const float4*>(&s.bvh[c.x]);
+            ref[side] = c.x;
+        } else {
+            const uint32_t pos = s.leaf_nodes[c.x].index;                 // sorted position
+            src = reinterpret_cast<const float4*>(&s.triangle_aabb[s.sorted_indices[pos]]);
+            ref[side] = 0x80000000u | pos;
+        }
+        b[2 * side + 0] = src[0];
+        b[2 * side + 1] = src[1];
+    }
+    float4* o = reinterpret_cast<float4*>(&nodes[i]);
+    o[0] = make_float4(b[0].x, b[0].y, b[0].z, __uint_as_float(ref[0]));
+    o[1] = make_float4(b[1].x, b[1].y, b[1].z, __uint_as_float(ref[1]));
+    o[2] = make_float4(b[2].x, b[2].y, b[2].z, 0.0f);
+    o[3] = make_float4(b[3].x, b[3].y, b[3].z, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh_fast_tri* __restrict__ tris)
+{
+    const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= s.n) return;
+    const uint32_t tri = s.sorted_indices[pos];
+    const float4* tv = reinterpret_cast<const float4*>(&s.triangles[tri]);
+    const float4 a = tv[0], b = tv[1], c = tv[2];
+    float4* o = reinterpret_cast<float4*>(&tris[pos]);
+    o[0] = make_float4(a.x, a.y, a.z, __uint_as_float(tri));
+    o[1] = make_float4(b.x, b.y, b.z, 0.0f);
+    o[2] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LBVH_TRACE_FAST
+// ---------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(64) void trace_fast_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
+                                                        const lbvh_fast_tri* __restrict__ tris,
+                                                        uint32_t n_tiles, lbvh_hit* __restrict__ hits,
+                                                        lbvh_trace_stats* stats)
+{
+    __shared__ uint32_t s_stack[kStackDepth][LBVH_WAVE];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tile = xcd_swizzle(blockIdx.x, n_tiles);
+    uint32_t px, py;
+    const bool active = tile_pixel(a, tile, lane, px, py);
+
+    uint32_t n_pops = 0, n_box = 0, n_leaf = 0, n_tri = 0, n_hit = 0;
+    if (active) {
+        const ray_t ray = make_ray(a.cam, px, py);
+        float best_t = LBVH_MAX_FLOAT;
+        uint32_t best_tri = 0;
+        float best_u = 0.0f, best_v = 0.0f;
+
+        uint32_t sp = 0;
+        uint32_t node = 0;   // root; its own box is never tested: both children are
+        while (true) {
+            const float4* nb = reinterpret_cast<const float4*>(&nodes[node]);
+            const float4 lmin = nb[0], lmax = nb[1], rmin = nb[2], rmax = nb[3];
+            if (STATS) n_pops++;
+            const uint32_t lref = __float_as_uint(lmin.w), rref = __float_as_uint(lmax.w);
+            float tl, tr;
+            bool hit_l = ray_box(lmin, lmax, ray, tl);
+            bool hit_r = ray_box(rmin, rmax, ray, tr);
+            if (STATS) n_box += (hit_l ? 1u : 0u) + (hit_r ? 1u : 0u);
+            // a box that starts beyond the best hit cannot hold a nearer one
+            hit_l = hit_l && !(tl > best_t);
+            hit_r = hit_r && !(tr > best_t);
+
+            // leaves first: their hits tighten best_t before anything is pushed
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const bool h = side == 0 ? hit_l : hit_r;
+                const uint32_t ref = side == 0 ? lref : rref;
+                if (h && (ref & 0x80000000u)) {
+                    if (STATS) { n_leaf++; n_tri++; }
+                    const float4* tv = reinterpret_cast<const float4*>(&tris[ref & 0x7FFFFFFFu]);
+                    const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+                    float u = 0.0f, v = 0.0f;
+                    const float dist = ray_triangle(ray, v0, v1, v2, u, v);
+                    if (dist < best_t) {
+                        best_t = dist; best_tri = __float_as_uint(v0.w); best_u = u; best_v = v;
+                    }
+                }
+            }
+            const bool go_l = hit_l && !(lref & 0x80000000u) && !(tl > best_t);
+            const bool go_r = hit_r && !(rref & 0x80000000u) && !(tr > best_t);
+            if (go_l && go_r) {
+                const bool l_near = tl <= tr;
+                const uint32_t far = l_near ? rref : lref;
+                node = l_near ? lref : rref;
+                if (sp < (uint32_t)kStackDepth) { s_stack[sp][lane] = far; sp++; }
+                continue;
+            }
+            if (go_l) { node = lref; continue; }
+            if (go_r) { node = rref; continue; }
+            if (sp == 0) break;
+            sp--;
+            node = s_stack[sp][lane];
+        }
+        const uint32_t rw = (uint32_t)(a.x1 - a.x0);
+        float4 out;
+        out.x = best_t;
+        out.y = __uint_as_float(best_tri);
+        out.z = best_u;
+        out.w = best_v;
+        reinterpret_cast<float4*>(hits)[(size_t)(py - (uint32_t)a.y0) * rw + (px - (uint32_t)a.x0)] = out;
+        if (STATS && best_t < LBVH_MAX_FLOAT) n_hit = 1;
+    }
+    if (STATS) add_stats(stats, n_pops, n_box, n_leaf, n_tri, n_hit);
+}
+
+}  // namespace
+
+extern "C" {
+
+lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, h_scene != nullptr);
+    const lbvh_scene s = *h_scene;
+    LBVH_REQUIRE(ctx, s.n >= 2 && s.n <= 0x7FFFFFFFu);
+    LBVH_REQUIRE(ctx, s.sorted_indices && s.triangle_aabb && s.internal_nodes && s.leaf_nodes && s.bvh &&
+                          s.triangles);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->fast_capacity < s.n) {
+        LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->fast_nodes) { LBVH_HIP_TRY(ctx, hipFree(ctx->fast_nodes)); ctx->fast_nodes = nullptr; }
+        if (ctx->fast_tris) { LBVH_HIP_TRY(ctx, hipFree(ctx->fast_tris)); ctx->fast_tris = nullptr; }
+        ctx->fast_capacity = 0;
+        LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->fast_nodes, (size_t)s.n * sizeof(lbvh_fast_node)));
+        LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->fast_tris, (size_t)s.n * sizeof(lbvh_fast_tri)));
+        ctx->fast_capacity = s.n;
+    }
+    hipLaunchKernelGGL(build_fast_nodes_kernel, dim3((s.n - 1 + 255) / 256), dim3(256), 0, ctx->stream, s,
+                       ctx->fast_nodes);
+    hipLaunchKernelGGL(build_fast_tris_kernel, dim3((s.n + 255) / 256), dim3(256), 0, ctx->stream, s,
+                       ctx->fast_tris);
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    ctx->fast_n = s.n;
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera, int32_t x0, int32_t y0,
+                               int32_t x1, int32_t y1, const lbvh_scene* h_scene, int32_t mode,
+                               lbvh_hit* d_hits, lbvh_trace_stats* d_stats)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, h_camera != nullptr && h_scene != nullptr);
+    LBVH_REQUIRE(ctx, mode == LBVH_TRACE_REFERENCE || mode == LBVH_TRACE_FAST);
+    const lbvh_camera cam = *h_camera;
+    const lbvh_scene s = *h_scene;
+    LBVH_REQUIRE(ctx, cam.screen_width > 0 && cam.screen_height > 0);
+    LBVH_REQUIRE(ctx, x0 >= 0 && y0 >= 0 && x1 >= x0 && y1 >= y0);
+    LBVH_REQUIRE(ctx, x1 <= cam.screen_width && y1 <= cam.screen_height);
+    LBVH_REQUIRE(ctx, s.n >= 2);
+    if (x1 == x0 || y1 == y0) return LBVH_OK;
+    LBVH_REQUIRE(ctx, d_hits != nullptr && ((uintptr_t)d_hits & 15) == 0);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    trace_args a;
+    a.cam = cam;
+    a.x0 = x0; a.y0 = y0; a.x1 = x1; a.y1 = y1;
+    a.tiles_x = (uint32_t)(x1 - x0 + 7) / 8;
+    a.tiles_y = (uint32_t)(y1 - y0 + 7) / 8;
+    const uint32_t n_tiles = a.tiles_x * a.tiles_y;
+    if (d_stats) LBVH_HIP_TRY(ctx, hipMemsetAsync(d_stats, 0, sizeof(lbvh_trace_stats), ctx->stream));
+
+    if (mode == LBVH_TRACE_REFERENCE) {
+        LBVH_REQUIRE(ctx, s.sorted_indices && s.triangle_aabb && s.internal_nodes && s.leaf_nodes && s.bvh &&
+                              s.triangles);
+        if (d_stats)
+            hipLaunchKernelGGL(trace_reference_kernel<true>, dim3(n_tiles), dim3(64), 0, ctx->stream, a, s,
+                               d_hits, d_stats);
+        else
+            hipLaunchKernelGGL(trace_reference_kernel<false>, dim3(n_tiles), dim3(64), 0, ctx->stream, a, s,
+                               d_hits, d_stats);
+    } else {
+        if (!ctx->fast_nodes || ctx->fast_n != s.n)
+            return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_trace_primary",
+                                  "LBVH_TRACE_FAST needs lbvh_build_fast_scene on this scene first");
+        if (d_stats)
+            hipLaunchKernelGGL(trace_fast_kernel<true>, dim3(n_tiles), dim3(64), 0, ctx->stream, a,
+                               ctx->fast_nodes, ctx->fast_tris, n_tiles, d_hits, d_stats);
+        else
+            hipLaunchKernelGGL(trace_fast_kernel<false>, dim3(n_tiles), dim3(64), 0, ctx->stream, a,
+                               ctx->fast_nodes, ctx->fast_tris, n_tiles, d_hits, d_stats);
+    }
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
+}
+
+}  // extern "C"

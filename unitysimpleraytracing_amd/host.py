@@ -1,0 +1,286 @@
+"""Host side of the hot path: the reference's C# classes mirrored over the C ABI.
+
+Same names, call order and argument meaning as Assets/_Scripts/{DataBuffer, MeshBufferContainer,
+ComputeBufferSorter, BVHConstructor, RaytracingMeshDrawer}.cs, so a test reads like the
+reference's Awake()/Update().  Every method is one C-ABI call (include/lbvh.h); nothing here
+computes.  (The compiled-language twin of this file is host/lbvh_host.hpp; the C# [DllImport]
+shim a Unity maintainer would add is in INTEGRATION.md.)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from . import layouts as L
+from .scenes import capacity_for
+
+
+class Context:
+    """One GPU + one HIP stream.  Stands in for the implicit Unity graphics device and the
+    IShaderContainer kernel registry (Assets/_Scripts/ShaderContainer.cs:6-40)."""
+
+    def __init__(self, device_id=0, stream=None):
+        h = C.c_void_p()
+        if stream is None:
+            N.check(None, N.lib.lbvh_create(device_id, C.byref(h)))
+        else:
+            N.check(None, N.lib.lbvh_create_on_stream(device_id, C.c_void_p(stream), C.byref(h)))
+        self.handle = h
+        self.device_id = device_id
+
+    def sync(self):
+        N.check(self.handle, N.lib.lbvh_sync(self.handle))
+
+    def close(self):
+        if self.handle:
+            N.lib.lbvh_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- measurement helpers ------------------------------------------------------------------
+    def event(self):
+        e = C.c_void_p()
+        N.check(self.handle, N.lib.lbvh_event_create(self.handle, C.byref(e)))
+        return e
+
+    def record(self, ev):
+        N.check(self.handle, N.lib.lbvh_event_record(self.handle, ev))
+
+    def elapsed_ms(self, start, stop):
+        ms = C.c_float()
+        N.check(self.handle, N.lib.lbvh_event_elapsed_ms(self.handle, start, stop, C.byref(ms)))
+        return ms.value
+
+    def destroy_event(self, ev):
+        N.lib.lbvh_event_destroy(self.handle, ev)
+
+
+class DataBuffer:
+    """Assets/_Scripts/DataBuffer.cs: a device buffer (ComputeBuffer) + a host mirror (T[])."""
+
+    def __init__(self, ctx, size, dtype, initial_value=None):
+        self.ctx = ctx
+        self.dtype = np.dtype(dtype)
+        self.size = int(size)
+        self.local = np.zeros(self.size, dtype=self.dtype)          # _localBuffer
+        p = C.c_void_p()
+        N.check(ctx.handle, N.lib.lbvh_buffer_alloc(ctx.handle, self.size, self.dtype.itemsize, C.byref(p)))
+        self.device = p                                             # _deviceBuffer
+        self._synced = False
+        if initial_value is not None:                               # DataBuffer(size, initialValue) :14-23
+            self.fill_u32(initial_value)
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    def fill_u32(self, word):
+        """Every 32-bit word of the buffer = `word` (0xFFFFFFFF = NullLeaf / uint.MaxValue)."""
+        N.check(self.ctx.handle, N.lib.lbvh_buffer_fill_u32(self.ctx.handle, self.device, word, self.nbytes // 4))
+        self.local.view(np.uint32)[:] = word
+        self._synced = True
+
+    def get_data(self):                                             # GetData :50-54 (blocking)
+        N.check(self.ctx.handle, N.lib.lbvh_buffer_download(
+            self.ctx.handle, self.local.ctypes.data_as(C.c_void_p), self.device, self.nbytes))
+        self._synced = True
+        return self.local
+
+    def sync(self):                                                 # Sync() = SetData :56-60
+        N.check(self.ctx.handle, N.lib.lbvh_buffer_upload(
+            self.ctx.handle, self.device, self.local.ctypes.data_as(C.c_void_p), self.nbytes))
+        self._synced = True
+
+    def dispose(self):                                              # Dispose :72-75
+        if self.device:
+            N.lib.lbvh_buffer_free(self.ctx.handle, self.device)
+            self.device = None
+
+
+class MeshBufferContainer:
+    """Assets/_Scripts/MeshBufferContainer.cs.  The constructor takes the triangle soup (the
+    reference's Mesh -> Triangle[] conversion, :117-146, stays on the caller's side) and runs the
+    per-triangle Morton/AABB loop on the GPU instead of the CPU."""
+
+    def __init__(self, ctx, triangles, capacity=None, box_min=L.SCENE_BOX_MIN, box_max=L.SCENE_BOX_MAX):
+        triangles = np.ascontiguousarray(triangles, dtype=L.TRIANGLE)
+        n = len(triangles)
+        self.ctx = ctx
+        self.triangles_length = n                                    # _trianglesLength
+        self.capacity = capacity_for(n) if capacity is None else int(capacity)
+        cap = self.capacity
+        self.keys = DataBuffer(ctx, cap, np.uint32)                  # :108 (filled by morton_aabb)
+        self.triangle_index = DataBuffer(ctx, cap, np.uint32)        # :109
+        self.triangle_data = DataBuffer(ctx, cap, L.TRIANGLE)        # :110
+        self.triangle_aabb = DataBuffer(ctx, cap, L.AABB)            # :111
+        self.bvh_data = DataBuffer(ctx, cap, L.AABB)                 # :113
+        self.bvh_leaf_node = DataBuffer(ctx, cap, L.LEAF_NODE, L.NULL)        # :114
+        self.bvh_internal_node = DataBuffer(ctx, cap, L.INTERNAL_NODE, L.NULL)  # :115
+        self.triangle_data.local[:n] = triangles
+        self.triangle_data.sync()                                    # :150
+        self.box_min = np.ascontiguousarray(box_min, dtype=np.float32)
+        self.box_max = np.ascontiguousarray(box_max, dtype=np.float32)
+        self.generate_keys()
+
+    def generate_keys(self):
+        """The loop of :123-146 + the Sync()s of :148-151 as one kernel."""
+        f3 = C.POINTER(C.c_float)
+        N.check(self.ctx.handle, N.lib.lbvh_morton_aabb(
+            self.ctx.handle, self.triangle_data.device, self.triangles_length, self.capacity,
+            self.box_min.ctypes.data_as(f3), self.box_max.ctypes.data_as(f3),
+            self.keys.device, self.triangle_index.device, self.triangle_aabb.device))
+
+    def distribute_keys(self):                                       # DistributeKeys :154-169
+        N.check(self.ctx.handle, N.lib.lbvh_distribute_keys(self.ctx.handle, self.keys.device, self.triangles_length))
+
+    def get_all_gpu_data(self):                                      # GetAllGpuData :171-196
+        for b in (self.keys, self.triangle_index, self.triangle_data, self.triangle_aabb,
+                  self.bvh_data, self.bvh_leaf_node, self.bvh_internal_node):
+            b.get_data()
+        n = self.triangles_length
+        leaf, inner = self.bvh_leaf_node.local, self.bvh_internal_node.local
+        bad_leaf = np.nonzero((leaf["index"][:n] == L.NULL) & (leaf["parent"][:n] == L.NULL))[0]
+        bad_inner = np.nonzero((inner["index"][:n - 1] == L.NULL) & (inner["parent"][:n - 1] == L.NULL))[0]
+        return bad_leaf, bad_inner                                   # "LEAF/INTERNAL CORRUPTED" :181-195
+
+    def scene(self):
+        s = N.Scene()
+        s.n = self.triangles_length
+        s.sorted_indices = self.triangle_index.device.value
+        s.triangle_aabb = self.triangle_aabb.device.value
+        s.internal_nodes = self.bvh_internal_node.device.value
+        s.leaf_nodes = self.bvh_leaf_node.device.value
+        s.bvh = self.bvh_data.device.value
+        s.triangles = self.triangle_data.device.value
+        return s
+
+    def dispose(self):                                               # Dispose :207-216
+        for b in (self.keys, self.triangle_index, self.triangle_data, self.triangle_aabb,
+                  self.bvh_data, self.bvh_leaf_node, self.bvh_internal_node):
+            b.dispose()
+
+
+class ComputeBufferSorter:
+    """Assets/_Scripts/ComputeBufferSorter.cs.  As in the reference, `data_length` (the triangle
+    count, RaytracingMeshDrawer.cs:36) only bounds the sortedness validation (:150-177); Sort()
+    always sorts the whole padded buffers (every dispatch covers DATA_ARRAY_COUNT, :107,116)."""
+
+    def __init__(self, ctx, data_length, keys, values):
+        self.ctx, self.data_length, self.keys, self.values = ctx, int(data_length), keys, values
+
+    def sort(self):                                                  # Sort() :100-126
+        N.check(self.ctx.handle, N.lib.lbvh_sort_pairs(
+            self.ctx.handle, self.keys.device, self.values.device, self.keys.size))
+
+    def validate_sorted_data(self):                                  # ValidateSortedData :150-177
+        k = self.keys.get_data()[: self.data_length]
+        return bool(np.all(k[1:] >= k[:-1])), int(np.count_nonzero(k[1:] == k[:-1]))
+
+    def dispose(self):                                               # scratch lives in the context
+        pass
+
+
+class BVHConstructor:
+    """Assets/_Scripts/BVHConstructor.cs."""
+
+    def __init__(self, ctx, triangles_count, sorted_morton_codes, sorted_triangle_indices, triangle_aabb,
+                 internal_nodes, leaf_nodes, bvh_data):
+        self.ctx = ctx
+        self.n = int(triangles_count)
+        self.keys, self.indices, self.triangle_aabb = sorted_morton_codes, sorted_triangle_indices, triangle_aabb
+        self.internal, self.leaf, self.bvh = internal_nodes, leaf_nodes, bvh_data
+
+    def construct_tree(self):                                        # ConstructTree :61-64
+        N.check(self.ctx.handle, N.lib.lbvh_build_tree(
+            self.ctx.handle, self.n, self.keys.device, self.internal.device, self.leaf.device))
+
+    def construct_bvh(self):                                         # ConstructBVH :66-69
+        N.check(self.ctx.handle, N.lib.lbvh_refit(
+            self.ctx.handle, self.n, self.internal.device, self.leaf.device, self.triangle_aabb.device,
+            self.indices.device, self.bvh.device))
+
+    def dispose(self):
+        pass
+
+
+class RaytracingMeshDrawer:
+    """Assets/_Scripts/RaytracingMeshDrawer.cs: awake() = the build chain of Awake() :30-51,
+    update() = the per-frame dispatch of Update() :76-84 (hit records instead of shaded pixels)."""
+
+    def __init__(self, ctx, triangles, capacity=None):
+        self.ctx = ctx
+        self._triangles = triangles
+        self._capacity = capacity
+        self.container = None
+        self._hits = None
+        self._stats = None
+
+    def awake(self, fast=True):
+        ctx = self.ctx
+        self.container = c = MeshBufferContainer(ctx, self._triangles, self._capacity)           # :34
+        self.sorter = ComputeBufferSorter(ctx, c.triangles_length, c.keys, c.triangle_index)     # :36
+        self.sorter.sort()                                                                       # :37
+        c.distribute_keys()                                                                      # :39
+        self.bvh_constructor = BVHConstructor(ctx, c.triangles_length, c.keys, c.triangle_index,
+                                              c.triangle_aabb, c.bvh_internal_node, c.bvh_leaf_node,
+                                              c.bvh_data)                                        # :41-48
+        self.bvh_constructor.construct_tree()                                                    # :50
+        self.bvh_constructor.construct_bvh()                                                     # :51
+        if fast:
+            self.build_fast_scene()
+        return self
+
+    def rebuild(self, fast=True):
+        """Per-frame rebuild on the same buffers (dynamic scenes): Morton -> ... -> refit."""
+        c = self.container
+        c.bvh_leaf_node.fill_u32(L.NULL)
+        c.bvh_internal_node.fill_u32(L.NULL)
+        c.generate_keys()
+        self.sorter.sort()
+        c.distribute_keys()
+        self.bvh_constructor.construct_tree()
+        self.bvh_constructor.construct_bvh()
+        if fast:
+            self.build_fast_scene()
+
+    def build_fast_scene(self):
+        s = self.container.scene()
+        N.check(self.ctx.handle, N.lib.lbvh_build_fast_scene(self.ctx.handle, C.byref(s)))
+
+    def update(self, camera, rect=None, mode=L.TRACE_FAST, stats=False):
+        """Enqueue one frame (or the sub-rectangle (x0, y0, x1, y1) of it).  Returns the device
+        hit buffer; read it back with hits()."""
+        cam = N.Camera.from_dict(camera)
+        x0, y0, x1, y1 = rect if rect is not None else (0, 0, cam.screen_width, cam.screen_height)
+        count = max((x1 - x0) * (y1 - y0), 1)
+        if self._hits is None or self._hits.size < count:
+            if self._hits is not None:
+                self._hits.dispose()
+            self._hits = DataBuffer(self.ctx, count, L.HIT)
+        if stats and self._stats is None:
+            self._stats = DataBuffer(self.ctx, 1, L.TRACE_STATS)
+        self._rect = (x0, y0, x1, y1)
+        s = self.container.scene()
+        N.check(self.ctx.handle, N.lib.lbvh_trace_primary(
+            self.ctx.handle, C.byref(cam), x0, y0, x1, y1, C.byref(s), mode, self._hits.device,
+            self._stats.device if stats else None))
+        return self._hits
+
+    def hits(self):
+        x0, y0, x1, y1 = self._rect
+        return self._hits.get_data()[: (x1 - x0) * (y1 - y0)].reshape(y1 - y0, x1 - x0).copy()
+
+    def stats(self):
+        return self._stats.get_data()[0].copy()
+
+    def on_destroy(self):                                            # OnDestroy :118-123
+        if self.container:
+            self.container.dispose()
+        for b in (self._hits, self._stats):
+            if b is not None:
+                b.dispose()
