@@ -1,0 +1,319 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline benchmark on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): "LBVH build Mtri/s + primary Mrays/s at 1080p on 1M-tri synthetic mesh".
+Workload = configs[1]: 1 000 000 triangles (125 tiles of an 8 000-face bumpy torus, seed 2),
+1920x1080 primary rays, camera at (0, 0, 250).
+
+A step = one full pass of the hot path with the triangles already resident in HBM:
+    Morton/AABB -> radix sort -> DistributeKeys -> Karras tree -> AABB refit (the reference's
+    Awake() chain, Assets/_Scripts/RaytracingMeshDrawer.cs:30-51) -> derived fast nodes ->
+    primary-ray traversal of the frame (Update(), :76-84).
+Nothing is skipped or cached between steps (the tree is rebuilt from the triangles every step).
+With N GPUs the BVH is replicated (every rank builds the whole tree) and the 1080p frame is
+sharded across ranks in interleaved row bands; no collective touches the data path.
+
+The JSON line carries both halves of the metric: `value` = primary Mrays/s = rays of the whole
+frame / the traversal part of a step (max over ranks), `build_Mtri_s` = triangles / the build
+part of a step; `ms_per_step` is the whole step (build + trace), wall clock, max over ranks.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+W, H = 1920, 1080
+CAMERA_POS = (0.0, 0.0, 250.0)
+N_TRIS = 1_000_000
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sort-bench", action="store_true")
+    ap.add_argument("--sort-keys-log2", type=int, default=26)
+    ap.add_argument("--mode", choices=["fast", "reference"], default="fast")
+    return ap.parse_args()
+
+
+def row_bands(rank, world, height, band=8):
+    """Rows of the frame owned by `rank`: 8-row bands dealt round-robin, merged into maximal
+    rectangles.  8 rows = one tile row of the traversal kernel; interleaving balances the hit-heavy
+    centre of the frame against the empty top and bottom."""
+    if world == 1:
+        return [(0, height)]
+    out = []
+    nb = (height + band - 1) // band
+    # deal contiguous groups so each rank launches few rectangles but still samples the whole frame
+    group = max(1, nb // (world * 4))
+    b = 0
+    k = 0
+    while b < nb:
+        e = min(b + group, nb)
+        if k % world == rank:
+            out.append((b * band, min(e * band, height)))
+        b = e
+        k += 1
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    from unitysimpleraytracing_amd import layouts as L
+    from unitysimpleraytracing_amd import scenes
+    from unitysimpleraytracing_amd.host import Context, DataBuffer, RaytracingMeshDrawer
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def reduce_max(x):
+        if dist is None:
+            return float(x)
+        import torch
+        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    tris = scenes.tiled_torus()                        # identical on every rank (seeded)
+    assert len(tris) == N_TRIS
+    cam = scenes.camera(W, H, CAMERA_POS)
+    mode = L.TRACE_FAST if args.mode == "fast" else L.TRACE_REFERENCE
+    ctx = Context(local_rank)
+    drawer = RaytracingMeshDrawer(ctx, tris)
+    drawer.awake(fast=True)                            # allocates everything; untimed
+    ctx.sync()
+    bands = row_bands(rank, world, H)
+    my_rays = sum((y1 - y0) * W for y0, y1 in bands)
+    hit_bufs = [DataBuffer(ctx, (y1 - y0) * W, L.HIT) for y0, y1 in bands]
+    from unitysimpleraytracing_amd import _native as N
+    ccam = N.Camera.from_dict(cam)
+
+    def trace_frame():
+        s = drawer.container.scene()
+        for (y0, y1), hb in zip(bands, hit_bufs):
+            N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, y0, W, y1, C.byref(s),
+                                                         mode, hb.device, None))
+
+    def step(ev=None):
+        if ev:
+            ctx.record(ev[0])
+        drawer.rebuild(fast=(mode == L.TRACE_FAST))
+        if ev:
+            ctx.record(ev[1])
+        trace_frame()
+        if ev:
+            ctx.record(ev[2])
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+
+    events = [(ctx.event(), ctx.event(), ctx.event()) for _ in range(args.steps)]
+    barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    ctx.sync()
+    barrier()
+    t1 = time.perf_counter()
+
+    build_ms = float(np.mean([ctx.elapsed_ms(e[0], e[1]) for e in events]))
+    trace_ms = float(np.mean([ctx.elapsed_ms(e[1], e[2]) for e in events]))
+    wall_ms = reduce_max((t1 - t0) * 1e3 / args.steps)
+    build_ms_max = reduce_max(build_ms)
+    trace_ms_max = reduce_max(trace_ms)
+
+    # ---- untimed extras (rank 0 prints them) ---------------------------------------------------
+    out = None
+    if rank == 0:
+        # algorithmic bytes of the traversal kernel from its own visit counters: one 64-B fused
+        # node per node visit + 48 B per triangle test + 16 B hit record per ray
+        stats_buf = DataBuffer(ctx, 1, L.TRACE_STATS)
+        full = DataBuffer(ctx, W * H, L.HIT)
+        s = drawer.container.scene()
+        N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s), mode,
+                                                     full.device, stats_buf.device))
+        st = stats_buf.get_data()[0]
+        hit_fraction = float(st["hits"]) / (W * H)
+        if mode == L.TRACE_FAST:
+            bytes_per_ray = (64.0 * float(st["pops"]) + 48.0 * float(st["tri_tests"])) / (W * H) + 16.0
+        else:   # 32 P + 24 B + 44 L + 48 T + 16 (hit record)
+            bytes_per_ray = (32.0 * float(st["pops"]) + 24.0 * float(st["box_hits"]) + 44.0 * float(st["leaf_tests"])
+                             + 48.0 * float(st["tri_tests"])) / (W * H) + 16.0
+
+        # the traversal kernel alone over the full frame, HIP events on its own stream
+        reps = max(5, min(args.steps, 20))
+        ctx.profile_begin()
+        for _ in range(reps):
+            N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s), mode,
+                                                         full.device, None))
+        prof = ctx.profile_end()
+        kname = [k for k in prof if "trace_" in k][0]
+        trace_kernel_ms = prof[kname][1] / prof[kname][0]
+        achieved = bytes_per_ray * W * H / (trace_kernel_ms * 1e-3) / 1e9
+
+        # per-kernel breakdown of one build
+        ctx.profile_begin()
+        for _ in range(5):
+            drawer.rebuild(fast=(mode == L.TRACE_FAST))
+        prof_build = {k: round(v[1] / 5.0, 4) for k, v in ctx.profile_end().items()}
+
+        # measured HBM copy rate of this box (float4 copy, 1 GiB)
+        nbytes = 1 << 30
+        a = DataBuffer(ctx, nbytes // 4, np.uint32)
+        b = DataBuffer(ctx, nbytes // 4, np.uint32)
+        a.fill_u32(1)
+        for _ in range(2):
+            ctx.copy_probe(b.device, a.device, nbytes)
+        e0, e1 = ctx.event(), ctx.event()
+        ctx.record(e0)
+        for _ in range(10):
+            ctx.copy_probe(b.device, a.device, nbytes)
+        ctx.record(e1)
+        copy_gbs = 2.0 * nbytes * 10 / (ctx.elapsed_ms(e0, e1) * 1e-3) / 1e9
+        a.dispose(); b.dispose()
+
+        roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_ray": round(bytes_per_ray, 1), "kernel_ms": round(trace_kernel_ms, 4),
+                    "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
+
+        sort_roofline = None
+        if not args.no_sort_bench:
+            sort_roofline = sort_microbench(ctx, args.sort_keys_log2, copy_gbs)
+
+        cpu_baseline = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu_baseline = cpu_leg(tris, cam)
+
+        out = {
+            "metric": "LBVH build Mtri/s + primary Mrays/s at 1080p on 1M-tri synthetic mesh",
+            "value": round(W * H / (trace_ms_max * 1e-3) / 1e6, 2),
+            "unit": "Mrays/s",
+            "build_Mtri_s": round(N_TRIS / (build_ms_max * 1e-3) / 1e6, 2),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall_ms, 4),
+            "build_ms": round(build_ms_max, 4), "trace_ms": round(trace_ms_max, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32+u32", "data": "synthetic",
+            "config": {"workload": "cfg2: 1,000,000-triangle tiled bumpy torus (seed 2), 1920x1080 primary rays, "
+                                   "camera (0,0,250) fov 60; full LBVH rebuild + frame trace per step",
+                       "triangles": N_TRIS, "rays": W * H, "trace_mode": args.mode,
+                       "sharding": f"rays in interleaved row bands over {world} GPU(s), BVH replicated, no collective",
+                       "hit_fraction": round(hit_fraction, 4)},
+            "roofline": roofline,
+            "roofline_sort_scatter": sort_roofline,
+            "cpu_baseline": cpu_baseline,
+            "build_kernels_ms": prof_build,
+        }
+    for e in events:
+        for x in e:
+            ctx.destroy_event(x)
+    drawer.on_destroy()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+def sort_microbench(ctx, log2n, copy_gbs):
+    """Radix-sort micro-bench on 2^log2n uniform random (key, value) pairs: large enough that the
+    pairs stream from HBM, not from L2 / Infinity Cache.  Reports the scatter (downsweep) kernel:
+    algorithmic 16 B per pair per launch (8 B read + 8 B written)."""
+    from unitysimpleraytracing_amd import _native as N
+    from unitysimpleraytracing_amd.host import DataBuffer
+    n = 1 << log2n
+    rng = np.random.default_rng(3)
+    keys = DataBuffer(ctx, n, np.uint32)
+    vals = DataBuffer(ctx, n, np.uint32)
+    keys.local[:] = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    vals.local[:] = np.arange(n, dtype=np.uint32)
+    reps = 3
+    total_ms = 0.0
+    prof_sum = {}
+    for r in range(reps + 1):
+        keys.sync(); vals.sync()
+        e0, e1 = ctx.event(), ctx.event()
+        if r > 0:
+            ctx.profile_begin()
+        ctx.record(e0)
+        N.check(ctx.handle, N.lib.lbvh_sort_pairs(ctx.handle, keys.device, vals.device, n))
+        ctx.record(e1)
+        ms = ctx.elapsed_ms(e0, e1)
+        if r > 0:
+            total_ms += ms
+            for k, v in ctx.profile_end().items():
+                a = prof_sum.setdefault(k, [0, 0.0])
+                a[0] += v[0]; a[1] += v[1]
+    k = keys.get_data()
+    assert (k[1:] >= k[:-1]).all()
+    keys.dispose(); vals.dispose()
+    sort_ms = total_ms / reps
+    down = [v for name, v in prof_sum.items() if "downsweep" in name or "onesweep" in name][0]
+    kernel_ms = down[1] / down[0]
+    achieved = 16.0 * n / (kernel_ms * 1e-3) / 1e9
+    return {"kernel": "sort scatter pass", "keys": n, "bound": "hbm", "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel_ms": round(kernel_ms, 4), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
+            "sort_Gkeys_s": round(n / (sort_ms * 1e-3) / 1e9, 3), "sort_ms": round(sort_ms, 3),
+            "kernels_ms": {name: round(v[1] / reps, 4) for name, v in prof_sum.items()}}
+
+
+def cpu_leg(tris, cam):
+    """CPU baseline (kind "port"): the oracle — a C restatement of the reference's C#/HLSL, the
+    only runnable form of it here (no dotnet/mono/dxc) — on this box's host cores with OpenMP.
+    Bounded sample: one full 1 M-triangle build + the 1080p frame sampled every 8th pixel in x
+    and y (32 400 rays)."""
+    import oracle as O
+    threads = O.num_threads()
+    t0 = time.perf_counter()
+    b = O.Built(tris, capacity=((len(tris) + 1023) // 1024) * 1024, threads=threads)
+    t1 = time.perf_counter()
+    hits, st = O.trace_primary(b, cam, step=(8, 8), threads=threads)
+    t2 = time.perf_counter()
+    nrays = hits.size
+    return {"value": round(nrays / (t2 - t1) / 1e6, 4), "unit": "Mrays/s",
+            "build_Mtri_s": round(len(tris) / (t1 - t0) / 1e6, 4), "cores": threads, "kind": "port",
+            "sample": f"1 full 1M-triangle build ({t1 - t0:.2f} s) + 1080p frame sampled every 8th pixel in x and y "
+                      f"({nrays} rays, {t2 - t1:.2f} s); reference visit order, OpenMP over triangles/nodes/rays, "
+                      f"serial LSD radix sort and refit"}
+
+
+if __name__ == "__main__":
+    main()

@@ -268,6 +268,20 @@ lbvh_status lbvh_event_record(lbvh_context* ctx, void* event);
 /* Waits for `stop`, then returns the elapsed milliseconds between the two recorded events. */
 lbvh_status lbvh_event_elapsed_ms(lbvh_context* ctx, void* start, void* stop, float* out_ms);
 
+/* Per-kernel timing: between lbvh_profile_begin and lbvh_profile_end every kernel the library
+ * launches on this context is bracketed by its own pair of HIP events (on the context's stream).
+ * lbvh_profile_end waits for the stream and returns one row per kernel name: launches and the
+ * summed device time.  Off by default: it adds two event records per launch, so it is never on
+ * inside a throughput measurement. */
+typedef struct lbvh_profile_row {
+    char     name[48];
+    uint32_t launches;
+    float    total_ms;
+} lbvh_profile_row;
+lbvh_status lbvh_profile_begin(lbvh_context* ctx);
+lbvh_status lbvh_profile_end(lbvh_context* ctx, lbvh_profile_row* h_rows, int32_t max_rows,
+                             int32_t* out_rows);
+
 /* Streaming device-to-device copy of `bytes` (float4 per lane) on the context's stream: the
  * box's own HBM copy rate is the measured roofline denominator quoted beside the 8 TB/s spec. */
 lbvh_status lbvh_copy_bandwidth_probe(lbvh_context* ctx, void* d_dst, const void* d_src,

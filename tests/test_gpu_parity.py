@@ -136,7 +136,7 @@ def test_morton_clamps_outside_scene_box(ctx):
 @pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 2047, 2048, 2049, 4096, 100001, 1000000])
 def test_distribute_keys(ctx, n):
     rng = np.random.default_rng(n)
-    keys = np.sort((rng.integers(0, 1 << 30, size=n, dtype=np.uint64) >> rng.integers(0, 16)).astype(np.uint32))
+    keys = np.sort((rng.integers(0, 1 << 30, size=n, dtype=np.uint64) >> np.uint64(rng.integers(0, 16))).astype(np.uint32))
     buf = np.concatenate([keys, np.full(100, F, dtype=np.uint32)])
     kb = up(ctx, buf)
     N().check(ctx.handle, N().lib.lbvh_distribute_keys(ctx.handle, kb.device, n))
@@ -165,7 +165,7 @@ def gpu_tree(ctx, keys, n, cap):
 @pytest.mark.parametrize("n", [2, 3, 6, 8, 1000, 4096, 65537, 1000000])
 def test_build_tree_bit_exact(ctx, n):
     rng = np.random.default_rng(n + 1)
-    raw = np.sort((rng.integers(0, 1 << 30, size=n, dtype=np.uint64) >> rng.integers(0, 12)).astype(np.uint32))
+    raw = np.sort((rng.integers(0, 1 << 30, size=n, dtype=np.uint64) >> np.uint64(rng.integers(0, 12))).astype(np.uint32))
     keys = O.distribute_keys(raw, n)
     cap = n + 5
     kb, ib, lb = gpu_tree(ctx, keys, n, cap)

@@ -42,7 +42,7 @@ def test_kat_duplicate_keys():
 
 def test_distribute_is_prefix_sum_of_max_diff_1():
     rng = np.random.default_rng(5)
-    keys = np.sort(rng.integers(0, 1 << 30, size=5000, dtype=np.uint32) >> rng.integers(0, 20))
+    keys = np.sort(rng.integers(0, 1 << 30, size=5000, dtype=np.uint32) >> np.uint64(rng.integers(0, 20)))
     pads = np.full(120, F, dtype=np.uint32)
     out = O.distribute_keys(np.concatenate([keys, pads]), 5000)
     diff = np.maximum(np.diff(keys.astype(np.int64)), 1)

@@ -40,6 +40,10 @@ class Camera(C.Structure):
         return cam
 
 
+class ProfileRow(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint32), ("total_ms", C.c_float)]
+
+
 class Scene(C.Structure):
     _fields_ = [("n", C.c_uint32), ("sorted_indices", C.c_void_p), ("triangle_aabb", C.c_void_p),
                 ("internal_nodes", C.c_void_p), ("leaf_nodes", C.c_void_p), ("bvh", C.c_void_p),
@@ -77,6 +81,8 @@ SIGNATURES = {
     "lbvh_event_destroy": (_I32, [_P, _P]),
     "lbvh_event_record": (_I32, [_P, _P]),
     "lbvh_event_elapsed_ms": (_I32, [_P, _P, _P, C.POINTER(C.c_float)]),
+    "lbvh_profile_begin": (_I32, [_P]),
+    "lbvh_profile_end": (_I32, [_P, C.POINTER(ProfileRow), _I32, C.POINTER(_I32)]),
     "lbvh_copy_bandwidth_probe": (_I32, [_P, _P, _P, _SZ]),
 }
 

@@ -29,6 +29,18 @@ int lbvh_reserve(lbvh_context* ctx, void** ptr, size_t* have, size_t bytes)
     return LBVH_OK;
 }
 
+hipEvent_t lbvh_prof_event(lbvh_context* ctx)
+{
+    hipEvent_t e = nullptr;
+    if (!ctx->prof_pool.empty()) {
+        e = ctx->prof_pool.back();
+        ctx->prof_pool.pop_back();
+        return e;
+    }
+    (void)hipEventCreate(&e);
+    return e;
+}
+
 extern "C" {
 
 int32_t lbvh_abi_version(void) { return LBVH_ABI_VERSION; }
@@ -95,6 +107,8 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
     if (ctx->refit_flags) (void)hipFree(ctx->refit_flags);
     if (ctx->fast_nodes) (void)hipFree(ctx->fast_nodes);
     if (ctx->fast_tris) (void)hipFree(ctx->fast_tris);
+    for (auto& s : ctx->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return LBVH_OK;
@@ -203,6 +217,46 @@ lbvh_status lbvh_event_elapsed_ms(lbvh_context* ctx, void* start, void* stop, fl
     return LBVH_OK;
 }
 
+// ---- per-kernel profiling --------------------------------------------------------------------
+
+lbvh_status lbvh_profile_begin(lbvh_context* ctx)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    for (auto& s : ctx->prof_spans) { ctx->prof_pool.push_back(s.a); ctx->prof_pool.push_back(s.b); }
+    ctx->prof_spans.clear();
+    ctx->prof_enabled = true;
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_profile_end(lbvh_context* ctx, lbvh_profile_row* h_rows, int32_t max_rows, int32_t* out_rows)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, out_rows != nullptr && (h_rows != nullptr || max_rows == 0));
+    ctx->prof_enabled = false;
+    LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int32_t n = 0;
+    for (auto& s : ctx->prof_spans) {
+        float ms = 0.0f;
+        LBVH_HIP_TRY(ctx, hipEventElapsedTime(&ms, s.a, s.b));
+        // kernel names arrive as "ns::kernel<...>" spellings of the launch site; keep the tail
+        const char* nm = s.name;
+        int32_t row = -1;
+        for (int32_t i = 0; i < n; i++)
+            if (strncmp(h_rows[i].name, nm, sizeof(h_rows[i].name) - 1) == 0) { row = i; break; }
+        if (row < 0 && n < max_rows) {
+            row = n++;
+            memset(&h_rows[row], 0, sizeof(h_rows[row]));
+            strncpy(h_rows[row].name, nm, sizeof(h_rows[row].name) - 1);
+        }
+        if (row >= 0) { h_rows[row].launches++; h_rows[row].total_ms += ms; }
+        ctx->prof_pool.push_back(s.a);
+        ctx->prof_pool.push_back(s.b);
+    }
+    ctx->prof_spans.clear();
+    *out_rows = n;
+    return LBVH_OK;
+}
+
 // ---- HBM copy-rate probe ---------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void copy_f4_kernel(float4* __restrict__ dst,
@@ -222,8 +276,7 @@ lbvh_status lbvh_copy_bandwidth_probe(lbvh_context* ctx, void* d_dst, const void
     if (n16 == 0) return LBVH_OK;
     size_t blocks = (n16 + 255) / 256;
     if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
-    hipLaunchKernelGGL(copy_f4_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                       (float4*)d_dst, (const float4*)d_src, n16);
+    LBVH_LAUNCH(ctx, copy_f4_kernel, dim3((unsigned)blocks), dim3(256), (float4*)d_dst, (const float4*)d_src, n16);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }

@@ -317,7 +317,7 @@ lbvh_status lbvh_morton_aabb(lbvh_context* ctx, const lbvh_triangle* d_triangles
     box3 scene;
     for (int k = 0; k < 3; k++) { scene.mn[k] = h_box_min[k]; scene.mx[k] = h_box_max[k]; }
     const uint32_t blocks = (capacity + 255) / 256;
-    hipLaunchKernelGGL(morton_aabb_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_triangles, n,
+    LBVH_LAUNCH(ctx, morton_aabb_kernel, dim3(blocks), dim3(256), d_triangles, n,
                        capacity, scene, d_keys, d_indices, d_aabb);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
@@ -334,11 +334,11 @@ lbvh_status lbvh_distribute_keys(lbvh_context* ctx, uint32_t* d_keys, uint32_t n
     if (rc != LBVH_OK) return rc;
     uint32_t* chunk_sums = (uint32_t*)ctx->scan_scratch;
     uint32_t* boundary = chunk_sums + chunks;
-    hipLaunchKernelGGL(distribute_reduce_kernel, dim3(chunks), dim3(kDistThreads), 0, ctx->stream,
+    LBVH_LAUNCH(ctx, distribute_reduce_kernel, dim3(chunks), dim3(kDistThreads),
                        d_keys, n, chunk_sums, boundary);
-    hipLaunchKernelGGL(distribute_scan_kernel, dim3(1), dim3(kDistThreads), 0, ctx->stream, chunk_sums,
+    LBVH_LAUNCH(ctx, distribute_scan_kernel, dim3(1), dim3(kDistThreads), chunk_sums,
                        chunks);
-    hipLaunchKernelGGL(distribute_apply_kernel, dim3(chunks), dim3(kDistThreads), 0, ctx->stream,
+    LBVH_LAUNCH(ctx, distribute_apply_kernel, dim3(chunks), dim3(kDistThreads),
                        d_keys, n, chunk_sums, boundary);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
@@ -354,7 +354,7 @@ lbvh_status lbvh_build_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_sor
     LBVH_REQUIRE(ctx, ((uintptr_t)d_internal & 7) == 0 && ((uintptr_t)d_leaf & 7) == 0);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t blocks = (n - 1 + 255) / 256;
-    hipLaunchKernelGGL(tree_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_sorted_keys, n,
+    LBVH_LAUNCH(ctx, tree_kernel, dim3(blocks), dim3(256), d_sorted_keys, n,
                        d_internal, d_leaf);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
@@ -383,7 +383,7 @@ lbvh_status lbvh_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* 
     // cannot rebuild)
     LBVH_HIP_TRY(ctx, hipMemsetAsync(ctx->refit_flags, 0, (size_t)n * 4, ctx->stream));
     const uint32_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(refit_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, d_internal, d_leaf,
+    LBVH_LAUNCH(ctx, refit_kernel, dim3(blocks), dim3(256), n, d_internal, d_leaf,
                        d_triangle_aabb, d_sorted_indices, d_bvh, ctx->refit_flags);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/lbvh.h"
 
@@ -57,7 +58,32 @@ struct lbvh_context {
     lbvh_fast_tri* fast_tris = nullptr;
     uint32_t fast_capacity = 0;
     uint32_t fast_n = 0;
+
+    // per-kernel event profiling (lbvh_profile_begin / lbvh_profile_end)
+    struct prof_span { const char* name; hipEvent_t a, b; };
+    bool prof_enabled = false;
+    std::vector<prof_span> prof_spans;
+    std::vector<hipEvent_t> prof_pool;
 };
+
+hipEvent_t lbvh_prof_event(lbvh_context* ctx);
+
+// Every kernel launch of the library goes through this: a plain launch on the context's stream,
+// bracketed by two events when profiling is on.
+#define LBVH_LAUNCH(ctx, kernel, grid, block, ...)                                      \
+    do {                                                                                \
+        hipEvent_t _a = nullptr, _b = nullptr;                                          \
+        if ((ctx)->prof_enabled) {                                                      \
+            _a = lbvh_prof_event(ctx);                                                  \
+            _b = lbvh_prof_event(ctx);                                                  \
+            (void)hipEventRecord(_a, (ctx)->stream);                                    \
+        }                                                                               \
+        hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);         \
+        if ((ctx)->prof_enabled) {                                                      \
+            (void)hipEventRecord(_b, (ctx)->stream);                                    \
+            (ctx)->prof_spans.push_back({#kernel, _a, _b});                             \
+        }                                                                               \
+    } while (0)
 
 int lbvh_set_error(lbvh_context* ctx, int code, const char* what, const char* detail);
 

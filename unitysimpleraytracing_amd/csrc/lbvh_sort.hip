@@ -247,15 +247,15 @@ extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint
 
     uint32_t *ks = d_keys, *vs = d_values, *kd = alt_keys, *vd = alt_vals;
     for (uint32_t shift = 0; shift < 32; shift += 8) {   // ComputeBufferSorter.cs:102
-        hipLaunchKernelGGL(sort_upsweep_kernel, dim3(tiles), dim3(kThreads), 0, ctx->stream, ks, count,
+        LBVH_LAUNCH(ctx, sort_upsweep_kernel, dim3(tiles), dim3(kThreads), ks, count,
                            shift, tile_hist);
-        hipLaunchKernelGGL(sort_scan_reduce_kernel, dim3(chunks), dim3(kRadix), 0, ctx->stream,
+        LBVH_LAUNCH(ctx, sort_scan_reduce_kernel, dim3(chunks), dim3(kRadix),
                            tile_hist, tiles, chunk_sums);
-        hipLaunchKernelGGL(sort_scan_chunks_kernel, dim3(1), dim3(kRadix), 0, ctx->stream, chunk_sums,
+        LBVH_LAUNCH(ctx, sort_scan_chunks_kernel, dim3(1), dim3(kRadix), chunk_sums,
                            chunks);
-        hipLaunchKernelGGL(sort_scan_apply_kernel, dim3(chunks), dim3(kRadix), 0, ctx->stream,
+        LBVH_LAUNCH(ctx, sort_scan_apply_kernel, dim3(chunks), dim3(kRadix),
                            tile_hist, tiles, chunk_sums);
-        hipLaunchKernelGGL(sort_downsweep_kernel, dim3(tiles), dim3(kThreads), 0, ctx->stream, ks, vs,
+        LBVH_LAUNCH(ctx, sort_downsweep_kernel, dim3(tiles), dim3(kThreads), ks, vs,
                            kd, vd, count, shift, tile_hist);
         uint32_t* tmp;
         tmp = ks; ks = kd; kd = tmp;

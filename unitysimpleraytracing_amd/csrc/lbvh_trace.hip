@@ -365,9 +365,9 @@ lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene)
         LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->fast_tris, (size_t)s.n * sizeof(lbvh_fast_tri)));
         ctx->fast_capacity = s.n;
     }
-    hipLaunchKernelGGL(build_fast_nodes_kernel, dim3((s.n - 1 + 255) / 256), dim3(256), 0, ctx->stream, s,
+    LBVH_LAUNCH(ctx, build_fast_nodes_kernel, dim3((s.n - 1 + 255) / 256), dim3(256), s,
                        ctx->fast_nodes);
-    hipLaunchKernelGGL(build_fast_tris_kernel, dim3((s.n + 255) / 256), dim3(256), 0, ctx->stream, s,
+    LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((s.n + 255) / 256), dim3(256), s,
                        ctx->fast_tris);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     ctx->fast_n = s.n;
@@ -403,20 +403,20 @@ lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera, i
         LBVH_REQUIRE(ctx, s.sorted_indices && s.triangle_aabb && s.internal_nodes && s.leaf_nodes && s.bvh &&
                               s.triangles);
         if (d_stats)
-            hipLaunchKernelGGL(trace_reference_kernel<true>, dim3(n_tiles), dim3(64), 0, ctx->stream, a, s,
+            LBVH_LAUNCH(ctx, trace_reference_kernel<true>, dim3(n_tiles), dim3(64), a, s,
                                d_hits, d_stats);
         else
-            hipLaunchKernelGGL(trace_reference_kernel<false>, dim3(n_tiles), dim3(64), 0, ctx->stream, a, s,
+            LBVH_LAUNCH(ctx, trace_reference_kernel<false>, dim3(n_tiles), dim3(64), a, s,
                                d_hits, d_stats);
     } else {
         if (!ctx->fast_nodes || ctx->fast_n != s.n)
             return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_trace_primary",
                                   "LBVH_TRACE_FAST needs lbvh_build_fast_scene on this scene first");
         if (d_stats)
-            hipLaunchKernelGGL(trace_fast_kernel<true>, dim3(n_tiles), dim3(64), 0, ctx->stream, a,
+            LBVH_LAUNCH(ctx, trace_fast_kernel<true>, dim3(n_tiles), dim3(64), a,
                                ctx->fast_nodes, ctx->fast_tris, n_tiles, d_hits, d_stats);
         else
-            hipLaunchKernelGGL(trace_fast_kernel<false>, dim3(n_tiles), dim3(64), 0, ctx->stream, a,
+            LBVH_LAUNCH(ctx, trace_fast_kernel<false>, dim3(n_tiles), dim3(64), a,
                                ctx->fast_nodes, ctx->fast_tris, n_tiles, d_hits, d_stats);
     }
     LBVH_HIP_TRY(ctx, hipGetLastError());

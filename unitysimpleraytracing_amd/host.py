@@ -59,6 +59,19 @@ class Context:
     def destroy_event(self, ev):
         N.lib.lbvh_event_destroy(self.handle, ev)
 
+    def profile_begin(self):
+        N.check(self.handle, N.lib.lbvh_profile_begin(self.handle))
+
+    def profile_end(self):
+        """{kernel name: (launches, total device ms)} since profile_begin."""
+        rows = (N.ProfileRow * 64)()
+        n = C.c_int32()
+        N.check(self.handle, N.lib.lbvh_profile_end(self.handle, rows, 64, C.byref(n)))
+        return {rows[i].name.decode(): (int(rows[i].launches), float(rows[i].total_ms)) for i in range(n.value)}
+
+    def copy_probe(self, dst, src, nbytes):
+        N.check(self.handle, N.lib.lbvh_copy_bandwidth_probe(self.handle, dst, src, nbytes))
+
 
 class DataBuffer:
     """Assets/_Scripts/DataBuffer.cs: a device buffer (ComputeBuffer) + a host mirror (T[])."""
@@ -79,11 +92,13 @@ class DataBuffer:
     def nbytes(self):
         return self.size * self.dtype.itemsize
 
-    def fill_u32(self, word):
-        """Every 32-bit word of the buffer = `word` (0xFFFFFFFF = NullLeaf / uint.MaxValue)."""
+    def fill_u32(self, word, mirror=True):
+        """Every 32-bit word of the buffer = `word` (0xFFFFFFFF = NullLeaf / uint.MaxValue).
+        mirror=False leaves the host copy alone (per-frame rebuilds)."""
         N.check(self.ctx.handle, N.lib.lbvh_buffer_fill_u32(self.ctx.handle, self.device, word, self.nbytes // 4))
-        self.local.view(np.uint32)[:] = word
-        self._synced = True
+        if mirror:
+            self.local.view(np.uint32)[:] = word
+        self._synced = mirror
 
     def get_data(self):                                             # GetData :50-54 (blocking)
         N.check(self.ctx.handle, N.lib.lbvh_buffer_download(
@@ -238,8 +253,8 @@ class RaytracingMeshDrawer:
     def rebuild(self, fast=True):
         """Per-frame rebuild on the same buffers (dynamic scenes): Morton -> ... -> refit."""
         c = self.container
-        c.bvh_leaf_node.fill_u32(L.NULL)
-        c.bvh_internal_node.fill_u32(L.NULL)
+        c.bvh_leaf_node.fill_u32(L.NULL, mirror=False)
+        c.bvh_internal_node.fill_u32(L.NULL, mirror=False)
         c.generate_keys()
         self.sorter.sort()
         c.distribute_keys()
