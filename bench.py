@@ -161,7 +161,7 @@ def main():
     out = None
     if rank == 0:
         # algorithmic bytes of the traversal kernel from its own visit counters: one 64-B fused
-        # node per node visit + 48 B per triangle test + 16 B hit record per ray
+        # node per node fetch + 48 B per triangle fetch + 16 B hit record per ray
         stats_buf = DataBuffer(ctx, 1, L.TRACE_STATS)
         full = DataBuffer(ctx, W * H, L.HIT)
         s = drawer.container.scene()
@@ -169,11 +169,19 @@ def main():
                                                      full.device, stats_buf.device))
         st = stats_buf.get_data()[0]
         hit_fraction = float(st["hits"]) / (W * H)
-        if mode == L.TRACE_FAST:
-            bytes_per_ray = (64.0 * float(st["pops"]) + 48.0 * float(st["tri_tests"])) / (W * H) + 16.0
-        else:   # 32 P + 24 B + 44 L + 48 T + 16 (hit record)
-            bytes_per_ray = (32.0 * float(st["pops"]) + 24.0 * float(st["box_hits"]) + 44.0 * float(st["leaf_tests"])
-                             + 48.0 * float(st["tri_tests"])) / (W * H) + 16.0
+        if mode == L.TRACE_FAST:   # packet kernel: node / triangle fetches are per 64-ray packet
+            own_bytes_per_ray = (64.0 * float(st["pops"]) + 48.0 * float(st["leaf_tests"])) / (W * H) + 16.0
+        else:
+            own_bytes_per_ray = None
+        # SURVEY.md section 8d per-ray figure in the REFERENCE's visit semantics:
+        # 32 P + 24 B + 44 L + 48 T + 8, P/B/L/T from the reference-order kernel's counters
+        # (tests pin them equal to the oracle's)
+        N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s),
+                                                     L.TRACE_REFERENCE, full.device, stats_buf.device))
+        rs = stats_buf.get_data()[0]
+        bytes_per_ray = (32.0 * float(rs["pops"]) + 24.0 * float(rs["box_hits"]) + 44.0 * float(rs["leaf_tests"])
+                         + 48.0 * float(rs["tri_tests"])) / (W * H) + 8.0
+        ref_counts = {k: round(float(rs[k]) / (W * H), 3) for k in ("pops", "box_hits", "leaf_tests", "tri_tests")}
 
         # the traversal kernel alone over the full frame, HIP events on its own stream
         reps = max(5, min(args.steps, 20))
@@ -209,7 +217,12 @@ def main():
 
         roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "bytes_per_ray": round(bytes_per_ray, 1), "kernel_ms": round(trace_kernel_ms, 4),
+                    "bytes_per_ray": round(bytes_per_ray, 1), "bytes_per_ray_basis": "reference visit order, "
+                    "32P+24B+44L+48T+8 (SURVEY 8d)", "reference_visits_per_ray": ref_counts,
+                    "own_bytes_per_ray": None if own_bytes_per_ray is None else round(own_bytes_per_ray, 1),
+                    "own_achieved": None if own_bytes_per_ray is None else
+                    round(own_bytes_per_ray * W * H / (trace_kernel_ms * 1e-3) / 1e9, 1),
+                    "kernel_ms": round(trace_kernel_ms, 4),
                     "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
 
         sort_roofline = None

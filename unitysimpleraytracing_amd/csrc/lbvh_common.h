@@ -58,6 +58,7 @@ struct lbvh_context {
     lbvh_fast_tri* fast_tris = nullptr;
     uint32_t fast_capacity = 0;
     uint32_t fast_n = 0;
+    void* trace_queues = nullptr;   // per-XCD tile cursors of the persistent traversal kernel
 
     // per-kernel event profiling (lbvh_profile_begin / lbvh_profile_end)
     struct prof_span { const char* name; hipEvent_t a, b; };

@@ -264,81 +264,183 @@ __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh
 }
 
 // ---------------------------------------------------------------------------------------------
-// LBVH_TRACE_FAST
+// LBVH_TRACE_FAST — packet traversal
+//
+// The 64 primary rays of an 8x8-pixel tile leave one pinhole and stay together almost to the
+// leaves, so the wave walks the tree ONCE for all of them:
+//   * the current node index is wave-uniform: the 64-byte fused node arrives as ONE coalesced line
+//     (lane k loads dword k, v_readlane broadcasts into SGPRs), not as 64 divergent vector gathers
+//     (the per-lane form measured 22 % lane utilisation and an L1 pipe stalled on pending misses;
+//     more waves per CU made it slower);
+//   * every lane tests ITS ray against the node's two child boxes; a child is entered when any lane
+//     hits it (ballot) and its entry t is not beyond that lane's best hit; order = majority vote of
+//     the lanes that hit both;
+//   * the traversal stack is shared by the wave: one VGPR used as a 64-slot array written by
+//     a lane-select and read by v_readlane with a scalar stack pointer — no LDS, no scratch;
+//   * all control flow is scalar (conditions come from ballots).
+// Each lane still sees every node it would visit alone (it votes for it), the leaf's own AABB slab
+// test gates the triangle test per lane, and the accept rule is the reference's strict t < best —
+// so per-ray results equal the reference order's min t.
+// Persistent waves pull tiles from eight per-XCD queues (contiguous screen regions per XCD for L2
+// locality; HW_REG_XCC_ID picks the home queue, other queues are stolen from when it is empty).
 // ---------------------------------------------------------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__(64) void trace_fast_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
-                                                        const lbvh_fast_tri* __restrict__ tris,
-                                                        uint32_t n_tiles, lbvh_hit* __restrict__ hits,
-                                                        lbvh_trace_stats* stats)
+constexpr uint32_t kNoTile = 0xFFFFFFFFu;
+
+struct tile_queues {
+    uint32_t next[8];     // per-XCD cursor (zeroed by the launch function every call)
+};
+
+__device__ __forceinline__ uint32_t xcc_id()
 {
-    __shared__ uint32_t s_stack[kStackDepth][LBVH_WAVE];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t tile = xcd_swizzle(blockIdx.x, n_tiles);
-    uint32_t px, py;
-    const bool active = tile_pixel(a, tile, lane, px, py);
+    // s_getreg_b32 HW_REG_XCC_ID (id 20), bits [3:0]
+    return (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u;
+}
+
+// next tile for this wave (wave-uniform), or kNoTile
+__device__ __forceinline__ uint32_t next_tile(tile_queues* q, uint32_t n_tiles, uint32_t home)
+{
+    const uint32_t per = n_tiles / 8, rem = n_tiles % 8;
+    uint32_t tile = kNoTile;
+    if (lane_id() == 0) {
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t x = (home + k) & 7u;
+            const uint32_t count = per + (x < rem ? 1u : 0u);
+            const uint32_t start = x * per + (x < rem ? x : rem);
+            // cheap pre-check so exhausted queues are not hammered
+            if (__hip_atomic_load(&q->next[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= count) continue;
+            const uint32_t i = __hip_atomic_fetch_add(&q->next[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i < count) { tile = start + i; break; }
+        }
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+}
+
+
+struct uniform_node {        // one fused node, wave-uniform (lives in SGPRs)
+    float4 lmin, lmax, rmin, rmax;
+};
+
+// Wave-uniform fetch of a 64-byte node WITHOUT the scalar cache (s_load of a ~100 MB working set
+// serialises on the scalar cache's miss path, which several CUs share): lane k loads dword k & 15,
+// i.e. one coalesced 64-byte line through the CU's vector L1, and v_readlane broadcasts the 16
+// dwords into SGPRs.
+#define LBVH_RL(v, k) __int_as_float(__builtin_amdgcn_readlane((v), (k)))
+__device__ __forceinline__ uniform_node load_node_uniform(const lbvh_fast_node* __restrict__ nodes, uint32_t nidx,
+                                                          uint32_t lane)
+{
+    const int w = reinterpret_cast<const int*>(&nodes[nidx])[lane & 15u];
+    uniform_node nd;
+    nd.lmin = make_float4(LBVH_RL(w, 0), LBVH_RL(w, 1), LBVH_RL(w, 2), LBVH_RL(w, 3));
+    nd.lmax = make_float4(LBVH_RL(w, 4), LBVH_RL(w, 5), LBVH_RL(w, 6), LBVH_RL(w, 7));
+    nd.rmin = make_float4(LBVH_RL(w, 8), LBVH_RL(w, 9), LBVH_RL(w, 10), LBVH_RL(w, 11));
+    nd.rmax = make_float4(LBVH_RL(w, 12), LBVH_RL(w, 13), LBVH_RL(w, 14), LBVH_RL(w, 15));
+    return nd;
+}
+
+// same for a 48-byte sorted triangle (12 dwords)
+__device__ __forceinline__ void load_tri_uniform(const lbvh_fast_tri* __restrict__ tris, uint32_t pos, uint32_t lane,
+                                                 float4& v0, float4& v1, float4& v2)
+{
+    const uint32_t k = lane & 15u;
+    const int w = reinterpret_cast<const int*>(&tris[pos])[k < 12u ? k : 11u];
+    v0 = make_float4(LBVH_RL(w, 0), LBVH_RL(w, 1), LBVH_RL(w, 2), LBVH_RL(w, 3));
+    v1 = make_float4(LBVH_RL(w, 4), LBVH_RL(w, 5), LBVH_RL(w, 6), 0.0f);
+    v2 = make_float4(LBVH_RL(w, 8), LBVH_RL(w, 9), LBVH_RL(w, 10), 0.0f);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
+                                                           const lbvh_fast_tri* __restrict__ tris,
+                                                           uint32_t n_tiles, tile_queues* queues,
+                                                           lbvh_hit* __restrict__ hits, lbvh_trace_stats* stats)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t home = xcc_id();
+    const uint32_t rw = (uint32_t)(a.x1 - a.x0);
 
     uint32_t n_pops = 0, n_box = 0, n_leaf = 0, n_tri = 0, n_hit = 0;
-    if (active) {
+    for (;;) {
+        const uint32_t tile = next_tile(queues, n_tiles, home);
+        if (tile == kNoTile) break;
+        uint32_t px, py;
+        const bool active = tile_pixel(a, tile, lane, px, py);
         const ray_t ray = make_ray(a.cam, px, py);
         float best_t = LBVH_MAX_FLOAT;
         uint32_t best_tri = 0;
         float best_u = 0.0f, best_v = 0.0f;
 
-        uint32_t sp = 0;
-        uint32_t node = 0;   // root; its own box is never tested: both children are
-        while (true) {
-            const float4* nb = reinterpret_cast<const float4*>(&nodes[node]);
-            const float4 lmin = nb[0], lmax = nb[1], rmin = nb[2], rmax = nb[3];
-            if (STATS) n_pops++;
-            const uint32_t lref = __float_as_uint(lmin.w), rref = __float_as_uint(lmax.w);
+        int stack = 0;            // wave-shared stack: slot k lives in lane k of this VGPR
+        uint32_t sp = 0;          // scalar
+        uint32_t node = 0;        // scalar; root: its own box is never tested, both children are
+        for (;;) {
+            const uint32_t nidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
+            const uniform_node nd = load_node_uniform(nodes, nidx, lane);
+            const uint32_t lref = __float_as_uint(nd.lmin.w), rref = __float_as_uint(nd.lmax.w);
+            const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
+            if (STATS && lane == 0) n_pops++;
             float tl, tr;
-            bool hit_l = ray_box(lmin, lmax, ray, tl);
-            bool hit_r = ray_box(rmin, rmax, ray, tr);
+            bool hit_l = active && ray_box(nd.lmin, nd.lmax, ray, tl);
+            bool hit_r = active && ray_box(nd.rmin, nd.rmax, ray, tr);
             if (STATS) n_box += (hit_l ? 1u : 0u) + (hit_r ? 1u : 0u);
-            // a box that starts beyond the best hit cannot hold a nearer one
+            // a box that starts beyond this lane's best hit cannot hold a nearer one
             hit_l = hit_l && !(tl > best_t);
             hit_r = hit_r && !(tr > best_t);
-
-            // leaves first: their hits tighten best_t before anything is pushed
-#pragma unroll
-            for (int side = 0; side < 2; side++) {
-                const bool h = side == 0 ? hit_l : hit_r;
-                const uint32_t ref = side == 0 ? lref : rref;
-                if (h && (ref & 0x80000000u)) {
-                    if (STATS) { n_leaf++; n_tri++; }
-                    const float4* tv = reinterpret_cast<const float4*>(&tris[ref & 0x7FFFFFFFu]);
-                    const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+            // leaves first: their hits tighten best_t before anything is entered
+            if (leaf_l && __any(hit_l)) {
+                float4 v0, v1, v2;
+                load_tri_uniform(tris, lref & 0x7FFFFFFFu, lane, v0, v1, v2);
+                if (STATS && lane == 0) n_leaf++;        // one 48-B triangle fetch for the packet
+                if (hit_l) {
+                    if (STATS) n_tri++;
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_triangle(ray, v0, v1, v2, u, v);
-                    if (dist < best_t) {
-                        best_t = dist; best_tri = __float_as_uint(v0.w); best_u = u; best_v = v;
-                    }
+                    if (dist < best_t) { best_t = dist; best_tri = __float_as_uint(v0.w); best_u = u; best_v = v; }
                 }
+                hit_r = hit_r && !(tr > best_t);
             }
-            const bool go_l = hit_l && !(lref & 0x80000000u) && !(tl > best_t);
-            const bool go_r = hit_r && !(rref & 0x80000000u) && !(tr > best_t);
-            if (go_l && go_r) {
-                const bool l_near = tl <= tr;
+            if (leaf_r && __any(hit_r)) {
+                float4 v0, v1, v2;
+                load_tri_uniform(tris, rref & 0x7FFFFFFFu, lane, v0, v1, v2);
+                if (STATS && lane == 0) n_leaf++;
+                if (hit_r) {
+                    if (STATS) n_tri++;
+                    float u = 0.0f, v = 0.0f;
+                    const float dist = ray_triangle(ray, v0, v1, v2, u, v);
+                    if (dist < best_t) { best_t = dist; best_tri = __float_as_uint(v0.w); best_u = u; best_v = v; }
+                }
+                hit_l = hit_l && !(tl > best_t);
+            }
+            const uint64_t ml = leaf_l ? 0ull : __ballot(hit_l);
+            const uint64_t mr = leaf_r ? 0ull : __ballot(hit_r);
+            if (ml != 0 && mr != 0) {
+                // both children wanted: the side most lanes reach first goes first
+                const uint64_t both = ml & mr;
+                const uint64_t l_first = __ballot(tl <= tr) & both;
+                const bool l_near = both == 0 ? (__popcll(ml) >= __popcll(mr))
+                                              : (2 * __popcll(l_first) >= __popcll(both));
                 const uint32_t far = l_near ? rref : lref;
                 node = l_near ? lref : rref;
-                if (sp < (uint32_t)kStackDepth) { s_stack[sp][lane] = far; sp++; }
-                continue;
+                stack = lane == (sp & 63u) ? (int)far : stack;      // v_cndmask: slot sp := far
+                sp++;
+            } else if (ml != 0) {
+                node = lref;
+            } else if (mr != 0) {
+                node = rref;
+            } else {
+                if (sp == 0) break;
+                sp--;
+                node = (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u);
             }
-            if (go_l) { node = lref; continue; }
-            if (go_r) { node = rref; continue; }
-            if (sp == 0) break;
-            sp--;
-            node = s_stack[sp][lane];
         }
-        const uint32_t rw = (uint32_t)(a.x1 - a.x0);
-        float4 out;
-        out.x = best_t;
-        out.y = __uint_as_float(best_tri);
-        out.z = best_u;
-        out.w = best_v;
-        reinterpret_cast<float4*>(hits)[(size_t)(py - (uint32_t)a.y0) * rw + (px - (uint32_t)a.x0)] = out;
-        if (STATS && best_t < LBVH_MAX_FLOAT) n_hit = 1;
+        if (active) {
+            float4 out;
+            out.x = best_t;
+            out.y = __uint_as_float(best_tri);
+            out.z = best_u;
+            out.w = best_v;
+            reinterpret_cast<float4*>(hits)[(size_t)(py - (uint32_t)a.y0) * rw + (px - (uint32_t)a.x0)] = out;
+            if (STATS && best_t < LBVH_MAX_FLOAT) n_hit++;
+        }
     }
     if (STATS) add_stats(stats, n_pops, n_box, n_leaf, n_tri, n_hit);
 }
@@ -412,12 +514,18 @@ lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera, i
         if (!ctx->fast_nodes || ctx->fast_n != s.n)
             return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_trace_primary",
                                   "LBVH_TRACE_FAST needs lbvh_build_fast_scene on this scene first");
+        // persistent 4-wave workgroups, 8 per CU (no LDS; 32 waves/CU if registers allow)
+        if (!ctx->trace_queues) LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->trace_queues, 256));
+        LBVH_HIP_TRY(ctx, hipMemsetAsync(ctx->trace_queues, 0, 32, ctx->stream));
+        uint32_t blocks = 256u * 8u;
+        if (blocks * 4 > n_tiles) blocks = (n_tiles + 3) / 4;
+        tile_queues* q = (tile_queues*)ctx->trace_queues;
         if (d_stats)
-            LBVH_LAUNCH(ctx, trace_fast_kernel<true>, dim3(n_tiles), dim3(64), a,
-                               ctx->fast_nodes, ctx->fast_tris, n_tiles, d_hits, d_stats);
+            LBVH_LAUNCH(ctx, trace_packet_kernel<true>, dim3(blocks), dim3(256), a, ctx->fast_nodes,
+                        ctx->fast_tris, n_tiles, q, d_hits, d_stats);
         else
-            LBVH_LAUNCH(ctx, trace_fast_kernel<false>, dim3(n_tiles), dim3(64), a,
-                               ctx->fast_nodes, ctx->fast_tris, n_tiles, d_hits, d_stats);
+            LBVH_LAUNCH(ctx, trace_packet_kernel<false>, dim3(blocks), dim3(256), a, ctx->fast_nodes,
+                        ctx->fast_tris, n_tiles, q, d_hits, d_stats);
     }
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
