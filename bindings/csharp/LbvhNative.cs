@@ -1,0 +1,105 @@
+// LbvhNative.cs — P/Invoke binding of liblbvh.so (include/lbvh.h) for the reference's C# host.
+//
+// SOURCE ONLY: this image has no C# toolchain (no dotnet/mono/csc), so this file is not compiled or
+// tested here; it is the shim a maintainer of drzhn/UnitySimpleRaytracing would add under
+// Assets/_Scripts/ to replace ComputeShader.Dispatch with the native library (see INTEGRATION.md).
+// Struct layouts are the reference's own Sequential/Pack=16 structs (SceneDataTypes.cs), which are
+// already byte-identical to lbvh_triangle / lbvh_aabb / lbvh_internal_node / lbvh_leaf_node.
+using System;
+using System.Runtime.InteropServices;
+
+public static class LbvhNative
+{
+    const string Lib = "lbvh";   // liblbvh.so on Linux
+
+    public const int TRACE_REFERENCE = 0, TRACE_FAST = 1;
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct Hit { public float t; public uint tri; public float u, v; }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public unsafe struct Camera
+    {
+        public int screenWidth, screenHeight;
+        public float cameraFov, nearPlane;
+        public fixed float cameraToWorld[16];      // row-major m00..m33 (Matrix4x4 m00,m01,...)
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct Scene
+    {
+        public uint n;
+        public IntPtr sortedIndices, triangleAabb, internalNodes, leafNodes, bvh, triangles;
+    }
+
+    [DllImport(Lib)] public static extern int lbvh_abi_version();
+    [DllImport(Lib)] public static extern int lbvh_device_count();
+    [DllImport(Lib)] public static extern int lbvh_create(int deviceId, out IntPtr ctx);
+    [DllImport(Lib)] public static extern int lbvh_destroy(IntPtr ctx);
+    [DllImport(Lib)] public static extern IntPtr lbvh_last_error(IntPtr ctx);
+    [DllImport(Lib)] public static extern int lbvh_sync(IntPtr ctx);
+
+    [DllImport(Lib)] public static extern int lbvh_buffer_alloc(IntPtr ctx, UIntPtr count, UIntPtr stride, out IntPtr dPtr);
+    [DllImport(Lib)] public static extern int lbvh_buffer_free(IntPtr ctx, IntPtr dPtr);
+    [DllImport(Lib)] public static extern int lbvh_buffer_fill_u32(IntPtr ctx, IntPtr dPtr, uint value, UIntPtr nWords);
+    [DllImport(Lib)] public static extern int lbvh_buffer_upload(IntPtr ctx, IntPtr dDst, IntPtr hSrc, UIntPtr bytes);
+    [DllImport(Lib)] public static extern int lbvh_buffer_download(IntPtr ctx, IntPtr hDst, IntPtr dSrc, UIntPtr bytes);
+
+    [DllImport(Lib)] public static extern int lbvh_morton_aabb(IntPtr ctx, IntPtr dTriangles, uint n, uint capacity,
+        float[] boxMin, float[] boxMax, IntPtr dKeys, IntPtr dIndices, IntPtr dAabb);
+    [DllImport(Lib)] public static extern int lbvh_sort_pairs(IntPtr ctx, IntPtr dKeys, IntPtr dValues, uint count);
+    [DllImport(Lib)] public static extern int lbvh_distribute_keys(IntPtr ctx, IntPtr dKeys, uint n);
+    [DllImport(Lib)] public static extern int lbvh_build_tree(IntPtr ctx, uint n, IntPtr dSortedKeys, IntPtr dInternal, IntPtr dLeaf);
+    [DllImport(Lib)] public static extern int lbvh_refit(IntPtr ctx, uint n, IntPtr dInternal, IntPtr dLeaf,
+        IntPtr dTriangleAabb, IntPtr dSortedIndices, IntPtr dBvh);
+    [DllImport(Lib)] public static extern int lbvh_build_fast_scene(IntPtr ctx, ref Scene scene);
+    [DllImport(Lib)] public static extern int lbvh_trace_primary(IntPtr ctx, ref Camera camera, int x0, int y0, int x1, int y1,
+        ref Scene scene, int mode, IntPtr dHits, IntPtr dStats);
+
+    public static void Check(IntPtr ctx, int status)
+    {
+        if (status != 0)
+            throw new InvalidOperationException($"lbvh status {status}: {Marshal.PtrToStringAnsi(lbvh_last_error(ctx))}");
+    }
+}
+
+// DataBuffer<T> with the ComputeBuffer replaced by a device pointer (Assets/_Scripts/DataBuffer.cs).
+public class NativeDataBuffer<T> : IDisposable where T : struct
+{
+    public IntPtr DeviceBuffer { get; private set; }
+    public T[] LocalBuffer { get; }
+    readonly IntPtr _ctx;
+    readonly int _stride = Marshal.SizeOf(typeof(T));
+
+    public NativeDataBuffer(IntPtr ctx, int size)
+    {
+        _ctx = ctx;
+        LocalBuffer = new T[size];
+        LbvhNative.Check(ctx, LbvhNative.lbvh_buffer_alloc(ctx, (UIntPtr)size, (UIntPtr)_stride, out var p));
+        DeviceBuffer = p;
+    }
+
+    public NativeDataBuffer(IntPtr ctx, int size, uint initialWord) : this(ctx, size)   // DataBuffer(size, initialValue)
+    {
+        LbvhNative.Check(ctx, LbvhNative.lbvh_buffer_fill_u32(ctx, DeviceBuffer, initialWord, (UIntPtr)((long)size * _stride / 4)));
+    }
+
+    public void GetData()                                                               // DataBuffer.GetData
+    {
+        var h = GCHandle.Alloc(LocalBuffer, GCHandleType.Pinned);
+        try { LbvhNative.Check(_ctx, LbvhNative.lbvh_buffer_download(_ctx, h.AddrOfPinnedObject(), DeviceBuffer, (UIntPtr)((long)LocalBuffer.Length * _stride))); }
+        finally { h.Free(); }
+    }
+
+    public void Sync()                                                                  // DataBuffer.Sync
+    {
+        var h = GCHandle.Alloc(LocalBuffer, GCHandleType.Pinned);
+        try { LbvhNative.Check(_ctx, LbvhNative.lbvh_buffer_upload(_ctx, DeviceBuffer, h.AddrOfPinnedObject(), (UIntPtr)((long)LocalBuffer.Length * _stride))); }
+        finally { h.Free(); }
+    }
+
+    public void Dispose()
+    {
+        if (DeviceBuffer != IntPtr.Zero) { LbvhNative.lbvh_buffer_free(_ctx, DeviceBuffer); DeviceBuffer = IntPtr.Zero; }
+    }
+}

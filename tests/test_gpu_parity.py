@@ -373,3 +373,54 @@ def test_cfg2_full_size(ctx):
     frac = float((ref["t"] < L.MAX_FLOAT).mean())
     assert 0.2 < frac < 0.95
     d.on_destroy()
+
+
+# ---- the compiled-language host layer (C++ classes over the C ABI) ---------------------------------------------
+
+def _splitmix_mesh(n):
+    """The mesh lbvh_driver.cpp generates (SplitMix64, seed 1)."""
+    mask = (1 << 64) - 1
+    state = 1
+    out = np.zeros((n, 3, 3), dtype=np.float32)          # [tri, vertex(a,b,c), axis]
+
+    def nxt():
+        nonlocal state
+        state = (state + 0x9E3779B97F4A7C15) & mask
+        z = state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+        return z ^ (z >> 31)
+
+    def uni(lo, hi):
+        return np.float32(lo) + np.float32(hi - lo) * np.float32((nxt() >> 40) * (1.0 / 16777216.0))
+
+    for i in range(n):
+        for k in range(3):
+            c = uni(-100.0, 100.0)
+            out[i, 0, k] = c
+            out[i, 1, k] = np.float32(c + uni(-2.0, 2.0))
+            out[i, 2, k] = np.float32(c + uni(-2.0, 2.0))
+    return out
+
+
+def test_cpp_host_driver_matches_oracle():
+    """BASELINE config 1 through host/lbvh_host.hpp (Awake + Update in the reference's call order)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "unitysimpleraytracing_amd", "host", "lbvh_driver")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    res = json.loads(subprocess.run([exe, "4096", "256", "256"], check=True, capture_output=True, text=True).stdout)
+    pos = _splitmix_mesh(4096)
+    tris = np.zeros(4096, dtype=L.TRIANGLE)
+    tris["a"], tris["b"], tris["c"] = pos[:, 0], pos[:, 1], pos[:, 2]
+    b = O.Built(tris, capacity=4096, threads=8)
+    assert res["key_sum"] == int(b.keys[:4096].astype(np.uint64).sum())
+    nd = b.internal[:4095]
+    node_sum = int((nd["leftNode"].astype(np.uint64) * 3 + nd["rightNode"].astype(np.uint64) * 5
+                    + nd["parent"].astype(np.uint64) * 7 + nd["leftNodeType"] + nd["rightNodeType"]).sum() % (1 << 64))
+    assert res["node_sum"] == node_sum
+    oh, _ = O.trace_primary(b, scenes.camera(256, 256, (0.0, 0.0, 300.0)), threads=8)
+    hit = oh["t"] < L.MAX_FLOAT
+    assert res["hits"] == int(hit.sum())
+    assert abs(res["t_sum"] - float(oh["t"][hit].astype(np.float64).sum())) < 1e-3

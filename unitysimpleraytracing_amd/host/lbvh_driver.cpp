@@ -1,0 +1,74 @@
+// lbvh_driver.cpp — BASELINE config 1 ("plumbing") through the C++ host classes: 4 096 random
+// triangles, 256x256 primary rays, the reference's Awake() + Update() call order.  Prints stage
+// timings and checksums the parity tests compare with the oracle.  Links only liblbvh.so.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "lbvh_host.hpp"
+
+static uint64_t splitmix64(uint64_t& s)
+{
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static float uniform(uint64_t& s, float lo, float hi) { return lo + (hi - lo) * (float)((splitmix64(s) >> 40) * (1.0 / 16777216.0)); }
+
+int main(int argc, char** argv)
+{
+    const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 4096;
+    const int w = argc > 2 ? atoi(argv[2]) : 256, h = argc > 3 ? atoi(argv[3]) : 256;
+    std::vector<lbvh_triangle> mesh(n);
+    uint64_t seed = 1;
+    for (auto& t : mesh) {
+        std::memset(&t, 0, sizeof t);
+        for (int k = 0; k < 3; k++) {
+            const float c = uniform(seed, -100.0f, 100.0f);
+            t.a[k] = c;
+            t.b[k] = c + uniform(seed, -2.0f, 2.0f);
+            t.c[k] = c + uniform(seed, -2.0f, 2.0f);
+        }
+        t.b_uv[0] = 1.0f; t.c_uv[1] = 1.0f;
+    }
+    try {
+        lbvh::Context ctx(0);
+        lbvh::RaytracingMeshDrawer drawer(ctx, mesh);
+        auto t0 = std::chrono::steady_clock::now();
+        drawer.Awake();
+        ctx.sync();
+        auto t1 = std::chrono::steady_clock::now();
+        lbvh_camera cam;
+        cam.screen_width = w; cam.screen_height = h;
+        cam.camera_fov = std::tan(60.0f * 3.14159265358979f / 180.0f / 2.0f);
+        cam.near_plane = 0.3f;
+        const float m[16] = {-1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 300, 0, 0, 0, 1};
+        std::memcpy(cam.camera_to_world, m, sizeof m);
+        drawer.Update(cam, LBVH_TRACE_FAST);
+        ctx.sync();
+        auto t2 = std::chrono::steady_clock::now();
+        drawer.Container().GetAllGpuData();          // throws on a corrupted node (MeshBufferContainer.cs:181-195)
+        drawer.Hits().GetData();
+        uint64_t key_sum = 0, node_sum = 0;
+        for (uint32_t i = 0; i < n; i++) key_sum += drawer.Container().Keys().LocalBuffer()[i];
+        for (uint32_t i = 0; i + 1 < n; i++) {
+            const auto& nd = drawer.Container().BvhInternalNode().LocalBuffer()[i];
+            node_sum += (uint64_t)nd.leftNode * 3 + nd.rightNode * 5 + nd.parent * 7 + nd.leftNodeType + nd.rightNodeType;
+        }
+        size_t hits = 0;
+        double tsum = 0;
+        for (size_t i = 0; i < (size_t)w * h; i++)
+            if (drawer.Hits().LocalBuffer()[i].t < LBVH_MAX_FLOAT) { hits++; tsum += drawer.Hits().LocalBuffer()[i].t; }
+        std::printf("{\"triangles\": %u, \"rays\": %d, \"awake_ms\": %.3f, \"update_ms\": %.3f, \"key_sum\": %llu, "
+                    "\"node_sum\": %llu, \"hits\": %zu, \"t_sum\": %.6f}\n",
+                    n, w * h, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    std::chrono::duration<double, std::milli>(t2 - t1).count(), (unsigned long long)key_sum,
+                    (unsigned long long)node_sum, hits, tsum);
+    } catch (const lbvh::Error& e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,253 @@
+// lbvh_host.hpp — the reference's C# host classes restated in C++ over the C ABI (include/lbvh.h).
+//
+// The reference's host side is compiled C# against UnityEngine (no C# toolchain in this image), so
+// the host layer above the C ABI is C++: same class names, constructor arguments, method names and
+// call order as Assets/_Scripts/{DataBuffer,MeshBufferContainer,ComputeBufferSorter,BVHConstructor,
+// RaytracingMeshDrawer}.cs.  Each method is one C-ABI call; nothing here computes.  Errors: the
+// reference logs and carries on; here every failing call throws lbvh::Error with the library's text.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/lbvh.h"
+
+namespace lbvh {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string& m) : std::runtime_error("lbvh status " + std::to_string(s) + ": " + m), status(s) {}
+};
+
+inline void check(lbvh_context* ctx, lbvh_status s)
+{
+    if (s != LBVH_OK) throw Error(s, lbvh_last_error(ctx));
+}
+
+// The implicit Unity graphics device + IShaderContainer (Assets/_Scripts/ShaderContainer.cs:6-40).
+class Context {
+public:
+    explicit Context(int device_id = 0) { check(nullptr, lbvh_create(device_id, &ctx_)); }
+    ~Context() { if (ctx_) lbvh_destroy(ctx_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    lbvh_context* get() const { return ctx_; }
+    void sync() { check(ctx_, lbvh_sync(ctx_)); }
+private:
+    lbvh_context* ctx_ = nullptr;
+};
+
+// Assets/_Scripts/DataBuffer.cs
+template <typename T>
+class DataBuffer {
+public:
+    DataBuffer(Context& ctx, size_t size) : ctx_(ctx), local_(size)                       // :25-30
+    {
+        check(ctx_.get(), lbvh_buffer_alloc(ctx_.get(), size, sizeof(T), &device_));
+    }
+    DataBuffer(Context& ctx, size_t size, uint32_t initial_word) : DataBuffer(ctx, size)  // :14-23
+    {
+        Fill(initial_word);
+    }
+    ~DataBuffer() { Dispose(); }
+    DataBuffer(const DataBuffer&) = delete;
+    DataBuffer& operator=(const DataBuffer&) = delete;
+
+    void* DeviceBuffer() const { return device_; }
+    std::vector<T>& LocalBuffer() { return local_; }
+    size_t Size() const { return local_.size(); }
+
+    void Fill(uint32_t word, bool mirror = true)
+    {
+        check(ctx_.get(), lbvh_buffer_fill_u32(ctx_.get(), device_, word, local_.size() * sizeof(T) / 4));
+        if (mirror) {
+            uint32_t* w = reinterpret_cast<uint32_t*>(local_.data());
+            for (size_t i = 0; i < local_.size() * sizeof(T) / 4; i++) w[i] = word;
+        }
+    }
+    void GetData()                                                                         // :50-54
+    {
+        check(ctx_.get(), lbvh_buffer_download(ctx_.get(), local_.data(), device_, local_.size() * sizeof(T)));
+    }
+    void Sync()                                                                            // :56-60
+    {
+        check(ctx_.get(), lbvh_buffer_upload(ctx_.get(), device_, local_.data(), local_.size() * sizeof(T)));
+    }
+    void Dispose()                                                                         // :72-75
+    {
+        if (device_) { lbvh_buffer_free(ctx_.get(), device_); device_ = nullptr; }
+    }
+private:
+    Context& ctx_;
+    void* device_ = nullptr;
+    std::vector<T> local_;
+};
+
+inline uint32_t CapacityFor(uint32_t n, uint32_t tile = 1024) { return (n + tile - 1) / tile * tile; }
+
+// Assets/_Scripts/MeshBufferContainer.cs
+class MeshBufferContainer {
+public:
+    MeshBufferContainer(Context& ctx, const std::vector<lbvh_triangle>& triangles, uint32_t capacity = 0)
+        : ctx_(ctx), n_((uint32_t)triangles.size()), cap_(capacity ? capacity : CapacityFor(n_)),
+          keys_(ctx, cap_), index_(ctx, cap_), tris_(ctx, cap_), aabb_(ctx, cap_), bvh_(ctx, cap_),
+          leaf_(ctx, cap_, LBVH_NULL), internal_(ctx, cap_, LBVH_NULL)                     // :108-115
+    {
+        std::memcpy(tris_.LocalBuffer().data(), triangles.data(), triangles.size() * sizeof(lbvh_triangle));
+        tris_.Sync();                                                                      // :150
+        GenerateKeys();                                                                    // :123-151 as one kernel
+    }
+    void GenerateKeys()
+    {
+        const float mn[3] = {-125.0f, -125.0f, -125.0f}, mx[3] = {125.0f, 125.0f, 125.0f}; // Whole, :9-15
+        check(ctx_.get(), lbvh_morton_aabb(ctx_.get(), (const lbvh_triangle*)tris_.DeviceBuffer(), n_, cap_, mn, mx,
+                                           (uint32_t*)keys_.DeviceBuffer(), (uint32_t*)index_.DeviceBuffer(),
+                                           (lbvh_aabb*)aabb_.DeviceBuffer()));
+    }
+    void DistributeKeys()                                                                  // :154-169
+    {
+        check(ctx_.get(), lbvh_distribute_keys(ctx_.get(), (uint32_t*)keys_.DeviceBuffer(), n_));
+    }
+    void GetAllGpuData()                                                                   // :171-196
+    {
+        keys_.GetData(); index_.GetData(); tris_.GetData(); aabb_.GetData(); bvh_.GetData(); leaf_.GetData();
+        internal_.GetData();
+        for (uint32_t i = 0; i < n_; i++)
+            if (leaf_.LocalBuffer()[i].index == LBVH_NULL && leaf_.LocalBuffer()[i].parent == LBVH_NULL)
+                throw Error(-100, "LEAF CORRUPTED " + std::to_string(i));                  // :183-186
+        for (uint32_t i = 0; i + 1 < n_; i++)
+            if (internal_.LocalBuffer()[i].index == LBVH_NULL && internal_.LocalBuffer()[i].parent == LBVH_NULL)
+                throw Error(-101, "INTERNAL CORRUPTED " + std::to_string(i));              // :191-194
+    }
+    lbvh_scene Scene() const
+    {
+        lbvh_scene s;
+        s.n = n_;
+        s.sorted_indices = (const uint32_t*)index_.DeviceBuffer();
+        s.triangle_aabb = (const lbvh_aabb*)aabb_.DeviceBuffer();
+        s.internal_nodes = (const lbvh_internal_node*)internal_.DeviceBuffer();
+        s.leaf_nodes = (const lbvh_leaf_node*)leaf_.DeviceBuffer();
+        s.bvh = (const lbvh_aabb*)bvh_.DeviceBuffer();
+        s.triangles = (const lbvh_triangle*)tris_.DeviceBuffer();
+        return s;
+    }
+    uint32_t TrianglesLength() const { return n_; }
+    uint32_t Capacity() const { return cap_; }
+    DataBuffer<uint32_t>& Keys() { return keys_; }
+    DataBuffer<uint32_t>& TriangleIndex() { return index_; }
+    DataBuffer<lbvh_triangle>& TriangleData() { return tris_; }
+    DataBuffer<lbvh_aabb>& TriangleAABB() { return aabb_; }
+    DataBuffer<lbvh_aabb>& BvhData() { return bvh_; }
+    DataBuffer<lbvh_leaf_node>& BvhLeafNode() { return leaf_; }
+    DataBuffer<lbvh_internal_node>& BvhInternalNode() { return internal_; }
+private:
+    Context& ctx_;
+    uint32_t n_, cap_;
+    DataBuffer<uint32_t> keys_, index_;
+    DataBuffer<lbvh_triangle> tris_;
+    DataBuffer<lbvh_aabb> aabb_, bvh_;
+    DataBuffer<lbvh_leaf_node> leaf_;
+    DataBuffer<lbvh_internal_node> internal_;
+};
+
+// Assets/_Scripts/ComputeBufferSorter.cs — dataLength only bounds the validation, Sort() covers the
+// whole padded buffers (every dispatch of the reference covers DATA_ARRAY_COUNT, :107,116).
+class ComputeBufferSorter {
+public:
+    ComputeBufferSorter(Context& ctx, uint32_t data_length, DataBuffer<uint32_t>& keys, DataBuffer<uint32_t>& values)
+        : ctx_(ctx), data_length_(data_length), keys_(keys), values_(values) {}
+    void Sort()                                                                            // :100-126
+    {
+        check(ctx_.get(), lbvh_sort_pairs(ctx_.get(), (uint32_t*)keys_.DeviceBuffer(), (uint32_t*)values_.DeviceBuffer(),
+                                          (uint32_t)keys_.Size()));
+    }
+    bool ValidateSortedData()                                                              // :150-177
+    {
+        keys_.GetData();
+        for (uint32_t i = 1; i < data_length_; i++)
+            if (keys_.LocalBuffer()[i] < keys_.LocalBuffer()[i - 1]) return false;
+        return true;
+    }
+private:
+    Context& ctx_;
+    uint32_t data_length_;
+    DataBuffer<uint32_t>& keys_;
+    DataBuffer<uint32_t>& values_;
+};
+
+// Assets/_Scripts/BVHConstructor.cs
+class BVHConstructor {
+public:
+    BVHConstructor(Context& ctx, uint32_t triangles_count, DataBuffer<uint32_t>& sorted_morton_codes,
+                   DataBuffer<uint32_t>& sorted_triangle_indices, DataBuffer<lbvh_aabb>& triangle_aabb,
+                   DataBuffer<lbvh_internal_node>& internal_nodes, DataBuffer<lbvh_leaf_node>& leaf_nodes,
+                   DataBuffer<lbvh_aabb>& bvh_data)
+        : ctx_(ctx), n_(triangles_count), keys_(sorted_morton_codes), idx_(sorted_triangle_indices), aabb_(triangle_aabb),
+          internal_(internal_nodes), leaf_(leaf_nodes), bvh_(bvh_data) {}
+    void ConstructTree()                                                                   // :61-64
+    {
+        check(ctx_.get(), lbvh_build_tree(ctx_.get(), n_, (const uint32_t*)keys_.DeviceBuffer(),
+                                          (lbvh_internal_node*)internal_.DeviceBuffer(), (lbvh_leaf_node*)leaf_.DeviceBuffer()));
+    }
+    void ConstructBVH()                                                                    // :66-69
+    {
+        check(ctx_.get(), lbvh_refit(ctx_.get(), n_, (const lbvh_internal_node*)internal_.DeviceBuffer(),
+                                     (const lbvh_leaf_node*)leaf_.DeviceBuffer(), (const lbvh_aabb*)aabb_.DeviceBuffer(),
+                                     (const uint32_t*)idx_.DeviceBuffer(), (lbvh_aabb*)bvh_.DeviceBuffer()));
+    }
+private:
+    Context& ctx_;
+    uint32_t n_;
+    DataBuffer<uint32_t>& keys_;
+    DataBuffer<uint32_t>& idx_;
+    DataBuffer<lbvh_aabb>& aabb_;
+    DataBuffer<lbvh_internal_node>& internal_;
+    DataBuffer<lbvh_leaf_node>& leaf_;
+    DataBuffer<lbvh_aabb>& bvh_;
+};
+
+// Assets/_Scripts/RaytracingMeshDrawer.cs: Awake() = build chain (:30-51), Update() = per-frame
+// dispatch (:76-84) producing hit records.
+class RaytracingMeshDrawer {
+public:
+    RaytracingMeshDrawer(Context& ctx, const std::vector<lbvh_triangle>& mesh) : ctx_(ctx), mesh_(mesh) {}
+    void Awake()
+    {
+        container_.reset(new MeshBufferContainer(ctx_, mesh_));                                            // :34
+        sorter_.reset(new ComputeBufferSorter(ctx_, container_->TrianglesLength(), container_->Keys(),
+                                              container_->TriangleIndex()));                               // :36
+        sorter_->Sort();                                                                                   // :37
+        container_->DistributeKeys();                                                                      // :39
+        bvh_.reset(new BVHConstructor(ctx_, container_->TrianglesLength(), container_->Keys(), container_->TriangleIndex(),
+                                      container_->TriangleAABB(), container_->BvhInternalNode(),
+                                      container_->BvhLeafNode(), container_->BvhData()));                  // :41-48
+        bvh_->ConstructTree();                                                                             // :50
+        bvh_->ConstructBVH();                                                                              // :51
+        const lbvh_scene s = container_->Scene();
+        check(ctx_.get(), lbvh_build_fast_scene(ctx_.get(), &s));
+    }
+    // screenWidth/screenHeight/cameraFov/cameraToWorldMatrix + Dispatch, :78-83
+    void Update(const lbvh_camera& cam, int mode = LBVH_TRACE_FAST)
+    {
+        const size_t rays = (size_t)cam.screen_width * cam.screen_height;
+        if (!hits_ || hits_->Size() < rays) hits_.reset(new DataBuffer<lbvh_hit>(ctx_, rays));
+        const lbvh_scene s = container_->Scene();
+        check(ctx_.get(), lbvh_trace_primary(ctx_.get(), &cam, 0, 0, cam.screen_width, cam.screen_height, &s, mode,
+                                             (lbvh_hit*)hits_->DeviceBuffer(), nullptr));
+    }
+    MeshBufferContainer& Container() { return *container_; }
+    DataBuffer<lbvh_hit>& Hits() { return *hits_; }
+private:
+    Context& ctx_;
+    std::vector<lbvh_triangle> mesh_;
+    std::unique_ptr<MeshBufferContainer> container_;
+    std::unique_ptr<ComputeBufferSorter> sorter_;
+    std::unique_ptr<BVHConstructor> bvh_;
+    std::unique_ptr<DataBuffer<lbvh_hit>> hits_;
+};
+
+}  // namespace lbvh
