@@ -417,8 +417,9 @@ def test_cpp_host_driver_matches_oracle():
     b = O.Built(tris, capacity=4096, threads=8)
     assert res["key_sum"] == int(b.keys[:4096].astype(np.uint64).sum())
     nd = b.internal[:4095]
-    node_sum = int((nd["leftNode"].astype(np.uint64) * 3 + nd["rightNode"].astype(np.uint64) * 5
-                    + nd["parent"].astype(np.uint64) * 7 + nd["leftNodeType"] + nd["rightNodeType"]).sum() % (1 << 64))
+    node_sum = int((nd["leftNode"].astype(np.uint64) * np.uint64(3) + nd["rightNode"].astype(np.uint64) * np.uint64(5)
+                    + nd["parent"].astype(np.uint64) * np.uint64(7) + nd["leftNodeType"].astype(np.uint64)
+                    + nd["rightNodeType"].astype(np.uint64)).sum(dtype=np.uint64))
     assert res["node_sum"] == node_sum
     oh, _ = O.trace_primary(b, scenes.camera(256, 256, (0.0, 0.0, 300.0)), threads=8)
     hit = oh["t"] < L.MAX_FLOAT

@@ -1,123 +1,84 @@
-// lbvh_sort.hip — stable LSD radix sort of (u32 key, u32 value) pairs for gfx950.
+// lbvh_sort.hip — stable LSD radix sort of (u32 key, u32 value) pairs for gfx950 ("onesweep" form).
 //
 // Replaces ComputeBufferSorter.Sort() (Assets/_Scripts/ComputeBufferSorter.cs:100-126) and its
 // kernels LocalRadixSort / PreScan / BlockSum / GlobalScan / GlobalRadixSort
-// (Assets/_Shaders/Sorting/*.compute).  Same decomposition of a pass — per-tile digit counts,
-// exclusive scan of the (digit, tile) table, scatter — but built for wave64:
-//   * a tile is 256 threads x ITEMS keys (4096), not 1024 x 1: digit runs in the scatter are
-//     4x longer, so the HBM writes coalesce;
-//   * the reference's 8 one-bit split passes with 5 group barriers each (LocalRadixSort.compute:
-//     64-91, WavePrefixCountBits over 32 lanes) become ONE ranking step per key: the wave's 64 keys
-//     are matched on the whole 8-bit digit with 8 ballots, rank = v_mbcnt of the peer mask, and the
-//     per-wave digit counters live in LDS;
-//   * the (digit, tile) table is tile-major so every access is a coalesced 1-KB row, and the scan
-//     over it is a column scan (three small kernels) instead of the reference's PreScan/BlockSum/
-//     GlobalScan over a digit-major table (which needs strided 4-B gathers in the scatter).
-// Stability (equal keys keep input order) inside a tile and across tiles makes the output the
-// unique stable sort = the reference's result, bit for bit.
+// (Assets/_Shaders/Sorting/*.compute).  Same digit width and pass count as the reference (8 bits x 4,
+// Assets/_Shaders/Constants.cginc:1-2) and the same per-pass contract — stable partition by digit —
+// so the output is the unique stable sort = the reference's result bit for bit.  What changes:
+//   * one histogram kernel reads the keys ONCE and produces all four 256-bin digit histograms
+//     (the reference recounts per pass inside LocalRadixSort);
+//   * each pass is ONE kernel: a tile (256 threads x ITEMS keys) ranks its keys, publishes its 256
+//     digit counts and obtains the counts of all earlier tiles by decoupled look-back over per-tile
+//     status words, instead of the reference's digit-major table + three scan dispatches
+//     (Scan.compute:15-96).  16 B/pair/pass + 4 B/pair once, against 20 B/pair/pass;
+//   * the reference's 8 one-bit split passes with 5 group barriers each (LocalRadixSort.compute:64-91,
+//     WavePrefixCountBits over 32 lanes) become one ranking step per key: the wave's 64 keys are
+//     matched on the whole 8-bit digit with 8 ballots, rank = v_mbcnt of the peer mask, per-wave digit
+//     counters in LDS;
+//   * the tile is digit-sorted in LDS and written so consecutive lanes hit consecutive addresses of a
+//     digit run (the reference scatters 1024-key tiles: 16-B runs).
+// Inter-workgroup protocol (MI355X: 8 XCDs, private non-coherent L2s): a status word carries its own
+// flag (2 bits) and value (30 bits), is written with an agent-scope relaxed atomic store
+// (global_store_dword sc1, write-through) and polled with agent-scope relaxed atomic loads (sc1, L1
+// bypass) — no fences, no ordering between words needed, placement-independent.  Tiles take their
+// index from an atomic ticket, so every tile a look-back waits for is already running.
 #include "lbvh_common.h"
 
 namespace {
 
 constexpr int kThreads = 256;          // 4 waves
 constexpr int kWaves = kThreads / LBVH_WAVE;
-constexpr int kRadix = 256;            // 8-bit digits, 4 passes (Assets/_Shaders/Constants.cginc:1-2)
-constexpr int kItems = 16;             // keys per thread
-constexpr int kTile = kThreads * kItems;
-constexpr int kChunkTiles = 32;        // tiles per column-scan chunk
+constexpr int kRadix = 256;
+constexpr int kPasses = 4;
 
-// ---- per-tile digit histogram ("upsweep") ---------------------------------------------------
-__global__ __launch_bounds__(kThreads) void sort_upsweep_kernel(const uint32_t* __restrict__ keys,
-                                                                uint32_t count, uint32_t shift,
-                                                                uint32_t* __restrict__ tile_hist)
+constexpr uint32_t kFlagAgg = 1u << 30;    // value = this tile's digit count
+constexpr uint32_t kFlagIncl = 2u << 30;   // value = digit count of tiles 0..this
+constexpr uint32_t kValueMask = (1u << 30) - 1u;
+constexpr int kLook = 4;                   // predecessors inspected per look-back step
+
+// ---- all four digit histograms in one read of the keys ------------------------------------------
+__global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t* __restrict__ keys,
+                                                                  uint32_t count, uint32_t* __restrict__ ghist)
 {
-    __shared__ uint32_t s_hist[kWaves][kRadix];
+    __shared__ uint32_t s_hist[kPasses][kRadix];
     const uint32_t t = threadIdx.x;
-    const uint32_t w = t >> 6;
-    const uint32_t tile = blockIdx.x;
-    const uint32_t base = tile * (uint32_t)kTile;
-
 #pragma unroll
-    for (int i = 0; i < kWaves; i++) s_hist[i][t] = 0;
+    for (int p = 0; p < kPasses; p++) s_hist[p][t] = 0;
     __syncthreads();
-
-    uint32_t k[kItems];
+    // grid-stride, 4 independent loads in flight per thread (count <= 2^30 and <= 2^19 threads: no wrap)
+    const uint32_t stride = gridDim.x * kThreads;
+    for (uint32_t i0 = blockIdx.x * kThreads + t; i0 - t < count; i0 += stride * 4) {
+        uint32_t k[4];
+        bool ok[4];
 #pragma unroll
-    for (int j = 0; j < kItems; j++) {
-        const uint32_t idx = base + (uint32_t)j * kThreads + t;
-        k[j] = idx < count ? keys[idx] : 0u;
-    }
+        for (int j = 0; j < 4; j++) {
+            const uint32_t idx = i0 + (uint32_t)j * stride;
+            ok[j] = idx < count;
+            k[j] = ok[j] ? keys[idx] : 0u;
+        }
 #pragma unroll
-    for (int j = 0; j < kItems; j++) {
-        const uint32_t idx = base + (uint32_t)j * kThreads + t;
-        const bool valid = idx < count;
-        const uint32_t d = valid ? ((k[j] >> shift) & (kRadix - 1)) : 0xFFFFFFFFu;
-        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-        if (__all(d == d0)) {
-            // whole wave on one digit (top bytes of Morton codes, pad keys): one plain update
-            if (lane_id() == 0 && d0 < (uint32_t)kRadix) s_hist[w][d0] += LBVH_WAVE;
-        } else if (valid) {
-            atomicAdd(&s_hist[w][d], 1u);
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int p = 0; p < kPasses; p++) {
+                const uint32_t d = ok[j] ? ((k[j] >> (8 * p)) & 255u) : 0xFFFFFFFFu;
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                if (__all(d == d0)) {
+                    // whole wave on one digit (top bytes of Morton codes, 0xFFFFFFFF pads)
+                    if (lane_id() == 0 && d0 < (uint32_t)kRadix) atomicAdd(&s_hist[p][d0], (uint32_t)LBVH_WAVE);
+                } else if (ok[j]) {
+                    atomicAdd(&s_hist[p][d], 1u);
+                }
+            }
         }
     }
     __syncthreads();
-    tile_hist[(size_t)tile * kRadix + t] = s_hist[0][t] + s_hist[1][t] + s_hist[2][t] + s_hist[3][t];
-}
-
-// ---- column scan of the tile-major table: H[tile][d] -> global output index of the tile's first
-// key with digit d.  Thread d owns column d everywhere.
-__global__ __launch_bounds__(kRadix) void sort_scan_reduce_kernel(const uint32_t* __restrict__ tile_hist,
-                                                                  uint32_t tiles,
-                                                                  uint32_t* __restrict__ chunk_sums)
-{
-    const uint32_t d = threadIdx.x;
-    const uint32_t c = blockIdx.x;
-    const uint32_t t0 = c * kChunkTiles;
-    const uint32_t t1 = min(t0 + (uint32_t)kChunkTiles, tiles);
-    uint32_t s = 0;
-    for (uint32_t t = t0; t < t1; t++) s += tile_hist[(size_t)t * kRadix + d];
-    chunk_sums[(size_t)c * kRadix + d] = s;
-}
-
-__global__ __launch_bounds__(kRadix) void sort_scan_chunks_kernel(uint32_t* __restrict__ chunk_sums,
-                                                                  uint32_t chunks)
-{
-    __shared__ uint32_t s_wave[kRadix / LBVH_WAVE];
-    const uint32_t d = threadIdx.x;
-    // exclusive prefix over chunks, per digit
-    uint32_t running = 0;
-    for (uint32_t c = 0; c < chunks; c++) {
-        const uint32_t x = chunk_sums[(size_t)c * kRadix + d];
-        chunk_sums[(size_t)c * kRadix + d] = running;
-        running += x;
-    }
-    // exclusive prefix of the digit totals over digits = first output index of each digit
-    const uint32_t incl = wave_inclusive_sum(running);
-    if ((d & 63) == 63) s_wave[d >> 6] = incl;
-    __syncthreads();
-    uint32_t wave_prefix = 0;
-    for (uint32_t i = 0; i < (d >> 6); i++) wave_prefix += s_wave[i];
-    const uint32_t digit_start = incl - running + wave_prefix;
-    for (uint32_t c = 0; c < chunks; c++) chunk_sums[(size_t)c * kRadix + d] += digit_start;
-}
-
-__global__ __launch_bounds__(kRadix) void sort_scan_apply_kernel(uint32_t* __restrict__ tile_hist,
-                                                                 uint32_t tiles,
-                                                                 const uint32_t* __restrict__ chunk_sums)
-{
-    const uint32_t d = threadIdx.x;
-    const uint32_t c = blockIdx.x;
-    const uint32_t t0 = c * kChunkTiles;
-    const uint32_t t1 = min(t0 + (uint32_t)kChunkTiles, tiles);
-    uint32_t running = chunk_sums[(size_t)c * kRadix + d];
-    for (uint32_t t = t0; t < t1; t++) {
-        const uint32_t x = tile_hist[(size_t)t * kRadix + d];
-        tile_hist[(size_t)t * kRadix + d] = running;
-        running += x;
+#pragma unroll
+    for (int p = 0; p < kPasses; p++) {
+        const uint32_t c = s_hist[p][t];
+        if (c) atomicAdd(&ghist[p * kRadix + t], c);
     }
 }
 
-// ---- rank + scatter ("downsweep") -----------------------------------------------------------
 // Lanes of a wave that hold the same 8-bit digit: 8 ballots, one per digit bit.
 __device__ __forceinline__ uint64_t match_digit(uint32_t digit)
 {
@@ -131,33 +92,54 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t digit)
     return peers;
 }
 
-__global__ __launch_bounds__(kThreads) void sort_downsweep_kernel(
+// ---- one pass: rank + look-back + scatter ----------------------------------------------------------
+template <int ITEMS>
+__global__ __launch_bounds__(kThreads) void sort_onesweep_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t count, uint32_t shift,
-    const uint32_t* __restrict__ tile_base)
+    const uint32_t* __restrict__ ghist,   // [256] digit totals of this pass
+    uint32_t* status,                     // [tiles][256] status words of this pass (zeroed per sort)
+    uint32_t* ticket)                     // tile ticket of this pass (zeroed per sort)
 {
-    __shared__ uint32_t s_keys[kTile];
-    __shared__ uint32_t s_vals[kTile];
+    constexpr int TILE = kThreads * ITEMS;
+    __shared__ uint32_t s_keys[TILE];
+    __shared__ uint32_t s_vals[TILE];
     __shared__ uint32_t s_wcnt[kWaves][kRadix];  // per-wave digit counts, then per-wave local bases
     __shared__ uint32_t s_gofs[kRadix];          // global base of digit d minus its local start
-    __shared__ uint32_t s_wsum[kWaves];
+    __shared__ uint32_t s_wsum[kWaves + 1];
+    __shared__ uint32_t s_tile;
 
     const uint32_t t = threadIdx.x;
     const uint32_t w = t >> 6;
     const uint32_t lane = lane_id();
-    const uint32_t tile = blockIdx.x;
-    const uint32_t base = tile * (uint32_t)kTile;
-    const uint32_t nvalid = min((uint32_t)kTile, count - base);
-
+    if (t == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int i = 0; i < kWaves; i++) s_wcnt[i][t] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t base = tile * (uint32_t)TILE;
+    const uint32_t nvalid = min((uint32_t)TILE, count - base);
+
+    // exclusive scan of the pass's digit totals = first output index of each digit (every tile
+    // recomputes it from 1 KB of L2-resident counters: cheaper than a launch)
+    uint32_t digit_start;
+    {
+        const uint32_t total = ghist[t];
+        const uint32_t incl = wave_inclusive_sum(total);
+        if (lane == 63) s_wsum[w] = incl;
+        __syncthreads();
+        uint32_t wave_prefix = 0;
+#pragma unroll
+        for (int i = 0; i < kWaves; i++) wave_prefix += (uint32_t)i < w ? s_wsum[i] : 0u;
+        digit_start = incl - total + wave_prefix;
+    }
 
     // wave-striped load: wave w owns keys [base + w*64*ITEMS, +64*ITEMS), item i = 64 consecutive
     // keys, so (item, lane) order is array order — what stability needs.
-    uint32_t key[kItems], val[kItems], rank[kItems];
-    const uint32_t wave_base = base + w * (uint32_t)(LBVH_WAVE * kItems);
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+    const uint32_t wave_base = base + w * (uint32_t)(LBVH_WAVE * ITEMS);
 #pragma unroll
-    for (int i = 0; i < kItems; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const uint32_t idx = wave_base + (uint32_t)i * LBVH_WAVE + lane;
         const bool valid = idx < count;
         // slots past the end behave as 0xFFFFFFFF keys: they are last in array order and carry the
@@ -165,10 +147,9 @@ __global__ __launch_bounds__(kThreads) void sort_downsweep_kernel(
         key[i] = valid ? keys_in[idx] : 0xFFFFFFFFu;
         val[i] = valid ? vals_in[idx] : 0xFFFFFFFFu;
     }
-    __syncthreads();
 
 #pragma unroll
-    for (int i = 0; i < kItems; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const uint32_t d = (key[i] >> shift) & (kRadix - 1);
         const uint64_t peers = match_digit(d);
         const uint32_t r = mbcnt64(peers);              // same-digit lanes below me
@@ -178,26 +159,66 @@ __global__ __launch_bounds__(kThreads) void sort_downsweep_kernel(
     }
     __syncthreads();
 
-    {   // thread t = digit t: wave prefix per digit, block scan over digits, global offsets
+    {   // thread t = digit t
         const uint32_t c0 = s_wcnt[0][t], c1 = s_wcnt[1][t], c2 = s_wcnt[2][t], c3 = s_wcnt[3][t];
-        const uint32_t total = c0 + c1 + c2 + c3;
-        const uint32_t incl = wave_inclusive_sum(total);
+        uint32_t total = c0 + c1 + c2 + c3;
+        // the padding slots of a partial last tile all landed on digit 255: they are not keys
+        if (t == kRadix - 1) total -= (uint32_t)TILE - nvalid;
+
+        // publish this tile's count, then sum the counts of all earlier tiles (decoupled look-back)
+        uint32_t* mine = status + (size_t)tile * kRadix + t;
+        uint32_t excl = 0;
+        if (tile == 0) {
+            __hip_atomic_store(mine, kFlagIncl | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(mine, kFlagAgg | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // walk back over earlier tiles, kLook status words in flight per step (one L2 round trip
+            // serves kLook predecessors); words are consumed strictly in order, nearest first
+            uint32_t p = tile;                       // next word to consume belongs to tile p - 1
+            bool done = false;
+            while (!done) {
+                uint32_t v[kLook];
+#pragma unroll
+                for (int j = 0; j < kLook; j++) {
+                    const uint32_t q = p - 1u - (uint32_t)j;
+                    v[j] = (uint32_t)j < p ? __hip_atomic_load(status + (size_t)q * kRadix + t, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT)
+                                           : kFlagIncl;     // before tile 0: inclusive prefix 0
+                }
+#pragma unroll
+                for (int j = 0; j < kLook; j++) {
+                    if (done) continue;
+                    const uint32_t f = v[j] & ~kValueMask;
+                    if (f == 0) break;                       // not published yet: re-read from here
+                    excl += v[j] & kValueMask;
+                    p--;
+                    if (f == kFlagIncl) done = true;
+                }
+            }
+            __hip_atomic_store(mine, kFlagIncl | ((excl + total) & kValueMask), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+
+        // local layout: digits in order, waves in order inside a digit
+        const uint32_t ltotal = c0 + c1 + c2 + c3;     // including padding slots (they sit last)
+        const uint32_t incl = wave_inclusive_sum(ltotal);
+        __syncthreads();                               // s_wsum reuse
         if (lane == 63) s_wsum[w] = incl;
         __syncthreads();
         uint32_t wave_prefix = 0;
 #pragma unroll
         for (int i = 0; i < kWaves; i++) wave_prefix += (uint32_t)i < w ? s_wsum[i] : 0u;
-        const uint32_t dstart = incl - total + wave_prefix;
+        const uint32_t dstart = incl - ltotal + wave_prefix;
         s_wcnt[0][t] = dstart;
         s_wcnt[1][t] = dstart + c0;
         s_wcnt[2][t] = dstart + c0 + c1;
         s_wcnt[3][t] = dstart + c0 + c1 + c2;
-        s_gofs[t] = tile_base[(size_t)tile * kRadix + t] - dstart;
+        s_gofs[t] = digit_start + excl - dstart;
     }
     __syncthreads();
 
 #pragma unroll
-    for (int i = 0; i < kItems; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const uint32_t d = (key[i] >> shift) & (kRadix - 1);
         const uint32_t pos = s_wcnt[w][d] + rank[i];
         s_keys[pos] = key[i];
@@ -208,7 +229,7 @@ __global__ __launch_bounds__(kThreads) void sort_downsweep_kernel(
     // tile is now digit-sorted in LDS: consecutive threads write consecutive addresses inside
     // each digit run.
 #pragma unroll
-    for (int j = 0; j < kItems; j++) {
+    for (int j = 0; j < ITEMS; j++) {
         const uint32_t pos = (uint32_t)j * kThreads + t;
         if (pos < nvalid) {
             const uint32_t k = s_keys[pos];
@@ -220,6 +241,20 @@ __global__ __launch_bounds__(kThreads) void sort_downsweep_kernel(
     }
 }
 
+template <int ITEMS>
+void launch_passes(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t* alt_keys, uint32_t* alt_vals,
+                   uint32_t count, uint32_t tiles, uint32_t* ghist, uint32_t* status, uint32_t* tickets)
+{
+    uint32_t *ks = d_keys, *vs = d_values, *kd = alt_keys, *vd = alt_vals;
+    for (uint32_t p = 0; p < (uint32_t)kPasses; p++) {   // ComputeBufferSorter.cs:102
+        LBVH_LAUNCH(ctx, sort_onesweep_kernel<ITEMS>, dim3(tiles), dim3(kThreads), ks, vs, kd, vd, count, 8u * p,
+                    ghist + p * kRadix, status + (size_t)p * tiles * kRadix, tickets + p);
+        uint32_t* tmp;
+        tmp = ks; ks = kd; kd = tmp;
+        tmp = vs; vs = vd; vd = tmp;
+    }
+}
+
 }  // namespace
 
 extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values,
@@ -228,39 +263,34 @@ extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     if (count == 0) return LBVH_OK;
     LBVH_REQUIRE(ctx, d_keys != nullptr && d_values != nullptr);
+    LBVH_REQUIRE(ctx, count <= kValueMask);       // status words carry 30-bit counts
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (count == 1) return LBVH_OK;
 
-    const uint32_t tiles = (uint32_t)(((uint64_t)count + kTile - 1) / kTile);
-    const uint32_t chunks = (tiles + kChunkTiles - 1) / kChunkTiles;
+    // tile size: 4096 keys when that still gives every CU several tiles, smaller for small inputs
+    const int items = count >= (1u << 21) ? 16 : (count >= (1u << 19) ? 8 : 4);
+    const uint32_t tile = (uint32_t)kThreads * (uint32_t)items;
+    const uint32_t tiles = (uint32_t)(((uint64_t)count + tile - 1) / tile);
     const size_t pair_bytes = (((size_t)count * 4) + 255) & ~(size_t)255;
-    const size_t hist_bytes = (size_t)tiles * kRadix * 4;
-    const size_t chunk_bytes = (size_t)chunks * kRadix * 4;
-    int rc = lbvh_reserve(ctx, &ctx->sort_scratch, &ctx->sort_scratch_bytes,
-                          2 * pair_bytes + hist_bytes + chunk_bytes);
+    // [ghist 4x256 | tickets (4, padded to 256 B) | status 4 x tiles x 256] is zeroed per sort
+    const size_t head_bytes = (size_t)kPasses * kRadix * 4 + 256;
+    const size_t status_bytes = (size_t)kPasses * tiles * kRadix * 4;
+    int rc = lbvh_reserve(ctx, &ctx->sort_scratch, &ctx->sort_scratch_bytes, 2 * pair_bytes + head_bytes + status_bytes);
     if (rc != LBVH_OK) return rc;
     char* p = (char*)ctx->sort_scratch;
     uint32_t* alt_keys = (uint32_t*)p;
     uint32_t* alt_vals = (uint32_t*)(p + pair_bytes);
-    uint32_t* tile_hist = (uint32_t*)(p + 2 * pair_bytes);
-    uint32_t* chunk_sums = (uint32_t*)(p + 2 * pair_bytes + hist_bytes);
+    uint32_t* ghist = (uint32_t*)(p + 2 * pair_bytes);
+    uint32_t* tickets = ghist + kPasses * kRadix;
+    uint32_t* status = (uint32_t*)(p + 2 * pair_bytes + head_bytes);
+    LBVH_HIP_TRY(ctx, hipMemsetAsync(ghist, 0, head_bytes + status_bytes, ctx->stream));
 
-    uint32_t *ks = d_keys, *vs = d_values, *kd = alt_keys, *vd = alt_vals;
-    for (uint32_t shift = 0; shift < 32; shift += 8) {   // ComputeBufferSorter.cs:102
-        LBVH_LAUNCH(ctx, sort_upsweep_kernel, dim3(tiles), dim3(kThreads), ks, count,
-                           shift, tile_hist);
-        LBVH_LAUNCH(ctx, sort_scan_reduce_kernel, dim3(chunks), dim3(kRadix),
-                           tile_hist, tiles, chunk_sums);
-        LBVH_LAUNCH(ctx, sort_scan_chunks_kernel, dim3(1), dim3(kRadix), chunk_sums,
-                           chunks);
-        LBVH_LAUNCH(ctx, sort_scan_apply_kernel, dim3(chunks), dim3(kRadix),
-                           tile_hist, tiles, chunk_sums);
-        LBVH_LAUNCH(ctx, sort_downsweep_kernel, dim3(tiles), dim3(kThreads), ks, vs,
-                           kd, vd, count, shift, tile_hist);
-        uint32_t* tmp;
-        tmp = ks; ks = kd; kd = tmp;
-        tmp = vs; vs = vd; vd = tmp;
-    }
+    uint32_t hblocks = (count + kThreads * 4 - 1) / (kThreads * 4);
+    if (hblocks > 256u * 8u) hblocks = 256u * 8u;
+    LBVH_LAUNCH(ctx, sort_histogram_kernel, dim3(hblocks), dim3(kThreads), d_keys, count, ghist);
+    if (items == 16) launch_passes<16>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, tickets);
+    else if (items == 8) launch_passes<8>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, tickets);
+    else launch_passes<4>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, tickets);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;   // 4 passes: the result is back in d_keys / d_values
 }

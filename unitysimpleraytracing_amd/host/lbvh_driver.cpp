@@ -42,7 +42,7 @@ int main(int argc, char** argv)
         auto t1 = std::chrono::steady_clock::now();
         lbvh_camera cam;
         cam.screen_width = w; cam.screen_height = h;
-        cam.camera_fov = std::tan(60.0f * 3.14159265358979f / 180.0f / 2.0f);
+        cam.camera_fov = (float)std::tan(60.0 * 3.14159265358979323846 / 180.0 / 2.0);   // Mathf.Tan(fov * Deg2Rad / 2)
         cam.near_plane = 0.3f;
         const float m[16] = {-1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 300, 0, 0, 0, 1};
         std::memcpy(cam.camera_to_world, m, sizeof m);
@@ -55,7 +55,7 @@ int main(int argc, char** argv)
         for (uint32_t i = 0; i < n; i++) key_sum += drawer.Container().Keys().LocalBuffer()[i];
         for (uint32_t i = 0; i + 1 < n; i++) {
             const auto& nd = drawer.Container().BvhInternalNode().LocalBuffer()[i];
-            node_sum += (uint64_t)nd.leftNode * 3 + nd.rightNode * 5 + nd.parent * 7 + nd.leftNodeType + nd.rightNodeType;
+            node_sum += (uint64_t)nd.leftNode * 3 + (uint64_t)nd.rightNode * 5 + (uint64_t)nd.parent * 7 + nd.leftNodeType + nd.rightNodeType;
         }
         size_t hits = 0;
         double tsum = 0;
