@@ -7,7 +7,7 @@
 // so the output is the unique stable sort = the reference's result bit for bit.  What changes:
 //   * one histogram kernel reads the keys ONCE and produces all four 256-bin digit histograms
 //     (the reference recounts per pass inside LocalRadixSort);
-//   * each pass is ONE kernel: a tile (256 threads x ITEMS keys) ranks its keys, publishes its 256
+//   * each pass is ONE kernel: a tile (512 threads x 8 or 16 keys) ranks its keys, publishes its 256
 //     digit counts and obtains the counts of all earlier tiles by decoupled look-back over per-tile
 //     status words, instead of the reference's digit-major table + three scan dispatches
 //     (Scan.compute:15-96).  16 B/pair/pass + 4 B/pair once, against 20 B/pair/pass;
@@ -27,7 +27,6 @@
 namespace {
 
 constexpr int kThreads = 256;          // 4 waves
-constexpr int kWaves = kThreads / LBVH_WAVE;
 constexpr int kRadix = 256;
 constexpr int kPasses = 4;
 
@@ -93,28 +92,29 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t digit)
 }
 
 // ---- one pass: rank + look-back + scatter ----------------------------------------------------------
-template <int ITEMS>
-__global__ __launch_bounds__(kThreads) void sort_onesweep_kernel(
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t count, uint32_t shift,
     const uint32_t* __restrict__ ghist,   // [256] digit totals of this pass
     uint32_t* status,                     // [tiles][256] status words of this pass (zeroed per sort)
     uint32_t* ticket)                     // tile ticket of this pass (zeroed per sort)
 {
-    constexpr int TILE = kThreads * ITEMS;
+    constexpr int TILE = THREADS * ITEMS;
+    constexpr int WAVES = THREADS / LBVH_WAVE;
+    constexpr int DWAVES = kRadix / LBVH_WAVE;   // waves that own the 256 digits
     __shared__ uint32_t s_keys[TILE];
     __shared__ uint32_t s_vals[TILE];
-    __shared__ uint32_t s_wcnt[kWaves][kRadix];  // per-wave digit counts, then per-wave local bases
+    __shared__ uint32_t s_wcnt[WAVES][kRadix];   // per-wave digit counts, then per-wave local bases
     __shared__ uint32_t s_gofs[kRadix];          // global base of digit d minus its local start
-    __shared__ uint32_t s_wsum[kWaves + 1];
+    __shared__ uint32_t s_wsum[DWAVES + 1];
     __shared__ uint32_t s_tile;
 
     const uint32_t t = threadIdx.x;
     const uint32_t w = t >> 6;
     const uint32_t lane = lane_id();
     if (t == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int i = 0; i < kWaves; i++) s_wcnt[i][t] = 0;
+    for (int i = t; i < WAVES * kRadix; i += THREADS) (&s_wcnt[0][0])[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint32_t base = tile * (uint32_t)TILE;
@@ -122,15 +122,15 @@ __global__ __launch_bounds__(kThreads) void sort_onesweep_kernel(
 
     // exclusive scan of the pass's digit totals = first output index of each digit (every tile
     // recomputes it from 1 KB of L2-resident counters: cheaper than a launch)
-    uint32_t digit_start;
+    uint32_t digit_start = 0;
     {
-        const uint32_t total = ghist[t];
+        const uint32_t total = t < (uint32_t)kRadix ? ghist[t] : 0u;
         const uint32_t incl = wave_inclusive_sum(total);
-        if (lane == 63) s_wsum[w] = incl;
+        if (lane == 63 && w < (uint32_t)DWAVES) s_wsum[w] = incl;
         __syncthreads();
         uint32_t wave_prefix = 0;
 #pragma unroll
-        for (int i = 0; i < kWaves; i++) wave_prefix += (uint32_t)i < w ? s_wsum[i] : 0u;
+        for (int i = 0; i < DWAVES; i++) wave_prefix += (uint32_t)i < w ? s_wsum[i] : 0u;
         digit_start = incl - total + wave_prefix;
     }
 
@@ -159,15 +159,17 @@ __global__ __launch_bounds__(kThreads) void sort_onesweep_kernel(
     }
     __syncthreads();
 
-    {   // thread t = digit t
-        const uint32_t c0 = s_wcnt[0][t], c1 = s_wcnt[1][t], c2 = s_wcnt[2][t], c3 = s_wcnt[3][t];
-        uint32_t total = c0 + c1 + c2 + c3;
+    uint32_t ltotal = 0, excl = 0;
+    if (t < (uint32_t)kRadix) {   // thread t = digit t
+        uint32_t total = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) total += s_wcnt[i][t];
+        ltotal = total;                                // including padding slots (they sit last)
         // the padding slots of a partial last tile all landed on digit 255: they are not keys
         if (t == kRadix - 1) total -= (uint32_t)TILE - nvalid;
 
         // publish this tile's count, then sum the counts of all earlier tiles (decoupled look-back)
         uint32_t* mine = status + (size_t)tile * kRadix + t;
-        uint32_t excl = 0;
         if (tile == 0) {
             __hip_atomic_store(mine, kFlagIncl | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
@@ -198,22 +200,26 @@ __global__ __launch_bounds__(kThreads) void sort_onesweep_kernel(
             __hip_atomic_store(mine, kFlagIncl | ((excl + total) & kValueMask), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
-
-        // local layout: digits in order, waves in order inside a digit
-        const uint32_t ltotal = c0 + c1 + c2 + c3;     // including padding slots (they sit last)
+    }
+    {   // local layout: digits in order, waves in order inside a digit
         const uint32_t incl = wave_inclusive_sum(ltotal);
         __syncthreads();                               // s_wsum reuse
-        if (lane == 63) s_wsum[w] = incl;
+        if (lane == 63 && w < (uint32_t)DWAVES) s_wsum[w] = incl;
         __syncthreads();
-        uint32_t wave_prefix = 0;
+        if (t < (uint32_t)kRadix) {
+            uint32_t wave_prefix = 0;
 #pragma unroll
-        for (int i = 0; i < kWaves; i++) wave_prefix += (uint32_t)i < w ? s_wsum[i] : 0u;
-        const uint32_t dstart = incl - ltotal + wave_prefix;
-        s_wcnt[0][t] = dstart;
-        s_wcnt[1][t] = dstart + c0;
-        s_wcnt[2][t] = dstart + c0 + c1;
-        s_wcnt[3][t] = dstart + c0 + c1 + c2;
-        s_gofs[t] = digit_start + excl - dstart;
+            for (int i = 0; i < DWAVES; i++) wave_prefix += (uint32_t)i < w ? s_wsum[i] : 0u;
+            const uint32_t dstart = incl - ltotal + wave_prefix;
+            uint32_t run = dstart;
+#pragma unroll
+            for (int i = 0; i < WAVES; i++) {
+                const uint32_t c = s_wcnt[i][t];
+                s_wcnt[i][t] = run;
+                run += c;
+            }
+            s_gofs[t] = digit_start + excl - dstart;
+        }
     }
     __syncthreads();
 
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(kThreads) void sort_onesweep_kernel(
     // each digit run.
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {
-        const uint32_t pos = (uint32_t)j * kThreads + t;
+        const uint32_t pos = (uint32_t)j * THREADS + t;
         if (pos < nvalid) {
             const uint32_t k = s_keys[pos];
             const uint32_t d = (k >> shift) & (kRadix - 1);
@@ -241,14 +247,14 @@ __global__ __launch_bounds__(kThreads) void sort_onesweep_kernel(
     }
 }
 
-template <int ITEMS>
+template <int THREADS, int ITEMS>
 void launch_passes(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t* alt_keys, uint32_t* alt_vals,
                    uint32_t count, uint32_t tiles, uint32_t* ghist, uint32_t* status, uint32_t* tickets)
 {
     uint32_t *ks = d_keys, *vs = d_values, *kd = alt_keys, *vd = alt_vals;
     for (uint32_t p = 0; p < (uint32_t)kPasses; p++) {   // ComputeBufferSorter.cs:102
-        LBVH_LAUNCH(ctx, sort_onesweep_kernel<ITEMS>, dim3(tiles), dim3(kThreads), ks, vs, kd, vd, count, 8u * p,
-                    ghist + p * kRadix, status + (size_t)p * tiles * kRadix, tickets + p);
+        LBVH_LAUNCH(ctx, (sort_onesweep_kernel<THREADS, ITEMS>), dim3(tiles), dim3(THREADS), ks, vs, kd, vd, count,
+                    8u * p, ghist + p * kRadix, status + (size_t)p * tiles * kRadix, tickets + p);
         uint32_t* tmp;
         tmp = ks; ks = kd; kd = tmp;
         tmp = vs; vs = vd; vd = tmp;
@@ -267,9 +273,11 @@ extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (count == 1) return LBVH_OK;
 
-    // tile size: 4096 keys when that still gives every CU several tiles, smaller for small inputs
-    const int items = count >= (1u << 21) ? 16 : (count >= (1u << 19) ? 8 : 4);
-    const uint32_t tile = (uint32_t)kThreads * (uint32_t)items;
+    // tile = 512 threads x 16 keys (8192) for big inputs: long digit runs = fuller cache lines in the
+    // scatter and short look-back chains (measured best of 256..1024 threads x 4..16 keys at 2^24..2^28);
+    // 512 x 8 below 2 M keys so every CU still gets tiles
+    const int threads = 512, items = count >= (1u << 21) ? 16 : 8;
+    const uint32_t tile = (uint32_t)threads * (uint32_t)items;
     const uint32_t tiles = (uint32_t)(((uint64_t)count + tile - 1) / tile);
     const size_t pair_bytes = (((size_t)count * 4) + 255) & ~(size_t)255;
     // [ghist 4x256 | tickets (4, padded to 256 B) | status 4 x tiles x 256] is zeroed per sort
@@ -285,12 +293,13 @@ extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint
     uint32_t* status = (uint32_t*)(p + 2 * pair_bytes + head_bytes);
     LBVH_HIP_TRY(ctx, hipMemsetAsync(ghist, 0, head_bytes + status_bytes, ctx->stream));
 
-    uint32_t hblocks = (count + kThreads * 4 - 1) / (kThreads * 4);
+    // 4 K keys per block up to 2048 blocks: enough blocks to hide the load latency, few enough that the
+    // 1024 global atomics each block ends with do not pile up on the same counters
+    uint32_t hblocks = (count + 4095u) / 4096u;
     if (hblocks > 256u * 8u) hblocks = 256u * 8u;
     LBVH_LAUNCH(ctx, sort_histogram_kernel, dim3(hblocks), dim3(kThreads), d_keys, count, ghist);
-    if (items == 16) launch_passes<16>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, tickets);
-    else if (items == 8) launch_passes<8>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, tickets);
-    else launch_passes<4>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, tickets);
+    if (items == 16) launch_passes<512, 16>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, tickets);
+    else launch_passes<512, 8>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, tickets);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;   // 4 passes: the result is back in d_keys / d_values
 }
