@@ -216,7 +216,8 @@ def main():
         a.dispose(); b.dispose()
 
         roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": measured_traffic("trace_packet_kernel<false>"),
                     "bytes_per_ray": round(bytes_per_ray, 1), "bytes_per_ray_basis": "reference visit order, "
                     "32P+24B+44L+48T+8 (SURVEY 8d)", "reference_visits_per_ray": ref_counts,
                     "own_bytes_per_ray": None if own_bytes_per_ray is None else round(own_bytes_per_ray, 1),
@@ -265,6 +266,25 @@ def main():
         print(json.dumps(out))
 
 
+def measured_traffic(kernel_substr, largest_grid=True):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (tools/prof.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950
+    note in MI355X_MICROARCH.md).  None if no profile has been committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*traffic.json")))
+    if not files:
+        return None
+    table = json.load(open(files[-1]))
+    rows = [(int(k.split("@")[1]), v) for k, v in table.items() if kernel_substr in k and v.get("fetch_bytes_x2") is not None
+            and v.get("write_bytes") is not None]
+    if not rows:
+        return None
+    rows.sort(key=lambda r: r[0])
+    v = rows[-1][1] if largest_grid else rows[0][1]
+    return {"bytes": round(v["fetch_bytes_x2"] + v["write_bytes"]), "fetch_bytes_x2": round(v["fetch_bytes_x2"]),
+            "write_bytes": round(v["write_bytes"]), "source": os.path.relpath(files[-1], ROOT)}
+
+
 def sort_microbench(ctx, log2n, copy_gbs):
     """Radix-sort micro-bench on 2^log2n uniform random (key, value) pairs: large enough that the
     pairs stream from HBM, not from L2 / Infinity Cache.  Reports the scatter (downsweep) kernel:
@@ -302,7 +322,8 @@ def sort_microbench(ctx, log2n, copy_gbs):
     kernel_ms = down[1] / down[0]
     achieved = 16.0 * n / (kernel_ms * 1e-3) / 1e9
     return {"kernel": "sort scatter pass", "keys": n, "bound": "hbm", "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": measured_traffic("sort_onesweep_kernel") if log2n == 26 else None,
             "kernel_ms": round(kernel_ms, 4), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
             "sort_Gkeys_s": round(n / (sort_ms * 1e-3) / 1e9, 3), "sort_ms": round(sort_ms, 3),
             "kernels_ms": {name: round(v[1] / reps, 4) for name, v in prof_sum.items()}}
