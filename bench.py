@@ -217,7 +217,7 @@ def main():
 
         roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": measured_traffic("trace_packet_kernel<false>"),
+                    "traffic": measured_traffic("trace_packet_kernel<false"),
                     "bytes_per_ray": round(bytes_per_ray, 1), "bytes_per_ray_basis": "reference visit order, "
                     "32P+24B+44L+48T+8 (SURVEY 8d)", "reference_visits_per_ray": ref_counts,
                     "own_bytes_per_ray": None if own_bytes_per_ray is None else round(own_bytes_per_ray, 1),

@@ -114,13 +114,13 @@ typedef struct lbvh_camera {
 
 /* Traversal flavours of lbvh_trace_primary. */
 #define LBVH_TRACE_REFERENCE 0  /* the reference's visit order, no pruning, separate node arrays */
-#define LBVH_TRACE_FAST      1  /* 8x8 packets over fused 64-B nodes, near-first, t-pruned; same min-t */
+#define LBVH_TRACE_FAST      1  /* 16x8 packets over fused 64-B nodes, near-first, t-pruned; same min-t */
 
 /* Optional per-launch traversal statistics (sums over all rays of the launch), in the
  * reference's visit semantics for LBVH_TRACE_REFERENCE: P nodes popped, B internal boxes hit,
  * L leaf-AABB tests, T triangle tests.  Used for the algorithmic-bytes figure.
- * LBVH_TRACE_FAST walks one 8x8-pixel packet per wave: there `pops` = 64-byte node fetches and
- * `leaf_tests` = 48-byte triangle fetches per PACKET (each shared by the packet's 64 rays),
+ * LBVH_TRACE_FAST walks one 16x8-pixel packet per wave: there `pops` = 64-byte node fetches and
+ * `leaf_tests` = 48-byte triangle fetches per PACKET (each shared by the packet's 128 rays),
  * `box_hits` and `tri_tests` stay per ray. */
 typedef struct lbvh_trace_stats {
     uint64_t pops;

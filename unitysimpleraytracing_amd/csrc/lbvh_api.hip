@@ -239,8 +239,16 @@ lbvh_status lbvh_profile_end(lbvh_context* ctx, lbvh_profile_row* h_rows, int32_
     for (auto& s : ctx->prof_spans) {
         float ms = 0.0f;
         LBVH_HIP_TRY(ctx, hipEventElapsedTime(&ms, s.a, s.b));
-        // kernel names arrive as "ns::kernel<...>" spellings of the launch site; keep the tail
-        const char* nm = s.name;
+        // launch sites spell templated kernels as "(name<...>)": drop the parentheses
+        char nm[sizeof(h_rows[0].name)];
+        {
+            const char* src = s.name;
+            size_t len = strlen(src);
+            if (len >= 2 && src[0] == '(' && src[len - 1] == ')') { src++; len -= 2; }
+            if (len > sizeof(nm) - 1) len = sizeof(nm) - 1;
+            memcpy(nm, src, len);
+            nm[len] = 0;
+        }
         int32_t row = -1;
         for (int32_t i = 0; i < n; i++)
             if (strncmp(h_rows[i].name, nm, sizeof(h_rows[i].name) - 1) == 0) { row = i; break; }

@@ -266,8 +266,8 @@ __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh
 // ---------------------------------------------------------------------------------------------
 // LBVH_TRACE_FAST — packet traversal
 //
-// The 64 primary rays of an 8x8-pixel tile leave one pinhole and stay together almost to the
-// leaves, so the wave walks the tree ONCE for all of them:
+// The primary rays of a small pixel tile (16x8 pixels: 2 rays per lane) leave one pinhole and stay
+// together almost to the leaves, so the wave walks the tree ONCE for all of them:
 //   * the current node index is wave-uniform: the 64-byte fused node arrives as ONE coalesced line
 //     (lane k loads dword k, v_readlane broadcasts into SGPRs), not as 64 divergent vector gathers
 //     (the per-lane form measured 22 % lane utilisation and an L1 pipe stalled on pending misses;
@@ -348,12 +348,15 @@ __device__ __forceinline__ void load_tri_uniform(const lbvh_fast_tri* __restrict
     v2 = make_float4(LBVH_RL(w, 8), LBVH_RL(w, 9), LBVH_RL(w, 10), 0.0f);
 }
 
-template <bool STATS>
+// RX x RY rays per lane: the packet is an (8 RX) x (8 RY)-pixel tile, lane (lx, ly) owns the RX x RY
+// pixel block at (lx RX, ly RY).  One tree walk, one node fetch and one vote serve all 64 RX RY rays.
+template <bool STATS, int RX, int RY>
 __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
                                                            const lbvh_fast_tri* __restrict__ tris,
                                                            uint32_t n_tiles, tile_queues* queues,
                                                            lbvh_hit* __restrict__ hits, lbvh_trace_stats* stats)
 {
+    constexpr int R = RX * RY;
     const uint32_t lane = lane_id();
     const uint32_t home = xcc_id();
     const uint32_t rw = (uint32_t)(a.x1 - a.x0);
@@ -362,12 +365,23 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
     for (;;) {
         const uint32_t tile = next_tile(queues, n_tiles, home);
         if (tile == kNoTile) break;
-        uint32_t px, py;
-        const bool active = tile_pixel(a, tile, lane, px, py);
-        const ray_t ray = make_ray(a.cam, px, py);
-        float best_t = LBVH_MAX_FLOAT;
-        uint32_t best_tri = 0;
-        float best_u = 0.0f, best_v = 0.0f;
+        const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const uint32_t px0 = (uint32_t)a.x0 + tx * (8u * RX) + (lane & 7u) * RX;
+        const uint32_t py0 = (uint32_t)a.y0 + ty * (8u * RY) + (lane >> 3) * RY;
+        ray_t ray[R];
+        bool act[R];
+        float best_t[R], best_u[R], best_v[R];
+        uint32_t best_tri[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t px = px0 + (uint32_t)(r % RX), py = py0 + (uint32_t)(r / RX);
+            act[r] = px < (uint32_t)a.x1 && py < (uint32_t)a.y1;
+            ray[r] = make_ray(a.cam, px, py);
+            best_t[r] = LBVH_MAX_FLOAT;
+            best_tri[r] = 0;
+            best_u[r] = 0.0f;
+            best_v[r] = 0.0f;
+        }
 
         int stack = 0;            // wave-shared stack: slot k lives in lane k of this VGPR
         uint32_t sp = 0;          // scalar
@@ -378,46 +392,65 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
             const uint32_t lref = __float_as_uint(nd.lmin.w), rref = __float_as_uint(nd.lmax.w);
             const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
             if (STATS && lane == 0) n_pops++;
-            float tl, tr;
-            bool hit_l = active && ray_box(nd.lmin, nd.lmax, ray, tl);
-            bool hit_r = active && ray_box(nd.rmin, nd.rmax, ray, tr);
-            if (STATS) n_box += (hit_l ? 1u : 0u) + (hit_r ? 1u : 0u);
-            // a box that starts beyond this lane's best hit cannot hold a nearer one
-            hit_l = hit_l && !(tl > best_t);
-            hit_r = hit_r && !(tr > best_t);
+            float tl[R], tr[R];
+            bool hit_l[R], hit_r[R];
+            bool any_l = false, any_r = false;
+            int pref = 0;     // > 0: this lane's rays that want both children reach the left one first
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                hit_l[r] = act[r] && ray_box(nd.lmin, nd.lmax, ray[r], tl[r]);
+                hit_r[r] = act[r] && ray_box(nd.rmin, nd.rmax, ray[r], tr[r]);
+                if (STATS) n_box += (hit_l[r] ? 1u : 0u) + (hit_r[r] ? 1u : 0u);
+                // a box that starts beyond this ray's best hit cannot hold a nearer one
+                hit_l[r] = hit_l[r] && !(tl[r] > best_t[r]);
+                hit_r[r] = hit_r[r] && !(tr[r] > best_t[r]);
+                any_l |= hit_l[r];
+                any_r |= hit_r[r];
+            }
             // leaves first: their hits tighten best_t before anything is entered
-            if (leaf_l && __any(hit_l)) {
+            if (leaf_l && __any(any_l)) {
                 float4 v0, v1, v2;
                 load_tri_uniform(tris, lref & 0x7FFFFFFFu, lane, v0, v1, v2);
                 if (STATS && lane == 0) n_leaf++;        // one 48-B triangle fetch for the packet
-                if (hit_l) {
-                    if (STATS) n_tri++;
-                    float u = 0.0f, v = 0.0f;
-                    const float dist = ray_triangle(ray, v0, v1, v2, u, v);
-                    if (dist < best_t) { best_t = dist; best_tri = __float_as_uint(v0.w); best_u = u; best_v = v; }
+                any_r = false;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (hit_l[r]) {
+                        if (STATS) n_tri++;
+                        float u = 0.0f, v = 0.0f;
+                        const float dist = ray_triangle(ray[r], v0, v1, v2, u, v);
+                        if (dist < best_t[r]) { best_t[r] = dist; best_tri[r] = __float_as_uint(v0.w); best_u[r] = u; best_v[r] = v; }
+                    }
+                    hit_r[r] = hit_r[r] && !(tr[r] > best_t[r]);
+                    any_r |= hit_r[r];
                 }
-                hit_r = hit_r && !(tr > best_t);
             }
-            if (leaf_r && __any(hit_r)) {
+            if (leaf_r && __any(any_r)) {
                 float4 v0, v1, v2;
                 load_tri_uniform(tris, rref & 0x7FFFFFFFu, lane, v0, v1, v2);
                 if (STATS && lane == 0) n_leaf++;
-                if (hit_r) {
-                    if (STATS) n_tri++;
-                    float u = 0.0f, v = 0.0f;
-                    const float dist = ray_triangle(ray, v0, v1, v2, u, v);
-                    if (dist < best_t) { best_t = dist; best_tri = __float_as_uint(v0.w); best_u = u; best_v = v; }
+                any_l = false;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (hit_r[r]) {
+                        if (STATS) n_tri++;
+                        float u = 0.0f, v = 0.0f;
+                        const float dist = ray_triangle(ray[r], v0, v1, v2, u, v);
+                        if (dist < best_t[r]) { best_t[r] = dist; best_tri[r] = __float_as_uint(v0.w); best_u[r] = u; best_v[r] = v; }
+                    }
+                    hit_l[r] = hit_l[r] && !(tl[r] > best_t[r]);
+                    any_l |= hit_l[r];
                 }
-                hit_l = hit_l && !(tl > best_t);
             }
-            const uint64_t ml = leaf_l ? 0ull : __ballot(hit_l);
-            const uint64_t mr = leaf_r ? 0ull : __ballot(hit_r);
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (hit_l[r] && hit_r[r]) pref += tl[r] <= tr[r] ? 1 : -1;
+            const uint64_t ml = leaf_l ? 0ull : __ballot(any_l);
+            const uint64_t mr = leaf_r ? 0ull : __ballot(any_r);
             if (ml != 0 && mr != 0) {
                 // both children wanted: the side most lanes reach first goes first
-                const uint64_t both = ml & mr;
-                const uint64_t l_first = __ballot(tl <= tr) & both;
-                const bool l_near = both == 0 ? (__popcll(ml) >= __popcll(mr))
-                                              : (2 * __popcll(l_first) >= __popcll(both));
+                const int l_votes = __popcll(__ballot(pref > 0)), r_votes = __popcll(__ballot(pref < 0));
+                const bool l_near = l_votes == r_votes ? (__popcll(ml) >= __popcll(mr)) : (l_votes > r_votes);
                 const uint32_t far = l_near ? rref : lref;
                 node = l_near ? lref : rref;
                 stack = lane == (sp & 63u) ? (int)far : stack;      // v_cndmask: slot sp := far
@@ -432,17 +465,37 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
                 node = (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u);
             }
         }
-        if (active) {
-            float4 out;
-            out.x = best_t;
-            out.y = __uint_as_float(best_tri);
-            out.z = best_u;
-            out.w = best_v;
-            reinterpret_cast<float4*>(hits)[(size_t)(py - (uint32_t)a.y0) * rw + (px - (uint32_t)a.x0)] = out;
-            if (STATS && best_t < LBVH_MAX_FLOAT) n_hit++;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (act[r]) {
+                const uint32_t px = px0 + (uint32_t)(r % RX), py = py0 + (uint32_t)(r / RX);
+                float4 out;
+                out.x = best_t[r];
+                out.y = __uint_as_float(best_tri[r]);
+                out.z = best_u[r];
+                out.w = best_v[r];
+                reinterpret_cast<float4*>(hits)[(size_t)(py - (uint32_t)a.y0) * rw + (px - (uint32_t)a.x0)] = out;
+                if (STATS && best_t[r] < LBVH_MAX_FLOAT) n_hit++;
+            }
         }
     }
     if (STATS) add_stats(stats, n_pops, n_box, n_leaf, n_tri, n_hit);
+}
+
+template <int RX, int RY>
+void launch_packets(lbvh_context* ctx, trace_args a, tile_queues* q, lbvh_hit* d_hits, lbvh_trace_stats* d_stats)
+{
+    a.tiles_x = (uint32_t)(a.x1 - a.x0 + 8 * RX - 1) / (8 * RX);
+    a.tiles_y = (uint32_t)(a.y1 - a.y0 + 8 * RY - 1) / (8 * RY);
+    const uint32_t n_tiles = a.tiles_x * a.tiles_y;
+    uint32_t blocks = 256u * 8u;       // persistent 4-wave workgroups, no LDS
+    if (blocks * 4 > n_tiles) blocks = (n_tiles + 3) / 4;
+    if (d_stats)
+        LBVH_LAUNCH(ctx, (trace_packet_kernel<true, RX, RY>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris,
+                    n_tiles, q, d_hits, d_stats);
+    else
+        LBVH_LAUNCH(ctx, (trace_packet_kernel<false, RX, RY>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris,
+                    n_tiles, q, d_hits, d_stats);
 }
 
 }  // namespace
@@ -514,18 +567,12 @@ lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera, i
         if (!ctx->fast_nodes || ctx->fast_n != s.n)
             return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_trace_primary",
                                   "LBVH_TRACE_FAST needs lbvh_build_fast_scene on this scene first");
-        // persistent 4-wave workgroups, 8 per CU (no LDS; 32 waves/CU if registers allow)
         if (!ctx->trace_queues) LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->trace_queues, 256));
         LBVH_HIP_TRY(ctx, hipMemsetAsync(ctx->trace_queues, 0, 32, ctx->stream));
-        uint32_t blocks = 256u * 8u;
-        if (blocks * 4 > n_tiles) blocks = (n_tiles + 3) / 4;
         tile_queues* q = (tile_queues*)ctx->trace_queues;
-        if (d_stats)
-            LBVH_LAUNCH(ctx, trace_packet_kernel<true>, dim3(blocks), dim3(256), a, ctx->fast_nodes,
-                        ctx->fast_tris, n_tiles, q, d_hits, d_stats);
-        else
-            LBVH_LAUNCH(ctx, trace_packet_kernel<false>, dim3(blocks), dim3(256), a, ctx->fast_nodes,
-                        ctx->fast_tris, n_tiles, q, d_hits, d_stats);
+        // 2 x 1 rays per lane = 16 x 8-pixel packets: measured best of 1x1 / 2x1 / 1x2 / 3x1 / 2x2 / 4x2
+        // (more rays per lane cut node fetches per ray further but the extra VGPRs cost more occupancy)
+        launch_packets<2, 1>(ctx, a, q, d_hits, d_stats);
     }
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
