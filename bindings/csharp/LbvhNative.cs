@@ -52,7 +52,7 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern int lbvh_build_tree(IntPtr ctx, uint n, IntPtr dSortedKeys, IntPtr dInternal, IntPtr dLeaf);
     [DllImport(Lib)] public static extern int lbvh_refit(IntPtr ctx, uint n, IntPtr dInternal, IntPtr dLeaf,
         IntPtr dTriangleAabb, IntPtr dSortedIndices, IntPtr dBvh);
-    [DllImport(Lib)] public static extern int lbvh_build_fast_scene(IntPtr ctx, ref Scene scene);
+    [DllImport(Lib)] public static extern int lbvh_build_fast_scene(IntPtr ctx, ref Scene scene, float[] boxMin, float[] boxMax);
     [DllImport(Lib)] public static extern int lbvh_trace_primary(IntPtr ctx, ref Camera camera, int x0, int y0, int x1, int y1,
         ref Scene scene, int mode, IntPtr dHits, IntPtr dStats);
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LBVH_ABI_VERSION 1
+#define LBVH_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------------- */
 typedef int32_t lbvh_status;
@@ -243,12 +243,18 @@ typedef struct lbvh_scene {
     const lbvh_triangle*      triangles;         /* triangleData (original order)                  */
 } lbvh_scene;
 
-/* Build the derived traversal structure used by LBVH_TRACE_FAST from the bit-exact arrays of
- * `scene` (fused 64-B nodes holding both child boxes + child references, and 48-B positions-only
- * triangles in sorted order).  Owned by the context, rebuilt on each call; call it after
- * lbvh_refit and before the first LBVH_TRACE_FAST launch.  No reference counterpart: it is a
- * cache of the reference arrays, which stay the ABI. */
-lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene);
+/* Build the derived traversal structure used by LBVH_TRACE_FAST for `scene`: its own "traversal
+ * tree" over the scene's SORTED triangle order (Karras topology over minimally perturbed Morton
+ * keys k'_i = i + max_{j<=i}(k_j - j) instead of DistributeKeys' shifted ones — tighter boxes — and
+ * its own refit), flattened to fused 64-B nodes (both child boxes + child references) plus 48-B
+ * positions-only triangles in sorted order.  h_box_min/max = the scene box given to
+ * lbvh_morton_aabb (the raw Morton code of a sorted position is recomputed from its triangle AABB).
+ * Owned by the context, rebuilt on each call; call it after lbvh_sort_pairs (+ lbvh_morton_aabb) and
+ * before the first LBVH_TRACE_FAST launch.  The scene's internalNodes / leafNodes / bvhData are not
+ * read.  No reference counterpart: hit results are those of the reference arrays (every leaf keeps
+ * the slab test of its own AABB), only the order and number of node visits differ. */
+lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene, const float h_box_min[3],
+                                  const float h_box_max[3]);
 
 /* Replaces RaytracingMeshDrawer.Update's Dispatch of kernel Raytracing
  * (Sc/RaytracingMeshDrawer.cs:76-84, Sh/Raytracing/Raytracing.compute:105-185) up to and

@@ -7,7 +7,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblbvh.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -74,7 +74,7 @@ SIGNATURES = {
     "lbvh_distribute_keys": (_I32, [_P, _P, _U32]),
     "lbvh_build_tree": (_I32, [_P, _U32, _P, _P, _P]),
     "lbvh_refit": (_I32, [_P, _U32, _P, _P, _P, _P, _P]),
-    "lbvh_build_fast_scene": (_I32, [_P, C.POINTER(Scene)]),
+    "lbvh_build_fast_scene": (_I32, [_P, C.POINTER(Scene), _F3, _F3]),
     "lbvh_trace_primary": (_I32, [_P, C.POINTER(Camera), _I32, _I32, _I32, _I32, C.POINTER(Scene),
                                   _I32, _P, _P]),
     "lbvh_event_create": (_I32, [_P, C.POINTER(_P)]),

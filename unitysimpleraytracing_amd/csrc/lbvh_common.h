@@ -59,6 +59,9 @@ struct lbvh_context {
     uint32_t fast_capacity = 0;
     uint32_t fast_n = 0;
     void* trace_queues = nullptr;   // per-XCD tile cursors of the persistent traversal kernel
+    // the traversal tree of the derived scene (aligned keys, own topology and boxes)
+    void* fast_tree = nullptr;
+    size_t fast_tree_bytes = 0;
 
     // per-kernel event profiling (lbvh_profile_begin / lbvh_profile_end)
     struct prof_span { const char* name; hipEvent_t a, b; };
@@ -101,6 +104,19 @@ int lbvh_set_error(lbvh_context* ctx, int code, const char* what, const char* de
     do {                                                                             \
         if (!(cond)) return lbvh_set_error((ctx), LBVH_ERR_INVALID_ARG, "invalid argument", #cond); \
     } while (0)
+
+// Stage launchers shared between translation units (validated arguments, no error reporting of
+// their own beyond hipGetLastError at the caller).
+int lbvh_launch_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, lbvh_internal_node* d_internal,
+                     lbvh_leaf_node* d_leaf);
+int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d_internal, const lbvh_leaf_node* d_leaf,
+                      const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh);
+// d_sorted_indices may be nullptr in lbvh_launch_refit / lbvh_launch_aligned_keys: boxes already in leaf order
+int lbvh_launch_gather_aabb(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_in, const uint32_t* d_index, lbvh_aabb* d_out);
+// aligned traversal keys: k'_i = i + max_{j<=i}(morton(centre of aabb[sorted[j]]) - j), strictly increasing
+int lbvh_launch_aligned_keys(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_triangle_aabb,
+                             const uint32_t* d_sorted_indices, const float box_min[3], const float box_max[3],
+                             uint32_t* d_keys_out);
 
 // Grow-only scratch helper: (re)allocates *ptr to at least `bytes`.
 int lbvh_reserve(lbvh_context* ctx, void** ptr, size_t* have, size_t bytes);

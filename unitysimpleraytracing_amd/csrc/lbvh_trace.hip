@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void build_fast_nodes_kernel(lbvh_scene s, lbv
             ref[side] = c.x;
         } else {
             const uint32_t pos = s.leaf_nodes[c.x].index;                 // sorted position
-            src = reinterpret_cast<const float4*>(&s.triangle_aabb[s.sorted_indices[pos]]);
+            src = reinterpret_cast<const float4*>(&s.triangle_aabb[s.sorted_indices ? s.sorted_indices[pos] : pos]);
             ref[side] = 0x80000000u | pos;
         }
         b[2 * side + 0] = src[0];
@@ -502,10 +502,11 @@ void launch_packets(lbvh_context* ctx, trace_args a, tile_queues* q, lbvh_hit* d
 
 extern "C" {
 
-lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene)
+lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene, const float h_box_min[3],
+                                  const float h_box_max[3])
 {
     if (!ctx) return LBVH_ERR_INVALID_ARG;
-    LBVH_REQUIRE(ctx, h_scene != nullptr);
+    LBVH_REQUIRE(ctx, h_scene != nullptr && h_box_min != nullptr && h_box_max != nullptr);
     const lbvh_scene s = *h_scene;
     LBVH_REQUIRE(ctx, s.n >= 2 && s.n <= 0x7FFFFFFFu);
     LBVH_REQUIRE(ctx, s.sorted_indices && s.triangle_aabb && s.internal_nodes && s.leaf_nodes && s.bvh &&
@@ -520,10 +521,36 @@ lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene)
         LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->fast_tris, (size_t)s.n * sizeof(lbvh_fast_tri)));
         ctx->fast_capacity = s.n;
     }
-    LBVH_LAUNCH(ctx, build_fast_nodes_kernel, dim3((s.n - 1 + 255) / 256), dim3(256), s,
-                       ctx->fast_nodes);
-    LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((s.n + 255) / 256), dim3(256), s,
-                       ctx->fast_tris);
+    // The traversal tree: same sorted triangle order as the scene, its own topology over aligned keys
+    // (lbvh_build.hip) and its own boxes.  The scene's internalNodes / leafNodes / bvhData — the
+    // reference's bit-exact arrays — are not read here: any tree over the same leaves gives the same
+    // hits (every leaf keeps its own AABB test), a tighter one just gives them sooner.
+    const size_t n = s.n;
+    const size_t keys_bytes = (n * 4 + 255) & ~(size_t)255, int_bytes = (n * sizeof(lbvh_internal_node) + 255) & ~(size_t)255,
+                 leaf_bytes = (n * sizeof(lbvh_leaf_node) + 255) & ~(size_t)255, box_bytes = n * sizeof(lbvh_aabb);
+    int rc = lbvh_reserve(ctx, &ctx->fast_tree, &ctx->fast_tree_bytes, keys_bytes + int_bytes + leaf_bytes + 2 * box_bytes);
+    if (rc != LBVH_OK) return rc;
+    char* p = (char*)ctx->fast_tree;
+    uint32_t* t_keys = (uint32_t*)p;
+    lbvh_internal_node* t_internal = (lbvh_internal_node*)(p + keys_bytes);
+    lbvh_leaf_node* t_leaf = (lbvh_leaf_node*)(p + keys_bytes + int_bytes);
+    lbvh_aabb* t_bvh = (lbvh_aabb*)(p + keys_bytes + int_bytes + leaf_bytes);
+    lbvh_aabb* t_leaf_box = (lbvh_aabb*)(p + keys_bytes + int_bytes + leaf_bytes + box_bytes);
+    // the one random gather: triangle AABBs into sorted (leaf) order; everything after reads them in order
+    lbvh_launch_gather_aabb(ctx, s.n, s.triangle_aabb, s.sorted_indices, t_leaf_box);
+    rc = lbvh_launch_aligned_keys(ctx, s.n, t_leaf_box, nullptr, h_box_min, h_box_max, t_keys);
+    if (rc != LBVH_OK) return rc;
+    lbvh_launch_tree(ctx, s.n, t_keys, t_internal, t_leaf);
+    rc = lbvh_launch_refit(ctx, s.n, t_internal, t_leaf, t_leaf_box, nullptr, t_bvh);
+    if (rc != LBVH_OK) return rc;
+    lbvh_scene ts = s;
+    ts.internal_nodes = t_internal;
+    ts.leaf_nodes = t_leaf;
+    ts.bvh = t_bvh;
+    ts.triangle_aabb = t_leaf_box;
+    ts.sorted_indices = nullptr;
+    LBVH_LAUNCH(ctx, build_fast_nodes_kernel, dim3((s.n - 1 + 255) / 256), dim3(256), ts, ctx->fast_nodes);
+    LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((s.n + 255) / 256), dim3(256), s, ctx->fast_tris);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     ctx->fast_n = s.n;
     return LBVH_OK;

@@ -264,8 +264,11 @@ class RaytracingMeshDrawer:
             self.build_fast_scene()
 
     def build_fast_scene(self):
-        s = self.container.scene()
-        N.check(self.ctx.handle, N.lib.lbvh_build_fast_scene(self.ctx.handle, C.byref(s)))
+        c = self.container
+        s = c.scene()
+        f3 = C.POINTER(C.c_float)
+        N.check(self.ctx.handle, N.lib.lbvh_build_fast_scene(self.ctx.handle, C.byref(s), c.box_min.ctypes.data_as(f3),
+                                                             c.box_max.ctypes.data_as(f3)))
 
     def update(self, camera, rect=None, mode=L.TRACE_FAST, stats=False):
         """Enqueue one frame (or the sub-rectangle (x0, y0, x1, y1) of it).  Returns the device

@@ -228,7 +228,8 @@ public:
         bvh_->ConstructTree();                                                                             // :50
         bvh_->ConstructBVH();                                                                              // :51
         const lbvh_scene s = container_->Scene();
-        check(ctx_.get(), lbvh_build_fast_scene(ctx_.get(), &s));
+        const float mn[3] = {-125.0f, -125.0f, -125.0f}, mx[3] = {125.0f, 125.0f, 125.0f};   // MeshBufferContainer.Whole
+        check(ctx_.get(), lbvh_build_fast_scene(ctx_.get(), &s, mn, mx));
     }
     // screenWidth/screenHeight/cameraFov/cameraToWorldMatrix + Dispatch, :78-83
     void Update(const lbvh_camera& cam, int mode = LBVH_TRACE_FAST)
