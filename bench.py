@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--no-sort-bench", action="store_true")
     ap.add_argument("--sort-keys-log2", type=int, default=26)
     ap.add_argument("--mode", choices=["fast", "reference"], default="fast")
+    # test hooks: run the N-rank path on fewer GPUs (ranks share --device, gloo instead of RCCL)
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--device", type=int, default=None)
     return ap.parse_args()
 
 
@@ -82,11 +85,15 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
+    device_id = local_rank if args.device is None else args.device
     if world > 1:
         import torch
         import torch.distributed as dist_mod
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(device_id)
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", device_id))
+        else:
+            dist_mod.init_process_group("gloo")
         dist = dist_mod
 
     from unitysimpleraytracing_amd import layouts as L
@@ -97,13 +104,14 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
 
     def reduce_max(x):
         if dist is None:
             return float(x)
         import torch
-        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -111,7 +119,7 @@ def main():
     assert len(tris) == N_TRIS
     cam = scenes.camera(W, H, CAMERA_POS)
     mode = L.TRACE_FAST if args.mode == "fast" else L.TRACE_REFERENCE
-    ctx = Context(local_rank)
+    ctx = Context(device_id)
     drawer = RaytracingMeshDrawer(ctx, tris)
     drawer.awake(fast=True)                            # allocates everything; untimed
     ctx.sync()

@@ -325,10 +325,17 @@ struct uniform_node {        // one fused node, wave-uniform (lives in SGPRs)
 // i.e. one coalesced 64-byte line through the CU's vector L1, and v_readlane broadcasts the 16
 // dwords into SGPRs.
 #define LBVH_RL(v, k) __int_as_float(__builtin_amdgcn_readlane((v), (k)))
-__device__ __forceinline__ uniform_node load_node_uniform(const lbvh_fast_node* __restrict__ nodes, uint32_t nidx,
-                                                          uint32_t lane)
+__device__ __forceinline__ int fetch_node_dword(const lbvh_fast_node* __restrict__ nodes, uint32_t nidx, uint32_t lane)
 {
-    const int w = reinterpret_cast<const int*>(&nodes[nidx])[lane & 15u];
+    return reinterpret_cast<const int*>(&nodes[nidx])[lane & 15u];
+}
+__device__ __forceinline__ int fetch_tri_dword(const lbvh_fast_tri* __restrict__ tris, uint32_t pos, uint32_t lane)
+{
+    const uint32_t k = lane & 15u;
+    return reinterpret_cast<const int*>(&tris[pos])[k < 12u ? k : 11u];
+}
+__device__ __forceinline__ uniform_node broadcast_node(int w)
+{
     uniform_node nd;
     nd.lmin = make_float4(LBVH_RL(w, 0), LBVH_RL(w, 1), LBVH_RL(w, 2), LBVH_RL(w, 3));
     nd.lmax = make_float4(LBVH_RL(w, 4), LBVH_RL(w, 5), LBVH_RL(w, 6), LBVH_RL(w, 7));
@@ -338,11 +345,8 @@ __device__ __forceinline__ uniform_node load_node_uniform(const lbvh_fast_node* 
 }
 
 // same for a 48-byte sorted triangle (12 dwords)
-__device__ __forceinline__ void load_tri_uniform(const lbvh_fast_tri* __restrict__ tris, uint32_t pos, uint32_t lane,
-                                                 float4& v0, float4& v1, float4& v2)
+__device__ __forceinline__ void broadcast_tri(int w, float4& v0, float4& v1, float4& v2)
 {
-    const uint32_t k = lane & 15u;
-    const int w = reinterpret_cast<const int*>(&tris[pos])[k < 12u ? k : 11u];
     v0 = make_float4(LBVH_RL(w, 0), LBVH_RL(w, 1), LBVH_RL(w, 2), LBVH_RL(w, 3));
     v1 = make_float4(LBVH_RL(w, 4), LBVH_RL(w, 5), LBVH_RL(w, 6), 0.0f);
     v2 = make_float4(LBVH_RL(w, 8), LBVH_RL(w, 9), LBVH_RL(w, 10), 0.0f);
@@ -385,12 +389,16 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
 
         int stack = 0;            // wave-shared stack: slot k lives in lane k of this VGPR
         uint32_t sp = 0;          // scalar
-        uint32_t node = 0;        // scalar; root: its own box is never tested, both children are
+        // root: its own box is never tested, both children are
+        int w_node = fetch_node_dword(nodes, 0, lane);
         for (;;) {
-            const uint32_t nidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
-            const uniform_node nd = load_node_uniform(nodes, nidx, lane);
+            const uniform_node nd = broadcast_node(w_node);
             const uint32_t lref = __float_as_uint(nd.lmin.w), rref = __float_as_uint(nd.lmax.w);
             const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
+            // both children are fetched NOW (node line or triangle line), before the box tests: whichever
+            // the packet goes to next is already in flight — one memory latency per step instead of two
+            const int w_l = leaf_l ? fetch_tri_dword(tris, lref & 0x7FFFFFFFu, lane) : fetch_node_dword(nodes, lref, lane);
+            const int w_r = leaf_r ? fetch_tri_dword(tris, rref & 0x7FFFFFFFu, lane) : fetch_node_dword(nodes, rref, lane);
             if (STATS && lane == 0) n_pops++;
             float tl[R], tr[R];
             bool hit_l[R], hit_r[R];
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
             // leaves first: their hits tighten best_t before anything is entered
             if (leaf_l && __any(any_l)) {
                 float4 v0, v1, v2;
-                load_tri_uniform(tris, lref & 0x7FFFFFFFu, lane, v0, v1, v2);
+                broadcast_tri(w_l, v0, v1, v2);
                 if (STATS && lane == 0) n_leaf++;        // one 48-B triangle fetch for the packet
                 any_r = false;
 #pragma unroll
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
             }
             if (leaf_r && __any(any_r)) {
                 float4 v0, v1, v2;
-                load_tri_uniform(tris, rref & 0x7FFFFFFFu, lane, v0, v1, v2);
+                broadcast_tri(w_r, v0, v1, v2);
                 if (STATS && lane == 0) n_leaf++;
                 any_l = false;
 #pragma unroll
@@ -452,17 +460,17 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
                 const int l_votes = __popcll(__ballot(pref > 0)), r_votes = __popcll(__ballot(pref < 0));
                 const bool l_near = l_votes == r_votes ? (__popcll(ml) >= __popcll(mr)) : (l_votes > r_votes);
                 const uint32_t far = l_near ? rref : lref;
-                node = l_near ? lref : rref;
+                w_node = l_near ? w_l : w_r;
                 stack = lane == (sp & 63u) ? (int)far : stack;      // v_cndmask: slot sp := far
                 sp++;
             } else if (ml != 0) {
-                node = lref;
+                w_node = w_l;
             } else if (mr != 0) {
-                node = rref;
+                w_node = w_r;
             } else {
                 if (sp == 0) break;
                 sp--;
-                node = (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u);
+                w_node = fetch_node_dword(nodes, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), lane);
             }
         }
 #pragma unroll
