@@ -15,7 +15,8 @@ A step = one full pass of the hot path with the triangles already resident in HB
     primary-ray traversal of the frame (Update(), :76-84).
 Nothing is skipped or cached between steps (the tree is rebuilt from the triangles every step).
 With N GPUs the BVH is replicated (every rank builds the whole tree) and the 1080p frame is
-sharded across ranks in interleaved row bands; no collective touches the data path.
+sharded across ranks in interleaved groups of 8 adjacent 16x8-pixel tiles (lbvh_trace_primary_shard,
+one launch per rank); no collective touches the data path.
 
 The JSON line carries both halves of the metric: `value` = primary Mrays/s = rays of the whole
 frame / the traversal part of a step (max over ranks), `build_Mtri_s` = triangles / the build
@@ -55,24 +56,21 @@ def parse():
     return ap.parse_args()
 
 
-def row_bands(rank, world, height, band=8):
-    """Rows of the frame owned by `rank`: 8-row bands dealt round-robin, merged into maximal
-    rectangles.  8 rows = one tile row of the traversal kernel; interleaving balances the hit-heavy
-    centre of the frame against the empty top and bottom."""
-    if world == 1:
-        return [(0, height)]
+TILE_W, TILE_H, SHARD_GROUP = 16, 8, 8      # LBVH_TRACE_FAST packet size and the tile group lbvh_trace_primary_shard deals
+
+
+def shard_tiles(shard_index, shard_count, width, height, tile_w=TILE_W, tile_h=TILE_H, group=SHARD_GROUP):
+    """Python mirror of lbvh_trace_primary_shard's ownership rule (csrc/lbvh_trace.hip shard_tile):
+    tiles of the full frame in row-major order, dealt to shards in groups of `group` adjacent tiles.
+    Returns the (x0, y0, x1, y1) pixel rectangles of the shard's tiles."""
+    tiles_x = (width + tile_w - 1) // tile_w
+    tiles_y = (height + tile_h - 1) // tile_h
+    n_tiles = tiles_x * tiles_y
     out = []
-    nb = (height + band - 1) // band
-    # deal contiguous groups so each rank launches few rectangles but still samples the whole frame
-    group = max(1, nb // (world * 4))
-    b = 0
-    k = 0
-    while b < nb:
-        e = min(b + group, nb)
-        if k % world == rank:
-            out.append((b * band, min(e * band, height)))
-        b = e
-        k += 1
+    for g in range(shard_index, (n_tiles + group - 1) // group, shard_count):
+        for t in range(g * group, min((g + 1) * group, n_tiles)):
+            ty, tx = divmod(t, tiles_x)
+            out.append((tx * tile_w, ty * tile_h, min((tx + 1) * tile_w, width), min((ty + 1) * tile_h, height)))
     return out
 
 
@@ -123,17 +121,15 @@ def main():
     drawer = RaytracingMeshDrawer(ctx, tris)
     drawer.awake(fast=True)                            # allocates everything; untimed
     ctx.sync()
-    bands = row_bands(rank, world, H)
-    my_rays = sum((y1 - y0) * W for y0, y1 in bands)
-    hit_bufs = [DataBuffer(ctx, (y1 - y0) * W, L.HIT) for y0, y1 in bands]
+    hit_buf = DataBuffer(ctx, W * H, L.HIT)             # full-frame layout on every rank
     from unitysimpleraytracing_amd import _native as N
     ccam = N.Camera.from_dict(cam)
 
     def trace_frame():
+        # this rank's share of the frame (every world-th group of 8 adjacent 16x8-pixel tiles), one launch
         s = drawer.container.scene()
-        for (y0, y1), hb in zip(bands, hit_bufs):
-            N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, y0, W, y1, C.byref(s),
-                                                         mode, hb.device, None))
+        N.check(ctx.handle, N.lib.lbvh_trace_primary_shard(ctx.handle, C.byref(ccam), rank, world, C.byref(s), mode,
+                                                           hit_buf.device, None))
 
     def step(ev=None):
         if ev:
@@ -255,7 +251,8 @@ def main():
             "config": {"workload": "cfg2: 1,000,000-triangle tiled bumpy torus (seed 2), 1920x1080 primary rays, "
                                    "camera (0,0,250) fov 60; full LBVH rebuild + frame trace per step",
                        "triangles": N_TRIS, "rays": W * H, "trace_mode": args.mode,
-                       "sharding": f"rays in interleaved row bands over {world} GPU(s), BVH replicated, no collective",
+                       "sharding": f"rays in interleaved groups of 8 tiles over {world} GPU(s) (one launch per GPU), BVH replicated, "
+                                   "no collective",
                        "hit_fraction": round(hit_fraction, 4)},
             "roofline": roofline,
             "roofline_sort_scatter": sort_roofline,

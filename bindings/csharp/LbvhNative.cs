@@ -56,6 +56,9 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern int lbvh_trace_primary(IntPtr ctx, ref Camera camera, int x0, int y0, int x1, int y1,
         ref Scene scene, int mode, IntPtr dHits, IntPtr dStats);
 
+    [DllImport(Lib)] public static extern int lbvh_trace_primary_shard(IntPtr ctx, ref Camera camera, uint shardIndex, uint shardCount,
+        ref Scene scene, int mode, IntPtr dHits, IntPtr dStats);
+
     public static void Check(IntPtr ctx, int status)
     {
         if (status != 0)

@@ -260,14 +260,25 @@ lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene, 
  * (Sc/RaytracingMeshDrawer.cs:76-84, Sh/Raytracing/Raytracing.compute:105-185) up to and
  * including the traversal loop: for every pixel (x, y) with x0 <= x < x1, y0 <= y < y1 generates
  * the camera ray (:108-126), traverses (:133-176) and writes the RaycastResult to
- * d_hits[(y - y0) * (x1 - x0) + (x - x0)].  The rectangle is how rays shard across GPUs;
- * the full frame is (0, 0, W, H).  Pixels outside the screen are never computed (the reference
+ * d_hits[(y - y0) * (x1 - x0) + (x - x0)].  The full frame is (0, 0, W, H); rectangles are one way to
+ * shard rays across GPUs (lbvh_trace_primary_shard below is the other).  Pixels outside the screen are never computed (the reference
  * over-dispatches and relies on D3D dropping out-of-bounds writes, RaytracingMeshDrawer.cs:83).
  * d_stats may be NULL; if not it receives the launch's lbvh_trace_stats (device memory). */
 lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera,
                                int32_t x0, int32_t y0, int32_t x1, int32_t y1,
                                const lbvh_scene* h_scene, int32_t mode,
                                lbvh_hit* d_hits, lbvh_trace_stats* d_stats);
+
+/* Ray sharding across GPUs in ONE launch per GPU: traces the pixels of shard `shard_index` of
+ * `shard_count` of the FULL frame — every shard_count-th group of 8 adjacent pixel tiles (a 128x8-
+ * or 64x8-pixel strip, by mode), so every shard samples the whole frame evenly — and writes them at
+ * their full-frame positions d_hits[y * W + x]; pixels of other shards are not touched.  d_hits
+ * holds W*H records on every GPU.  The BVH is replicated; no collective is involved.  The union over
+ * all shards equals lbvh_trace_primary(0, 0, W, H).  Tile sizes differ by mode, so use ONE mode for
+ * all shards of a frame. */
+lbvh_status lbvh_trace_primary_shard(lbvh_context* ctx, const lbvh_camera* h_camera, uint32_t shard_index,
+                                     uint32_t shard_count, const lbvh_scene* h_scene, int32_t mode,
+                                     lbvh_hit* d_hits, lbvh_trace_stats* d_stats);
 
 /* ---- measurement helpers (HIP events on the context's stream) --------------------------------- */
 

@@ -325,6 +325,39 @@ def test_trace_rectangles_stitch_to_the_full_frame(ctx):
     d.on_destroy()
 
 
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_shards_union_equals_the_full_frame(ctx, shards):
+    """lbvh_trace_primary_shard: one launch per GPU; the shards partition the frame exactly as bench.shard_tiles
+    says and together reproduce the unsharded frame."""
+    from bench import shard_tiles
+    tris = scenes.random_triangles(4096, seed=1)
+    d = H().RaytracingMeshDrawer(ctx, tris).awake()
+    cam = scenes.camera(250, 131, (0.0, 0.0, 300.0))
+    d.update(cam, mode=L.TRACE_FAST)
+    full = d.hits()
+    stitched = np.zeros_like(full)
+    for r in range(shards):
+        d._hits.fill_u32(0xFFFFFFFF)
+        d.update_shard(cam, r, shards, mode=L.TRACE_FAST)
+        part = d.hits()
+        owned = np.zeros(full.shape, dtype=bool)
+        for x0, y0, x1, y1 in shard_tiles(r, shards, 250, 131):
+            owned[y0:y1, x0:x1] = True
+        assert (part.view(np.uint32).reshape(131, 250, 4)[~owned] == 0xFFFFFFFF).all()     # other shards' pixels untouched
+        stitched[owned] = part[owned]
+    assert (stitched == full).all()
+    # reference mode shards too (8x8 tiles): union equals its full frame
+    d.update(cam, mode=L.TRACE_REFERENCE)
+    ref_full = d.hits()
+    acc = np.zeros_like(ref_full)
+    d._hits.fill_u32(0xFFFFFFFF)
+    for r in range(shards):
+        d.update_shard(cam, r, shards, mode=L.TRACE_REFERENCE)
+    acc = d.hits()
+    assert (acc == ref_full).all()
+    d.on_destroy()
+
+
 def test_camera_inside_the_scene_and_negative_t(ctx):
     """The reference accepts t < 0 hits (no t > 0 test, Raytracing.compute:70) when the leaf box
     straddles the origin; both traversal modes must keep that."""

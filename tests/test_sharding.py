@@ -1,6 +1,6 @@
-"""The N>1 path on CPU: world_size-2 gloo run of bench.py's ray sharding (row bands per rank, BVH
-replicated, no data-path collective) with the oracle standing in for the GPU kernels.  Checks that
-the bands partition the frame, that per-rank pieces stitch to the unsharded frame, and that the
+"""The N>1 path on CPU: world_size-2 gloo run of bench.py's ray sharding (interleaved tile groups per rank,
+BVH replicated, no data-path collective) with the oracle standing in for the GPU kernels.  Checks that
+the shards partition the frame, that per-rank pieces stitch to the unsharded frame, and that the
 max-over-ranks timing reduction works over gloo."""
 import os
 import socket
@@ -12,21 +12,23 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from bench import row_bands  # noqa: E402
+from bench import shard_tiles  # noqa: E402
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
-@pytest.mark.parametrize("height", [8, 135, 1080, 1083])
-def test_row_bands_partition_the_frame(world, height):
-    covered = np.zeros(height, dtype=np.int32)
+@pytest.mark.parametrize("size", [(16, 8), (250, 131), (1920, 1080), (1921, 1083)])
+def test_shards_partition_the_frame(world, size):
+    width, height = size
+    covered = np.zeros((height, width), dtype=np.int32)
+    counts = []
     for r in range(world):
-        for y0, y1 in row_bands(r, world, height):
-            assert 0 <= y0 < y1 <= height and y0 % 8 == 0
-            covered[y0:y1] += 1
+        tiles = shard_tiles(r, world, width, height)
+        counts.append(len(tiles))
+        for x0, y0, x1, y1 in tiles:
+            assert 0 <= x0 < x1 <= width and 0 <= y0 < y1 <= height and x0 % 16 == 0 and y0 % 8 == 0
+            covered[y0:y1, x0:x1] += 1
     assert (covered == 1).all()
-    sizes = [sum(y1 - y0 for y0, y1 in row_bands(r, world, height)) for r in range(world)]
-    if height >= 8 * world * 4:
-        assert max(sizes) - min(sizes) <= max(8 * (height // 8 // (world * 4)), 8) + 8   # balanced to one group
+    assert max(counts) - min(counts) <= 8             # balanced to one group of tiles
 
 
 def _worker(rank, world, port, out_path):
@@ -45,10 +47,10 @@ def _worker(rank, world, port, out_path):
     cam = scenes.camera(W, H, (0.0, 0.0, 300.0))
     mine = np.zeros((H, W), dtype=np.float32)
     owned = np.zeros((H, W), dtype=np.float32)
-    for y0, y1 in row_bands(rank, world, H):
-        hits, _ = O.trace_primary(b, cam, rect=(0, y0, W, y1))
-        mine[y0:y1] = hits["t"]
-        owned[y0:y1] = 1.0
+    for x0, y0, x1, y1 in shard_tiles(rank, world, W, H):
+        hits, _ = O.trace_primary(b, cam, rect=(x0, y0, x1, y1))
+        mine[y0:y1, x0:x1] = hits["t"]
+        owned[y0:y1, x0:x1] = 1.0
     t_mine = torch.from_numpy(mine * owned)
     t_owned = torch.from_numpy(owned)
     dist.all_reduce(t_mine)                                # test-side gather only; the data path has none

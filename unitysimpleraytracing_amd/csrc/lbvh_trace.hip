@@ -102,7 +102,24 @@ struct trace_args {
     lbvh_camera cam;
     int32_t x0, y0, x1, y1;
     uint32_t tiles_x, tiles_y;
+    uint32_t shard_index, shard_count;   // this launch traces every shard_count-th GROUP of tiles
 };
+
+constexpr uint32_t kShardGroup = 8;      // adjacent tiles (one strip of the frame) that stay together
+
+// k-th work item of this shard -> tile of the rectangle (row-major); identity for shard_count == 1
+__device__ __host__ __forceinline__ uint32_t shard_tile(uint32_t k, uint32_t shard_index, uint32_t shard_count)
+{
+    return ((k / kShardGroup) * shard_count + shard_index) * kShardGroup + k % kShardGroup;
+}
+
+// number of work items (tile slots, the last group may run past n_tiles) owned by a shard
+static inline uint32_t shard_work(uint32_t n_tiles, uint32_t shard_index, uint32_t shard_count)
+{
+    const uint32_t groups = (n_tiles + kShardGroup - 1) / kShardGroup;
+    const uint32_t owned = groups > shard_index ? (groups - shard_index + shard_count - 1) / shard_count : 0;
+    return owned * kShardGroup;
+}
 
 // Workgroup id -> 8x8 pixel tile.  Workgroups are dealt round-robin over the 8 XCDs, so ids
 // b, b+8, b+16, ... share one XCD (and its 4-MiB L2); give each XCD a contiguous run of tiles in
@@ -155,9 +172,9 @@ __global__ __launch_bounds__(64) void trace_reference_kernel(trace_args a, lbvh_
 {
     __shared__ uint32_t s_stack[kStackDepth][LBVH_WAVE];
     const uint32_t lane = threadIdx.x;
-    const uint32_t tile = blockIdx.x;
+    const uint32_t tile = shard_tile(blockIdx.x, a.shard_index, a.shard_count);
     uint32_t px, py;
-    const bool active = tile_pixel(a, tile, lane, px, py);
+    const bool active = tile < a.tiles_x * a.tiles_y && tile_pixel(a, tile, lane, px, py);
 
     uint32_t n_pops = 0, n_box = 0, n_leaf = 0, n_tri = 0, n_hit = 0;
     if (active) {
@@ -367,8 +384,10 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
 
     uint32_t n_pops = 0, n_box = 0, n_leaf = 0, n_tri = 0, n_hit = 0;
     for (;;) {
-        const uint32_t tile = next_tile(queues, n_tiles, home);
-        if (tile == kNoTile) break;
+        const uint32_t work = next_tile(queues, n_tiles, home);      // n_tiles = this shard's work items
+        if (work == kNoTile) break;
+        const uint32_t tile = shard_tile(work, a.shard_index, a.shard_count);
+        if (tile >= a.tiles_x * a.tiles_y) continue;                 // tail of the last group
         const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const uint32_t px0 = (uint32_t)a.x0 + tx * (8u * RX) + (lane & 7u) * RX;
         const uint32_t py0 = (uint32_t)a.y0 + ty * (8u * RY) + (lane >> 3) * RY;
@@ -495,7 +514,8 @@ void launch_packets(lbvh_context* ctx, trace_args a, tile_queues* q, lbvh_hit* d
 {
     a.tiles_x = (uint32_t)(a.x1 - a.x0 + 8 * RX - 1) / (8 * RX);
     a.tiles_y = (uint32_t)(a.y1 - a.y0 + 8 * RY - 1) / (8 * RY);
-    const uint32_t n_tiles = a.tiles_x * a.tiles_y;
+    const uint32_t n_tiles = shard_work(a.tiles_x * a.tiles_y, a.shard_index, a.shard_count);
+    if (n_tiles == 0) return;
     uint32_t blocks = 256u * 8u;       // persistent 4-wave workgroups, no LDS
     if (blocks * 4 > n_tiles) blocks = (n_tiles + 3) / 4;
     if (d_stats)
@@ -564,9 +584,9 @@ lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene, 
     return LBVH_OK;
 }
 
-lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera, int32_t x0, int32_t y0,
-                               int32_t x1, int32_t y1, const lbvh_scene* h_scene, int32_t mode,
-                               lbvh_hit* d_hits, lbvh_trace_stats* d_stats)
+static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, int32_t x0, int32_t y0, int32_t x1,
+                              int32_t y1, uint32_t shard_index, uint32_t shard_count, const lbvh_scene* h_scene,
+                              int32_t mode, lbvh_hit* d_hits, lbvh_trace_stats* d_stats)
 {
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     LBVH_REQUIRE(ctx, h_camera != nullptr && h_scene != nullptr);
@@ -584,11 +604,13 @@ lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera, i
     trace_args a;
     a.cam = cam;
     a.x0 = x0; a.y0 = y0; a.x1 = x1; a.y1 = y1;
+    a.shard_index = shard_index; a.shard_count = shard_count;
     a.tiles_x = (uint32_t)(x1 - x0 + 7) / 8;
     a.tiles_y = (uint32_t)(y1 - y0 + 7) / 8;
-    const uint32_t n_tiles = a.tiles_x * a.tiles_y;
+    const uint32_t n_tiles = shard_work(a.tiles_x * a.tiles_y, shard_index, shard_count);
     if (d_stats) LBVH_HIP_TRY(ctx, hipMemsetAsync(d_stats, 0, sizeof(lbvh_trace_stats), ctx->stream));
 
+    if (n_tiles == 0) return LBVH_OK;
     if (mode == LBVH_TRACE_REFERENCE) {
         LBVH_REQUIRE(ctx, s.sorted_indices && s.triangle_aabb && s.internal_nodes && s.leaf_nodes && s.bvh &&
                               s.triangles);
@@ -611,6 +633,24 @@ lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera, i
     }
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
+}
+
+lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera, int32_t x0, int32_t y0,
+                               int32_t x1, int32_t y1, const lbvh_scene* h_scene, int32_t mode,
+                               lbvh_hit* d_hits, lbvh_trace_stats* d_stats)
+{
+    return trace_impl(ctx, h_camera, x0, y0, x1, y1, 0, 1, h_scene, mode, d_hits, d_stats);
+}
+
+lbvh_status lbvh_trace_primary_shard(lbvh_context* ctx, const lbvh_camera* h_camera, uint32_t shard_index,
+                                     uint32_t shard_count, const lbvh_scene* h_scene, int32_t mode,
+                                     lbvh_hit* d_hits, lbvh_trace_stats* d_stats)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, h_camera != nullptr);
+    LBVH_REQUIRE(ctx, shard_count >= 1 && shard_index < shard_count);
+    return trace_impl(ctx, h_camera, 0, 0, h_camera->screen_width, h_camera->screen_height, shard_index, shard_count,
+                      h_scene, mode, d_hits, d_stats);
 }
 
 }  // extern "C"

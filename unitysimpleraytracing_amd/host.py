@@ -289,6 +289,24 @@ class RaytracingMeshDrawer:
             self._stats.device if stats else None))
         return self._hits
 
+    def update_shard(self, camera, shard_index, shard_count, mode=L.TRACE_FAST, stats=False):
+        """One launch tracing this GPU's share of the full frame: every shard_count-th group of 8
+        adjacent tiles.  The hit buffer is full-frame sized; only the shard's pixels are written."""
+        cam = N.Camera.from_dict(camera)
+        count = cam.screen_width * cam.screen_height
+        if self._hits is None or self._hits.size < count:
+            if self._hits is not None:
+                self._hits.dispose()
+            self._hits = DataBuffer(self.ctx, count, L.HIT)
+        if stats and self._stats is None:
+            self._stats = DataBuffer(self.ctx, 1, L.TRACE_STATS)
+        self._rect = (0, 0, cam.screen_width, cam.screen_height)
+        s = self.container.scene()
+        N.check(self.ctx.handle, N.lib.lbvh_trace_primary_shard(
+            self.ctx.handle, C.byref(cam), shard_index, shard_count, C.byref(s), mode, self._hits.device,
+            self._stats.device if stats else None))
+        return self._hits
+
     def hits(self):
         x0, y0, x1, y1 = self._rect
         return self._hits.get_data()[: (x1 - x0) * (y1 - y0)].reshape(y1 - y0, x1 - x0).copy()
