@@ -59,6 +59,9 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern int lbvh_trace_primary_shard(IntPtr ctx, ref Camera camera, uint shardIndex, uint shardCount,
         ref Scene scene, int mode, IntPtr dHits, IntPtr dStats);
 
+    [DllImport(Lib)] public static extern int lbvh_shade(IntPtr ctx, IntPtr dHits, UIntPtr count, IntPtr dTriangles,
+        IntPtr dTextureRgba8, int texW, int texH, IntPtr dRgba16f);
+
     public static void Check(IntPtr ctx, int status)
     {
         if (status != 0)

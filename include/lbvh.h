@@ -280,6 +280,21 @@ lbvh_status lbvh_trace_primary_shard(lbvh_context* ctx, const lbvh_camera* h_cam
                                      uint32_t shard_count, const lbvh_scene* h_scene, int32_t mode,
                                      lbvh_hit* d_hits, lbvh_trace_stats* d_stats);
 
+/* ---- stage a-9, tail: shading -------------------------------------------------------------------- */
+
+/* Replaces the rest of kernel Raytracing's body (Sh/Raytracing/Raytracing.compute:178-184) for `count`
+ * RaycastResults in any layout:  t = triangleData[hit.tri] (triangle 0 on a miss, as in the reference),
+ * uv = (1-u-v) a_uv + u b_uv + v c_uv, normal likewise (:179-180), lightDir = the SCALAR 0.57735026
+ * (normalize(float3(1,1,1)) assigned to a `float`, :181), colour = texture(uv).rgb * max(0.4,
+ * dot(lightDir, normal)) (:183), output float4(colour, hit ? 1 : 0) stored as RGBA16F like the
+ * reference's render target (Sc/RaytracingMeshDrawer.cs:56).
+ * Texture: d_texture_rgba8 = tex_h rows of tex_w RGBA8 texels, row 0 at v = 0 (Unity's convention), no
+ * sRGB decode (the project is in Gamma colour space, ProjectSettings.asset:50), sampled like
+ * SampleLevel(linearClampSampler, uv, 0): bilinear on texel centres in fp32, clamp addressing, mip 0.
+ * d_rgba16f receives count x 4 IEEE half floats. */
+lbvh_status lbvh_shade(lbvh_context* ctx, const lbvh_hit* d_hits, size_t count, const lbvh_triangle* d_triangles,
+                       const uint8_t* d_texture_rgba8, int32_t tex_w, int32_t tex_h, uint16_t* d_rgba16f);
+
 /* ---- measurement helpers (HIP events on the context's stream) --------------------------------- */
 
 lbvh_status lbvh_event_create(lbvh_context* ctx, void** out_event);

@@ -59,6 +59,21 @@ _lib.orc_build_all.argtypes = [_P, _U32, _U32, _F3, _F3, _P, _P, _P, _P, _P, _P,
 _lib.orc_build_all.restype = _I32
 
 
+_lib.orc_shade.argtypes = [_P, C.c_size_t, _P, _P, _I32, _I32, _P]
+_lib.orc_shade.restype = None
+
+
+def shade(hits, triangles, texture_rgba8):
+    """hits: array of layouts.HIT (any shape); texture: (h, w, 4) uint8, row 0 at v = 0.
+    Returns float16 array hits.shape + (4,)."""
+    h = np.ascontiguousarray(hits, dtype=L.HIT)
+    tris = np.ascontiguousarray(triangles, dtype=L.TRIANGLE)
+    tex = np.ascontiguousarray(texture_rgba8, dtype=np.uint8)
+    out = np.zeros(h.shape + (4,), dtype=np.uint16)
+    _lib.orc_shade(_ptr(h), h.size, _ptr(tris), _ptr(tex), tex.shape[1], tex.shape[0], _ptr(out))
+    return out.view(np.float16)
+
+
 def _ptr(a):
     return a.ctypes.data_as(_P)
 

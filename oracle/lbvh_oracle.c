@@ -611,6 +611,80 @@ int orc_trace_primary(const lbvh_camera* cam, int32_t x0, int32_t y0, int32_t x1
     return overflow ? -3 : 0;
 }
 
+/* ------------------------------------------------------------------------------------------- */
+/* a-9 tail  shading     Sh/Raytracing/Raytracing.compute:178-184                               */
+/* ------------------------------------------------------------------------------------------- */
+
+/* float -> IEEE half, round to nearest even (the RGBA16F store of the render target) */
+static uint16_t float_to_half(float f)
+{
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | (x > 0x7F800000u ? 0x7E00u : 0x7C00u));   /* nan / inf */
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                                  /* rounds to inf */
+    if (x < 0x33000001u) return (uint16_t)sign;                                                /* rounds to 0 */
+    uint32_t e = x >> 23, m = x & 0x7FFFFFu;
+    if (e < 113) {                                                                             /* subnormal half */
+        m |= 0x800000u;
+        const uint32_t shift = 126 - e;              /* 14 .. 24 */
+        uint32_t h = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) h++;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((e - 112) << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+}
+
+static void texel_rgba(const uint8_t* tex, int w, int x, int y, float c[4])
+{
+    const uint8_t* p = tex + ((size_t)y * w + x) * 4;
+    for (int k = 0; k < 4; k++) c[k] = (float)p[k] / 255.0f;
+}
+
+/* SampleLevel(linearClampSampler, uv, 0)  :183 — bilinear on texel centres, clamp addressing, fp32 */
+static void sample_bilinear_clamp(const uint8_t* tex, int w, int h, float u, float v, float out[4])
+{
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float xf = floorf(x), yf = floorf(y);
+    const float fx = x - xf, fy = y - yf;
+    const float xc0 = fminf(fmaxf(xf, 0.0f), (float)(w - 1)), xc1 = fminf(fmaxf(xf + 1.0f, 0.0f), (float)(w - 1));
+    const float yc0 = fminf(fmaxf(yf, 0.0f), (float)(h - 1)), yc1 = fminf(fmaxf(yf + 1.0f, 0.0f), (float)(h - 1));
+    float c00[4], c10[4], c01[4], c11[4];
+    texel_rgba(tex, w, (int)xc0, (int)yc0, c00);
+    texel_rgba(tex, w, (int)xc1, (int)yc0, c10);
+    texel_rgba(tex, w, (int)xc0, (int)yc1, c01);
+    texel_rgba(tex, w, (int)xc1, (int)yc1, c11);
+    const float gx = 1.0f - fx, gy = 1.0f - fy;
+    for (int k = 0; k < 4; k++) out[k] = (c00[k] * gx + c10[k] * fx) * gy + (c01[k] * gx + c11[k] * fx) * fy;
+}
+
+void orc_shade(const lbvh_hit* hits, size_t count, const lbvh_triangle* tris, const uint8_t* tex, int32_t tex_w,
+               int32_t tex_h, uint16_t* rgba16f)
+{
+    for (size_t i = 0; i < count; i++) {
+        const lbvh_hit* r = &hits[i];
+        const lbvh_triangle* t = &tris[r->tri];                                              /* :178 */
+        const float w = (1.0f - r->u) - r->v;
+        const float tu = (w * t->a_uv[0] + r->u * t->b_uv[0]) + r->v * t->c_uv[0];          /* :179 */
+        const float tv = (w * t->a_uv[1] + r->u * t->b_uv[1]) + r->v * t->c_uv[1];
+        float n[3];
+        for (int k = 0; k < 3; k++) n[k] = (w * t->a_normal[k] + r->u * t->b_normal[k]) + r->v * t->c_normal[k]; /* :180 */
+        const float light_dir = 0.57735026f;               /* const float lightDir = normalize(float3(1,1,1))  :181 */
+        const float lambert = fmaxf(0.4f, (light_dir * n[0] + light_dir * n[1]) + light_dir * n[2]);
+        float c[4];
+        sample_bilinear_clamp(tex, tex_w, tex_h, tu, tv, c);                                 /* :183 */
+        rgba16f[4 * i + 0] = float_to_half(c[0] * lambert);
+        rgba16f[4 * i + 1] = float_to_half(c[1] * lambert);
+        rgba16f[4 * i + 2] = float_to_half(c[2] * lambert);
+        rgba16f[4 * i + 3] = float_to_half(r->t != LBVH_MAX_FLOAT ? 1.0f : 0.0f);           /* :184 */
+    }
+}
+
 /* The whole Awake() build (Sc/RaytracingMeshDrawer.cs:30-51) on the host, for the CPU baseline:
  * Morton/AABB -> sort -> DistributeKeys -> ConstructTree -> ConstructBVH. */
 int orc_build_all(const lbvh_triangle* tris, uint32_t n, uint32_t capacity, const float box_min[3],

@@ -5,6 +5,7 @@
 #ifndef LBVH_ORACLE_H
 #define LBVH_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 #include "../include/lbvh.h"
 
@@ -52,6 +53,10 @@ void orc_make_ray(const lbvh_camera* cam, uint32_t px, uint32_t py, float origin
 int orc_trace_primary(const lbvh_camera* cam, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
                       int32_t x_step, int32_t y_step, const lbvh_scene* scene, lbvh_hit* hits,
                       lbvh_trace_stats* stats, int threads);
+
+/* a-9 tail  Assets/_Shaders/Raytracing/Raytracing.compute:178-184 (see include/lbvh.h lbvh_shade) */
+void orc_shade(const lbvh_hit* hits, size_t count, const lbvh_triangle* tris, const uint8_t* tex, int32_t tex_w,
+               int32_t tex_h, uint16_t* rgba16f);
 
 /* Awake() build chain on the host (Assets/_Scripts/RaytracingMeshDrawer.cs:30-51). */
 int orc_build_all(const lbvh_triangle* tris, uint32_t n, uint32_t capacity, const float box_min[3],

@@ -458,3 +458,34 @@ def test_cpp_host_driver_matches_oracle():
     hit = oh["t"] < L.MAX_FLOAT
     assert res["hits"] == int(hit.sum())
     assert abs(res["t_sum"] - float(oh["t"][hit].astype(np.float64).sum())) < 1e-3
+
+
+# ---- a-9 tail: shading ---------------------------------------------------------------------------------------
+
+def test_shade_bit_exact(ctx):
+    """lbvh_shade over a traced frame equals the oracle's shading of the oracle's hit records, half for half."""
+    rng = np.random.default_rng(21)
+    tris = scenes.random_triangles(4096, seed=1)
+    for f in ("a_uv", "b_uv", "c_uv"):
+        tris[f] = rng.uniform(-0.3, 1.3, (4096, 2))
+    for f in ("a_normal", "b_normal", "c_normal"):
+        v = rng.normal(size=(4096, 3))
+        tris[f] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    tex = rng.integers(0, 256, (64, 128, 4), dtype=np.uint8)
+    d, c, b = build_both(ctx, tris)
+    cam = scenes.camera(200, 120, (0.0, 0.0, 300.0))
+    d.set_texture(tex)
+    d.update(cam, mode=L.TRACE_REFERENCE)
+    d.shade()
+    img = d.image()
+    oh, _ = O.trace_primary(b, cam, threads=8)
+    oimg = O.shade(oh, b.triangles, tex)
+    assert (img.view(np.uint16) == oimg.view(np.uint16)).all()
+    assert set(np.unique(img[..., 3]).tolist()) <= {0.0, 1.0} and (img[..., 3] == 1).sum() == (oh["t"] < L.MAX_FLOAT).sum()
+    # fast mode: same image except where an exact tie picked another triangle
+    d.update(cam, mode=L.TRACE_FAST)
+    fh = d.hits()
+    d.shade()
+    same = fh["tri"] == oh["tri"]
+    assert (d.image().view(np.uint16)[same] == oimg.view(np.uint16)[same]).all() and same.mean() > 0.999
+    d.on_destroy()

@@ -232,3 +232,65 @@ def test_openmp_paths_equal_scalar():
     h1, s1 = O.trace_primary(b1, cam, threads=1)
     h4, s4 = O.trace_primary(b4, cam, threads=4)
     assert (h1 == h4).all() and s1 == s4
+
+
+# ---- a-9 tail: shading (Raytracing.compute:178-184) -------------------------------------------------------
+
+def _shade_inputs(n_hits=300, seed=0):
+    rng = np.random.default_rng(seed)
+    tris = scenes.random_triangles(64, seed=3)
+    for f in ("a_uv", "b_uv", "c_uv"):
+        tris[f] = rng.uniform(-0.2, 1.2, (64, 2))          # some uv outside [0,1]: clamp addressing
+    tex = rng.integers(0, 256, (16, 32, 4), dtype=np.uint8)
+    hits = np.zeros(n_hits, dtype=L.HIT)
+    hits["tri"] = rng.integers(0, 64, n_hits)
+    hits["u"] = rng.uniform(0, 1, n_hits)
+    hits["v"] = rng.uniform(0, 1, n_hits) * (1 - hits["u"])
+    hits["t"] = np.where(rng.uniform(size=n_hits) < 0.5, 10.0, L.MAX_FLOAT)
+    return tris, tex, hits
+
+
+def test_shade_matches_an_independent_float32_recomputation():
+    tris, tex, hits = _shade_inputs()
+    img = O.shade(hits, tris, tex)
+    f = np.float32
+    out = np.zeros((len(hits), 4), np.float16)
+    for i in range(len(hits)):
+        t = tris[hits["tri"][i]]
+        u, v = f(hits["u"][i]), f(hits["v"][i])
+        w = f(f(1) - u) - v
+        tu = f(f(w * t["a_uv"][0] + u * t["b_uv"][0]) + v * t["c_uv"][0])
+        tv = f(f(w * t["a_uv"][1] + u * t["b_uv"][1]) + v * t["c_uv"][1])
+        n = [f(f(w * t["a_normal"][k] + u * t["b_normal"][k]) + v * t["c_normal"][k]) for k in range(3)]
+        l = f(0.57735026)                                   # scalar lightDir (Raytracing.compute:181)
+        lam = max(f(0.4), f(f(l * n[0] + l * n[1]) + l * n[2]))
+        x, y = f(tu * f(32) - f(0.5)), f(tv * f(16) - f(0.5))
+        xf, yf = np.floor(x), np.floor(y)
+        fx, fy = f(x - xf), f(y - yf)
+        x0, x1 = int(min(max(xf, 0), 31)), int(min(max(xf + 1, 0), 31))
+        y0, y1 = int(min(max(yf, 0), 15)), int(min(max(yf + 1, 0), 15))
+
+        def c(yy, xx):
+            return (tex[yy, xx].astype(f) / f(255)).astype(f)
+        gx, gy = f(f(1) - fx), f(f(1) - fy)
+        col = ((c(y0, x0) * gx + c(y0, x1) * fx).astype(f) * gy + (c(y1, x0) * gx + c(y1, x1) * fx).astype(f) * fy).astype(f)
+        out[i, :3] = (col[:3] * lam).astype(f).astype(np.float16)
+        out[i, 3] = 1.0 if hits["t"][i] != L.MAX_FLOAT else 0.0
+    assert (img.view(np.uint16) == out.view(np.uint16)).all()
+
+
+def test_shade_known_answers():
+    # one white texel texture, normal (1,1,1)/sqrt(3): lambert = 0.57735026 * sum(n) = 1.0 -> colour 1, alpha by hit flag
+    tris = np.zeros(1, dtype=L.TRIANGLE)
+    nrm = np.float32(1 / np.sqrt(3))
+    for f in ("a_normal", "b_normal", "c_normal"):
+        tris[f] = (nrm, nrm, nrm)
+    tex = np.full((1, 1, 4), 255, dtype=np.uint8)
+    hits = np.zeros(2, dtype=L.HIT)
+    hits["t"] = (5.0, L.MAX_FLOAT)
+    img = O.shade(hits, tris, tex).astype(np.float32)
+    assert np.allclose(img[0], (1, 1, 1, 1), atol=2e-3) and np.allclose(img[1], (1, 1, 1, 0), atol=2e-3)
+    # a normal facing away is floored at 0.4 (max(0.4, .))
+    for f in ("a_normal", "b_normal", "c_normal"):
+        tris[f] = (-nrm, -nrm, -nrm)
+    assert np.allclose(O.shade(hits, tris, tex).astype(np.float32)[0, :3], 0.4, atol=1e-3)

@@ -311,6 +311,32 @@ class RaytracingMeshDrawer:
         x0, y0, x1, y1 = self._rect
         return self._hits.get_data()[: (x1 - x0) * (y1 - y0)].reshape(y1 - y0, x1 - x0).copy()
 
+    def set_texture(self, rgba8):
+        """_objectDrawer.SetTexture("_meshTexture", ...) (Assets/_Scripts/RaytracingMeshDrawer.cs:61):
+        (h, w, 4) uint8, row 0 at v = 0."""
+        tex = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        assert tex.ndim == 3 and tex.shape[2] == 4
+        self._tex_shape = tex.shape
+        self._tex = DataBuffer(self.ctx, tex.size // 4, np.uint32)
+        self._tex.local[:] = tex.reshape(-1, 4).view(np.uint32).reshape(-1)
+        self._tex.sync()
+
+    def shade(self):
+        """The shading tail of the Raytracing kernel over the last update()'s hit records -> RGBA16F."""
+        x0, y0, x1, y1 = self._rect
+        count = (x1 - x0) * (y1 - y0)
+        if getattr(self, "_image", None) is None or self._image.size < count:
+            self._image = DataBuffer(self.ctx, count, np.uint64)       # 4 halves per pixel
+        N.check(self.ctx.handle, N.lib.lbvh_shade(
+            self.ctx.handle, self._hits.device, count, self.container.triangle_data.device, self._tex.device,
+            self._tex_shape[1], self._tex_shape[0], self._image.device))
+        return self._image
+
+    def image(self):
+        x0, y0, x1, y1 = self._rect
+        n = (x1 - x0) * (y1 - y0)
+        return self._image.get_data()[:n].view(np.float16).reshape(y1 - y0, x1 - x0, 4).copy()
+
     def stats(self):
         return self._stats.get_data()[0].copy()
 

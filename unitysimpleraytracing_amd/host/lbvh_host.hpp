@@ -240,6 +240,24 @@ public:
         check(ctx_.get(), lbvh_trace_primary(ctx_.get(), &cam, 0, 0, cam.screen_width, cam.screen_height, &s, mode,
                                              (lbvh_hit*)hits_->DeviceBuffer(), nullptr));
     }
+    // _objectDrawer.SetTexture("_meshTexture", ...) :61 — RGBA8, row 0 at v = 0
+    void SetTexture(const std::vector<uint8_t>& rgba8, int width, int height)
+    {
+        tex_.reset(new DataBuffer<uint32_t>(ctx_, (size_t)width * height));
+        std::memcpy(tex_->LocalBuffer().data(), rgba8.data(), (size_t)width * height * 4);
+        tex_->Sync();
+        tex_w_ = width; tex_h_ = height;
+    }
+    // the shading tail of the Raytracing kernel (Raytracing.compute:178-184) -> RGBA16F, 4 halves per pixel
+    void Shade()
+    {
+        const size_t rays = hits_->Size();
+        if (!image_ || image_->Size() < rays) image_.reset(new DataBuffer<uint64_t>(ctx_, rays));
+        check(ctx_.get(), lbvh_shade(ctx_.get(), (const lbvh_hit*)hits_->DeviceBuffer(), rays,
+                                     (const lbvh_triangle*)container_->TriangleData().DeviceBuffer(),
+                                     (const uint8_t*)tex_->DeviceBuffer(), tex_w_, tex_h_, (uint16_t*)image_->DeviceBuffer()));
+    }
+    DataBuffer<uint64_t>& Image() { return *image_; }
     MeshBufferContainer& Container() { return *container_; }
     DataBuffer<lbvh_hit>& Hits() { return *hits_; }
 private:
@@ -249,6 +267,9 @@ private:
     std::unique_ptr<ComputeBufferSorter> sorter_;
     std::unique_ptr<BVHConstructor> bvh_;
     std::unique_ptr<DataBuffer<lbvh_hit>> hits_;
+    std::unique_ptr<DataBuffer<uint32_t>> tex_;
+    std::unique_ptr<DataBuffer<uint64_t>> image_;
+    int tex_w_ = 0, tex_h_ = 0;
 };
 
 }  // namespace lbvh
