@@ -295,6 +295,11 @@ lbvh_status lbvh_trace_primary_shard(lbvh_context* ctx, const lbvh_camera* h_cam
 lbvh_status lbvh_shade(lbvh_context* ctx, const lbvh_hit* d_hits, size_t count, const lbvh_triangle* d_triangles,
                        const uint8_t* d_texture_rgba8, int32_t tex_w, int32_t tex_h, uint16_t* d_rgba16f);
 
+/* Profiling aid: one LBVH_TRACE_FAST frame that also records, per 16x8-pixel tile (row-major,
+ * ceil(W/16) x ceil(H/8) entries), the number of node fetches its packet needed. */
+lbvh_status lbvh_trace_tile_costs(lbvh_context* ctx, const lbvh_camera* h_camera, const lbvh_scene* h_scene,
+                                  lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_steps);
+
 /* ---- measurement helpers (HIP events on the context's stream) --------------------------------- */
 
 lbvh_status lbvh_event_create(lbvh_context* ctx, void** out_event);

@@ -375,7 +375,8 @@ template <bool STATS, int RX, int RY>
 __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
                                                            const lbvh_fast_tri* __restrict__ tris,
                                                            uint32_t n_tiles, tile_queues* queues,
-                                                           lbvh_hit* __restrict__ hits, lbvh_trace_stats* stats)
+                                                           lbvh_hit* __restrict__ hits, lbvh_trace_stats* stats,
+                                                           uint32_t* __restrict__ tile_cost)
 {
     constexpr int R = RX * RY;
     const uint32_t lane = lane_id();
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
 
         int stack = 0;            // wave-shared stack: slot k lives in lane k of this VGPR
         uint32_t sp = 0;          // scalar
+        uint32_t steps = 0;       // node fetches of this packet (profiling aid, only stored when asked for)
         // root: its own box is never tested, both children are
         int w_node = fetch_node_dword(nodes, 0, lane);
         for (;;) {
@@ -419,6 +421,7 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
             const int w_l = leaf_l ? fetch_tri_dword(tris, lref & 0x7FFFFFFFu, lane) : fetch_node_dword(nodes, lref, lane);
             const int w_r = leaf_r ? fetch_tri_dword(tris, rref & 0x7FFFFFFFu, lane) : fetch_node_dword(nodes, rref, lane);
             if (STATS && lane == 0) n_pops++;
+            if (STATS) steps++;
             float tl[R], tr[R];
             bool hit_l[R], hit_r[R];
             bool any_l = false, any_r = false;
@@ -492,6 +495,7 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
                 w_node = fetch_node_dword(nodes, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), lane);
             }
         }
+        if (STATS && tile_cost && lane == 0) tile_cost[tile] = steps;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (act[r]) {
@@ -510,7 +514,8 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
 }
 
 template <int RX, int RY>
-void launch_packets(lbvh_context* ctx, trace_args a, tile_queues* q, lbvh_hit* d_hits, lbvh_trace_stats* d_stats)
+void launch_packets(lbvh_context* ctx, trace_args a, tile_queues* q, lbvh_hit* d_hits, lbvh_trace_stats* d_stats,
+                    uint32_t* d_tile_cost)
 {
     a.tiles_x = (uint32_t)(a.x1 - a.x0 + 8 * RX - 1) / (8 * RX);
     a.tiles_y = (uint32_t)(a.y1 - a.y0 + 8 * RY - 1) / (8 * RY);
@@ -520,10 +525,10 @@ void launch_packets(lbvh_context* ctx, trace_args a, tile_queues* q, lbvh_hit* d
     if (blocks * 4 > n_tiles) blocks = (n_tiles + 3) / 4;
     if (d_stats)
         LBVH_LAUNCH(ctx, (trace_packet_kernel<true, RX, RY>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris,
-                    n_tiles, q, d_hits, d_stats);
+                    n_tiles, q, d_hits, d_stats, d_tile_cost);
     else
         LBVH_LAUNCH(ctx, (trace_packet_kernel<false, RX, RY>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris,
-                    n_tiles, q, d_hits, d_stats);
+                    n_tiles, q, d_hits, d_stats, d_tile_cost);
 }
 
 }  // namespace
@@ -586,7 +591,7 @@ lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene, 
 
 static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, int32_t x0, int32_t y0, int32_t x1,
                               int32_t y1, uint32_t shard_index, uint32_t shard_count, const lbvh_scene* h_scene,
-                              int32_t mode, lbvh_hit* d_hits, lbvh_trace_stats* d_stats)
+                              int32_t mode, lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_cost = nullptr)
 {
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     LBVH_REQUIRE(ctx, h_camera != nullptr && h_scene != nullptr);
@@ -627,9 +632,10 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
         if (!ctx->trace_queues) LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->trace_queues, 256));
         LBVH_HIP_TRY(ctx, hipMemsetAsync(ctx->trace_queues, 0, 32, ctx->stream));
         tile_queues* q = (tile_queues*)ctx->trace_queues;
-        // 2 x 1 rays per lane = 16 x 8-pixel packets: measured best of 1x1 / 2x1 / 1x2 / 3x1 / 2x2 / 4x2
-        // (more rays per lane cut node fetches per ray further but the extra VGPRs cost more occupancy)
-        launch_packets<2, 1>(ctx, a, q, d_hits, d_stats);
+        // 2 x 1 rays per lane = 16 x 8-pixel packets over 2-wide nodes: measured best of 1x1 / 2x1 / 1x2 / 3x1 /
+        // 2x2 / 4x2 rays per lane (more rays cut node fetches per ray but the extra VGPRs cost occupancy) and of
+        // 2-wide vs 4-wide (128-byte) nodes (half the steps, twice the work per step: 1.19 vs 1.12 ms)
+        launch_packets<2, 1>(ctx, a, q, d_hits, d_stats, d_tile_cost);
     }
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
@@ -640,6 +646,15 @@ lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera, i
                                lbvh_hit* d_hits, lbvh_trace_stats* d_stats)
 {
     return trace_impl(ctx, h_camera, x0, y0, x1, y1, 0, 1, h_scene, mode, d_hits, d_stats);
+}
+
+lbvh_status lbvh_trace_tile_costs(lbvh_context* ctx, const lbvh_camera* h_camera, const lbvh_scene* h_scene,
+                                  lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_steps)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, h_camera != nullptr && d_stats != nullptr && d_tile_steps != nullptr);
+    return trace_impl(ctx, h_camera, 0, 0, h_camera->screen_width, h_camera->screen_height, 0, 1, h_scene, LBVH_TRACE_FAST,
+                      d_hits, d_stats, d_tile_steps);
 }
 
 lbvh_status lbvh_trace_primary_shard(lbvh_context* ctx, const lbvh_camera* h_camera, uint32_t shard_index,
