@@ -103,8 +103,7 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     constexpr int TILE = THREADS * ITEMS;
     constexpr int WAVES = THREADS / LBVH_WAVE;
     constexpr int DWAVES = kRadix / LBVH_WAVE;   // waves that own the 256 digits
-    __shared__ uint32_t s_keys[TILE];
-    __shared__ uint32_t s_vals[TILE];
+    __shared__ uint32_t s_xchg[TILE];            // tile exchange buffer: keys first, then values
     __shared__ uint32_t s_wcnt[WAVES][kRadix];   // per-wave digit counts, then per-wave local bases
     __shared__ uint32_t s_gofs[kRadix];          // global base of digit d minus its local start
     __shared__ uint32_t s_wsum[DWAVES + 1];
@@ -136,16 +135,14 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
 
     // wave-striped load: wave w owns keys [base + w*64*ITEMS, +64*ITEMS), item i = 64 consecutive
     // keys, so (item, lane) order is array order — what stability needs.
-    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+    uint32_t key[ITEMS], rank[ITEMS];
     const uint32_t wave_base = base + w * (uint32_t)(LBVH_WAVE * ITEMS);
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const uint32_t idx = wave_base + (uint32_t)i * LBVH_WAVE + lane;
-        const bool valid = idx < count;
         // slots past the end behave as 0xFFFFFFFF keys: they are last in array order and carry the
         // largest digit in every pass, so they rank after every real key and are never written.
-        key[i] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        val[i] = valid ? vals_in[idx] : 0xFFFFFFFFu;
+        key[i] = idx < count ? keys_in[idx] : 0xFFFFFFFFu;
     }
 
 #pragma unroll
@@ -223,27 +220,40 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     }
     __syncthreads();
 
+    // Keys and values go through the SAME LDS buffer one after the other: half the LDS per tile.
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const uint32_t d = (key[i] >> shift) & (kRadix - 1);
-        const uint32_t pos = s_wcnt[w][d] + rank[i];
-        s_keys[pos] = key[i];
-        s_vals[pos] = val[i];
+        rank[i] = s_wcnt[w][d] + rank[i];            // local position in the digit-sorted tile
+        s_xchg[rank[i]] = key[i];
+    }
+    // values are requested now (the key registers are free) and land while the keys are written out
+    uint32_t val[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const uint32_t idx = wave_base + (uint32_t)i * LBVH_WAVE + lane;
+        val[i] = idx < count ? vals_in[idx] : 0xFFFFFFFFu;
     }
     __syncthreads();
 
-    // tile is now digit-sorted in LDS: consecutive threads write consecutive addresses inside
+    // the tile's keys are digit-sorted in LDS: consecutive threads write consecutive addresses inside
     // each digit run.
+    uint32_t dst[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {
         const uint32_t pos = (uint32_t)j * THREADS + t;
-        if (pos < nvalid) {
-            const uint32_t k = s_keys[pos];
-            const uint32_t d = (k >> shift) & (kRadix - 1);
-            const uint32_t dst = s_gofs[d] + pos;
-            keys_out[dst] = k;
-            vals_out[dst] = s_vals[pos];
-        }
+        const uint32_t k = s_xchg[pos];
+        dst[j] = s_gofs[(k >> shift) & (kRadix - 1)] + pos;
+        if (pos < nvalid) keys_out[dst[j]] = k;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) s_xchg[rank[i]] = val[i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+        const uint32_t pos = (uint32_t)j * THREADS + t;
+        if (pos < nvalid) vals_out[dst[j]] = s_xchg[pos];
     }
 }
 

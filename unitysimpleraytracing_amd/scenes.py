@@ -131,6 +131,53 @@ def tiled_torus(nu=80, nv=50, grid=5, pitch=45.0, seed=2, shuffle=True):
     return _pack_triangles(a, b, c)
 
 
+def load_obj(path_or_text, is_text=False):
+    """Mesh ingest for Wavefront OBJ (the reference's assets are OBJ, Assets/_Assets/*.obj, imported by Unity and
+    flattened to Triangle[] by Assets/_Scripts/MeshBufferContainer.cs:117-146): v / vt / vn, faces with
+    v, v/vt, v//vn or v/vt/vn corners, negative indices, polygons fanned into triangles (a quad a b c d ->
+    a b c, a c d).  Missing uv -> (0,0); missing normals -> the face normal.  Returns TRIANGLE[n]."""
+    text = path_or_text if is_text else open(path_or_text).read()
+    v, vt, vn = [], [], []
+    corners = []          # per triangle: 3 x (vi, ti, ni), -1 = absent
+    for line in text.splitlines():
+        p = line.split("#", 1)[0].split()
+        if not p:
+            continue
+        if p[0] == "v":
+            v.append([float(x) for x in p[1:4]])
+        elif p[0] == "vt":
+            vt.append([float(x) for x in (p[1:3] + ["0"])[:2]])
+        elif p[0] == "vn":
+            vn.append([float(x) for x in p[1:4]])
+        elif p[0] == "f":
+            poly = []
+            for c in p[1:]:
+                idx = (c.split("/") + ["", ""])[:3]
+                def rel(tok, count):
+                    if tok == "":
+                        return -1
+                    k = int(tok)
+                    return k - 1 if k > 0 else count + k
+                poly.append((rel(idx[0], len(v)), rel(idx[1], len(vt)), rel(idx[2], len(vn))))
+            for k in range(1, len(poly) - 1):
+                corners.append((poly[0], poly[k], poly[k + 1]))
+    n = len(corners)
+    va = np.asarray(v, dtype=np.float32).reshape(-1, 3)
+    c = np.asarray(corners, dtype=np.int64).reshape(n, 3, 3)
+    a, b, cc = va[c[:, 0, 0]], va[c[:, 1, 0]], va[c[:, 2, 0]]
+    uv = normals = None
+    if len(vt) and (c[:, :, 1] >= 0).all():
+        ta = np.asarray(vt, dtype=np.float32)
+        uv = (ta[c[:, 0, 1]], ta[c[:, 1, 1]], ta[c[:, 2, 1]])
+    if len(vn) and (c[:, :, 2] >= 0).all():
+        na = np.asarray(vn, dtype=np.float32)
+        normals = (na[c[:, 0, 2]], na[c[:, 1, 2]], na[c[:, 2, 2]])
+    t = _pack_triangles(a, b, cc, uv=uv, normals=normals)
+    if uv is None:
+        t["a_uv"] = t["b_uv"] = t["c_uv"] = (0.0, 0.0)
+    return t
+
+
 def camera(width, height, position, fov_y_deg=60.0, near=0.3):
     """Camera uniforms as RaytracingMeshDrawer.Update sets them
     (Assets/_Scripts/RaytracingMeshDrawer.cs:78-81) for a Unity camera at `position` rotated 180
