@@ -295,6 +295,51 @@ lbvh_status lbvh_trace_primary_shard(lbvh_context* ctx, const lbvh_camera* h_cam
 lbvh_status lbvh_shade(lbvh_context* ctx, const lbvh_hit* d_hits, size_t count, const lbvh_triangle* d_triangles,
                        const uint8_t* d_texture_rgba8, int32_t tex_w, int32_t tex_h, uint16_t* d_rgba16f);
 
+/* ---- dynamic scenes and secondary rays (extension; no reference counterpart) ----
+ * The reference traces primary rays of a static mesh only (Sh/Raytracing/Raytracing.compute has no
+ * secondary rays and no RNG; Sc/BVHConstructor.cs:41 zeroes the refit flags once, so it cannot even
+ * rebuild).  BASELINE configs[4] asks for a per-frame rebuild + 4-bounce 1-spp path trace; the pieces
+ * below provide it.  Parity for them is against this repo's own CPU restatement (oracle/), bit for bit:
+ * everything is strict fp32, trig-free, and driven by a counter-based RNG. */
+
+/* Rigid per-body animation: triangle i of the rest pose belongs to body d_body[i]; its three positions
+ * and normals are rotated about the Y axis through that body's centre h/d_centres[body] by the angle
+ * whose cosine / sine the HOST passes (no device trig), uv copied.  d_out may not alias d_rest. */
+lbvh_status lbvh_animate(lbvh_context* ctx, const lbvh_triangle* d_rest, uint32_t n, const uint32_t* d_body,
+                         const float* d_centres /* n_bodies x 4 floats (xyz, pad) */, float cos_angle, float sin_angle,
+                         lbvh_triangle* d_out);
+
+/* One path vertex per pixel: 64 bytes. */
+typedef struct lbvh_path_state {
+    float origin[3];     uint32_t alive;     /* 1 while the path continues                      */
+    float dir[3];        float    pad0;      /* unit direction of the ray to trace next          */
+    float throughput[3]; float    pad1;
+    float radiance[3];   float    alpha;     /* alpha = 1 if the primary ray hit, as Raytracing.compute:184 */
+} lbvh_path_state;
+
+/* Closest hit for `count` arbitrary rays taken from the path states (origin, dir; dead paths are skipped and
+ * get a miss record): one ray per lane over the derived traversal scene (lbvh_build_fast_scene), near-first,
+ * t-pruned, per-lane LDS stack.  Accept rule = the reference's (own-AABB slab test, Moeller-Trumbore, strict
+ * t < best) plus t > t_min, which secondary rays need to leave their surface and the reference lacks
+ * (Raytracing.compute:70). */
+lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, float t_min,
+                            const lbvh_scene* h_scene, lbvh_hit* d_hits);
+
+/* Camera rays into path states (origin/dir as Raytracing.compute:108-126, throughput 1, radiance 0, alive). */
+lbvh_status lbvh_path_begin(lbvh_context* ctx, const lbvh_camera* h_camera, lbvh_path_state* d_states);
+
+/* One bounce for every live path given its hit record: a miss adds throughput * sky(dir) and ends the path
+ * (sky = (1 - s) * (1,1,1) + s * (0.5,0.7,1), s = 0.5 * (dir.y + 1)); a hit multiplies the throughput by
+ * `albedo`, moves the origin to the hit point and draws a cosine-weighted direction about the geometric
+ * normal (flipped toward the incoming ray): normalize(n + p) with p uniform on the unit sphere by
+ * Marsaglia's rejection method, random numbers = PCG hash of (seed, path index, bounce, draw).  `bounce` = 0
+ * for the primary hit (it also sets alpha). */
+lbvh_status lbvh_path_scatter(lbvh_context* ctx, const lbvh_scene* h_scene, const lbvh_hit* d_hits, size_t count,
+                              uint32_t bounce, uint32_t seed, float albedo, lbvh_path_state* d_states);
+
+/* radiance (+ alpha) of the path states as RGBA16F, the reference's render-target format. */
+lbvh_status lbvh_path_resolve(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, uint16_t* d_rgba16f);
+
 /* Profiling aid: one LBVH_TRACE_FAST frame that also records, per 16x8-pixel tile (row-major,
  * ceil(W/16) x ceil(H/8) entries), the number of node fetches its packet needed. */
 lbvh_status lbvh_trace_tile_costs(lbvh_context* ctx, const lbvh_camera* h_camera, const lbvh_scene* h_scene,

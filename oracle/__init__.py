@@ -74,6 +74,68 @@ def shade(hits, triangles, texture_rgba8):
     return out.view(np.float16)
 
 
+_lib.orc_animate.argtypes = [_P, _U32, _P, _P, C.c_float, C.c_float, _P]
+_lib.orc_animate.restype = None
+_lib.orc_path_begin.argtypes = [C.POINTER(_Camera), _P]
+_lib.orc_path_begin.restype = None
+_lib.orc_trace_rays.argtypes = [_P, C.c_size_t, C.c_float, C.POINTER(_Scene), _P, _I32]
+_lib.orc_trace_rays.restype = _I32
+_lib.orc_path_scatter.argtypes = [C.POINTER(_Scene), _P, C.c_size_t, _U32, _U32, C.c_float, _P]
+_lib.orc_path_scatter.restype = None
+_lib.orc_path_resolve.argtypes = [_P, C.c_size_t, _P]
+_lib.orc_path_resolve.restype = None
+
+
+def animate(rest, body, centres, angle):
+    rest = np.ascontiguousarray(rest, dtype=L.TRIANGLE)
+    out = np.zeros_like(rest)
+    _lib.orc_animate(_ptr(rest), len(rest), _ptr(np.ascontiguousarray(body, dtype=np.uint32)),
+                     _ptr(np.ascontiguousarray(centres, dtype=np.float32)),
+                     float(np.float32(np.cos(angle))), float(np.float32(np.sin(angle))), _ptr(out))
+    return out
+
+
+def path_begin(camera):
+    cam = _camera(camera)
+    st = np.zeros(cam.screen_width * cam.screen_height, dtype=L.PATH_STATE)
+    _lib.orc_path_begin(C.byref(cam), _ptr(st))
+    return st
+
+
+def trace_rays(built, states, t_min, threads=1):
+    hits = np.zeros(len(states), dtype=L.HIT)
+    s = built.scene()
+    rc = _lib.orc_trace_rays(_ptr(states), len(states), float(t_min), C.byref(s), _ptr(hits), threads)
+    if rc != 0:
+        raise ValueError(f"orc_trace_rays rc={rc}")
+    return hits
+
+
+def path_scatter(built, hits, states, bounce, seed, albedo):
+    s = built.scene()
+    _lib.orc_path_scatter(C.byref(s), _ptr(np.ascontiguousarray(hits, dtype=L.HIT)), len(states), int(bounce), int(seed),
+                          float(albedo), _ptr(states))
+    return states
+
+
+def path_resolve(states):
+    out = np.zeros((len(states), 4), dtype=np.uint16)
+    _lib.orc_path_resolve(_ptr(states), len(states), _ptr(out))
+    return out.view(np.float16)
+
+
+def path_trace(built, camera, bounces=4, t_min=1e-3, albedo=0.7, seed=1, threads=1):
+    """The DynamicPathTracer.render pipeline on the host (primary rays = reference traversal)."""
+    st = path_begin(camera)
+    hits, _ = trace_primary(built, camera, threads=threads)
+    path_scatter(built, hits.reshape(-1), st, 0, seed, albedo)
+    for b in range(1, bounces + 1):
+        h = trace_rays(built, st, t_min, threads=threads)
+        path_scatter(built, h, st, b, seed, albedo)
+    cam = _camera(camera)
+    return path_resolve(st).reshape(cam.screen_height, cam.screen_width, 4), st
+
+
 def _ptr(a):
     return a.ctypes.data_as(_P)
 

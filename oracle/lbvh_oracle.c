@@ -685,6 +685,156 @@ void orc_shade(const lbvh_hit* hits, size_t count, const lbvh_triangle* tris, co
     }
 }
 
+/* ------------------------------------------------------------------------------------------- */
+/* dynamic scene + secondary rays.  NOT in the reference (it has neither); these  */
+/* restate include/lbvh.h's definitions so the GPU kernels have a bit-exact checker.                  */
+/* ------------------------------------------------------------------------------------------- */
+
+void orc_animate(const lbvh_triangle* rest, uint32_t n, const uint32_t* body, const float* centres, float c, float s,
+                 lbvh_triangle* out)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const float* ctr = &centres[4 * body[i]];
+        lbvh_triangle t = rest[i];
+        float* pos[3] = {t.a, t.b, t.c};
+        float* nrm[3] = {t.a_normal, t.b_normal, t.c_normal};
+        for (int k = 0; k < 3; k++) {
+            const float x = pos[k][0] - ctr[0], z = pos[k][2] - ctr[2];
+            pos[k][0] = (c * x + s * z) + ctr[0];          /* rotation about Y through the body centre */
+            pos[k][2] = (c * z - s * x) + ctr[2];
+            const float nx = nrm[k][0], nz = nrm[k][2];
+            nrm[k][0] = c * nx + s * nz;
+            nrm[k][2] = c * nz - s * nx;
+        }
+        out[i] = t;
+    }
+}
+
+void orc_path_begin(const lbvh_camera* cam, lbvh_path_state* states)
+{
+    for (int32_t y = 0; y < cam->screen_height; y++)
+        for (int32_t x = 0; x < cam->screen_width; x++) {
+            lbvh_path_state* st = &states[(size_t)y * cam->screen_width + x];
+            float inv[3];
+            orc_make_ray(cam, (uint32_t)x, (uint32_t)y, st->origin, st->dir, inv);
+            st->alive = 1; st->pad0 = 0.0f; st->pad1 = 0.0f; st->alpha = 0.0f;
+            for (int k = 0; k < 3; k++) { st->throughput[k] = 1.0f; st->radiance[k] = 0.0f; }
+        }
+}
+
+/* closest hit of arbitrary rays, reference visit order over the reference arrays, accept rule + t > t_min */
+int orc_trace_rays(const lbvh_path_state* states, size_t count, float t_min, const lbvh_scene* s, lbvh_hit* hits,
+                   int threads)
+{
+    (void)threads;
+    int overflow = 0;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 256) reduction(| : overflow)
+#endif
+    for (int64_t ii = 0; ii < (int64_t)count; ii++) {
+        lbvh_hit* result = &hits[ii];
+        result->t = LBVH_MAX_FLOAT; result->tri = 0; result->u = 0.0f; result->v = 0.0f;
+        if (!states[ii].alive) continue;
+        ray_t ray;
+        for (int k = 0; k < 3; k++) {
+            ray.origin[k] = states[ii].origin[k];
+            ray.dir[k] = states[ii].dir[k];
+            ray.inv_dir[k] = 1.0f / states[ii].dir[k];
+        }
+        uint32_t stack[64];
+        uint32_t sp = 1;
+        stack[0] = 0;
+        while (sp != 0) {
+            const uint32_t index = stack[--sp];
+            const lbvh_aabb* nb = &s->bvh[index];
+            if (!orc_ray_box(nb->min, nb->max, ray.origin, ray.inv_dir)) continue;
+            const lbvh_internal_node* nd = &s->internal_nodes[index];
+            const uint32_t child[2] = {nd->leftNode, nd->rightNode}, type[2] = {nd->leftNodeType, nd->rightNodeType};
+            for (int side = 0; side < 2; side++) {
+                if (type[side] == LBVH_INTERNAL_NODE) {
+                    if (sp >= 64) { overflow = 1; break; }
+                    stack[sp++] = child[side];
+                } else {
+                    const uint32_t tri = s->sorted_indices[s->leaf_nodes[child[side]].index];
+                    const lbvh_aabb* b = &s->triangle_aabb[tri];
+                    if (!orc_ray_box(b->min, b->max, ray.origin, ray.inv_dir)) continue;
+                    const lbvh_triangle* t = &s->triangles[tri];
+                    float u = 0.0f, v = 0.0f;
+                    const float dist = ray_triangle(ray.origin, ray.dir, t->a, t->b, t->c, &u, &v);
+                    if (dist > t_min && dist < result->t) { result->t = dist; result->tri = tri; result->u = u; result->v = v; }
+                }
+            }
+        }
+    }
+    return overflow ? -3 : 0;
+}
+
+static uint32_t pcg_hash(uint32_t v)
+{
+    const uint32_t state = v * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+
+static float path_rnd(uint32_t seed, uint32_t index, uint32_t bounce, uint32_t draw)
+{
+    const uint32_t h = pcg_hash(pcg_hash(pcg_hash(seed + 0x9E3779B9u * index) + bounce) + draw);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+void orc_path_scatter(const lbvh_scene* s, const lbvh_hit* hits, size_t count, uint32_t bounce, uint32_t seed,
+                      float albedo, lbvh_path_state* states)
+{
+    for (size_t i = 0; i < count; i++) {
+        lbvh_path_state* st = &states[i];
+        if (!st->alive) continue;
+        const lbvh_hit* h = &hits[i];
+        if (!(h->t < LBVH_MAX_FLOAT)) {
+            const float sk = 0.5f * (st->dir[1] + 1.0f);
+            const float sky[3] = {(1.0f - sk) * 1.0f + sk * 0.5f, (1.0f - sk) * 1.0f + sk * 0.7f, (1.0f - sk) * 1.0f + sk * 1.0f};
+            for (int k = 0; k < 3; k++) st->radiance[k] = st->radiance[k] + st->throughput[k] * sky[k];
+            st->alive = 0;
+            continue;
+        }
+        if (bounce == 0) st->alpha = 1.0f;
+        const lbvh_triangle* t = &s->triangles[h->tri];
+        float e1[3], e2[3], n[3];
+        for (int k = 0; k < 3; k++) { e1[k] = t->b[k] - t->a[k]; e2[k] = t->c[k] - t->a[k]; }
+        cross3(e1, e2, n);
+        const float nl = sqrtf(dot3(n, n));
+        if (nl > 0.0f) { n[0] = n[0] / nl; n[1] = n[1] / nl; n[2] = n[2] / nl; } else { n[0] = 0.0f; n[1] = 1.0f; n[2] = 0.0f; }
+        if (dot3(n, st->dir) > 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+        for (int k = 0; k < 3; k++) {
+            st->origin[k] = st->origin[k] + st->dir[k] * h->t;
+            st->throughput[k] = st->throughput[k] * albedo;
+        }
+        /* uniform point on the unit sphere, Marsaglia 1972, at most 8 tries */
+        float p[3] = {0.0f, 0.0f, 1.0f};
+        for (uint32_t k = 0; k < 16; k += 2) {
+            const float x1 = 2.0f * path_rnd(seed, (uint32_t)i, bounce, k) - 1.0f;
+            const float x2 = 2.0f * path_rnd(seed, (uint32_t)i, bounce, k + 1) - 1.0f;
+            const float ss = x1 * x1 + x2 * x2;
+            if (ss < 1.0f) {
+                const float r = sqrtf(1.0f - ss);
+                p[0] = 2.0f * x1 * r; p[1] = 2.0f * x2 * r; p[2] = 1.0f - 2.0f * ss;
+                break;
+            }
+        }
+        float d[3] = {n[0] + p[0], n[1] + p[1], n[2] + p[2]};
+        const float dl = sqrtf(dot3(d, d));
+        if (dl > 1e-6f) { d[0] = d[0] / dl; d[1] = d[1] / dl; d[2] = d[2] / dl; } else { d[0] = n[0]; d[1] = n[1]; d[2] = n[2]; }
+        for (int k = 0; k < 3; k++) st->dir[k] = d[k];
+    }
+}
+
+void orc_path_resolve(const lbvh_path_state* states, size_t count, uint16_t* rgba16f)
+{
+    for (size_t i = 0; i < count; i++) {
+        for (int k = 0; k < 3; k++) rgba16f[4 * i + k] = float_to_half(states[i].radiance[k]);
+        rgba16f[4 * i + 3] = float_to_half(states[i].alpha);
+    }
+}
+
 /* The whole Awake() build (Sc/RaytracingMeshDrawer.cs:30-51) on the host, for the CPU baseline:
  * Morton/AABB -> sort -> DistributeKeys -> ConstructTree -> ConstructBVH. */
 int orc_build_all(const lbvh_triangle* tris, uint32_t n, uint32_t capacity, const float box_min[3],

@@ -58,6 +58,17 @@ int orc_trace_primary(const lbvh_camera* cam, int32_t x0, int32_t y0, int32_t x1
 void orc_shade(const lbvh_hit* hits, size_t count, const lbvh_triangle* tris, const uint8_t* tex, int32_t tex_w,
                int32_t tex_h, uint16_t* rgba16f);
 
+/* SURVEY 8(f) rank 3 (extension, no reference counterpart): see include/lbvh.h lbvh_animate, lbvh_path_*,
+ * lbvh_trace_rays.  `s` holds HOST pointers to the reference arrays. */
+void orc_animate(const lbvh_triangle* rest, uint32_t n, const uint32_t* body, const float* centres, float c, float s,
+                 lbvh_triangle* out);
+void orc_path_begin(const lbvh_camera* cam, lbvh_path_state* states);
+int orc_trace_rays(const lbvh_path_state* states, size_t count, float t_min, const lbvh_scene* s, lbvh_hit* hits,
+                   int threads);
+void orc_path_scatter(const lbvh_scene* s, const lbvh_hit* hits, size_t count, uint32_t bounce, uint32_t seed,
+                      float albedo, lbvh_path_state* states);
+void orc_path_resolve(const lbvh_path_state* states, size_t count, uint16_t* rgba16f);
+
 /* Awake() build chain on the host (Assets/_Scripts/RaytracingMeshDrawer.cs:30-51). */
 int orc_build_all(const lbvh_triangle* tris, uint32_t n, uint32_t capacity, const float box_min[3],
                   const float box_max[3], uint32_t* keys, uint32_t* indices, lbvh_aabb* tri_aabb,

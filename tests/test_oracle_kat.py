@@ -294,3 +294,44 @@ def test_shade_known_answers():
     for f in ("a_normal", "b_normal", "c_normal"):
         tris[f] = (-nrm, -nrm, -nrm)
     assert np.allclose(O.shade(hits, tris, tex).astype(np.float32)[0, :3], 0.4, atol=1e-3)
+
+
+# ---- SURVEY 8(f) rank 3 (extension): dynamic scene + secondary rays ----------------------------------------
+
+def test_animate_is_a_rigid_rotation_about_each_body_centre():
+    tris, body, centres = scenes.tiled_torus(nu=8, nv=6, grid=2, with_bodies=True)
+    same = O.animate(tris, body, centres, 0.0)
+    # (p - c) + c is not exact in fp32, hence the tolerance; normals and uvs are
+    assert np.allclose(same["a"], tris["a"], atol=1e-5) and (same["a_normal"] == tris["a_normal"]).all() and (same["a_uv"] == tris["a_uv"]).all()
+    rot = O.animate(tris, body, centres, 0.3)
+    ctr = centres[body][:, :3]
+    for f in ("a", "b", "c"):
+        assert np.allclose(np.linalg.norm(rot[f] - ctr, axis=1), np.linalg.norm(tris[f] - ctr, axis=1), atol=1e-4)
+        assert np.allclose(rot[f][:, 1], tris[f][:, 1])                                  # Y axis
+    assert np.allclose(np.linalg.norm(rot["b"] - rot["a"], axis=1), np.linalg.norm(tris["b"] - tris["a"], axis=1), atol=1e-4)
+    assert not np.allclose(rot["a"], tris["a"])
+
+
+def test_path_trace_is_deterministic_and_energy_bounded():
+    tris = scenes.random_triangles(3000, seed=2, extent=40.0, edge=8.0)
+    b = O.Built(tris, capacity=3072)
+    cam = scenes.camera(40, 30, (0.0, 0.0, 120.0))
+    img1, st1 = O.path_trace(b, cam, bounces=4, seed=7)
+    img2, _ = O.path_trace(b, cam, bounces=4, seed=7, threads=4)
+    img3, _ = O.path_trace(b, cam, bounces=4, seed=8)
+    assert (img1.view(np.uint16) == img2.view(np.uint16)).all()                         # counter-based RNG
+    assert not (img1.view(np.uint16) == img3.view(np.uint16)).all()
+    hits, _ = O.trace_primary(b, cam)
+    assert ((img1[..., 3] == 1) == (hits["t"] < L.MAX_FLOAT)).all()
+    rgb = img1[..., :3].astype(np.float32)
+    assert rgb.min() >= 0 and rgb.max() <= 1.0 + 1e-3                                   # albedo < 1, sky <= 1
+    miss = hits["t"] >= L.MAX_FLOAT
+    assert (rgb[miss].min(axis=1) >= 0.5 - 1e-3).all()                                  # primary misses see the sky
+    # secondary rays never re-hit their own surface (t > t_min) and directions stay unit length
+    st = O.path_begin(cam)
+    O.path_scatter(b, hits.reshape(-1), st, 0, 7, 0.7)
+    alive = st["alive"] == 1
+    assert np.allclose(np.linalg.norm(st["dir"][alive], axis=1), 1.0, atol=1e-5)
+    h2 = O.trace_rays(b, st, 1e-3)
+    assert (h2["t"][alive & (h2["t"] < L.MAX_FLOAT)] > 1e-3).all()
+    assert (h2["t"][~alive] == L.MAX_FLOAT).all()

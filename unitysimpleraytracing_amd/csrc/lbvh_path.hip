@@ -1,0 +1,275 @@
+// lbvh_path.hip — SURVEY 8(f) rank 3: rigid per-body animation, arbitrary-ray traversal and the bounce
+// step of a 1-spp path tracer (BASELINE configs[4]).  No reference counterpart: the reference traces
+// primary rays of a static mesh only.  Definitions: include/lbvh.h; bit-exact checker: oracle/.
+// Strict fp32 (-ffp-contract=off), no device trig, counter-based RNG.
+#include "lbvh_common.h"
+#include "lbvh_rt.h"
+
+namespace {
+
+// ---- animation --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void animate_kernel(const lbvh_triangle* __restrict__ rest, uint32_t n,
+                                                      const uint32_t* __restrict__ body, const float4* __restrict__ centres,
+                                                      float c, float s, lbvh_triangle* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 ctr = centres[body[i]];
+    const float4* src = reinterpret_cast<const float4*>(&rest[i]);
+    float4* dst = reinterpret_cast<float4*>(&out[i]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {                        // positions a, b, c
+        float4 p = src[k];
+        const float x = p.x - ctr.x, z = p.z - ctr.z;
+        p.x = (c * x + s * z) + ctr.x;                   // rotation about Y through the body centre
+        p.z = (c * z - s * x) + ctr.z;
+        dst[k] = p;
+    }
+    dst[3] = src[3];                                     // uv
+    dst[4] = src[4];
+#pragma unroll
+    for (int k = 5; k < 8; k++) {                        // normals
+        float4 q = src[k];
+        const float nx = q.x, nz = q.z;
+        q.x = c * nx + s * nz;
+        q.z = c * nz - s * nx;
+        dst[k] = q;
+    }
+}
+
+// ---- camera rays -> path states ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void path_begin_kernel(lbvh_camera cam, lbvh_path_state* __restrict__ states)
+{
+    const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= (uint32_t)cam.screen_width || y >= (uint32_t)cam.screen_height) return;
+    const ray_t r = make_ray(cam, x, y);
+    float4* o = reinterpret_cast<float4*>(&states[(size_t)y * cam.screen_width + x]);
+    o[0] = make_float4(r.ox, r.oy, r.oz, __uint_as_float(1u));
+    o[1] = make_float4(r.dx, r.dy, r.dz, 0.0f);
+    o[2] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    o[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// ---- arbitrary rays: one ray per lane over the derived traversal scene -----------------------------------
+// Secondary rays are incoherent, so the packet walk of lbvh_trace.hip does not apply: every lane walks on its
+// own (64-byte fused nodes, near child first, boxes beyond the best hit skipped) with its stack in LDS as
+// [entry][lane].  One wave per workgroup, no barriers.
+constexpr int kRayStack = 34;
+
+__global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* __restrict__ states, size_t count, float t_min,
+                                                        const lbvh_fast_node* __restrict__ nodes,
+                                                        const lbvh_fast_tri* __restrict__ tris, lbvh_hit* __restrict__ hits)
+{
+    __shared__ uint32_t s_stack[kRayStack][LBVH_WAVE];
+    const uint32_t lane = threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * LBVH_WAVE + lane;
+    if (i >= count) return;
+    const float4* st = reinterpret_cast<const float4*>(&states[i]);
+    const float4 o = st[0], d = st[1];
+    float best_t = LBVH_MAX_FLOAT;
+    uint32_t best_tri = 0;
+    float best_u = 0.0f, best_v = 0.0f;
+    if (__float_as_uint(o.w) != 0u) {
+        ray_t ray;
+        ray.ox = o.x; ray.oy = o.y; ray.oz = o.z;
+        ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
+        ray.ix = 1.0f / d.x; ray.iy = 1.0f / d.y; ray.iz = 1.0f / d.z;
+        uint32_t sp = 0, node = 0;
+        for (;;) {
+            const float4* nb = reinterpret_cast<const float4*>(&nodes[node]);
+            const float4 lmin = nb[0], lmax = nb[1], rmin = nb[2], rmax = nb[3];
+            const uint32_t lref = __float_as_uint(lmin.w), rref = __float_as_uint(lmax.w);
+            float tl, tr;
+            bool hit_l = ray_box(lmin, lmax, ray, tl) && !(tl > best_t);
+            bool hit_r = ray_box(rmin, rmax, ray, tr) && !(tr > best_t);
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const bool h = side == 0 ? hit_l : hit_r;
+                const uint32_t ref = side == 0 ? lref : rref;
+                if (h && (ref & 0x80000000u)) {
+                    const float4* tv = reinterpret_cast<const float4*>(&tris[ref & 0x7FFFFFFFu]);
+                    const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+                    float u = 0.0f, v = 0.0f;
+                    const float dist = ray_triangle(ray, v0, v1, v2, u, v);
+                    if (dist > t_min && dist < best_t) { best_t = dist; best_tri = __float_as_uint(v0.w); best_u = u; best_v = v; }
+                }
+            }
+            const bool go_l = hit_l && !(lref & 0x80000000u) && !(tl > best_t);
+            const bool go_r = hit_r && !(rref & 0x80000000u) && !(tr > best_t);
+            if (go_l && go_r) {
+                const bool l_near = tl <= tr;
+                node = l_near ? lref : rref;
+                if (sp < (uint32_t)kRayStack) { s_stack[sp][lane] = l_near ? rref : lref; sp++; }
+            } else if (go_l) {
+                node = lref;
+            } else if (go_r) {
+                node = rref;
+            } else {
+                if (sp == 0) break;
+                sp--;
+                node = s_stack[sp][lane];
+            }
+        }
+    }
+    float4 out;
+    out.x = best_t;
+    out.y = __uint_as_float(best_tri);
+    out.z = best_u;
+    out.w = best_v;
+    reinterpret_cast<float4*>(hits)[i] = out;
+}
+
+// ---- bounce ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t v)
+{
+    const uint32_t state = v * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+
+__device__ __forceinline__ float path_rnd(uint32_t seed, uint32_t index, uint32_t bounce, uint32_t draw)
+{
+    const uint32_t h = pcg_hash(pcg_hash(pcg_hash(seed + 0x9E3779B9u * index) + bounce) + draw);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(256) void path_scatter_kernel(const lbvh_triangle* __restrict__ triangles,
+                                                           const lbvh_hit* __restrict__ hits, size_t count, uint32_t bounce,
+                                                           uint32_t seed, float albedo, lbvh_path_state* __restrict__ states)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float4* st = reinterpret_cast<float4*>(&states[i]);
+    float4 o = st[0], d = st[1], thr = st[2], rad = st[3];
+    if (__float_as_uint(o.w) == 0u) return;
+    const float4 h = reinterpret_cast<const float4*>(hits)[i];
+    if (!(h.x < LBVH_MAX_FLOAT)) {
+        const float sk = 0.5f * (d.y + 1.0f);
+        rad.x = rad.x + thr.x * ((1.0f - sk) * 1.0f + sk * 0.5f);
+        rad.y = rad.y + thr.y * ((1.0f - sk) * 1.0f + sk * 0.7f);
+        rad.z = rad.z + thr.z * ((1.0f - sk) * 1.0f + sk * 1.0f);
+        o.w = __uint_as_float(0u);
+        st[0] = o;
+        st[3] = rad;
+        return;
+    }
+    if (bounce == 0) rad.w = 1.0f;
+    const float4* tp = reinterpret_cast<const float4*>(&triangles[__float_as_uint(h.y)]);
+    const float4 a = tp[0], b = tp[1], c = tp[2];
+    const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
+    const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+    float nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+    const float nl = sqrtf(dot3(nx, ny, nz, nx, ny, nz));
+    if (nl > 0.0f) { nx = nx / nl; ny = ny / nl; nz = nz / nl; } else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
+    if (dot3(nx, ny, nz, d.x, d.y, d.z) > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+    o.x = o.x + d.x * h.x; o.y = o.y + d.y * h.x; o.z = o.z + d.z * h.x;
+    thr.x = thr.x * albedo; thr.y = thr.y * albedo; thr.z = thr.z * albedo;
+    // uniform point on the unit sphere, Marsaglia 1972, at most 8 tries
+    float px = 0.0f, py = 0.0f, pz = 1.0f;
+    for (uint32_t k = 0; k < 16; k += 2) {
+        const float x1 = 2.0f * path_rnd(seed, (uint32_t)i, bounce, k) - 1.0f;
+        const float x2 = 2.0f * path_rnd(seed, (uint32_t)i, bounce, k + 1) - 1.0f;
+        const float ss = x1 * x1 + x2 * x2;
+        if (ss < 1.0f) {
+            const float r = sqrtf(1.0f - ss);
+            px = 2.0f * x1 * r; py = 2.0f * x2 * r; pz = 1.0f - 2.0f * ss;
+            break;
+        }
+    }
+    float vx = nx + px, vy = ny + py, vz = nz + pz;
+    const float dl = sqrtf(dot3(vx, vy, vz, vx, vy, vz));
+    if (dl > 1e-6f) { vx = vx / dl; vy = vy / dl; vz = vz / dl; } else { vx = nx; vy = ny; vz = nz; }
+    d.x = vx; d.y = vy; d.z = vz;
+    st[0] = o; st[1] = d; st[2] = thr; st[3] = rad;
+}
+
+__global__ __launch_bounds__(256) void path_resolve_kernel(const lbvh_path_state* __restrict__ states, size_t count,
+                                                           uint16_t* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float4 rad = reinterpret_cast<const float4*>(&states[i])[3];
+    ushort4 o;
+    o.x = __half_as_ushort(__float2half_rn(rad.x));
+    o.y = __half_as_ushort(__float2half_rn(rad.y));
+    o.z = __half_as_ushort(__float2half_rn(rad.z));
+    o.w = __half_as_ushort(__float2half_rn(rad.w));
+    reinterpret_cast<ushort4*>(out)[i] = o;
+}
+
+}  // namespace
+
+static_assert(sizeof(lbvh_path_state) == 64, "path state must be 64 bytes");
+
+extern "C" {
+
+lbvh_status lbvh_animate(lbvh_context* ctx, const lbvh_triangle* d_rest, uint32_t n, const uint32_t* d_body,
+                         const float* d_centres, float cos_angle, float sin_angle, lbvh_triangle* d_out)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    if (n == 0) return LBVH_OK;
+    LBVH_REQUIRE(ctx, d_rest != nullptr && d_body != nullptr && d_centres != nullptr && d_out != nullptr);
+    LBVH_REQUIRE(ctx, d_rest != d_out);
+    LBVH_REQUIRE(ctx, ((uintptr_t)d_rest & 15) == 0 && ((uintptr_t)d_out & 15) == 0 && ((uintptr_t)d_centres & 15) == 0);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LBVH_LAUNCH(ctx, animate_kernel, dim3((n + 255) / 256), dim3(256), d_rest, n, d_body, (const float4*)d_centres, cos_angle,
+                sin_angle, d_out);
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_path_begin(lbvh_context* ctx, const lbvh_camera* h_camera, lbvh_path_state* d_states)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, h_camera != nullptr && d_states != nullptr && ((uintptr_t)d_states & 15) == 0);
+    const lbvh_camera cam = *h_camera;
+    LBVH_REQUIRE(ctx, cam.screen_width > 0 && cam.screen_height > 0);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LBVH_LAUNCH(ctx, path_begin_kernel, dim3((cam.screen_width + 15) / 16, (cam.screen_height + 15) / 16), dim3(256), cam,
+                d_states);
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, float t_min,
+                            const lbvh_scene* h_scene, lbvh_hit* d_hits)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    if (count == 0) return LBVH_OK;
+    LBVH_REQUIRE(ctx, d_states != nullptr && h_scene != nullptr && d_hits != nullptr);
+    LBVH_REQUIRE(ctx, ((uintptr_t)d_states & 15) == 0 && ((uintptr_t)d_hits & 15) == 0);
+    LBVH_REQUIRE(ctx, (count + LBVH_WAVE - 1) / LBVH_WAVE <= 0x7FFFFFFFu);
+    if (!ctx->fast_nodes || ctx->fast_n != h_scene->n)
+        return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_trace_rays", "needs lbvh_build_fast_scene on this scene first");
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LBVH_LAUNCH(ctx, trace_rays_kernel, dim3((unsigned)((count + LBVH_WAVE - 1) / LBVH_WAVE)), dim3(LBVH_WAVE), d_states, count,
+                t_min, ctx->fast_nodes, ctx->fast_tris, d_hits);
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_path_scatter(lbvh_context* ctx, const lbvh_scene* h_scene, const lbvh_hit* d_hits, size_t count,
+                              uint32_t bounce, uint32_t seed, float albedo, lbvh_path_state* d_states)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    if (count == 0) return LBVH_OK;
+    LBVH_REQUIRE(ctx, h_scene != nullptr && h_scene->triangles != nullptr && d_hits != nullptr && d_states != nullptr);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LBVH_LAUNCH(ctx, path_scatter_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), h_scene->triangles, d_hits, count,
+                bounce, seed, albedo, d_states);
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_path_resolve(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, uint16_t* d_rgba16f)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    if (count == 0) return LBVH_OK;
+    LBVH_REQUIRE(ctx, d_states != nullptr && d_rgba16f != nullptr && ((uintptr_t)d_rgba16f & 7) == 0);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LBVH_LAUNCH(ctx, path_resolve_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), d_states, count, d_rgba16f);
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
+}
+
+}  // extern "C"

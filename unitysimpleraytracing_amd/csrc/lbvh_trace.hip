@@ -17,86 +17,12 @@
 // One wave (8x8 pixels) per workgroup; the traversal stack lives in LDS as [entry][lane]
 // (bank-conflict-free, no scratch memory); no barriers anywhere.
 #include "lbvh_common.h"
+#include "lbvh_rt.h"
 
 namespace {
 
 constexpr int kStackDepth = 34;   // distributed keys are < 2^31 => <= 31 internal levels below the
                                   // root; the reference's push-both order needs depth + 1 entries
-
-struct ray_t {
-    float ox, oy, oz;
-    float dx, dy, dz;
-    float ix, iy, iz;
-};
-
-// Raytracing.compute:108-126; same expression order as oracle/lbvh_oracle.c orc_make_ray
-__device__ __forceinline__ ray_t make_ray(const lbvh_camera& cam, uint32_t px, uint32_t py)
-{
-    const float near = cam.near_plane;
-    const float fov = cam.camera_fov;
-    const float height = 2.0f * near * fov;
-    const float width = (float)cam.screen_width * height / (float)cam.screen_height;
-    const float d0 = -width / 2.0f + width / (float)cam.screen_width * ((float)px + 0.5f);
-    const float d1 = -height / 2.0f + height / (float)cam.screen_height * ((float)py + 0.5f);
-    const float d2 = -near;
-    const float* m = cam.camera_to_world;
-    float o[3], w[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        o[r] = ((m[4 * r + 0] * 0.0f + m[4 * r + 1] * 0.0f) + m[4 * r + 2] * 0.0f) + m[4 * r + 3] * 1.0f;
-        w[r] = ((m[4 * r + 0] * d0 + m[4 * r + 1] * d1) + m[4 * r + 2] * d2) + m[4 * r + 3] * 0.0f;
-    }
-    const float len = sqrtf((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]);
-    ray_t ray;
-    ray.ox = o[0]; ray.oy = o[1]; ray.oz = o[2];
-    ray.dx = w[0] / len; ray.dy = w[1] / len; ray.dz = w[2] / len;
-    ray.ix = 1.0f / ray.dx; ray.iy = 1.0f / ray.dy; ray.iz = 1.0f / ray.dz;
-    return ray;
-}
-
-// RayBoxIntersection, Raytracing.compute:75-87.  Returns the hit predicate; tmin_out = entry t.
-__device__ __forceinline__ bool ray_box(const float4 bmin, const float4 bmax, const ray_t& r, float& tmin_out)
-{
-    const float t1x = (bmin.x - r.ox) * r.ix, t2x = (bmax.x - r.ox) * r.ix;
-    const float t1y = (bmin.y - r.oy) * r.iy, t2y = (bmax.y - r.oy) * r.iy;
-    const float t1z = (bmin.z - r.oz) * r.iz, t2z = (bmax.z - r.oz) * r.iz;
-    const float tmin = fmaxf(fminf(t1x, t2x), fmaxf(fminf(t1y, t2y), fminf(t1z, t2z)));
-    const float tmax = fminf(fmaxf(t1x, t2x), fminf(fmaxf(t1y, t2y), fmaxf(t1z, t2z)));
-    tmin_out = tmin;
-    return tmax > tmin && tmax > 0.0f;
-}
-
-__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
-{
-    return (ax * bx + ay * by) + az * bz;
-}
-
-// RayTriangleIntersection, Raytracing.compute:37-73.  Returns distance (LBVH_MAX_FLOAT = miss).
-__device__ __forceinline__ float ray_triangle(const ray_t& r, const float4 v0, const float4 v1,
-                                              const float4 v2, float& u_out, float& v_out)
-{
-    const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
-    const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
-    // pvec = cross(dir, e2)
-    const float px = r.dy * e2z - r.dz * e2y;
-    const float py = r.dz * e2x - r.dx * e2z;
-    const float pz = r.dx * e2y - r.dy * e2x;
-    const float det = dot3(e1x, e1y, e1z, px, py, pz);
-    if (det < 1e-8f && det > -1e-8f) return LBVH_MAX_FLOAT;
-    const float inv_det = 1.0f / det;
-    const float tx = r.ox - v0.x, ty = r.oy - v0.y, tz = r.oz - v0.z;
-    const float u = dot3(tx, ty, tz, px, py, pz) * inv_det;
-    if (u < 0.0f || u > 1.0f) return LBVH_MAX_FLOAT;
-    // qvec = cross(tvec, e1)
-    const float qx = ty * e1z - tz * e1y;
-    const float qy = tz * e1x - tx * e1z;
-    const float qz = tx * e1y - ty * e1x;
-    const float v = dot3(r.dx, r.dy, r.dz, qx, qy, qz) * inv_det;
-    if (v < 0.0f || u + v > 1.0f) return LBVH_MAX_FLOAT;
-    u_out = u;
-    v_out = v;
-    return dot3(e2x, e2y, e2z, qx, qy, qz) * inv_det;
-}
 
 struct trace_args {
     lbvh_camera cam;

@@ -346,3 +346,59 @@ class RaytracingMeshDrawer:
         for b in (self._hits, self._stats):
             if b is not None:
                 b.dispose()
+
+
+class DynamicPathTracer:
+    """SURVEY 8(f) rank 3 / BASELINE configs[4] (extension, no reference counterpart): per frame the rigid bodies
+    are rotated (lbvh_animate), the whole LBVH is rebuilt on the same buffers (RaytracingMeshDrawer.rebuild), primary
+    rays go through the packet kernel and `bounces` diffuse bounces through lbvh_trace_rays / lbvh_path_scatter."""
+
+    def __init__(self, ctx, rest_triangles, body_ids, body_centres, t_min=1e-3, albedo=0.7, seed=1):
+        self.ctx = ctx
+        self.drawer = RaytracingMeshDrawer(ctx, rest_triangles).awake()
+        n = self.drawer.container.triangles_length
+        self.rest = DataBuffer(ctx, n, L.TRIANGLE)
+        self.rest.local[:] = np.ascontiguousarray(rest_triangles, dtype=L.TRIANGLE)
+        self.rest.sync()
+        self.body = DataBuffer(ctx, n, np.uint32)
+        self.body.local[:] = np.ascontiguousarray(body_ids, dtype=np.uint32)
+        self.body.sync()
+        ctr = np.ascontiguousarray(body_centres, dtype=np.float32).reshape(-1, 4)
+        self.centres = DataBuffer(ctx, ctr.size, np.float32)
+        self.centres.local[:] = ctr.reshape(-1)
+        self.centres.sync()
+        self.t_min, self.albedo, self.seed = float(t_min), float(albedo), int(seed)
+        self.states = self.hits = self.image_buf = None
+
+    def animate(self, angle):
+        c = self.drawer.container
+        N.check(self.ctx.handle, N.lib.lbvh_animate(
+            self.ctx.handle, self.rest.device, c.triangles_length, self.body.device, self.centres.device,
+            float(np.float32(np.cos(angle))), float(np.float32(np.sin(angle))), c.triangle_data.device))
+        self.drawer.rebuild(fast=True)
+
+    def render(self, camera, bounces=4):
+        cam = N.Camera.from_dict(camera)
+        count = cam.screen_width * cam.screen_height
+        if self.states is None or self.states.size < count:
+            self.states = DataBuffer(self.ctx, count, L.PATH_STATE)
+            self.hits = DataBuffer(self.ctx, count, L.HIT)
+            self.image_buf = DataBuffer(self.ctx, count, np.uint64)
+        h = self.ctx.handle
+        s = self.drawer.container.scene()
+        N.check(h, N.lib.lbvh_path_begin(h, C.byref(cam), self.states.device))
+        # primary rays: the coherent packet kernel
+        N.check(h, N.lib.lbvh_trace_primary(h, C.byref(cam), 0, 0, cam.screen_width, cam.screen_height, C.byref(s),
+                                            L.TRACE_FAST, self.hits.device, None))
+        N.check(h, N.lib.lbvh_path_scatter(h, C.byref(s), self.hits.device, count, 0, self.seed, self.albedo, self.states.device))
+        for b in range(1, bounces + 1):
+            N.check(h, N.lib.lbvh_trace_rays(h, self.states.device, count, self.t_min, C.byref(s), self.hits.device))
+            N.check(h, N.lib.lbvh_path_scatter(h, C.byref(s), self.hits.device, count, b, self.seed, self.albedo,
+                                               self.states.device))
+        N.check(h, N.lib.lbvh_path_resolve(h, self.states.device, count, self.image_buf.device))
+        self._shape = (cam.screen_height, cam.screen_width)
+        return self.image_buf
+
+    def image(self):
+        n = self._shape[0] * self._shape[1]
+        return self.image_buf.get_data()[:n].view(np.float16).reshape(self._shape + (4,)).copy()

@@ -24,6 +24,10 @@ HIT = np.dtype([("t", "<f4"), ("tri", "<u4"), ("u", "<f4"), ("v", "<f4")])
 TRACE_STATS = np.dtype([("pops", "<u8"), ("box_hits", "<u8"), ("leaf_tests", "<u8"),
                         ("tri_tests", "<u8"), ("hits", "<u8")])
 
+PATH_STATE = np.dtype([("origin", "<f4", 3), ("alive", "<u4"), ("dir", "<f4", 3), ("pad0", "<f4"),
+                       ("throughput", "<f4", 3), ("pad1", "<f4"), ("radiance", "<f4", 3), ("alpha", "<f4")])
+assert PATH_STATE.itemsize == 64
+
 assert AABB.itemsize == 32          # Assets/_Scripts/MeshBufferContainer.cs:103
 assert TRIANGLE.itemsize == 128     # Assets/_Scripts/MeshBufferContainer.cs:98
 assert INTERNAL_NODE.itemsize == 24

@@ -101,7 +101,7 @@ def _rotation(rng):
     return q
 
 
-def tiled_torus(nu=80, nv=50, grid=5, pitch=45.0, seed=2, shuffle=True):
+def tiled_torus(nu=80, nv=50, grid=5, pitch=45.0, seed=2, shuffle=True, with_bodies=False):
     """cfg2/3/5 ("tiled bunny" stand-in): one bumpy torus of 2*nu*nv faces tiled on a grid^3
     lattice with pitch `pitch`, centred in the reference's Morton box [-125, 125]^3, each tile with
     its own seeded rotation, triangle order shuffled.  Defaults: 8 000 faces x 125 tiles =
@@ -125,10 +125,23 @@ def tiled_torus(nu=80, nv=50, grid=5, pitch=45.0, seed=2, shuffle=True):
                 b[sl] = (b0 @ rot.T + t).astype(np.float32)
                 c[sl] = (c0 @ rot.T + t).astype(np.float32)
                 k += 1
+    body = np.repeat(np.arange(grid ** 3, dtype=np.uint32), faces)
     if shuffle:
         perm = rng.permutation(n)
         a, b, c = a[perm], b[perm], c[perm]
-    return _pack_triangles(a, b, c)
+        body = body[perm]
+    tris = _pack_triangles(a, b, c)
+    if not with_bodies:
+        return tris
+    # cfg5 (dynamic scene): every tile is a rigid body rotating about the Y axis through its centre
+    centres = np.zeros((grid ** 3, 4), dtype=np.float32)
+    k = 0
+    for ix in range(grid):
+        for iy in range(grid):
+            for iz in range(grid):
+                centres[k, :3] = (offs[ix], offs[iy], offs[iz])
+                k += 1
+    return tris, body, centres
 
 
 def load_obj(path_or_text, is_text=False):
