@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--no-sort-bench", action="store_true")
     ap.add_argument("--sort-keys-log2", type=int, default=26)
     ap.add_argument("--mode", choices=["fast", "reference"], default="fast")
+    # cfg2 = BASELINE configs[1]/[2] (the metric's workload, default); cfg4 = configs[3]: 16 M triangles with the
+    # key-range sharded sort (RCCL digit-histogram all-reduce + one all-to-all) when launched on more than one rank
+    ap.add_argument("--workload", choices=["cfg2", "cfg4"], default="cfg2")
+    ap.add_argument("--no-dynamic", action="store_true", help="skip the untimed cfg5 (dynamic scene + 4 bounces) extra")
     # test hooks: run the N-rank path on fewer GPUs (ranks share --device, gloo instead of RCCL)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--device", type=int, default=None)
@@ -113,14 +117,40 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    tris = scenes.tiled_torus()                        # identical on every rank (seeded)
-    assert len(tris) == N_TRIS
+    cfg4 = args.workload == "cfg4"
+    tris = scenes.tiled_torus(nu=400, nv=160) if cfg4 else scenes.tiled_torus()      # identical on every rank (seeded)
+    n_tris = len(tris)
+    assert n_tris == (16 * N_TRIS if cfg4 else N_TRIS)
     cam = scenes.camera(W, H, CAMERA_POS)
     mode = L.TRACE_FAST if args.mode == "fast" else L.TRACE_REFERENCE
-    ctx = Context(device_id)
+    sorter = None
+    if cfg4 and world > 1:
+        # the sharded sort mixes library kernels with RCCL collectives: one stream (torch's) orders both
+        import torch
+        from unitysimpleraytracing_amd.sharded_sort import ShardedSorter, sort_container
+        torch.cuda.set_device(device_id)
+        ctx = Context(device_id, stream=torch.cuda.current_stream().cuda_stream)
+        sorter = ShardedSorter(ctx)
+    else:
+        ctx = Context(device_id)
     drawer = RaytracingMeshDrawer(ctx, tris)
     drawer.awake(fast=True)                            # allocates everything; untimed
     ctx.sync()
+
+    def rebuild():
+        if sorter is None:
+            drawer.rebuild(fast=(mode == L.TRACE_FAST))
+            return
+        c = drawer.container                           # RaytracingMeshDrawer.rebuild with the sort sharded over the ranks
+        c.bvh_leaf_node.fill_u32(L.NULL, mirror=False)
+        c.bvh_internal_node.fill_u32(L.NULL, mirror=False)
+        c.generate_keys()
+        sort_container(sorter, c)
+        c.distribute_keys()
+        drawer.bvh_constructor.construct_tree()
+        drawer.bvh_constructor.construct_bvh()
+        if mode == L.TRACE_FAST:
+            drawer.build_fast_scene()
     hit_buf = DataBuffer(ctx, W * H, L.HIT)             # full-frame layout on every rank
     from unitysimpleraytracing_amd import _native as N
     ccam = N.Camera.from_dict(cam)
@@ -134,7 +164,7 @@ def main():
     def step(ev=None):
         if ev:
             ctx.record(ev[0])
-        drawer.rebuild(fast=(mode == L.TRACE_FAST))
+        rebuild()
         if ev:
             ctx.record(ev[1])
         trace_frame()
@@ -163,6 +193,14 @@ def main():
 
     # ---- untimed extras (rank 0 prints them) ---------------------------------------------------
     out = None
+    sharded_sort_check = None
+    if sorter is not None and rank == 0:
+        # the timed steps left the sharded sort's result in the container: compare it with the one-GPU sort
+        c = drawer.container
+        ctx.sync()
+        k_sh, i_sh = c.keys.get_data().copy(), c.triangle_index.get_data().copy()
+        drawer.rebuild(fast=False)
+        sharded_sort_check = bool((c.keys.get_data() == k_sh).all() and (c.triangle_index.get_data() == i_sh).all())
     if rank == 0:
         # algorithmic bytes of the traversal kernel from its own visit counters: one 64-B fused
         # node per node fetch + 48 B per triangle fetch + 16 B hit record per ray
@@ -201,7 +239,7 @@ def main():
         # per-kernel breakdown of one build
         ctx.profile_begin()
         for _ in range(5):
-            drawer.rebuild(fast=(mode == L.TRACE_FAST))
+            drawer.rebuild(fast=(mode == L.TRACE_FAST))      # single-GPU build (no collective: the other ranks are past this)
         prof_build = {k: round(v[1] / 5.0, 4) for k, v in ctx.profile_end().items()}
 
         # measured HBM copy rate of this box (float4 copy, 1 GiB)
@@ -221,7 +259,7 @@ def main():
 
         roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": measured_traffic("trace_packet_kernel<false"),
+                    "traffic": None if cfg4 else measured_traffic("trace_packet_kernel<false"),
                     "bytes_per_ray": round(bytes_per_ray, 1), "bytes_per_ray_basis": "reference visit order, "
                     "32P+24B+44L+48T+8 (SURVEY 8d)", "reference_visits_per_ray": ref_counts,
                     "own_bytes_per_ray": None if own_bytes_per_ray is None else round(own_bytes_per_ray, 1),
@@ -235,22 +273,32 @@ def main():
             sort_roofline = sort_microbench(ctx, args.sort_keys_log2, copy_gbs)
 
         cpu_baseline = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not cfg4:
             cpu_baseline = cpu_leg(tris, cam)
+
+        dynamic = None
+        if world == 1 and not args.no_dynamic and not cfg4:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import dynamic_bench                               # cfg5: animate + rebuild + primary + 4 bounces per frame
+            dynamic = dynamic_bench.run(ctx, frames=10, warmup=2)
 
         out = {
             "metric": "LBVH build Mtri/s + primary Mrays/s at 1080p on 1M-tri synthetic mesh",
             "value": round(W * H / (trace_ms_max * 1e-3) / 1e6, 2),
             "unit": "Mrays/s",
-            "build_Mtri_s": round(N_TRIS / (build_ms_max * 1e-3) / 1e6, 2),
+            "build_Mtri_s": round(n_tris / (build_ms_max * 1e-3) / 1e6, 2),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall_ms, 4),
             "build_ms": round(build_ms_max, 4), "trace_ms": round(trace_ms_max, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32+u32", "data": "synthetic",
-            "config": {"workload": "cfg2: 1,000,000-triangle tiled bumpy torus (seed 2), 1920x1080 primary rays, "
+            "config": {"workload": ("cfg4: 16,000,000-triangle tiled bumpy torus (400x160 quads x 125 tiles, seed 2), sort "
+                                    + (f"key-range sharded over {world} GPUs (RCCL digit-histogram all-reduce + one all-to-all), "
+                                       if world > 1 else "on one GPU, ") + "1920x1080 primary rays; full LBVH rebuild + frame trace per step")
+                       if cfg4 else
+                                   "cfg2: 1,000,000-triangle tiled bumpy torus (seed 2), 1920x1080 primary rays, "
                                    "camera (0,0,250) fov 60; full LBVH rebuild + frame trace per step",
-                       "triangles": N_TRIS, "rays": W * H, "trace_mode": args.mode,
+                       "triangles": n_tris, "rays": W * H, "trace_mode": args.mode,
                        "sharding": f"rays in interleaved groups of 8 tiles over {world} GPU(s) (one launch per GPU), BVH replicated, "
                                    "no collective",
                        "hit_fraction": round(hit_fraction, 4)},
@@ -258,7 +306,10 @@ def main():
             "roofline_sort_scatter": sort_roofline,
             "cpu_baseline": cpu_baseline,
             "build_kernels_ms": prof_build,
+            "cfg5_dynamic": dynamic,
         }
+        if sharded_sort_check is not None:
+            out["sharded_sort_matches_single_gpu"] = sharded_sort_check
     for e in events:
         for x in e:
             ctx.destroy_event(x)

@@ -62,6 +62,21 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern int lbvh_shade(IntPtr ctx, IntPtr dHits, UIntPtr count, IntPtr dTriangles,
         IntPtr dTextureRgba8, int texW, int texH, IntPtr dRgba16f);
 
+    // dynamic scene + secondary rays (BASELINE configs[4]; extension, no reference counterpart)
+    [DllImport(Lib)] public static extern int lbvh_animate(IntPtr ctx, IntPtr dRestTriangles, uint n, IntPtr dBodyIds, IntPtr dBodyCentres,
+        float cosAngle, float sinAngle, IntPtr dTrianglesOut);
+    [DllImport(Lib)] public static extern int lbvh_path_begin(IntPtr ctx, ref Camera camera, IntPtr dStates);
+    [DllImport(Lib)] public static extern int lbvh_trace_rays(IntPtr ctx, IntPtr dStates, UIntPtr count, float tMin, ref Scene scene, IntPtr dHits);
+    [DllImport(Lib)] public static extern int lbvh_path_scatter(IntPtr ctx, ref Scene scene, IntPtr dHits, UIntPtr count, uint bounce, uint seed,
+        float albedo, IntPtr dStates);
+    [DllImport(Lib)] public static extern int lbvh_path_resolve(IntPtr ctx, IntPtr dStates, UIntPtr count, IntPtr dRgba16f);
+
+    // local kernels of the multi-GPU key-range sharded sort (BASELINE configs[3])
+    [DllImport(Lib)] public static extern int lbvh_key_histogram(IntPtr ctx, IntPtr dKeys, uint count, uint[] prefixes, uint nPrefixes,
+        uint prefixShift, uint shift, IntPtr dHist);
+    [DllImport(Lib)] public static extern int lbvh_lower_bound(IntPtr ctx, IntPtr dSortedKeys, uint count, uint[] probes, uint nProbes,
+        IntPtr dPositions);
+
     public static void Check(IntPtr ctx, int status)
     {
         if (status != 0)

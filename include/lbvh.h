@@ -200,6 +200,27 @@ lbvh_status lbvh_morton_aabb(lbvh_context* ctx, const lbvh_triangle* d_triangles
 lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values,
                             uint32_t count);
 
+/* ---- cfg4: building blocks of the multi-GPU (key-range sharded) sort, SURVEY 8(e) ------------- *
+ * The reference has no multi-GPU path; these are the local kernels of the sharded sort that
+ * unitysimpleraytracing_amd/sharded_sort.py drives (one process per GPU): every rank sorts its own
+ * block, the ranks agree on W-1 splitter keys by all-reducing (RCCL) MSD digit histograms,
+ * exchange key ranges with one all-to-all and sort what they received.  The concatenation over
+ * ranks is bit-identical to lbvh_sort_pairs over the whole array (stability: ties never straddle
+ * ranks and arrive in source-rank order). */
+
+/* d_hist[p * 256 + d] = number of keys k among d_keys[0..count) with ((k >> shift) & 255) == d and,
+ * when prefix_shift < 32, (k >> prefix_shift) == h_prefixes[p].  prefix_shift == 32 selects every
+ * key (then n_prefixes must be 1 and h_prefixes may be NULL).  n_prefixes <= 16.  d_hist is
+ * overwritten.  Keys need not be sorted. */
+lbvh_status lbvh_key_histogram(lbvh_context* ctx, const uint32_t* d_keys, uint32_t count,
+                               const uint32_t* h_prefixes, uint32_t n_prefixes, uint32_t prefix_shift,
+                               uint32_t shift, uint32_t* d_hist);
+
+/* d_positions[j] = the first i in [0, count] with d_sorted_keys[i] >= h_probes[j] (count if none);
+ * n_probes <= 64. */
+lbvh_status lbvh_lower_bound(lbvh_context* ctx, const uint32_t* d_sorted_keys, uint32_t count,
+                             const uint32_t* h_probes, uint32_t n_probes, uint32_t* d_positions);
+
 /* ---- stage a-6: DistributeKeys ---------------------------------------------------------------- */
 
 /* Replaces MeshBufferContainer.DistributeKeys (Sc/MeshBufferContainer.cs:154-169), a serial CPU

@@ -221,6 +221,23 @@ def assert_build_equal(c, b):
     assert (c.bvh_data.local["_dummy0"][: n - 1] == 0).all()
 
 
+def test_cfg4_sixteen_million_triangles_on_one_gpu(ctx):
+    """BASELINE configs[3]'s mesh (400x160 quads x 125 tiles) on one GPU: whole build bit-exact, traversal modes agree."""
+    tris = scenes.tiled_torus(nu=400, nv=160)
+    assert len(tris) == 16_000_000
+    d, c, b = build_both(ctx, tris)
+    assert_build_equal(c, b)
+    cam = scenes.camera(480, 270, (0.0, 0.0, 250.0))
+    d.update(cam, mode=L.TRACE_FAST)
+    fast = d.hits()
+    d.update(cam, mode=L.TRACE_REFERENCE)
+    ref = d.hits()
+    assert (fast["t"] == ref["t"]).all()
+    oh, _ = O.trace_primary(b, cam, step=(4, 4), threads=O.num_threads())
+    assert (oh["t"] == ref["t"][::4, ::4][: oh.shape[0], : oh.shape[1]]).all()
+    d.on_destroy()
+
+
 @pytest.mark.parametrize("scene", ["cfg1", "grid", "torus64k", "tiny2", "tiny3"])
 def test_full_build_bit_exact(ctx, scene):
     tris = {"cfg1": lambda: scenes.random_triangles(4096, seed=1), "grid": scenes.grid_scene,
@@ -458,6 +475,27 @@ def test_cpp_host_driver_matches_oracle():
     hit = oh["t"] < L.MAX_FLOAT
     assert res["hits"] == int(hit.sum())
     assert abs(res["t_sum"] - float(oh["t"][hit].astype(np.float64).sum())) < 1e-3
+
+
+def test_cpp_dynamic_path_tracer_matches_oracle():
+    """BASELINE configs[4] in miniature through host/lbvh_host.hpp DynamicPathTracer (animate, rebuild, 2 bounces)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "unitysimpleraytracing_amd", "host", "lbvh_driver")
+    res = json.loads(subprocess.run([exe, "4096", "128", "96", "dynamic"], check=True, capture_output=True, text=True).stdout)
+    pos = _splitmix_mesh(4096)
+    tris = np.zeros(4096, dtype=L.TRIANGLE)
+    tris["a"], tris["b"], tris["c"] = pos[:, 0], pos[:, 1], pos[:, 2]
+    body = np.arange(4096, dtype=np.uint32) % 8
+    centres = np.zeros((8, 4), dtype=np.float32)
+    for k in range(8):
+        centres[k, :3] = [40.0 if k & 1 else -40.0, 40.0 if k & 2 else -40.0, 40.0 if k & 4 else -40.0]
+    moved = O.animate(tris, body, centres, np.float32(0.1))
+    b = O.Built(moved, capacity=4096, threads=8)
+    img, _ = O.path_trace(b, scenes.camera(128, 96, (0.0, 0.0, 300.0)), bounces=2, t_min=1e-3, albedo=0.7, seed=3, threads=8)
+    px = img.view(np.uint16).reshape(-1, 4).astype(np.uint64)
+    assert res["image_sum"] == int((px * np.array([1, 3, 5, 7], dtype=np.uint64)).sum(dtype=np.uint64))
 
 
 # ---- a-9 tail: shading ---------------------------------------------------------------------------------------

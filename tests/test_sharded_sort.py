@@ -1,0 +1,186 @@
+"""cfg4: the key-range sharded sort.  CPU: world_size 2 and 3 over gloo with the oracle standing in
+for the local kernels (host logic: splitters from all-reduced MSD digit histograms, one exchange, stability).
+GPU: the same with the HIP kernels, ranks sharing cuda:0 over gloo, and the RCCL collectives with one rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _inputs(kind, n, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        k = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    elif kind == "morton":                 # < 2^30, clustered, with 0xFFFFFFFF pads at the end
+        k = (rng.integers(0, 1 << 12, size=n, dtype=np.uint64) << np.uint64(18)).astype(np.uint32)
+        k |= rng.integers(0, 64, size=n, dtype=np.uint64).astype(np.uint32)
+        k[n - n // 10:] = 0xFFFFFFFF
+    elif kind == "few":                    # heavy duplicates: ties must stay in input order
+        k = rng.integers(0, 5, size=n, dtype=np.uint64).astype(np.uint32) * np.uint32(0x01010101)
+    elif kind == "equal":
+        k = np.full(n, 12345, dtype=np.uint32)
+    elif kind == "sorted_desc":
+        k = np.arange(n, 0, -1, dtype=np.uint32) * np.uint32(977)
+    else:
+        raise ValueError(kind)
+    return k, np.arange(n, dtype=np.uint32)
+
+
+class OracleKeyOps:
+    """Test stand-in for HipKeyOps on CPU tensors: the oracle's stable sort + numpy restatements of
+    lbvh_key_histogram / lbvh_lower_bound (include/lbvh.h)."""
+    device = "cpu"
+
+    def sort_pairs(self, keys, vals):
+        import torch
+        import oracle as O
+        k, v = O.sort_pairs(keys.numpy().view(np.uint32), vals.numpy().view(np.uint32))
+        keys.copy_(torch.from_numpy(k.view(np.int32)))
+        vals.copy_(torch.from_numpy(v.view(np.int32)))
+
+    def key_histogram(self, keys, prefixes, prefix_shift, shift):
+        import torch
+        k = keys.numpy().view(np.uint32)
+        d = (k >> np.uint32(shift)) & np.uint32(255)
+        if prefixes is None:
+            rows = [np.bincount(d, minlength=256)]
+        else:
+            top = k.astype(np.uint64) >> np.uint64(prefix_shift)
+            rows = [np.bincount(d[top == p], minlength=256) for p in prefixes]
+        return torch.from_numpy(np.stack(rows).astype(np.uint32).view(np.int32))
+
+    def lower_bound(self, sorted_keys, probes):
+        import torch
+        pos = np.searchsorted(sorted_keys.numpy().view(np.uint32), np.asarray(probes, dtype=np.uint32), side="left")
+        return torch.from_numpy(pos.astype(np.int32))
+
+    def empty(self, n):
+        import torch
+        return torch.empty(n, dtype=torch.int32)
+
+
+def _run_case(sorter, ops, kind, n, seed, rank, world, uneven):
+    import torch
+    from unitysimpleraytracing_amd.sharded_sort import block_of
+    keys, vals = _inputs(kind, n, seed)
+    if uneven and world > 1:                    # ragged blocks, rank 0 may hold nothing
+        cuts = np.linspace(0, n, world + 1).astype(int)
+        cuts[1] = 0 if uneven == "empty0" else cuts[1] // 3
+        lo, hi = cuts[rank], cuts[rank + 1]
+    else:
+        lo, hi = block_of(rank, world, n)
+    dev = ops.device
+    k = torch.from_numpy(keys[lo:hi].view(np.int32).copy()).to(dev)
+    v = torch.from_numpy(vals[lo:hi].view(np.int32).copy()).to(dev)
+    k, v, counts = sorter.sort(k, v)
+    assert k.numel() == counts[rank] and sum(counts) == n
+    gk, gv = sorter.gather(k, v, counts)
+    order = np.argsort(keys, kind="stable")
+    ok = (gk.cpu().numpy().view(np.uint32) == keys[order]).all() and (gv.cpu().numpy().view(np.uint32) == vals[order]).all()
+    # balance: a rank's slice exceeds N/W only by duplicates of its first/last key
+    if kind in ("uniform", "sorted_desc") and world > 1:
+        ok = ok and max(counts) - min(counts) <= 2
+    return bool(ok)
+
+
+CASES = [("uniform", 50_000, 1, None), ("morton", 40_000, 2, None), ("few", 30_000, 3, None), ("equal", 10_000, 4, None),
+         ("sorted_desc", 20_001, 5, None), ("uniform", 30_000, 6, "ragged"), ("morton", 9_999, 7, "empty0"),
+         ("uniform", 7, 8, None)]
+
+
+def _cpu_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    from unitysimpleraytracing_amd.sharded_sort import ShardedSorter
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ops = OracleKeyOps()
+    sorter = ShardedSorter(ops=ops)
+    res = [_run_case(sorter, ops, kind, n, seed, rank, world, uneven) for kind, n, seed, uneven in CASES]
+    with open(f"{out_path}.{rank}", "w") as f:
+        f.write("ok" if all(res) else "mismatch " + str(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_sort_host_logic_over_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result")
+    mp.spawn(_cpu_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        assert open(f"{out}.{r}").read() == "ok"
+
+
+def test_block_of_partitions_the_capacity():
+    from unitysimpleraytracing_amd.sharded_sort import block_of
+    for cap in (0, 1, 7, 1024, 1_000_448, 16_000_000):
+        for world in (1, 2, 3, 8):
+            edges = [block_of(r, world, cap) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == cap
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(world - 1))
+
+
+def test_sharded_sorter_refuses_to_run_without_the_hip_context():
+    from unitysimpleraytracing_amd.sharded_sort import ShardedSorter
+    with pytest.raises(ValueError):
+        ShardedSorter()
+
+
+# ---- GPU ----------------------------------------------------------------------------------------------------
+
+def _gpu_worker(rank, world, port, out_path, backend):
+    import torch
+    import torch.distributed as dist
+    from unitysimpleraytracing_amd.host import Context, MeshBufferContainer
+    from unitysimpleraytracing_amd.sharded_sort import HipKeyOps, ShardedSorter, sort_container
+    from unitysimpleraytracing_amd import scenes
+    import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    ops = HipKeyOps(ctx)
+    sorter = ShardedSorter(ctx, always_exchange=True)
+    res = [_run_case(sorter, ops, kind, n, seed, rank, world, uneven) for kind, n, seed, uneven in CASES]
+    res.append(_run_case(sorter, ops, "uniform", 3_000_000, 9, rank, world, None))
+    # the container path: Morton replicated, sort sharded, result back in the reference's buffers
+    tris = scenes.tiled_torus(nu=40, nv=24, grid=3)
+    c = MeshBufferContainer(ctx, tris)
+    counts = sort_container(sorter, c)
+    torch.cuda.synchronize()
+    b = O.Built(tris, capacity=c.capacity, threads=4)
+    k0, i0 = O.morton_aabb(tris, c.capacity)[:2]
+    ks, vs = O.sort_pairs(k0, i0)
+    res.append(bool((c.keys.get_data() == ks).all() and (c.triangle_index.get_data() == vs).all() and sum(counts) == c.capacity))
+    with open(f"{out_path}.{rank}", "w") as f:
+        f.write("ok" if all(res) else "mismatch " + str(res))
+    c.dispose()
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (1, "nccl")])
+def test_sharded_sort_hip_kernels(tmp_path, world, backend):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result")
+    mp.spawn(_gpu_worker, args=(world, _free_port(), out, backend), nprocs=world, join=True)
+    for r in range(world):
+        assert open(f"{out}.{r}").read() == "ok"

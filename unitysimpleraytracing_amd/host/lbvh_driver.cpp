@@ -33,8 +33,38 @@ int main(int argc, char** argv)
         }
         t.b_uv[0] = 1.0f; t.c_uv[1] = 1.0f;
     }
+    const bool dynamic = argc > 4 && std::strcmp(argv[4], "dynamic") == 0;
     try {
         lbvh::Context ctx(0);
+        if (dynamic) {
+            // BASELINE configs[4] in miniature: 8 rigid bodies (triangle i belongs to body i % 8), one animated frame,
+            // primary rays + 2 bounces; prints a checksum of the RGBA16F image
+            std::vector<uint32_t> body(n);
+            for (uint32_t i = 0; i < n; i++) body[i] = i % 8;
+            std::vector<float> centres(8 * 4, 0.0f);
+            for (int bdy = 0; bdy < 8; bdy++) {
+                centres[bdy * 4 + 0] = (bdy & 1) ? 40.0f : -40.0f;
+                centres[bdy * 4 + 1] = (bdy & 2) ? 40.0f : -40.0f;
+                centres[bdy * 4 + 2] = (bdy & 4) ? 40.0f : -40.0f;
+            }
+            lbvh::DynamicPathTracer pt(ctx, mesh, body, centres, 1e-3f, 0.7f, 3);
+            pt.Animate(0.1f);
+            lbvh_camera cam;
+            cam.screen_width = w; cam.screen_height = h;
+            cam.camera_fov = (float)std::tan(60.0 * 3.14159265358979323846 / 180.0 / 2.0);
+            cam.near_plane = 0.3f;
+            const float m[16] = {-1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 300, 0, 0, 0, 1};
+            std::memcpy(cam.camera_to_world, m, sizeof m);
+            pt.Render(cam, 2);
+            pt.Image().GetData();
+            uint64_t image_sum = 0;
+            for (size_t i = 0; i < (size_t)w * h; i++) {
+                const uint64_t px = pt.Image().LocalBuffer()[i];
+                image_sum += (px & 0xFFFF) + ((px >> 16) & 0xFFFF) * 3 + ((px >> 32) & 0xFFFF) * 5 + ((px >> 48) & 0xFFFF) * 7;
+            }
+            std::printf("{\"triangles\": %u, \"rays\": %d, \"image_sum\": %llu}\n", n, w * h, (unsigned long long)image_sum);
+            return 0;
+        }
         lbvh::RaytracingMeshDrawer drawer(ctx, mesh);
         auto t0 = std::chrono::steady_clock::now();
         drawer.Awake();

@@ -7,6 +7,7 @@
 // reference logs and carries on; here every failing call throws lbvh::Error with the library's text.
 #pragma once
 
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -257,6 +258,20 @@ public:
                                      (const lbvh_triangle*)container_->TriangleData().DeviceBuffer(),
                                      (const uint8_t*)tex_->DeviceBuffer(), tex_w_, tex_h_, (uint16_t*)image_->DeviceBuffer()));
     }
+    // per-frame rebuild on the same buffers (dynamic scenes): Morton -> sort -> DistributeKeys -> tree -> refit
+    void Rebuild()
+    {
+        container_->BvhLeafNode().Fill(0xFFFFFFFFu, false);
+        container_->BvhInternalNode().Fill(0xFFFFFFFFu, false);
+        container_->GenerateKeys();
+        sorter_->Sort();
+        container_->DistributeKeys();
+        bvh_->ConstructTree();
+        bvh_->ConstructBVH();
+        const lbvh_scene s = container_->Scene();
+        const float mn[3] = {-125.0f, -125.0f, -125.0f}, mx[3] = {125.0f, 125.0f, 125.0f};
+        check(ctx_.get(), lbvh_build_fast_scene(ctx_.get(), &s, mn, mx));
+    }
     DataBuffer<uint64_t>& Image() { return *image_; }
     MeshBufferContainer& Container() { return *container_; }
     DataBuffer<lbvh_hit>& Hits() { return *hits_; }
@@ -270,6 +285,61 @@ private:
     std::unique_ptr<DataBuffer<uint32_t>> tex_;
     std::unique_ptr<DataBuffer<uint64_t>> image_;
     int tex_w_ = 0, tex_h_ = 0;
+};
+
+// BASELINE configs[4] (extension): rigid bodies rotate every frame, the LBVH is rebuilt, primary rays + `bounces`
+// diffuse bounces at 1 spp.  Twin of host.py DynamicPathTracer.
+class DynamicPathTracer {
+public:
+    DynamicPathTracer(Context& ctx, const std::vector<lbvh_triangle>& rest, const std::vector<uint32_t>& body_ids,
+                      const std::vector<float>& body_centres_xyzw, float t_min = 1e-3f, float albedo = 0.7f, uint32_t seed = 1)
+        : ctx_(ctx), drawer_(ctx, rest), rest_(ctx, rest.size()), body_(ctx, body_ids.size()),
+          centres_(ctx, body_centres_xyzw.size()), t_min_(t_min), albedo_(albedo), seed_(seed)
+    {
+        drawer_.Awake();
+        rest_.LocalBuffer() = rest;                 rest_.Sync();
+        body_.LocalBuffer() = body_ids;             body_.Sync();
+        centres_.LocalBuffer() = body_centres_xyzw; centres_.Sync();
+    }
+    void Animate(float angle)
+    {
+        MeshBufferContainer& c = drawer_.Container();
+        check(ctx_.get(), lbvh_animate(ctx_.get(), (const lbvh_triangle*)rest_.DeviceBuffer(), c.TrianglesLength(),
+                                       (const uint32_t*)body_.DeviceBuffer(), (const float*)centres_.DeviceBuffer(),
+                                       std::cos(angle), std::sin(angle), (lbvh_triangle*)c.TriangleData().DeviceBuffer()));
+        drawer_.Rebuild();
+    }
+    void Render(const lbvh_camera& cam, uint32_t bounces = 4)
+    {
+        const size_t rays = (size_t)cam.screen_width * cam.screen_height;
+        if (!states_ || states_->Size() < rays) {
+            states_.reset(new DataBuffer<lbvh_path_state>(ctx_, rays));
+            image_.reset(new DataBuffer<uint64_t>(ctx_, rays));
+        }
+        drawer_.Update(cam);                                                     // primary rays: the packet kernel
+        const lbvh_scene s = drawer_.Container().Scene();
+        lbvh_path_state* st = (lbvh_path_state*)states_->DeviceBuffer();
+        lbvh_hit* hits = (lbvh_hit*)drawer_.Hits().DeviceBuffer();
+        check(ctx_.get(), lbvh_path_begin(ctx_.get(), &cam, st));
+        check(ctx_.get(), lbvh_path_scatter(ctx_.get(), &s, hits, rays, 0, seed_, albedo_, st));
+        for (uint32_t b = 1; b <= bounces; ++b) {
+            check(ctx_.get(), lbvh_trace_rays(ctx_.get(), st, rays, t_min_, &s, hits));
+            check(ctx_.get(), lbvh_path_scatter(ctx_.get(), &s, hits, rays, b, seed_, albedo_, st));
+        }
+        check(ctx_.get(), lbvh_path_resolve(ctx_.get(), st, rays, (uint16_t*)image_->DeviceBuffer()));
+    }
+    DataBuffer<uint64_t>& Image() { return *image_; }
+    RaytracingMeshDrawer& Drawer() { return drawer_; }
+private:
+    Context& ctx_;
+    RaytracingMeshDrawer drawer_;
+    DataBuffer<lbvh_triangle> rest_;
+    DataBuffer<uint32_t> body_;
+    DataBuffer<float> centres_;
+    std::unique_ptr<DataBuffer<lbvh_path_state>> states_;
+    std::unique_ptr<DataBuffer<uint64_t>> image_;
+    float t_min_, albedo_;
+    uint32_t seed_;
 };
 
 }  // namespace lbvh
