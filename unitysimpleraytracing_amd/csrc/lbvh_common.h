@@ -129,6 +129,12 @@ __device__ __forceinline__ uint32_t lane_id()
 }
 
 // number of set bits of `mask` in lanes below the calling lane (v_mbcnt_lo + v_mbcnt_hi)
+// which of the 8 XCDs (each with its own L2) this wave runs on: s_getreg_b32 HW_REG_XCC_ID (id 20), bits [3:0]
+__device__ __forceinline__ uint32_t xcc_id()
+{
+    return (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u;
+}
+
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),

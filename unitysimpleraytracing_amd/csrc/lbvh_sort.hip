@@ -21,7 +21,12 @@
 // flag (2 bits) and value (30 bits), is written with an agent-scope relaxed atomic store
 // (global_store_dword sc1, write-through) and polled with agent-scope relaxed atomic loads (sc1, L1
 // bypass) — no fences, no ordering between words needed, placement-independent.  Tiles take their
-// index from an atomic ticket, so every tile a look-back waits for is already running.
+// index from atomic tickets, so every tile a look-back waits for is already running.
+// XCD-aware tile order: a digit run written by tile T ends in the 128-B line where tile T+1's run of the
+// same digit begins.  If the two tiles run on different XCDs the line is half-written in two L2s and
+// reaches memory as two masked partial writes; on one XCD the halves merge in its L2.  So tickets are
+// per XCD and hand out kGroup CONSECUTIVE tiles to each XCD in turn (measured on the access pattern
+// alone, tools/ubench/tilecopy.hip: 2.9 -> 4.0 TB/s for unaligned 128-B runs).
 #include "lbvh_common.h"
 
 namespace {
@@ -30,10 +35,14 @@ constexpr int kThreads = 256;          // 4 waves
 constexpr int kRadix = 256;
 constexpr int kPasses = 4;
 
-constexpr uint32_t kFlagAgg = 1u << 30;    // value = this tile's digit count
-constexpr uint32_t kFlagIncl = 2u << 30;   // value = digit count of tiles 0..this
+constexpr uint32_t kFlagAgg = 1u << 30;    // value = this tile's (this group's) digit count
+constexpr uint32_t kFlagIncl = 2u << 30;   // group words: value = digit count of groups 0..this
 constexpr uint32_t kValueMask = (1u << 30) - 1u;
-constexpr int kLook = 4;                   // predecessors inspected per look-back step
+constexpr int kLook = 4;                   // group words inspected per look-back step
+#ifndef LBVH_LB_GROUP
+#define LBVH_LB_GROUP 16
+#endif
+constexpr int kLbGroup = LBVH_LB_GROUP;    // tiles per look-back group
 
 // ---- all four digit histograms in one read of the keys ------------------------------------------
 __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t* __restrict__ keys,
@@ -97,8 +106,10 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t count, uint32_t shift,
     const uint32_t* __restrict__ ghist,   // [256] digit totals of this pass
-    uint32_t* status,                     // [tiles][256] status words of this pass (zeroed per sort)
-    uint32_t* ticket)                     // tile ticket of this pass (zeroed per sort)
+    uint32_t* status,                     // [tiles][256] tile words of this pass (zeroed per sort)
+    uint32_t* gstatus,                    // [ceil(tiles / kLbGroup)][256] group words of this pass (zeroed per sort)
+    uint32_t* tickets,                    // [8] per-XCD tile tickets of this pass (zeroed per sort)
+    uint32_t tiles, uint32_t group)       // group = consecutive tiles handed to one XCD
 {
     constexpr int TILE = THREADS * ITEMS;
     constexpr int WAVES = THREADS / LBVH_WAVE;
@@ -112,7 +123,19 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     const uint32_t t = threadIdx.x;
     const uint32_t w = t >> 6;
     const uint32_t lane = lane_id();
-    if (t == 0) s_tile = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) {
+        // queue x holds the tiles whose (tile / group) % 8 == x, in increasing order; when the home queue is
+        // drained take from the others.  grid == tiles and every workgroup takes exactly one, so one is found.
+        const uint32_t home = xcc_id();
+        uint32_t tile = 0;
+        for (uint32_t a = 0; a < 8u; a++) {
+            const uint32_t x = (home + a) & 7u;
+            const uint32_t k = __hip_atomic_fetch_add(tickets + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tile = (k / group) * (8u * group) + x * group + (k % group);
+            if (tile < tiles) break;
+        }
+        s_tile = tile;
+    }
     for (int i = t; i < WAVES * kRadix; i += THREADS) (&s_wcnt[0][0])[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
@@ -148,7 +171,11 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const uint32_t d = (key[i] >> shift) & (kRadix - 1);
+#ifdef LBVH_EXPERIMENT_NORANK
+        const uint64_t peers = 1ull << lane;
+#else
         const uint64_t peers = match_digit(d);
+#endif
         const uint32_t r = mbcnt64(peers);              // same-digit lanes below me
         const uint32_t old = s_wcnt[w][d];              // same-digit keys of earlier items (LDS is in
         if (r == 0) s_wcnt[w][d] = old + (uint32_t)__popcll(peers);  // order within a wave)
@@ -165,38 +192,86 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         // the padding slots of a partial last tile all landed on digit 255: they are not keys
         if (t == kRadix - 1) total -= (uint32_t)TILE - nvalid;
 
-        // publish this tile's count, then sum the counts of all earlier tiles (decoupled look-back)
-        uint32_t* mine = status + (size_t)tile * kRadix + t;
-        if (tile == 0) {
-            __hip_atomic_store(mine, kFlagIncl | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            __hip_atomic_store(mine, kFlagAgg | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // walk back over earlier tiles, kLook status words in flight per step (one L2 round trip
-            // serves kLook predecessors); words are consumed strictly in order, nearest first
-            uint32_t p = tile;                       // next word to consume belongs to tile p - 1
+        // Two-level look-back.  A tile publishes its digit counts (tile words) and needs the counts of all
+        // earlier tiles.  With single-level decoupled look-back the walk length is (tiles finishing per
+        // round trip to the coherence point) ~ 30 words on this chip (41 tiles/us x 0.7 us), 14 dependent
+        // round trips per tile (measured) — the pass ran at 0.36 ms against 0.22 ms without any look-back.
+        // Here tiles form groups of kLbGroup: tile i of group g sums (a) the i earlier tile words of its own
+        // group, all requested at once, and (b) the groups before g by a decoupled look-back over GROUP
+        // words (aggregate, then inclusive prefix), which only the last tile of each group publishes:
+        // ~2 dependent round trips per tile.
+        constexpr uint32_t G = (uint32_t)kLbGroup;
+        const uint32_t g = tile / G, gi = tile % G;
+        __hip_atomic_store(status + (size_t)tile * kRadix + t, kFlagAgg | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef LBVH_EXPERIMENT_NOLOOKBACK
+        uint32_t in_group = 0;
+        {
+            const uint32_t* row0 = status + (size_t)(g * G) * kRadix + t;
+            uint32_t v[kLbGroup - 1];
+#pragma unroll
+            for (int j = 0; j < kLbGroup - 1; j++)
+                if ((uint32_t)j < gi) v[j] = __hip_atomic_load(row0 + (size_t)j * kRadix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < kLbGroup - 1; j++) {
+                if ((uint32_t)j >= gi) continue;
+                while ((v[j] & ~kValueMask) == 0) {
+#ifdef LBVH_EXPERIMENT_COUNT
+                    if (t == 0) __hip_atomic_fetch_add(tickets + 40, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+#ifdef LBVH_EXPERIMENT_SLEEP
+                    __builtin_amdgcn_s_sleep(LBVH_EXPERIMENT_SLEEP);
+#endif
+                    v[j] = __hip_atomic_load(row0 + (size_t)j * kRadix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                in_group += v[j] & kValueMask;
+            }
+        }
+        const bool leader = gi == G - 1u;               // a partial last group has no leader: nothing follows it
+        uint32_t* gmine = gstatus + (size_t)g * kRadix + t;
+        if (leader)
+            __hip_atomic_store(gmine, (g == 0 ? kFlagIncl : kFlagAgg) | ((in_group + total) & kValueMask), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t before = 0;
+        if (g > 0) {
+            uint32_t p = g;                              // next word to consume belongs to group p - 1
             bool done = false;
             while (!done) {
                 uint32_t v[kLook];
 #pragma unroll
                 for (int j = 0; j < kLook; j++) {
                     const uint32_t q = p - 1u - (uint32_t)j;
-                    v[j] = (uint32_t)j < p ? __hip_atomic_load(status + (size_t)q * kRadix + t, __ATOMIC_RELAXED,
+                    v[j] = (uint32_t)j < p ? __hip_atomic_load(gstatus + (size_t)q * kRadix + t, __ATOMIC_RELAXED,
                                                                __HIP_MEMORY_SCOPE_AGENT)
-                                           : kFlagIncl;     // before tile 0: inclusive prefix 0
+                                           : kFlagIncl;     // before group 0: inclusive prefix 0
                 }
 #pragma unroll
                 for (int j = 0; j < kLook; j++) {
                     if (done) continue;
                     const uint32_t f = v[j] & ~kValueMask;
-                    if (f == 0) break;                       // not published yet: re-read from here
-                    excl += v[j] & kValueMask;
+                    if (f == 0) {
+#ifdef LBVH_EXPERIMENT_SLEEP
+                        __builtin_amdgcn_s_sleep(LBVH_EXPERIMENT_SLEEP);
+#endif
+                        break;                               // not published yet: re-read from here
+                    }
+                    before += v[j] & kValueMask;
                     p--;
                     if (f == kFlagIncl) done = true;
                 }
-            }
-            __hip_atomic_store(mine, kFlagIncl | ((excl + total) & kValueMask), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+#ifdef LBVH_EXPERIMENT_COUNT
+                if (t == 0) __hip_atomic_fetch_add(tickets + 41, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+            }   // while
+#ifdef LBVH_EXPERIMENT_COUNT
+            if (t == 0 && tile == tiles - 1 && shift == 0)
+                printf("tiles %u: in-group re-reads %u, group-level steps %u\n", tiles, tickets[40], tickets[41]);
+#endif
+            if (leader)
+                __hip_atomic_store(gmine, kFlagIncl | ((before + in_group + total) & kValueMask), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
+        excl = before + in_group;
+#endif
     }
     {   // local layout: digits in order, waves in order inside a digit
         const uint32_t incl = wave_inclusive_sum(ltotal);
@@ -244,6 +319,9 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         const uint32_t pos = (uint32_t)j * THREADS + t;
         const uint32_t k = s_xchg[pos];
         dst[j] = s_gofs[(k >> shift) & (kRadix - 1)] + pos;
+#ifdef LBVH_EXPERIMENT_NOSCATTER
+        dst[j] = base + pos;
+#endif
         if (pos < nvalid) keys_out[dst[j]] = k;
     }
     __syncthreads();
@@ -259,12 +337,14 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
 
 template <int THREADS, int ITEMS>
 void launch_passes(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t* alt_keys, uint32_t* alt_vals,
-                   uint32_t count, uint32_t tiles, uint32_t* ghist, uint32_t* status, uint32_t* tickets)
+                   uint32_t count, uint32_t tiles, uint32_t* ghist, uint32_t* status, uint32_t* gstatus, uint32_t groups,
+                   uint32_t* tickets, uint32_t group)
 {
     uint32_t *ks = d_keys, *vs = d_values, *kd = alt_keys, *vd = alt_vals;
     for (uint32_t p = 0; p < (uint32_t)kPasses; p++) {   // ComputeBufferSorter.cs:102
         LBVH_LAUNCH(ctx, (sort_onesweep_kernel<THREADS, ITEMS>), dim3(tiles), dim3(THREADS), ks, vs, kd, vd, count,
-                    8u * p, ghist + p * kRadix, status + (size_t)p * tiles * kRadix, tickets + p);
+                    8u * p, ghist + p * kRadix, status + (size_t)p * tiles * kRadix,
+                    gstatus + (size_t)p * groups * kRadix, tickets + 8u * p, tiles, group);
         uint32_t* tmp;
         tmp = ks; ks = kd; kd = tmp;
         tmp = vs; vs = vd; vd = tmp;
@@ -290,9 +370,10 @@ extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint
     const uint32_t tile = (uint32_t)threads * (uint32_t)items;
     const uint32_t tiles = (uint32_t)(((uint64_t)count + tile - 1) / tile);
     const size_t pair_bytes = (((size_t)count * 4) + 255) & ~(size_t)255;
-    // [ghist 4x256 | tickets (4, padded to 256 B) | status 4 x tiles x 256] is zeroed per sort
+    // [ghist 4x256 | tickets (4 passes x 8 XCDs, padded to 256 B) | tile words 4 x tiles x 256 | group words] is zeroed per sort
     const size_t head_bytes = (size_t)kPasses * kRadix * 4 + 256;
-    const size_t status_bytes = (size_t)kPasses * tiles * kRadix * 4;
+    const uint32_t groups = (tiles + (uint32_t)kLbGroup - 1u) / (uint32_t)kLbGroup;
+    const size_t status_bytes = (size_t)kPasses * ((size_t)tiles + groups) * kRadix * 4;
     int rc = lbvh_reserve(ctx, &ctx->sort_scratch, &ctx->sort_scratch_bytes, 2 * pair_bytes + head_bytes + status_bytes);
     if (rc != LBVH_OK) return rc;
     char* p = (char*)ctx->sort_scratch;
@@ -301,6 +382,7 @@ extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint
     uint32_t* ghist = (uint32_t*)(p + 2 * pair_bytes);
     uint32_t* tickets = ghist + kPasses * kRadix;
     uint32_t* status = (uint32_t*)(p + 2 * pair_bytes + head_bytes);
+    uint32_t* gstatus = status + (size_t)kPasses * tiles * kRadix;
     LBVH_HIP_TRY(ctx, hipMemsetAsync(ghist, 0, head_bytes + status_bytes, ctx->stream));
 
     // 4 K keys per block up to 2048 blocks: enough blocks to hide the load latency, few enough that the
@@ -308,8 +390,12 @@ extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint
     uint32_t hblocks = (count + 4095u) / 4096u;
     if (hblocks > 256u * 8u) hblocks = 256u * 8u;
     LBVH_LAUNCH(ctx, sort_histogram_kernel, dim3(hblocks), dim3(kThreads), d_keys, count, ghist);
-    if (items == 16) launch_passes<512, 16>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, tickets);
-    else launch_passes<512, 8>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, tickets);
+    // consecutive tiles per XCD: 16 when every XCD still gets several groups, fewer for small sorts
+    const uint32_t group = tiles >= 1024u ? 16u : tiles >= 128u ? 4u : 1u;
+    if (items == 16)
+        launch_passes<512, 16>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
+    else
+        launch_passes<512, 8>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;   // 4 passes: the result is back in d_keys / d_values
 }

@@ -233,12 +233,6 @@ struct tile_queues {
     uint32_t next[8];     // per-XCD cursor (zeroed by the launch function every call)
 };
 
-__device__ __forceinline__ uint32_t xcc_id()
-{
-    // s_getreg_b32 HW_REG_XCC_ID (id 20), bits [3:0]
-    return (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u;
-}
-
 // next tile for this wave (wave-uniform), or kNoTile
 __device__ __forceinline__ uint32_t next_tile(tile_queues* q, uint32_t n_tiles, uint32_t home)
 {
