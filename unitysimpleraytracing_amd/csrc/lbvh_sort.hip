@@ -40,7 +40,7 @@ constexpr uint32_t kFlagIncl = 2u << 30;   // group words: value = digit count o
 constexpr uint32_t kValueMask = (1u << 30) - 1u;
 constexpr int kLook = 4;                   // group words inspected per look-back step
 #ifndef LBVH_LB_GROUP
-#define LBVH_LB_GROUP 16
+#define LBVH_LB_GROUP 8
 #endif
 constexpr int kLbGroup = LBVH_LB_GROUP;    // tiles per look-back group
 
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     constexpr int WAVES = THREADS / LBVH_WAVE;
     constexpr int DWAVES = kRadix / LBVH_WAVE;   // waves that own the 256 digits
     __shared__ uint32_t s_xchg[TILE];            // tile exchange buffer: keys first, then values
-    __shared__ uint32_t s_wcnt[WAVES][kRadix];   // per-wave digit counts, then per-wave local bases
+    __shared__ uint16_t s_wcnt[WAVES][kRadix];   // per-wave digit counts, then per-wave local bases (<= TILE <= 8192)
     __shared__ uint32_t s_gofs[kRadix];          // global base of digit d minus its local start
     __shared__ uint32_t s_wsum[DWAVES + 1];
     __shared__ uint32_t s_tile;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         }
         s_tile = tile;
     }
-    for (int i = t; i < WAVES * kRadix; i += THREADS) (&s_wcnt[0][0])[i] = 0;
+    for (int i = t; i < WAVES * kRadix / 2; i += THREADS) reinterpret_cast<uint32_t*>(&s_wcnt[0][0])[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint32_t base = tile * (uint32_t)TILE;
@@ -158,14 +158,26 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
 
     // wave-striped load: wave w owns keys [base + w*64*ITEMS, +64*ITEMS), item i = 64 consecutive
     // keys, so (item, lane) order is array order — what stability needs.
-    uint32_t key[ITEMS], rank[ITEMS];
+    // Register budget: 64 VGPRs = 8 waves per SIMD = 4 tiles per CU (the look-back and the loads are latency,
+    // and residency is what hides it).  Hence ranks / local positions are kept two per register (13 bits each)
+    // and the digits of the sorted keys four per register instead of 16 destination indices.
+    uint32_t key[ITEMS], rank2[ITEMS / 2];
     const uint32_t wave_base = base + w * (uint32_t)(LBVH_WAVE * ITEMS);
+    const bool full = nvalid == (uint32_t)TILE;       // uniform: all but the last tile take the unpredicated loads
+    {
+        const uint32_t* kp = keys_in + wave_base + lane;  // item i sits i * 256 B further: one address, immediate offsets
+        if (full) {
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const uint32_t idx = wave_base + (uint32_t)i * LBVH_WAVE + lane;
-        // slots past the end behave as 0xFFFFFFFF keys: they are last in array order and carry the
-        // largest digit in every pass, so they rank after every real key and are never written.
-        key[i] = idx < count ? keys_in[idx] : 0xFFFFFFFFu;
+            for (int i = 0; i < ITEMS; i++) key[i] = kp[i * LBVH_WAVE];
+        } else {
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const uint32_t idx = wave_base + (uint32_t)i * LBVH_WAVE + lane;
+                // slots past the end behave as 0xFFFFFFFF keys: they are last in array order and carry the
+                // largest digit in every pass, so they rank after every real key and are never written.
+                key[i] = idx < count ? kp[i * LBVH_WAVE] : 0xFFFFFFFFu;
+            }
+        }
     }
 
 #pragma unroll
@@ -178,12 +190,18 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
 #endif
         const uint32_t r = mbcnt64(peers);              // same-digit lanes below me
         const uint32_t old = s_wcnt[w][d];              // same-digit keys of earlier items (LDS is in
-        if (r == 0) s_wcnt[w][d] = old + (uint32_t)__popcll(peers);  // order within a wave)
-        rank[i] = old + r;
+        if (r == 0) s_wcnt[w][d] = (uint16_t)(old + (uint32_t)__popcll(peers));  // order within a wave)
+        if (i & 1) rank2[i / 2] |= (old + r) << 16; else rank2[i / 2] = old + r;
+        // pin the packed value here: otherwise the compiler sinks the adds to the first use and carries
+        // `old` and `r` of all 16 items (32 registers) across the phase instead of 8
+        asm volatile("" : "+v"(rank2[i / 2]));
     }
     __syncthreads();
 
-    uint32_t ltotal = 0, excl = 0;
+    uint32_t ltotal = 0;
+    uint32_t gv[kLook] = {};                           // look-back state carried across the LDS exchange
+    uint32_t lb_group = 0, lb_partial = 0, lb_total = 0;
+    bool lb_leader = false;
     if (t < (uint32_t)kRadix) {   // thread t = digit t
         uint32_t total = 0;
 #pragma unroll
@@ -231,48 +249,21 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         if (leader)
             __hip_atomic_store(gmine, (g == 0 ? kFlagIncl : kFlagAgg) | ((in_group + total) & kValueMask), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t before = 0;
-        if (g > 0) {
-            uint32_t p = g;                              // next word to consume belongs to group p - 1
-            bool done = false;
-            while (!done) {
-                uint32_t v[kLook];
+        // the group-level words are requested now and consumed after the tile's LDS exchange below: the
+        // round trips to the coherence point overlap with work that does not need the global offsets
 #pragma unroll
-                for (int j = 0; j < kLook; j++) {
-                    const uint32_t q = p - 1u - (uint32_t)j;
-                    v[j] = (uint32_t)j < p ? __hip_atomic_load(gstatus + (size_t)q * kRadix + t, __ATOMIC_RELAXED,
-                                                               __HIP_MEMORY_SCOPE_AGENT)
-                                           : kFlagIncl;     // before group 0: inclusive prefix 0
-                }
-#pragma unroll
-                for (int j = 0; j < kLook; j++) {
-                    if (done) continue;
-                    const uint32_t f = v[j] & ~kValueMask;
-                    if (f == 0) {
-#ifdef LBVH_EXPERIMENT_SLEEP
-                        __builtin_amdgcn_s_sleep(LBVH_EXPERIMENT_SLEEP);
-#endif
-                        break;                               // not published yet: re-read from here
-                    }
-                    before += v[j] & kValueMask;
-                    p--;
-                    if (f == kFlagIncl) done = true;
-                }
-#ifdef LBVH_EXPERIMENT_COUNT
-                if (t == 0) __hip_atomic_fetch_add(tickets + 41, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-            }   // while
-#ifdef LBVH_EXPERIMENT_COUNT
-            if (t == 0 && tile == tiles - 1 && shift == 0)
-                printf("tiles %u: in-group re-reads %u, group-level steps %u\n", tiles, tickets[40], tickets[41]);
-#endif
-            if (leader)
-                __hip_atomic_store(gmine, kFlagIncl | ((before + in_group + total) & kValueMask), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < kLook; j++) {
+            const uint32_t q = g - 1u - (uint32_t)j;
+            gv[j] = (uint32_t)j < g ? __hip_atomic_load(gstatus + (size_t)q * kRadix + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : kFlagIncl;         // before group 0: inclusive prefix 0
         }
-        excl = before + in_group;
+        lb_group = g;
+        lb_leader = leader;
+        lb_partial = in_group;
+        lb_total = total;
 #endif
     }
+    uint32_t gbase = 0;                                // first output index of digit t minus its local start
     {   // local layout: digits in order, waves in order inside a digit
         const uint32_t incl = wave_inclusive_sum(ltotal);
         __syncthreads();                               // s_wsum reuse
@@ -287,10 +278,10 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
 #pragma unroll
             for (int i = 0; i < WAVES; i++) {
                 const uint32_t c = s_wcnt[i][t];
-                s_wcnt[i][t] = run;
+                s_wcnt[i][t] = (uint16_t)run;
                 run += c;
             }
-            s_gofs[t] = digit_start + excl - dstart;
+            gbase = digit_start - dstart;
         }
     }
     __syncthreads();
@@ -299,39 +290,92 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const uint32_t d = (key[i] >> shift) & (kRadix - 1);
-        rank[i] = s_wcnt[w][d] + rank[i];            // local position in the digit-sorted tile
-        s_xchg[rank[i]] = key[i];
+        const uint32_t r = (i & 1) ? rank2[i / 2] >> 16 : rank2[i / 2] & 0xFFFFu;
+        const uint32_t lpos = (uint32_t)s_wcnt[w][d] + r;            // local position in the digit-sorted tile
+        if (i & 1) rank2[i / 2] = (rank2[i / 2] & 0xFFFFu) | (lpos << 16); else rank2[i / 2] = (rank2[i / 2] & 0xFFFF0000u) | lpos;
+        s_xchg[lpos] = key[i];
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four LDS round trips in flight, not sixteen (registers)
     }
     // values are requested now (the key registers are free) and land while the keys are written out
     uint32_t val[ITEMS];
+    {
+        const uint32_t* vp = vals_in + wave_base + lane;
+        if (full) {
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const uint32_t idx = wave_base + (uint32_t)i * LBVH_WAVE + lane;
-        val[i] = idx < count ? vals_in[idx] : 0xFFFFFFFFu;
+            for (int i = 0; i < ITEMS; i++) val[i] = vp[i * LBVH_WAVE];
+        } else {
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const uint32_t idx = wave_base + (uint32_t)i * LBVH_WAVE + lane;
+                val[i] = idx < count ? vp[i * LBVH_WAVE] : 0xFFFFFFFFu;
+            }
+        }
+    }
+    if (t < (uint32_t)kRadix) {   // finish the look-back: decoupled walk over the group words, nearest first
+        uint32_t before = 0;
+#ifndef LBVH_EXPERIMENT_NOLOOKBACK
+        uint32_t p = lb_group;                       // next word to consume belongs to group p - 1
+        bool done = p == 0;
+        while (!done) {
+#pragma unroll
+            for (int j = 0; j < kLook; j++) {
+                if (done) continue;
+                const uint32_t f = gv[j] & ~kValueMask;
+                if (f == 0) break;                   // not published yet: re-read from here
+                before += gv[j] & kValueMask;
+                p--;
+                if (f == kFlagIncl) done = true;
+            }
+            if (!done) {
+#pragma unroll
+                for (int j = 0; j < kLook; j++) {
+                    const uint32_t q = p - 1u - (uint32_t)j;
+                    gv[j] = (uint32_t)j < p ? __hip_atomic_load(gstatus + (size_t)q * kRadix + t, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT)
+                                            : kFlagIncl;
+                }
+            }
+        }
+        if (lb_leader && lb_group > 0)
+            __hip_atomic_store(gstatus + (size_t)lb_group * kRadix + t, kFlagIncl | ((before + lb_partial + lb_total) & kValueMask),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        s_gofs[t] = gbase + before + lb_partial;
     }
     __syncthreads();
 
     // the tile's keys are digit-sorted in LDS: consecutive threads write consecutive addresses inside
-    // each digit run.
-    uint32_t dst[ITEMS];
+    // each digit run.  Buffer stores: a 32-bit byte offset per store instead of a 64-bit address
+    // (count < 2^30, so offsets fit), which is what keeps 16 stores in flight inside the register budget.
+    const __amdgpu_buffer_rsrc_t keys_rsrc = __builtin_amdgcn_make_buffer_rsrc(keys_out, 0, (int)(count * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vals_rsrc = __builtin_amdgcn_make_buffer_rsrc(vals_out, 0, (int)(count * 4u), 0x00020000);
+    uint32_t dig4[ITEMS / 4];
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {
         const uint32_t pos = (uint32_t)j * THREADS + t;
         const uint32_t k = s_xchg[pos];
-        dst[j] = s_gofs[(k >> shift) & (kRadix - 1)] + pos;
+        const uint32_t d = (k >> shift) & (kRadix - 1);
+        if (j & 3) dig4[j / 4] |= d << (8 * (j & 3)); else dig4[j / 4] = d;
+        uint32_t dst = s_gofs[d] + pos;
 #ifdef LBVH_EXPERIMENT_NOSCATTER
-        dst[j] = base + pos;
+        dst = base + pos;
 #endif
-        if (pos < nvalid) keys_out[dst[j]] = k;
+        if (pos < nvalid) __builtin_amdgcn_raw_buffer_store_b32(k, keys_rsrc, dst * 4u, 0, 0);
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) s_xchg[rank[i]] = val[i];
+    for (int i = 0; i < ITEMS; i++) s_xchg[(i & 1) ? rank2[i / 2] >> 16 : rank2[i / 2] & 0xFFFFu] = val[i];
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {
         const uint32_t pos = (uint32_t)j * THREADS + t;
-        if (pos < nvalid) vals_out[dst[j]] = s_xchg[pos];
+        uint32_t dst = s_gofs[(dig4[j / 4] >> (8 * (j & 3))) & 255u] + pos;
+#ifdef LBVH_EXPERIMENT_NOSCATTER
+        dst = base + pos;
+#endif
+        if (pos < nvalid) __builtin_amdgcn_raw_buffer_store_b32(s_xchg[pos], vals_rsrc, dst * 4u, 0, 0);
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
