@@ -114,11 +114,17 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     constexpr int TILE = THREADS * ITEMS;
     constexpr int WAVES = THREADS / LBVH_WAVE;
     constexpr int DWAVES = kRadix / LBVH_WAVE;   // waves that own the 256 digits
-    __shared__ uint32_t s_xchg[TILE];            // tile exchange buffer: keys first, then values
-    __shared__ uint16_t s_wcnt[WAVES][kRadix];   // per-wave digit counts, then per-wave local bases (<= TILE <= 8192)
+    // tile exchange buffer: keys first, then values; during ranking it holds the per-wave rank cells
+    constexpr int XCHG_WORDS = TILE > WAVES * kRadix * 4 ? TILE : WAVES * kRadix * 4;
+    __shared__ __attribute__((aligned(16))) uint32_t s_xchg[XCHG_WORDS];
+    __shared__ uint16_t s_wcnt[WAVES][kRadix];   // per-wave local bases (<= TILE <= 8192)
     __shared__ uint32_t s_gofs[kRadix];          // global base of digit d minus its local start
     __shared__ uint32_t s_wsum[DWAVES + 1];
     __shared__ uint32_t s_tile;
+#ifdef LBVH_EXPERIMENT_LDSPAD
+    __shared__ uint32_t s_pad[LBVH_EXPERIMENT_LDSPAD];   // occupancy experiment: fewer tiles per CU
+    if (count == 0xFFFFFFFFu) s_pad[threadIdx.x] = 1;
+#endif
 
     const uint32_t t = threadIdx.x;
     const uint32_t w = t >> 6;
@@ -136,7 +142,8 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         }
         s_tile = tile;
     }
-    for (int i = t; i < WAVES * kRadix / 2; i += THREADS) reinterpret_cast<uint32_t*>(&s_wcnt[0][0])[i] = 0;
+    // rank cells {peer mask lo, hi, count, -} per (wave, digit), 16 B each, all zero
+    for (int i = t; i < WAVES * kRadix; i += THREADS) reinterpret_cast<uint4*>(s_xchg)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint32_t base = tile * (uint32_t)TILE;
@@ -163,38 +170,48 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     // and the digits of the sorted keys four per register instead of 16 destination indices.
     uint32_t key[ITEMS], rank2[ITEMS / 2];
     const uint32_t wave_base = base + w * (uint32_t)(LBVH_WAVE * ITEMS);
-    const bool full = nvalid == (uint32_t)TILE;       // uniform: all but the last tile take the unpredicated loads
-    {
-        const uint32_t* kp = keys_in + wave_base + lane;  // item i sits i * 256 B further: one address, immediate offsets
-        if (full) {
-#pragma unroll
-            for (int i = 0; i < ITEMS; i++) key[i] = kp[i * LBVH_WAVE];
-        } else {
-#pragma unroll
-            for (int i = 0; i < ITEMS; i++) {
-                const uint32_t idx = wave_base + (uint32_t)i * LBVH_WAVE + lane;
-                // slots past the end behave as 0xFFFFFFFF keys: they are last in array order and carry the
-                // largest digit in every pass, so they rank after every real key and are never written.
-                key[i] = idx < count ? kp[i * LBVH_WAVE] : 0xFFFFFFFFu;
-            }
-        }
-    }
-
+    // Buffer loads: out-of-range lanes of the last tile read 0 (range-checked against count) and are then set to
+    // 0xFFFFFFFF — slots past the end behave as the largest key: last in array order, largest digit in every
+    // pass, so they rank after every real key and are never written.  No branch, so the ranking of item 0
+    // starts when its load lands instead of waiting for all sixteen.
+    const __amdgpu_buffer_rsrc_t keys_in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(keys_in), 0, (int)(count * 4u), 0x00020000);
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
-        const uint32_t d = (key[i] >> shift) & (kRadix - 1);
+        const uint32_t idx = wave_base + (uint32_t)i * LBVH_WAVE + lane;
+        const uint32_t k = __builtin_amdgcn_raw_buffer_load_b32(keys_in_rsrc, idx * 4u, 0, 0);
+        key[i] = idx < count ? k : 0xFFFFFFFFu;
+    }
+
+    // Ranking.  The wave's 64 keys of one item are matched on the whole 8-bit digit THROUGH LDS: every lane ORs its
+    // lane bit into the 64-bit peer mask of cell (wave, digit) and reads the cell back — LDS executes a wave's
+    // instructions in order, so the read sees all 64 ORs.  rank = count of the same digit in earlier items (kept in
+    // the cell) + same-digit lanes below me (v_mbcnt of the mask); the lowest peer lane clears the mask and adds
+    // the group size to the count.  12 VALU instructions per key instead of 82 for the 8-ballot form: the pass
+    // was as much VALU-bound (196 us of wave64 issue per 2^26 pairs) as HBM-bound.
+    {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4* cells = reinterpret_cast<u32x4*>(s_xchg) + w * kRadix;
+        const unsigned long long lane_bit = 1ull << lane;
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const uint32_t d = (key[i] >> shift) & (kRadix - 1);
+            u32x4* cell = cells + d;
 #ifdef LBVH_EXPERIMENT_NORANK
-        const uint64_t peers = 1ull << lane;
+            const u32x4 c = {(uint32_t)lane_bit, (uint32_t)(lane_bit >> 32), 0u, 0u};
 #else
-        const uint64_t peers = match_digit(d);
+            __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(cell), lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u32x4 c = *reinterpret_cast<volatile u32x4*>(cell);
 #endif
-        const uint32_t r = mbcnt64(peers);              // same-digit lanes below me
-        const uint32_t old = s_wcnt[w][d];              // same-digit keys of earlier items (LDS is in
-        if (r == 0) s_wcnt[w][d] = (uint16_t)(old + (uint32_t)__popcll(peers));  // order within a wave)
-        if (i & 1) rank2[i / 2] |= (old + r) << 16; else rank2[i / 2] = old + r;
-        // pin the packed value here: otherwise the compiler sinks the adds to the first use and carries
-        // `old` and `r` of all 16 items (32 registers) across the phase instead of 8
-        asm volatile("" : "+v"(rank2[i / 2]));
+            const uint64_t peers = ((uint64_t)c.y << 32) | c.x;
+            const uint32_t r = mbcnt64(peers);              // same-digit lanes below me
+            const uint32_t old = c.z;                       // same-digit keys of earlier items
+            if (r == 0) *cell = u32x4{0u, 0u, old + (uint32_t)__popcll(peers), 0u};
+            if (i & 1) rank2[i / 2] |= (old + r) << 16; else rank2[i / 2] = old + r;
+            // pin the packed value here: otherwise the compiler sinks the adds to the first use and carries
+            // `old` and `r` of all 16 items (32 registers) across the phase instead of 8
+            asm volatile("" : "+v"(rank2[i / 2]));
+        }
     }
     __syncthreads();
 
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     if (t < (uint32_t)kRadix) {   // thread t = digit t
         uint32_t total = 0;
 #pragma unroll
-        for (int i = 0; i < WAVES; i++) total += s_wcnt[i][t];
+        for (int i = 0; i < WAVES; i++) total += s_xchg[(i * kRadix + t) * 4 + 2];
         ltotal = total;                                // including padding slots (they sit last)
         // the padding slots of a partial last tile all landed on digit 255: they are not keys
         if (t == kRadix - 1) total -= (uint32_t)TILE - nvalid;
@@ -277,7 +294,7 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
             uint32_t run = dstart;
 #pragma unroll
             for (int i = 0; i < WAVES; i++) {
-                const uint32_t c = s_wcnt[i][t];
+                const uint32_t c = s_xchg[(i * kRadix + t) * 4 + 2];
                 s_wcnt[i][t] = (uint16_t)run;
                 run += c;
             }
@@ -299,17 +316,11 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     // values are requested now (the key registers are free) and land while the keys are written out
     uint32_t val[ITEMS];
     {
-        const uint32_t* vp = vals_in + wave_base + lane;
-        if (full) {
+        const __amdgpu_buffer_rsrc_t vals_in_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(vals_in), 0, (int)(count * 4u), 0x00020000);
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) val[i] = vp[i * LBVH_WAVE];
-        } else {
-#pragma unroll
-            for (int i = 0; i < ITEMS; i++) {
-                const uint32_t idx = wave_base + (uint32_t)i * LBVH_WAVE + lane;
-                val[i] = idx < count ? vp[i * LBVH_WAVE] : 0xFFFFFFFFu;
-            }
-        }
+        for (int i = 0; i < ITEMS; i++)
+            val[i] = __builtin_amdgcn_raw_buffer_load_b32(vals_in_rsrc, (wave_base + (uint32_t)i * LBVH_WAVE + lane) * 4u, 0, 0);
     }
     if (t < (uint32_t)kRadix) {   // finish the look-back: decoupled walk over the group words, nearest first
         uint32_t before = 0;
@@ -435,7 +446,11 @@ extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint
     if (hblocks > 256u * 8u) hblocks = 256u * 8u;
     LBVH_LAUNCH(ctx, sort_histogram_kernel, dim3(hblocks), dim3(kThreads), d_keys, count, ghist);
     // consecutive tiles per XCD: 16 when every XCD still gets several groups, fewer for small sorts
-    const uint32_t group = tiles >= 1024u ? 16u : tiles >= 128u ? 4u : 1u;
+#ifdef LBVH_EXPERIMENT_XCDGROUP
+    const uint32_t group = LBVH_EXPERIMENT_XCDGROUP;
+#else
+    const uint32_t group = tiles >= 1024u ? 16u : tiles >= 128u ? 8u : 1u;
+#endif
     if (items == 16)
         launch_passes<512, 16>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     else
