@@ -53,30 +53,58 @@ __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t
 #pragma unroll
     for (int p = 0; p < kPasses; p++) s_hist[p][t] = 0;
     __syncthreads();
-    // grid-stride, 4 independent loads in flight per thread (count <= 2^30 and <= 2^19 threads: no wrap)
+    // grid-stride over 16-B vectors (4 keys per lane per load), 2 loads in flight per thread
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // [head | whole 16-B vectors | tail]: head = keys before the first 16-B boundary (callers may pass any 4-B
+    // aligned pointer)
+    uint32_t head = (uint32_t)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(keys) & 15u)) & 15u) >> 2);
+    if (head > count) head = count;
+    const uint32_t nvec = (count - head) >> 2;
+    const uint32_t tail0 = head + (nvec << 2);
+    const u32x4* vkeys = reinterpret_cast<const u32x4*>(keys + head);
     const uint32_t stride = gridDim.x * kThreads;
-    for (uint32_t i0 = blockIdx.x * kThreads + t; i0 - t < count; i0 += stride * 4) {
-        uint32_t k[4];
-        bool ok[4];
+    auto add_key = [&](uint32_t k) {
+        // a wave whose 64 keys agree on a digit would serialise 64 LDS atomics on one counter (top bytes of
+        // clustered Morton codes, 0xFFFFFFFF pads, already-sorted input): one lane adds 64 instead.  Only the two
+        // high digits are checked — the low bytes of distinct keys differ — plus whole-key equality.
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+        const uint64_t active = __ballot(1);
+        const bool first = lane_id() == (uint32_t)__builtin_ctzll(active);
+        const uint32_t nactive = (uint32_t)__popcll(active);
+        if (__all(k == k0)) {
+            if (first) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t idx = i0 + (uint32_t)j * stride;
-            ok[j] = idx < count;
-            k[j] = ok[j] ? keys[idx] : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-#pragma unroll
-            for (int p = 0; p < kPasses; p++) {
-                const uint32_t d = ok[j] ? ((k[j] >> (8 * p)) & 255u) : 0xFFFFFFFFu;
-                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-                if (__all(d == d0)) {
-                    // whole wave on one digit (top bytes of Morton codes, 0xFFFFFFFF pads)
-                    if (lane_id() == 0 && d0 < (uint32_t)kRadix) atomicAdd(&s_hist[p][d0], (uint32_t)LBVH_WAVE);
-                } else if (ok[j]) {
-                    atomicAdd(&s_hist[p][d], 1u);
-                }
+                for (int p = 0; p < kPasses; p++) atomicAdd(&s_hist[p][(k0 >> (8 * p)) & 255u], nactive);
             }
+            return;
+        }
+        atomicAdd(&s_hist[0][k & 255u], 1u);
+        atomicAdd(&s_hist[1][(k >> 8) & 255u], 1u);
+#pragma unroll
+        for (int p = 2; p < kPasses; p++) {
+            const uint32_t d = (k >> (8 * p)) & 255u;
+            const uint32_t d0 = (k0 >> (8 * p)) & 255u;
+            if (__all(d == d0)) {
+                if (first) atomicAdd(&s_hist[p][d0], nactive);
+            } else {
+                atomicAdd(&s_hist[p][d], 1u);
+            }
+        }
+    };
+    for (uint32_t i0 = blockIdx.x * kThreads + t; i0 < nvec; i0 += stride * 2) {
+        const bool ok1 = i0 + stride < nvec;
+        const u32x4 a = vkeys[i0];
+        u32x4 b2 = {0u, 0u, 0u, 0u};
+        if (ok1) b2 = vkeys[i0 + stride];
+        add_key(a.x); add_key(a.y); add_key(a.z); add_key(a.w);
+        if (ok1) { add_key(b2.x); add_key(b2.y); add_key(b2.z); add_key(b2.w); }
+    }
+    if (blockIdx.x == 0 && t < 8u) {                   // at most 3 head + 3 tail keys
+        const uint32_t idx = t < 4u ? t : tail0 + (t - 4u);
+        if (t < 4u ? t < head : idx < count) {
+            const uint32_t k = keys[idx];
+#pragma unroll
+            for (int p = 0; p < kPasses; p++) atomicAdd(&s_hist[p][(k >> (8 * p)) & 255u], 1u);
         }
     }
     __syncthreads();
@@ -442,7 +470,7 @@ extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint
 
     // 4 K keys per block up to 2048 blocks: enough blocks to hide the load latency, few enough that the
     // 1024 global atomics each block ends with do not pile up on the same counters
-    uint32_t hblocks = (count + 4095u) / 4096u;
+    uint32_t hblocks = (count + 8191u) / 8192u;
     if (hblocks > 256u * 8u) hblocks = 256u * 8u;
     LBVH_LAUNCH(ctx, sort_histogram_kernel, dim3(hblocks), dim3(kThreads), d_keys, count, ghist);
     // consecutive tiles per XCD: 16 when every XCD still gets several groups, fewer for small sorts
