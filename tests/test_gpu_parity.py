@@ -259,6 +259,37 @@ def test_refit_race_stress(ctx):
         d.on_destroy()
 
 
+@pytest.mark.parametrize("n", [1025, 5000, 70000, 300001])
+def test_refit_does_not_depend_on_the_roots_parent_word_or_stale_boxes(ctx, n):
+    """The root's parent word is never written by ConstructTree (BVH.compute:126,144): whatever the caller's buffer
+    held there must not matter, and every node box must be rewritten (no reliance on an earlier build's boxes)."""
+    tris = scenes.random_triangles(n, seed=n, extent=90.0, edge=3.0)
+    d, c, b = build_both(ctx, tris)
+    h, nn = ctx.handle, N()
+    nodes = c.bvh_internal_node.get_data()
+    for garbage in (0, 7, n // 2, n - 2):
+        nodes["parent"][0] = garbage
+        c.bvh_internal_node.sync()
+        c.bvh_data.fill_u32(0x7FC00000, mirror=False)          # NaNs: a node left unwritten cannot pass
+        nn.check(h, nn.lib.lbvh_refit(h, n, c.bvh_internal_node.device, c.bvh_leaf_node.device, c.triangle_aabb.device,
+                                      c.triangle_index.device, c.bvh_data.device))
+        got = c.bvh_data.get_data()
+        assert (got["min"][: n - 1] == b.bvh["min"][: n - 1]).all() and (got["max"][: n - 1] == b.bvh["max"][: n - 1]).all()
+    # the derived traversal structure after an unrelated scene used the same context scratch
+    other = scenes.random_triangles(n + 1234, seed=5, extent=60.0, edge=9.0)
+    d2 = H().RaytracingMeshDrawer(ctx, other).awake()
+    d2.on_destroy()
+    nodes["parent"][0] = 0xFFFFFFFF
+    c.bvh_internal_node.sync()
+    d.rebuild()
+    cam = scenes.camera(160, 120, (0.0, 0.0, 260.0))
+    d.update(cam, mode=L.TRACE_FAST)
+    fast = d.hits()
+    d.update(cam, mode=L.TRACE_REFERENCE)
+    assert (fast["t"] == d.hits()["t"]).all()
+    d.on_destroy()
+
+
 def test_golden_cfg1_through_the_c_abi(ctx):
     g = np.load(os.path.join(GOLDEN, "cfg1_4096.npz"))
     tris = scenes.random_triangles(4096, seed=1)

@@ -249,39 +249,30 @@ __global__ __launch_bounds__(256) void tree_kernel(const uint32_t* __restrict__ 
 // a-8  BVHConstructor (bottom-up refit)       BVH.compute:152-220
 // The reference: one thread per leaf walks to the root; the second thread to arrive at a node (per-node
 // counter, InterlockedCompareExchange) merges the child boxes — with no fence between a thread's box
-// store and the sibling's read (BVH.compute:185-215).  On MI355X a CU's L1 is never refreshed by other
-// CUs' stores and the 8 XCD L2s are not coherent with each other, so that hand-off must not cross
-// workgroups unprotected.  Here it never crosses workgroups at all:
+// store and the sibling's read (BVH.compute:185-215).  The result is the union of the leaf AABBs under each
+// node, and min/max are exact, so ANY evaluation order gives the same floats.  On MI355X a CU's L1 is never
+// refreshed by other CUs' stores and the 8 XCD L2s are not coherent with each other, so a cross-workgroup
+// hand-off per tree level costs a write-through store, a device-scope atomic and L1-bypassing loads — about
+// three trips to the coherence point per level, ~12 levels deep above a 1024-leaf subtree: that chain measured
+// 81 of the kernel's 128 us at 1 M leaves (fence pair per level: 3.99 ms; all-global sc1 walk: 0.18 ms).
+// Here NO hand-off crosses a workgroup:
+//   refit_kernel    one workgroup per 1024 consecutive leaves; a thread carries its subtree's box and leaf
+//                   range upward, merging through LDS arrival counters and LDS-parked sibling boxes while
+//                   the parent's subtree stays inside the workgroup's leaves (> 95 % of all nodes).  It also
+//                   emits the union box of every aligned group of 64 and of 1024 leaves (range levels 1, 2).
+//   refit_levels    one workgroup: range levels 3.. (aligned groups of 16^k * 64 leaves).
+//   refit_ranges    one thread per internal node recovers the node's leaf range from the node arrays alone
+//                   (see below) and appends the FRONTIER nodes — range crossing a 1024-leaf boundary, i.e.
+//                   exactly the nodes refit_kernel could not finish — to a list.
+//   refit_frontier  one wave per frontier node, all independent: its box is the union of <= 63 + 63 leaves
+//                   and <= 15 + 15 entries per range level covering [first, last] — no dependence on any
+//                   other frontier node, so no chain, no atomics, no sc1 traffic.
+// Leaf range of node p from the arrays (Karras numbering): p is one end of its range and its split is its
+// left child's index g; p <= g means p is the FIRST leaf (p is the root or a right child), else the LAST
+// (a left child).  A right child shares its parent's last leaf, a left child its parent's first; so the
+// unknown end is the index of the nearest ancestor of the OTHER kind (or 0 / n-1 above the root): a walk
+// over consecutive same-kind ancestors, 2 nodes on average, bounded by the tree depth.
 typedef unsigned long long u64;
-
-__device__ __forceinline__ u64 pack2(float a, float b)
-{
-    return (u64)__float_as_uint(a) | ((u64)__float_as_uint(b) << 32);
-}
-
-// 8-byte agent-scope stores/loads = global_store/load_dwordx2 sc1: write-through / L1-bypassing
-__device__ __forceinline__ void store_box_agent(lbvh_aabb* p, float mnx, float mny, float mnz, float mxx,
-                                                float mxy, float mxz)
-{
-    u64* q = reinterpret_cast<u64*>(p);
-    __hip_atomic_store(q + 0, pack2(mnx, mny), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 1, pack2(mnz, 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 2, pack2(mxx, mxy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 3, pack2(mxz, 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ void load_box_agent(const lbvh_aabb* p, float mn[3], float mx[3])
-{
-    u64* q = reinterpret_cast<u64*>(const_cast<lbvh_aabb*>(p));
-    const u64 a = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u64 b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u64 c = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u64 d = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    mn[0] = __uint_as_float((uint32_t)a); mn[1] = __uint_as_float((uint32_t)(a >> 32));
-    mn[2] = __uint_as_float((uint32_t)b);
-    mx[0] = __uint_as_float((uint32_t)c); mx[1] = __uint_as_float((uint32_t)(c >> 32));
-    mx[2] = __uint_as_float((uint32_t)d);
-}
 
 __device__ __forceinline__ void load_box_plain(const lbvh_aabb* p, float mn[3], float mx[3])
 {
@@ -291,85 +282,92 @@ __device__ __forceinline__ void load_box_plain(const lbvh_aabb* p, float mn[3], 
     mx[0] = b.x; mx[1] = b.y; mx[2] = b.z;
 }
 
-// One kernel, two phases per 1024-leaf workgroup.
-//  Phase 1 (LDS): a thread carries its subtree's box AND leaf range [first, last] upward.  An arrival at
-//    parent q is LOCAL when q's index and the carried range lie inside the workgroup's 1024 indices:
-//    the thread parks its box in the LDS slot (q, side) and bumps an LDS counter that encodes which
-//    side arrived; the second arriver finds the sibling's box and range in LDS, merges, writes bvhData[q]
-//    with a plain store and goes on.  No global atomics, no sc1 traffic: > 95 % of all merges.
-//  Phase 2 (global): what is left is the frontier — threads whose next arrival is not local, and LDS
-//    slots that received only one child (the sibling subtree lives in another workgroup).  Those
-//    arrivals cross workgroups, so they use an explicit protocol: the child's box is (re)stored
-//    WRITE-THROUGH (8-byte agent-scope stores = global_store_dwordx2 sc1), s_waitcnt vmcnt(0), then the
-//    agent-scope arrival counter; the second arriver reads both child boxes with sc1 loads (L1 bypass).
-//    No L2 write-back / L1 invalidate fences: a release+acquire fence pair per level measured 3.99 ms
-//    for the whole tree, the sc1 form alone 0.18 ms, this hybrid 0.13 ms.  (Replaying the frontier in a
-//    second single-workgroup kernel measured slower: the frontier is tens of thousands of subtrees.)
-// The rule "local iff carried range and q inside the workgroup" is evaluated identically by whichever
-// thread arrives, so the LDS and global counters never disagree about who is second.
-constexpr int kRefitThreads = 1024;
-
-__device__ __forceinline__ void refit_global_walk(uint32_t n, const lbvh_internal_node* __restrict__ internal,
-                                                  const lbvh_aabb* __restrict__ tri_aabb,
-                                                  const uint32_t* __restrict__ sorted_indices, lbvh_aabb* bvh,
-                                                  uint32_t* flags, uint32_t parent, bool child_internal, uint32_t child_id,
-                                                  const float cmn[3], const float cmx[3])
+__device__ __forceinline__ void store_box_plain(lbvh_aabb* p, const float mn[3], const float mx[3])
 {
-    // the child this thread brings must be readable by a merger on another XCD
-    if (child_internal) store_box_agent(&bvh[child_id], cmn[0], cmn[1], cmn[2], cmx[0], cmx[1], cmx[2]);
-    for (int guard = 0; parent != 0xFFFFFFFFu && guard < 64; guard++) {                    // BVH.compute:182
-        if (parent >= n - 1) break;
-        // every box store of this thread has completed before it signals the parent
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t old = __hip_atomic_fetch_add(&flags[parent], 1u, __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_AGENT);             // :185
-        if (old == 0) break;                                                               // :186-189
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only: loads stay below
+    float4* q = reinterpret_cast<float4*>(p);
+    q[0] = make_float4(mn[0], mn[1], mn[2], 0.0f);                                         // :215
+    q[1] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+}
 
-        const uint32_t* nd = reinterpret_cast<const uint32_t*>(&internal[parent]);
-        const uint2 l = *reinterpret_cast<const uint2*>(nd + 0);
-        const uint2 r = *reinterpret_cast<const uint2*>(nd + 2);
-        const uint32_t next = nd[4];
-        float lmn[3], lmx[3], rmn[3], rmx[3];
-        if (l.y == LBVH_INTERNAL_NODE) load_box_agent(&bvh[l.x], lmn, lmx);                // :197-204
-        else load_box_plain(&tri_aabb[sorted_indices ? sorted_indices[l.x] : l.x], lmn, lmx);
-        if (r.y == LBVH_INTERNAL_NODE) load_box_agent(&bvh[r.x], rmn, rmx);                // :206-213
-        else load_box_plain(&tri_aabb[sorted_indices ? sorted_indices[r.x] : r.x], rmn, rmx);
-        store_box_agent(&bvh[parent], fminf(lmn[0], rmn[0]), fminf(lmn[1], rmn[1]), fminf(lmn[2], rmn[2]),
-                        fmaxf(lmx[0], rmx[0]), fmaxf(lmx[1], rmx[1]), fmaxf(lmx[2], rmx[2])); // MergeAABB :152-170
-        parent = next;                                                                     // :217
+__device__ __forceinline__ void wave_union(float mn[3], float mx[3])
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], d));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d));
+        }
     }
 }
+
+constexpr int kRefitThreads = 1024;     // leaves per workgroup = range level 2
+constexpr int kLevel1Shift = 6;         // range level 1 = 64 leaves (one wave of refit_kernel)
+constexpr int kFanShift = 4;            // level k + 1 = 16 entries of level k
+constexpr int kMaxLevels = 8;           // 64 * 16^7 > 2^31 leaves
+
+struct refit_levels_t {
+    lbvh_aabb* box[kMaxLevels + 1];     // [1..levels]; box[k][e] = union of leaves [e * g_k, (e + 1) * g_k) below n
+    uint32_t count[kMaxLevels + 1];
+    int levels;
+};
 
 // sorted_indices == nullptr: tri_aabb is already in sorted (leaf) order
 __global__ __launch_bounds__(kRefitThreads) void refit_kernel(uint32_t n, const lbvh_internal_node* __restrict__ internal,
                                                               const lbvh_leaf_node* __restrict__ leaf,
                                                               const lbvh_aabb* __restrict__ tri_aabb,
                                                               const uint32_t* __restrict__ sorted_indices,
-                                                              lbvh_aabb* bvh, uint32_t* flags)
+                                                              lbvh_aabb* bvh, refit_levels_t lv,
+                                                              uint32_t* __restrict__ frontier_count,
+                                                              uint32_t* __restrict__ frontier_list)
 {
     __shared__ float s_box[2][6][kRefitThreads];        // [side][min xyz, max xyz][slot]: 48 KB
     __shared__ uint32_t s_range[2][kRefitThreads];      // first | last << 16, relative to the workgroup: 8 KB
     __shared__ uint32_t s_flag[kRefitThreads];          // +1 = left child arrived, +0x10000 = right child
+    __shared__ float s_wave[6][kRefitThreads / LBVH_WAVE];
+    __shared__ uint32_t s_front_n, s_front_base;
     const uint32_t t = threadIdx.x;
     const uint32_t b0 = blockIdx.x * (uint32_t)kRefitThreads;
     s_flag[t] = 0;
+    if (t == 0) s_front_n = 0;
     __syncthreads();
 
-    // ---- phase 1 ----
     const uint32_t j = b0 + t;
-    bool pending = false;
     uint32_t q = 0xFFFFFFFFu, child_id = j, first = j, last = j;
     bool child_internal = false;
-    float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (j < n) {                                                                           // :179
         load_box_plain(&tri_aabb[sorted_indices ? sorted_indices[j] : j], mn, mx);
         q = leaf[j].parent;                                                                // :181
+    }
+    {   // range levels 1 and 2 from the leaf boxes (slots past n are neutral)
+        float wmn[3] = {mn[0], mn[1], mn[2]}, wmx[3] = {mx[0], mx[1], mx[2]};
+        wave_union(wmn, wmx);
+        if ((t & 63u) == 0) {
+            if ((j >> kLevel1Shift) < lv.count[1]) store_box_plain(&lv.box[1][j >> kLevel1Shift], wmn, wmx);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { s_wave[k][t >> 6] = wmn[k]; s_wave[3 + k][t >> 6] = wmx[k]; }
+        }
+        __syncthreads();
+        if (t < 64u) {
+            float bmn[3], bmx[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                bmn[k] = t < (uint32_t)(kRefitThreads / LBVH_WAVE) ? s_wave[k][t] : INFINITY;
+                bmx[k] = t < (uint32_t)(kRefitThreads / LBVH_WAVE) ? s_wave[3 + k][t] : -INFINITY;
+            }
+            wave_union(bmn, bmx);
+            if (t == 0 && lv.levels >= 2) store_box_plain(&lv.box[2][blockIdx.x], bmn, bmx);
+        }
+    }
+    if (j < n) {
         for (int guard = 0; q != 0xFFFFFFFFu && guard < 64; guard++) {
-            if (q >= n - 1) { q = 0xFFFFFFFFu; break; }
+            if (q >= n - 1) break;
+            // LOCAL arrival: q's index and the carried range lie inside the workgroup's 1024 indices.  Anything
+            // else is a frontier node (refit_frontier computes it from the range levels).
             const bool local = q >= b0 && q - b0 < (uint32_t)kRefitThreads && first >= b0 &&
                                last - b0 < (uint32_t)kRefitThreads;
-            if (!local) { pending = true; break; }
+            if (!local) break;
             const uint32_t slot = q - b0;
             const uint32_t* nd = reinterpret_cast<const uint32_t*>(&internal[q]);
             const uint2 l = *reinterpret_cast<const uint2*>(nd + 0);
@@ -381,7 +379,7 @@ __global__ __launch_bounds__(kRefitThreads) void refit_kernel(uint32_t n, const 
             for (int k = 0; k < 3; k++) { s_box[side][k][slot] = mn[k]; s_box[side][3 + k][slot] = mx[k]; }
             s_range[side][slot] = (first - b0) | ((last - b0) << 16);
             const uint32_t old = atomicAdd(&s_flag[slot], side == 0 ? 1u : 0x10000u);      // :185 (LDS)
-            if (old == 0) { q = 0xFFFFFFFFu; break; }                                      // first arrival :186-189
+            if (old == 0) break;                                                           // first arrival :186-189
             const uint32_t o = side ^ 1u;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
@@ -391,29 +389,106 @@ __global__ __launch_bounds__(kRefitThreads) void refit_kernel(uint32_t n, const 
             const uint32_t orange = s_range[o][slot];
             first = min(first, b0 + (orange & 0xFFFFu));
             last = max(last, b0 + (orange >> 16));
-            float4* ob = reinterpret_cast<float4*>(&bvh[q]);                               // :215
-            ob[0] = make_float4(mn[0], mn[1], mn[2], 0.0f);
-            ob[1] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+            store_box_plain(&bvh[q], mn, mx);                                              // :215
+            if (q == 0) break;                          // the root: its parent word is whatever the caller's buffer held
             child_id = q;
             child_internal = true;
             q = next;                                                                      // :217
         }
     }
+    // internal nodes of this index block that did not see both children arrive through LDS are the frontier
+    // (one global atomic per workgroup: the list order is irrelevant)
     __syncthreads();
+    const bool is_front = j < n - 1 && s_flag[t] != 0x10001u;
+    uint32_t my = 0;
+    if (is_front) my = atomicAdd(&s_front_n, 1u);
+    __syncthreads();
+    if (t == 0 && s_front_n)
+        s_front_base = __hip_atomic_fetch_add(frontier_count, s_front_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (is_front) frontier_list[s_front_base + my] = j;
+}
 
-    // ---- phase 2 ----
-    if (pending) refit_global_walk(n, internal, tri_aabb, sorted_indices, bvh, flags, q, child_internal, child_id, mn, mx);
-    // LDS slots that saw exactly one child: its sibling subtree belongs to another workgroup
-    const uint32_t f = s_flag[t];
-    if (f == 1u || f == 0x10000u) {
-        const uint32_t side = f == 1u ? 0u : 1u;
-        const uint32_t node = b0 + t;
-        const uint32_t* nd = reinterpret_cast<const uint32_t*>(&internal[node]);
-        const uint2 c = *reinterpret_cast<const uint2*>(nd + 2 * side);
-        float cmn[3], cmx[3];
+// range level k >= 3 from level k - 1 (only built when level 2 alone would leave the top nodes with thousands of
+// entries to union: more than 4 M leaves)
+__global__ __launch_bounds__(256) void refit_level_kernel(refit_levels_t lv, int k)
+{
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= lv.count[k]) return;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const uint32_t c0 = e << kFanShift, c1 = min(c0 + (1u << kFanShift), lv.count[k - 1]);
+    for (uint32_t c = c0; c < c1; c++) {
+        float a[3], b[3];
+        load_box_plain(&lv.box[k - 1][c], a, b);
 #pragma unroll
-        for (int k = 0; k < 3; k++) { cmn[k] = s_box[side][k][t]; cmx[k] = s_box[side][3 + k][t]; }
-        refit_global_walk(n, internal, tri_aabb, sorted_indices, bvh, flags, node, c.y == LBVH_INTERNAL_NODE, c.x, cmn, cmx);
+        for (int d = 0; d < 3; d++) { mn[d] = fminf(mn[d], a[d]); mx[d] = fmaxf(mx[d], b[d]); }
+    }
+    store_box_plain(&lv.box[k][e], mn, mx);
+}
+
+// The leaf range [first, last] of internal node p from the node arrays alone (see the header comment).
+__device__ __forceinline__ void node_range(uint32_t n, const lbvh_internal_node* __restrict__ internal, uint32_t p,
+                                           uint32_t* first, uint32_t* last)
+{
+    const uint32_t* nd = reinterpret_cast<const uint32_t*>(&internal[p]);
+    const bool first_kind = p <= nd[0];                 // leftNode = split
+    uint32_t other = first_kind ? n - 1 : 0u;           // nothing of the other kind up to the root
+    uint32_t c = nd[4];                                 // parent
+    if (p == 0) c = 0xFFFFFFFFu;                        // the root's parent word is never written (BVH.compute:126,144)
+    for (int guard = 0; c < n - 1 && guard < 64; guard++) {
+        const uint32_t* cd = reinterpret_cast<const uint32_t*>(&internal[c]);
+        if ((c <= cd[0]) != first_kind) { other = c; break; }
+        if (c == 0) break;                              // the root is of my kind: the range runs to the end of the array
+        c = cd[4];
+    }
+    *first = first_kind ? p : other;
+    *last = first_kind ? other : p;
+}
+
+__global__ __launch_bounds__(256) void refit_frontier_kernel(uint32_t n, const lbvh_internal_node* __restrict__ internal,
+                                                             const uint32_t* __restrict__ count, const uint32_t* __restrict__ list,
+                                                             const lbvh_aabb* __restrict__ tri_aabb,
+                                                             const uint32_t* __restrict__ sorted_indices, lbvh_aabb* bvh,
+                                                             refit_levels_t lv)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t waves = gridDim.x * 4u;
+    const uint32_t total = *count;
+    for (uint32_t e = blockIdx.x * 4u + (threadIdx.x >> 6); e < total; e += waves) {
+        const uint32_t node = list[e];
+        uint32_t first, last;
+        node_range(n, internal, node, &first, &last);           // wave-uniform walk
+        if (first > last || last >= n) continue;                // malformed caller tree
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        auto take = [&](const lbvh_aabb* p) {
+            float a[3], b[3];
+            load_box_plain(p, a, b);
+#pragma unroll
+            for (int d = 0; d < 3; d++) { mn[d] = fminf(mn[d], a[d]); mx[d] = fmaxf(mx[d], b[d]); }
+        };
+        // [lo, hi) in units of the current level: the ragged ends are taken at this level, the aligned middle
+        // moves one level up
+        uint32_t lo = first, hi = last + 1u;
+        {
+            const uint32_t a_end = min(hi, (lo + 63u) & ~63u), b_start = max(a_end, hi & ~63u);
+            if (lo + lane < a_end) { const uint32_t i = lo + lane; take(&tri_aabb[sorted_indices ? sorted_indices[i] : i]); }
+            if (b_start + lane < hi) { const uint32_t i = b_start + lane; take(&tri_aabb[sorted_indices ? sorted_indices[i] : i]); }
+            lo = (lo + 63u) >> kLevel1Shift;
+            hi >>= kLevel1Shift;
+        }
+        for (int k = 1; k <= lv.levels && lo < hi; k++) {
+            if (k == lv.levels) {                       // top stored level: everything that is left
+                for (uint32_t c = lo + lane; c < hi; c += 64u) take(&lv.box[k][c]);
+                break;
+            }
+            const uint32_t a_end = min(hi, (lo + 15u) & ~15u), b_start = max(a_end, hi & ~15u);
+            if (lane < 16u) { if (lo + lane < a_end) take(&lv.box[k][lo + lane]); }
+            else if (lane < 32u) { if (b_start + (lane - 16u) < hi) take(&lv.box[k][b_start + (lane - 16u)]); }
+            lo = (lo + 15u) >> kFanShift;
+            hi >>= kFanShift;
+        }
+        wave_union(mn, mx);
+        if (lane == 0) store_box_plain(&bvh[node], mn, mx);
     }
 }
 
@@ -544,20 +619,54 @@ int lbvh_launch_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, lbvh
 int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d_internal, const lbvh_leaf_node* d_leaf,
                       const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh)
 {
-    if (ctx->refit_flags_words < (size_t)n) {
+    // scratch: [frontier count (256 B) | frontier list, one u32 per internal node (every node could be one) | range levels]
+    refit_levels_t lv = {};
+    size_t level_bytes = 0;
+    {
+        uint32_t c = (n + (1u << kLevel1Shift) - 1) >> kLevel1Shift;
+        int k = 1;
+        for (;; k++) {
+            lv.count[k] = c;
+            level_bytes += (size_t)c * sizeof(lbvh_aabb);
+            if (c <= 1 || k == kMaxLevels) break;
+            c = (c + (1u << kFanShift) - 1) >> kFanShift;
+        }
+        // the top nodes loop over whatever the highest stored level leaves them: stop adding levels once that is
+        // at most 4096 entries (64 iterations of a wave)
+        while (k > 2 && lv.count[k - 1] <= 4096u) k--;
+        lv.levels = k;
+        level_bytes = 0;
+        for (int i = 1; i <= k; i++) level_bytes += (size_t)lv.count[i] * sizeof(lbvh_aabb);
+    }
+    const size_t list_bytes = (((size_t)n * 4) + 255) & ~(size_t)255;
+    const size_t need = 256 + list_bytes + level_bytes;
+    if (ctx->refit_flags_words * 4 < need) {
         void* p = ctx->refit_flags;
         size_t have = ctx->refit_flags_words * 4;
-        int rc = lbvh_reserve(ctx, &p, &have, (size_t)n * 4);
+        int rc = lbvh_reserve(ctx, &p, &have, need);
         ctx->refit_flags = (uint32_t*)p;
         ctx->refit_flags_words = have / 4;
         if (rc != LBVH_OK) return rc;
     }
-    // counters zeroed per build (the reference zeroes its atomicsData once, Sc/BVHConstructor.cs:41, and
-    // so cannot rebuild)
-    LBVH_HIP_TRY(ctx, hipMemsetAsync(ctx->refit_flags, 0, (size_t)n * 4, ctx->stream));
+    char* base = (char*)ctx->refit_flags;
+    uint32_t* count = (uint32_t*)base;
+    uint32_t* list = (uint32_t*)(base + 256);
+    {
+        char* p = base + 256 + list_bytes;
+        for (int k = 1; k <= lv.levels; k++) { lv.box[k] = (lbvh_aabb*)p; p += (size_t)lv.count[k] * sizeof(lbvh_aabb); }
+    }
+    LBVH_HIP_TRY(ctx, hipMemsetAsync(count, 0, 256, ctx->stream));
     const uint32_t blocks = (n + kRefitThreads - 1) / kRefitThreads;
     LBVH_LAUNCH(ctx, refit_kernel, dim3(blocks), dim3(kRefitThreads), n, d_internal, d_leaf, d_triangle_aabb,
-                d_sorted_indices, d_bvh, ctx->refit_flags);
+                d_sorted_indices, d_bvh, lv, count, list);
+    if (blocks > 1) {       // a single workgroup finishes the whole tree in LDS
+        for (int k = 3; k <= lv.levels; k++)
+            LBVH_LAUNCH(ctx, refit_level_kernel, dim3((lv.count[k] + 255) / 256), dim3(256), lv, k);
+        uint32_t fblocks = blocks * 4u;                      // frontier nodes are a few per leaf block
+        if (fblocks > 2048u) fblocks = 2048u;
+        LBVH_LAUNCH(ctx, refit_frontier_kernel, dim3(fblocks), dim3(256), n, d_internal, count, list, d_triangle_aabb,
+                    d_sorted_indices, d_bvh, lv);
+    }
     return LBVH_OK;
 }
 
