@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LBVH_ABI_VERSION 2
+#define LBVH_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------------------------- */
 typedef int32_t lbvh_status;
@@ -150,7 +150,7 @@ lbvh_status lbvh_create(int32_t device_id, lbvh_context** out_ctx);
  * never destroys that stream. */
 lbvh_status lbvh_create_on_stream(int32_t device_id, void* hip_stream, lbvh_context** out_ctx);
 
-/* Frees the context's scratch (sort ping-pong, histograms, refit flags) and its stream.
+/* Frees the context's scratch (sort ping-pong, histograms, refit scratch) and its stream.
  * Replaces the Dispose chains (Sc/ComputeBufferSorter.cs:274-281, Sc/BVHConstructor.cs:71-74). */
 lbvh_status lbvh_destroy(lbvh_context* ctx);
 
@@ -242,10 +242,14 @@ lbvh_status lbvh_build_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_sor
 /* ---- stage a-8: bottom-up AABB refit ------------------------------------------------------------ */
 
 /* Replaces BVHConstructor.ConstructBVH -> kernel BVHConstructor
- * (Sc/BVHConstructor.cs:66-69, Sh/BVH/BVH.compute:152-220).  The context owns the per-node flag
- * buffer (the reference's atomicsData, Sc/BVHConstructor.cs:41) and zeroes it on every call, so
- * the tree can be rebuilt per frame.  d_triangle_aabb is in ORIGINAL triangle order and is
- * gathered through d_sorted_indices, as in the reference (:203,:212). */
+ * (Sc/BVHConstructor.cs:66-69, Sh/BVH/BVH.compute:152-220): d_bvh[i] = union of the leaf AABBs under
+ * internal node i (min/max are exact, so the result equals the reference's arrival-order merge bit for
+ * bit).  The reference's per-node arrival flags (atomicsData, Sc/BVHConstructor.cs:41, zeroed once) have
+ * no counterpart: the context owns the scratch of the refit and every call is self-contained, so the
+ * tree can be rebuilt per frame.  d_internal / d_leaf must hold a tree in ConstructTree's numbering
+ * (left child index = split, right = split + 1, root = node 0); the root's parent word is not read.
+ * d_triangle_aabb is in ORIGINAL triangle order and is gathered through d_sorted_indices, as in the
+ * reference (:203,:212). */
 lbvh_status lbvh_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d_internal,
                        const lbvh_leaf_node* d_leaf, const lbvh_aabb* d_triangle_aabb,
                        const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh);

@@ -104,7 +104,7 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->sort_scratch) (void)hipFree(ctx->sort_scratch);
     if (ctx->scan_scratch) (void)hipFree(ctx->scan_scratch);
-    if (ctx->refit_flags) (void)hipFree(ctx->refit_flags);
+    if (ctx->refit_scratch) (void)hipFree(ctx->refit_scratch);
     if (ctx->fast_nodes) (void)hipFree(ctx->fast_nodes);
     if (ctx->fast_tris) (void)hipFree(ctx->fast_tris);
     if (ctx->trace_queues) (void)hipFree(ctx->trace_queues);

@@ -640,15 +640,15 @@ int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d
     }
     const size_t list_bytes = (((size_t)n * 4) + 255) & ~(size_t)255;
     const size_t need = 256 + list_bytes + level_bytes;
-    if (ctx->refit_flags_words * 4 < need) {
-        void* p = ctx->refit_flags;
-        size_t have = ctx->refit_flags_words * 4;
+    if (ctx->refit_scratch_words * 4 < need) {
+        void* p = ctx->refit_scratch;
+        size_t have = ctx->refit_scratch_words * 4;
         int rc = lbvh_reserve(ctx, &p, &have, need);
-        ctx->refit_flags = (uint32_t*)p;
-        ctx->refit_flags_words = have / 4;
+        ctx->refit_scratch = (uint32_t*)p;
+        ctx->refit_scratch_words = have / 4;
         if (rc != LBVH_OK) return rc;
     }
-    char* base = (char*)ctx->refit_flags;
+    char* base = (char*)ctx->refit_scratch;
     uint32_t* count = (uint32_t*)base;
     uint32_t* list = (uint32_t*)(base + 256);
     {

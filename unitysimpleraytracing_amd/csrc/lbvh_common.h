@@ -52,8 +52,8 @@ struct lbvh_context {
     void* scan_scratch = nullptr;
     size_t scan_scratch_bytes = 0;
     // refit arrival flags (the reference's atomicsData, Sc/BVHConstructor.cs:41)
-    uint32_t* refit_flags = nullptr;
-    size_t refit_flags_words = 0;
+    uint32_t* refit_scratch = nullptr;
+    size_t refit_scratch_words = 0;
     // derived fast-traversal scene
     lbvh_fast_node* fast_nodes = nullptr;
     lbvh_fast_tri* fast_tris = nullptr;
