@@ -62,6 +62,10 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern int lbvh_shade(IntPtr ctx, IntPtr dHits, UIntPtr count, IntPtr dTriangles,
         IntPtr dTextureRgba8, int texW, int texH, IntPtr dRgba16f);
 
+    // the whole Awake() build chain in one call (per-frame rebuilds); flags: 1 = fast scene, 2 = reset node arrays
+    [DllImport(Lib)] public static extern int lbvh_build_scene(IntPtr ctx, IntPtr dTriangles, uint n, uint capacity, float[] boxMin,
+        float[] boxMax, IntPtr dKeys, IntPtr dIndices, IntPtr dAabb, IntPtr dInternal, IntPtr dLeaf, IntPtr dBvh, uint flags);
+
     // dynamic scene + secondary rays (BASELINE configs[4]; extension, no reference counterpart)
     [DllImport(Lib)] public static extern int lbvh_animate(IntPtr ctx, IntPtr dRestTriangles, uint n, IntPtr dBodyIds, IntPtr dBodyCentres,
         float cosAngle, float sinAngle, IntPtr dTrianglesOut);

@@ -254,6 +254,22 @@ lbvh_status lbvh_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* 
                        const lbvh_leaf_node* d_leaf, const lbvh_aabb* d_triangle_aabb,
                        const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh);
 
+/* ---- the whole build chain in one call ----------------------------------------------------------- */
+
+#define LBVH_BUILD_FAST_SCENE  1u   /* also build the derived traversal scene (= lbvh_build_fast_scene)        */
+#define LBVH_BUILD_RESET_NODES 2u   /* refill d_internal / d_leaf with 0xFFFFFFFF first (capacity slots)       */
+
+/* RaytracingMeshDrawer.Awake()'s build chain (Sc/RaytracingMeshDrawer.cs:34-51) = lbvh_morton_aabb ->
+ * lbvh_sort_pairs(capacity) -> lbvh_distribute_keys -> lbvh_build_tree -> lbvh_refit (+ lbvh_build_fast_scene
+ * with LBVH_BUILD_FAST_SCENE), with identical results.  After the sort the reference's arrays and the derived
+ * traversal scene are two independent chains of short latency-bound kernels; this call runs them concurrently
+ * on the context's stream and an internal side stream and joins them before it returns control to the
+ * stream, so later calls on the context see both.  For per-frame rebuilds of dynamic scenes. */
+lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
+                             const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys,
+                             uint32_t* d_indices, lbvh_aabb* d_aabb, lbvh_internal_node* d_internal,
+                             lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh, uint32_t flags);
+
 /* ---- stage a-9: primary-ray traversal ------------------------------------------------------------ */
 
 /* The scene buffers RaytracingMeshDrawer binds to the Raytracing kernel

@@ -248,6 +248,30 @@ def test_full_build_bit_exact(ctx, scene):
     d.on_destroy()
 
 
+@pytest.mark.parametrize("scene", ["cfg1", "torus64k", "rand300k"])
+def test_build_scene_one_call_equals_the_staged_chain(ctx, scene):
+    """lbvh_build_scene (two concurrent lanes after the sort) against the oracle and against the staged calls."""
+    tris = {"cfg1": lambda: scenes.random_triangles(4096, seed=1), "torus64k": lambda: scenes.tiled_torus(grid=2),
+            "rand300k": lambda: scenes.random_triangles(300_000, seed=9, extent=110.0, edge=1.5)}[scene]()
+    d, c, b = build_both(ctx, tris)
+    cam = scenes.camera(200, 150, (0.0, 0.0, 260.0))
+    d.update(cam, mode=L.TRACE_FAST)
+    staged = d.hits()
+    for rep in range(3):
+        c.bvh_data.fill_u32(0x7FC00000, mirror=False)
+        c.keys.fill_u32(0, mirror=False)
+        d.rebuild()                                   # lbvh_build_scene
+        assert_build_equal(c, b)
+        d.update(cam, mode=L.TRACE_FAST)
+        one = d.hits()
+        assert (one["t"] == staged["t"]).all() and (one["tri"] == staged["tri"]).all()
+        d.update(cam, mode=L.TRACE_REFERENCE)
+        assert (d.hits()["t"] == one["t"]).all()
+    d.rebuild(staged=True)
+    assert_build_equal(c, b)
+    d.on_destroy()
+
+
 def test_refit_race_stress(ctx):
     """Many small trees, repeated: the flag hand-off must never read a stale sibling box."""
     for rep in range(30):

@@ -78,6 +78,7 @@ SIGNATURES = {
     "lbvh_trace_primary": (_I32, [_P, C.POINTER(Camera), _I32, _I32, _I32, _I32, C.POINTER(Scene),
                                   _I32, _P, _P]),
     "lbvh_trace_primary_shard": (_I32, [_P, C.POINTER(Camera), _U32, _U32, C.POINTER(Scene), _I32, _P, _P]),
+    "lbvh_build_scene": (_I32, [_P, _P, _U32, _U32, _F3, _F3, _P, _P, _P, _P, _P, _P, _U32]),
     "lbvh_key_histogram": (_I32, [_P, _P, _U32, _P, _U32, _U32, _U32, _P]),
     "lbvh_lower_bound": (_I32, [_P, _P, _U32, _P, _U32, _P]),
     "lbvh_animate": (_I32, [_P, _P, _U32, _P, _P, C.c_float, C.c_float, _P]),

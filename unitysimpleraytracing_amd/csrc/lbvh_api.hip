@@ -19,6 +19,7 @@ int lbvh_reserve(lbvh_context* ctx, void** ptr, size_t* have, size_t bytes)
     if (*ptr) {
         // earlier launches may still be using the old block
         LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->side_stream) LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->side_stream));
         LBVH_HIP_TRY(ctx, hipFree(*ptr));
         *ptr = nullptr;
         *have = 0;
@@ -83,6 +84,7 @@ static lbvh_status create_impl(int32_t device_id, void* stream, bool own, lbvh_c
         ctx->stream = (hipStream_t)stream;
         ctx->own_stream = false;
     }
+    ctx->cur_stream = ctx->stream;
     *out_ctx = ctx;
     return LBVH_OK;
 }
@@ -103,8 +105,14 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->sort_scratch) (void)hipFree(ctx->sort_scratch);
-    if (ctx->scan_scratch) (void)hipFree(ctx->scan_scratch);
-    if (ctx->refit_scratch) (void)hipFree(ctx->refit_scratch);
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
+    for (int l = 0; l < 2; l++) {
+        if (ctx->scan_scratch[l]) (void)hipFree(ctx->scan_scratch[l]);
+        if (ctx->refit_scratch[l]) (void)hipFree(ctx->refit_scratch[l]);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->fast_nodes) (void)hipFree(ctx->fast_nodes);
     if (ctx->fast_tris) (void)hipFree(ctx->fast_tris);
     if (ctx->trace_queues) (void)hipFree(ctx->trace_queues);

@@ -640,22 +640,23 @@ int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d
     }
     const size_t list_bytes = (((size_t)n * 4) + 255) & ~(size_t)255;
     const size_t need = 256 + list_bytes + level_bytes;
-    if (ctx->refit_scratch_words * 4 < need) {
-        void* p = ctx->refit_scratch;
-        size_t have = ctx->refit_scratch_words * 4;
+    const int L = ctx->lane;
+    if (ctx->refit_scratch_words[L] * 4 < need) {
+        void* p = ctx->refit_scratch[L];
+        size_t have = ctx->refit_scratch_words[L] * 4;
         int rc = lbvh_reserve(ctx, &p, &have, need);
-        ctx->refit_scratch = (uint32_t*)p;
-        ctx->refit_scratch_words = have / 4;
+        ctx->refit_scratch[L] = (uint32_t*)p;
+        ctx->refit_scratch_words[L] = have / 4;
         if (rc != LBVH_OK) return rc;
     }
-    char* base = (char*)ctx->refit_scratch;
+    char* base = (char*)ctx->refit_scratch[L];
     uint32_t* count = (uint32_t*)base;
     uint32_t* list = (uint32_t*)(base + 256);
     {
         char* p = base + 256 + list_bytes;
         for (int k = 1; k <= lv.levels; k++) { lv.box[k] = (lbvh_aabb*)p; p += (size_t)lv.count[k] * sizeof(lbvh_aabb); }
     }
-    LBVH_HIP_TRY(ctx, hipMemsetAsync(count, 0, 256, ctx->stream));
+    LBVH_HIP_TRY(ctx, hipMemsetAsync(count, 0, 256, ctx->cur_stream));
     const uint32_t blocks = (n + kRefitThreads - 1) / kRefitThreads;
     LBVH_LAUNCH(ctx, refit_kernel, dim3(blocks), dim3(kRefitThreads), n, d_internal, d_leaf, d_triangle_aabb,
                 d_sorted_indices, d_bvh, lv, count, list);
@@ -683,9 +684,9 @@ int lbvh_launch_aligned_keys(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_t
     box3 scene;
     for (int k = 0; k < 3; k++) { scene.mn[k] = box_min[k]; scene.mx[k] = box_max[k]; }
     const uint32_t chunks = (n + kAkThreads - 1) / kAkThreads;
-    int rc = lbvh_reserve(ctx, &ctx->scan_scratch, &ctx->scan_scratch_bytes, (size_t)chunks * 8);
+    int rc = lbvh_reserve(ctx, &ctx->scan_scratch[ctx->lane], &ctx->scan_scratch_bytes[ctx->lane], (size_t)chunks * 8);
     if (rc != LBVH_OK) return rc;
-    int32_t* chunk_max = (int32_t*)ctx->scan_scratch;
+    int32_t* chunk_max = (int32_t*)ctx->scan_scratch[ctx->lane];
     LBVH_LAUNCH(ctx, aligned_keys_reduce_kernel, dim3(chunks), dim3(kAkThreads), d_triangle_aabb, d_sorted_indices, n, scene,
                 chunk_max);
     LBVH_LAUNCH(ctx, aligned_keys_scan_kernel, dim3(1), dim3(kAkThreads), chunk_max, chunks);
@@ -724,9 +725,9 @@ lbvh_status lbvh_distribute_keys(lbvh_context* ctx, uint32_t* d_keys, uint32_t n
     LBVH_REQUIRE(ctx, d_keys != nullptr);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t chunks = (uint32_t)(((uint64_t)n + kDistChunk - 1) / kDistChunk);
-    int rc = lbvh_reserve(ctx, &ctx->scan_scratch, &ctx->scan_scratch_bytes, (size_t)chunks * 8);
+    int rc = lbvh_reserve(ctx, &ctx->scan_scratch[ctx->lane], &ctx->scan_scratch_bytes[ctx->lane], (size_t)chunks * 8);
     if (rc != LBVH_OK) return rc;
-    uint32_t* chunk_sums = (uint32_t*)ctx->scan_scratch;
+    uint32_t* chunk_sums = (uint32_t*)ctx->scan_scratch[ctx->lane];
     uint32_t* boundary = chunk_sums + chunks;
     LBVH_LAUNCH(ctx, distribute_reduce_kernel, dim3(chunks), dim3(kDistThreads),
                        d_keys, n, chunk_sums, boundary);

@@ -48,12 +48,19 @@ struct lbvh_context {
     // radix sort scratch (ping-pong pairs + per-tile digit tables), grown lazily
     void* sort_scratch = nullptr;
     size_t sort_scratch_bytes = 0;
-    // distribute-keys scratch
-    void* scan_scratch = nullptr;
-    size_t scan_scratch_bytes = 0;
-    // refit arrival flags (the reference's atomicsData, Sc/BVHConstructor.cs:41)
-    uint32_t* refit_scratch = nullptr;
-    size_t refit_scratch_words = 0;
+    // Two lanes: lane 0 = the context's stream; lane 1 = an internal side stream on which lbvh_build_scene
+    // builds the derived traversal scene while lane 0 builds the reference's arrays (independent chains
+    // of latency-bound kernels).  Launches go to cur_stream; scan / refit scratch exists once per lane.
+    hipStream_t side_stream = nullptr;
+    hipStream_t cur_stream = nullptr;
+    int lane = 0;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // distribute-keys / aligned-keys scan scratch
+    void* scan_scratch[2] = {nullptr, nullptr};
+    size_t scan_scratch_bytes[2] = {0, 0};
+    // refit scratch: frontier list + range levels (the reference's atomicsData has no counterpart)
+    uint32_t* refit_scratch[2] = {nullptr, nullptr};
+    size_t refit_scratch_words[2] = {0, 0};
     // derived fast-traversal scene
     lbvh_fast_node* fast_nodes = nullptr;
     lbvh_fast_tri* fast_tris = nullptr;
@@ -73,7 +80,7 @@ struct lbvh_context {
 
 hipEvent_t lbvh_prof_event(lbvh_context* ctx);
 
-// Every kernel launch of the library goes through this: a plain launch on the context's stream,
+// Every kernel launch of the library goes through this: a plain launch on the context's current lane,
 // bracketed by two events when profiling is on.
 #define LBVH_LAUNCH(ctx, kernel, grid, block, ...)                                      \
     do {                                                                                \
@@ -81,11 +88,11 @@ hipEvent_t lbvh_prof_event(lbvh_context* ctx);
         if ((ctx)->prof_enabled) {                                                      \
             _a = lbvh_prof_event(ctx);                                                  \
             _b = lbvh_prof_event(ctx);                                                  \
-            (void)hipEventRecord(_a, (ctx)->stream);                                    \
+            (void)hipEventRecord(_a, (ctx)->cur_stream);                                \
         }                                                                               \
-        hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);         \
+        hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->cur_stream, __VA_ARGS__);     \
         if ((ctx)->prof_enabled) {                                                      \
-            (void)hipEventRecord(_b, (ctx)->stream);                                    \
+            (void)hipEventRecord(_b, (ctx)->cur_stream);                                \
             (ctx)->prof_spans.push_back({#kernel, _a, _b});                             \
         }                                                                               \
     } while (0)

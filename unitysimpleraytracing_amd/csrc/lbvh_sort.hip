@@ -466,7 +466,7 @@ extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint
     uint32_t* tickets = ghist + kPasses * kRadix;
     uint32_t* status = (uint32_t*)(p + 2 * pair_bytes + head_bytes);
     uint32_t* gstatus = status + (size_t)kPasses * tiles * kRadix;
-    LBVH_HIP_TRY(ctx, hipMemsetAsync(ghist, 0, head_bytes + status_bytes, ctx->stream));
+    LBVH_HIP_TRY(ctx, hipMemsetAsync(ghist, 0, head_bytes + status_bytes, ctx->cur_stream));
 
     // 4 K keys per block up to 2048 blocks: enough blocks to hide the load latency, few enough that the
     // 1024 global atomics each block ends with do not pile up on the same counters
@@ -544,7 +544,7 @@ extern "C" lbvh_status lbvh_key_histogram(lbvh_context* ctx, const uint32_t* d_k
     LBVH_REQUIRE(ctx, (prefix_shift == 32 && n_prefixes == 1) || (prefix_shift < 32 && h_prefixes != nullptr));
     LBVH_REQUIRE(ctx, count == 0 || d_keys != nullptr);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    LBVH_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, (size_t)n_prefixes * 256 * 4, ctx->stream));
+    LBVH_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, (size_t)n_prefixes * 256 * 4, ctx->cur_stream));
     if (count == 0) return LBVH_OK;
     prefix_args pa = {};
     if (prefix_shift < 32) for (uint32_t p = 0; p < n_prefixes; ++p) pa.v[p] = h_prefixes[p];

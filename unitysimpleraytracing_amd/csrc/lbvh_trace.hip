@@ -467,6 +467,7 @@ lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene, 
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->fast_capacity < s.n) {
         LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->side_stream) LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->side_stream));
         if (ctx->fast_nodes) { LBVH_HIP_TRY(ctx, hipFree(ctx->fast_nodes)); ctx->fast_nodes = nullptr; }
         if (ctx->fast_tris) { LBVH_HIP_TRY(ctx, hipFree(ctx->fast_tris)); ctx->fast_tris = nullptr; }
         ctx->fast_capacity = 0;
@@ -509,6 +510,59 @@ lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene, 
     return LBVH_OK;
 }
 
+// RaytracingMeshDrawer.Awake()'s whole build chain in one call, as two concurrent lanes after the sort.
+lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
+                             const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
+                             lbvh_aabb* d_aabb, lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh,
+                             uint32_t flags)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, n >= 2 && capacity >= n);
+    LBVH_REQUIRE(ctx, d_triangles && d_keys && d_indices && d_aabb && d_internal && d_leaf && d_bvh);
+    LBVH_REQUIRE(ctx, ctx->lane == 0);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->side_stream) {
+        LBVH_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    lbvh_status rc;
+    if (flags & LBVH_BUILD_RESET_NODES) {        // NullLeaf / uint.MaxValue fills, Sc/MeshBufferContainer.cs:114-115
+        LBVH_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_internal, 0xFFFFFFFFu, (size_t)capacity * 6, ctx->stream));
+        LBVH_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_leaf, 0xFFFFFFFFu, (size_t)capacity * 2, ctx->stream));
+    }
+    if ((rc = lbvh_morton_aabb(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb)) != LBVH_OK) return rc;
+    if ((rc = lbvh_sort_pairs(ctx, d_keys, d_indices, capacity)) != LBVH_OK) return rc;
+    const bool fast = (flags & LBVH_BUILD_FAST_SCENE) != 0;
+    if (fast) {
+        // lane 1: the derived traversal scene needs only the sorted indices and the triangle AABBs
+        LBVH_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+        lbvh_scene s;
+        s.n = n;
+        s.sorted_indices = d_indices;
+        s.triangle_aabb = d_aabb;
+        s.internal_nodes = d_internal;
+        s.leaf_nodes = d_leaf;
+        s.bvh = d_bvh;
+        s.triangles = d_triangles;
+        ctx->lane = 1;
+        ctx->cur_stream = ctx->side_stream;
+        rc = lbvh_build_fast_scene(ctx, &s, h_box_min, h_box_max);
+        hipError_t e = hipEventRecord(ctx->ev_join, ctx->side_stream);
+        ctx->lane = 0;
+        ctx->cur_stream = ctx->stream;
+        if (rc != LBVH_OK) return rc;
+        LBVH_HIP_TRY(ctx, e);
+    }
+    // lane 0: the reference's arrays
+    if ((rc = lbvh_distribute_keys(ctx, d_keys, n)) != LBVH_OK) return rc;
+    if ((rc = lbvh_build_tree(ctx, n, d_keys, d_internal, d_leaf)) != LBVH_OK) return rc;
+    if ((rc = lbvh_refit(ctx, n, d_internal, d_leaf, d_aabb, d_indices, d_bvh)) != LBVH_OK) return rc;
+    if (fast) LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return LBVH_OK;
+}
+
 static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, int32_t x0, int32_t y0, int32_t x1,
                               int32_t y1, uint32_t shard_index, uint32_t shard_count, const lbvh_scene* h_scene,
                               int32_t mode, lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_cost = nullptr)
@@ -533,7 +587,7 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
     a.tiles_x = (uint32_t)(x1 - x0 + 7) / 8;
     a.tiles_y = (uint32_t)(y1 - y0 + 7) / 8;
     const uint32_t n_tiles = shard_work(a.tiles_x * a.tiles_y, shard_index, shard_count);
-    if (d_stats) LBVH_HIP_TRY(ctx, hipMemsetAsync(d_stats, 0, sizeof(lbvh_trace_stats), ctx->stream));
+    if (d_stats) LBVH_HIP_TRY(ctx, hipMemsetAsync(d_stats, 0, sizeof(lbvh_trace_stats), ctx->cur_stream));
 
     if (n_tiles == 0) return LBVH_OK;
     if (mode == LBVH_TRACE_REFERENCE) {
@@ -550,7 +604,7 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
             return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_trace_primary",
                                   "LBVH_TRACE_FAST needs lbvh_build_fast_scene on this scene first");
         if (!ctx->trace_queues) LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->trace_queues, 256));
-        LBVH_HIP_TRY(ctx, hipMemsetAsync(ctx->trace_queues, 0, 32, ctx->stream));
+        LBVH_HIP_TRY(ctx, hipMemsetAsync(ctx->trace_queues, 0, 32, ctx->cur_stream));
         tile_queues* q = (tile_queues*)ctx->trace_queues;
         // 2 x 1 rays per lane = 16 x 8-pixel packets over 2-wide nodes: measured best of 1x1 / 2x1 / 1x2 / 3x1 /
         // 2x2 / 4x2 rays per lane (more rays cut node fetches per ray but the extra VGPRs cost occupancy) and of

@@ -250,18 +250,28 @@ class RaytracingMeshDrawer:
             self.build_fast_scene()
         return self
 
-    def rebuild(self, fast=True):
-        """Per-frame rebuild on the same buffers (dynamic scenes): Morton -> ... -> refit."""
+    def rebuild(self, fast=True, staged=False):
+        """Per-frame rebuild on the same buffers (dynamic scenes): Morton -> ... -> refit (+ the derived traversal
+        scene).  One lbvh_build_scene call (the two chains after the sort run concurrently); staged=True issues
+        the reference's stage calls one by one instead — same results."""
         c = self.container
-        c.bvh_leaf_node.fill_u32(L.NULL, mirror=False)
-        c.bvh_internal_node.fill_u32(L.NULL, mirror=False)
-        c.generate_keys()
-        self.sorter.sort()
-        c.distribute_keys()
-        self.bvh_constructor.construct_tree()
-        self.bvh_constructor.construct_bvh()
-        if fast:
-            self.build_fast_scene()
+        if staged:
+            c.bvh_leaf_node.fill_u32(L.NULL, mirror=False)
+            c.bvh_internal_node.fill_u32(L.NULL, mirror=False)
+            c.generate_keys()
+            self.sorter.sort()
+            c.distribute_keys()
+            self.bvh_constructor.construct_tree()
+            self.bvh_constructor.construct_bvh()
+            if fast:
+                self.build_fast_scene()
+            return
+        f3 = C.POINTER(C.c_float)
+        N.check(self.ctx.handle, N.lib.lbvh_build_scene(
+            self.ctx.handle, c.triangle_data.device, c.triangles_length, c.capacity, c.box_min.ctypes.data_as(f3),
+            c.box_max.ctypes.data_as(f3), c.keys.device, c.triangle_index.device, c.triangle_aabb.device,
+            c.bvh_internal_node.device, c.bvh_leaf_node.device, c.bvh_data.device,
+            L.BUILD_RESET_NODES | (L.BUILD_FAST_SCENE if fast else 0)))
 
     def build_fast_scene(self):
         c = self.container

@@ -258,19 +258,17 @@ public:
                                      (const lbvh_triangle*)container_->TriangleData().DeviceBuffer(),
                                      (const uint8_t*)tex_->DeviceBuffer(), tex_w_, tex_h_, (uint16_t*)image_->DeviceBuffer()));
     }
-    // per-frame rebuild on the same buffers (dynamic scenes): Morton -> sort -> DistributeKeys -> tree -> refit
+    // per-frame rebuild on the same buffers (dynamic scenes): the whole Awake() chain in one call
     void Rebuild()
     {
-        container_->BvhLeafNode().Fill(0xFFFFFFFFu, false);
-        container_->BvhInternalNode().Fill(0xFFFFFFFFu, false);
-        container_->GenerateKeys();
-        sorter_->Sort();
-        container_->DistributeKeys();
-        bvh_->ConstructTree();
-        bvh_->ConstructBVH();
-        const lbvh_scene s = container_->Scene();
-        const float mn[3] = {-125.0f, -125.0f, -125.0f}, mx[3] = {125.0f, 125.0f, 125.0f};
-        check(ctx_.get(), lbvh_build_fast_scene(ctx_.get(), &s, mn, mx));
+        MeshBufferContainer& c = *container_;
+        const float mn[3] = {-125.0f, -125.0f, -125.0f}, mx[3] = {125.0f, 125.0f, 125.0f};   // MeshBufferContainer.Whole
+        check(ctx_.get(), lbvh_build_scene(ctx_.get(), (const lbvh_triangle*)c.TriangleData().DeviceBuffer(), c.TrianglesLength(),
+                                           c.Capacity(), mn, mx, (uint32_t*)c.Keys().DeviceBuffer(),
+                                           (uint32_t*)c.TriangleIndex().DeviceBuffer(), (lbvh_aabb*)c.TriangleAABB().DeviceBuffer(),
+                                           (lbvh_internal_node*)c.BvhInternalNode().DeviceBuffer(),
+                                           (lbvh_leaf_node*)c.BvhLeafNode().DeviceBuffer(), (lbvh_aabb*)c.BvhData().DeviceBuffer(),
+                                           LBVH_BUILD_FAST_SCENE | LBVH_BUILD_RESET_NODES));
     }
     DataBuffer<uint64_t>& Image() { return *image_; }
     MeshBufferContainer& Container() { return *container_; }

@@ -24,6 +24,8 @@ HIT = np.dtype([("t", "<f4"), ("tri", "<u4"), ("u", "<f4"), ("v", "<f4")])
 TRACE_STATS = np.dtype([("pops", "<u8"), ("box_hits", "<u8"), ("leaf_tests", "<u8"),
                         ("tri_tests", "<u8"), ("hits", "<u8")])
 
+BUILD_FAST_SCENE, BUILD_RESET_NODES = 1, 2      # lbvh_build_scene flags
+
 PATH_STATE = np.dtype([("origin", "<f4", 3), ("alive", "<u4"), ("dir", "<f4", 3), ("pad0", "<f4"),
                        ("throughput", "<f4", 3), ("pad1", "<f4"), ("radiance", "<f4", 3), ("alpha", "<f4")])
 assert PATH_STATE.itemsize == 64
