@@ -1,5 +1,6 @@
 // lbvh_api.hip — context, buffers, events: the DataBuffer/ComputeBuffer half of the C ABI
 // (reference: Assets/_Scripts/DataBuffer.cs, Assets/_Scripts/ShaderContainer.cs).
+#include <cstdlib>
 #include "lbvh_common.h"
 
 #include <string.h>

@@ -66,7 +66,12 @@ struct lbvh_context {
     lbvh_fast_tri* fast_tris = nullptr;
     uint32_t fast_capacity = 0;
     uint32_t fast_n = 0;
-    void* trace_queues = nullptr;   // per-XCD tile cursors of the persistent traversal kernel
+    // packet traversal scheduling: step count of every tile in the last trace + the dispatch order made from it
+    void* trace_queues = nullptr;
+    size_t trace_queues_bytes = 0;
+    uint64_t trace_layout = 0;      // frame layout (tiles, shard, origin) the history belongs to
+    uint32_t trace_layout_work = 0;
+    bool trace_history = false;
     // the traversal tree of the derived scene (aligned keys, own topology and boxes)
     void* fast_tree = nullptr;
     size_t fast_tree_bytes = 0;

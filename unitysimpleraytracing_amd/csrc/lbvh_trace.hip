@@ -16,6 +16,8 @@
 //
 // One wave (8x8 pixels) per workgroup; the traversal stack lives in LDS as [entry][lane]
 // (bank-conflict-free, no scratch memory); no barriers anywhere.
+#include <cstdio>
+#include <cstdlib>
 #include "lbvh_common.h"
 #include "lbvh_rt.h"
 
@@ -227,32 +229,18 @@ __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh
 // Persistent waves pull tiles from eight per-XCD queues (contiguous screen regions per XCD for L2
 // locality; HW_REG_XCC_ID picks the home queue, other queues are stolen from when it is empty).
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kNoTile = 0xFFFFFFFFu;
-
-struct tile_queues {
-    uint32_t next[8];     // per-XCD cursor (zeroed by the launch function every call)
-};
-
-// next tile for this wave (wave-uniform), or kNoTile
-__device__ __forceinline__ uint32_t next_tile(tile_queues* q, uint32_t n_tiles, uint32_t home)
-{
-    const uint32_t per = n_tiles / 8, rem = n_tiles % 8;
-    uint32_t tile = kNoTile;
-    if (lane_id() == 0) {
-        for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t x = (home + k) & 7u;
-            const uint32_t count = per + (x < rem ? 1u : 0u);
-            const uint32_t start = x * per + (x < rem ? x : rem);
-            // cheap pre-check so exhausted queues are not hammered
-            if (__hip_atomic_load(&q->next[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= count) continue;
-            const uint32_t i = __hip_atomic_fetch_add(&q->next[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (i < count) { tile = start + i; break; }
-        }
-    }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-}
-
-
+// Work distribution (measured, 1 M triangles / 1080p; per-tile steps: median 48, p99 323, max 594):
+//   * persistent waves pulling tiles from per-XCD atomic queues: 1.13 ms — 0.70 ms of it with the traversal
+//     switched off (two dependent device-scope round trips per tile on eight hot counters);
+//   * one tile per wave, handed out by the hardware dispatcher in row-major order: 0.65 ms;
+//   * the same with the tiles dispatched HEAVIEST FIRST: 0.49 ms (lightest first 0.67, random 0.66, screen
+//     centre first 0.58): the run time is the tail of late-starting heavy tiles.  The kernel therefore records
+//     every tile's step count, and the next trace of the same frame layout dispatches in descending order of
+//     those counts (a scheduling hint only — any order gives the same hits; the first frame is row-major).
+//   * cutting packets at a step budget and re-queueing their unfinished subtrees as (tile, subtree) items for
+//     further passes (results merged per pixel by compare-and-swap) was built and measured: no gain over
+//     heaviest-first (0.49 ms either way), so it is not in the code.
+// ---------------------------------------------------------------------------------------------
 struct uniform_node {        // one fused node, wave-uniform (lives in SGPRs)
     float4 lmin, lmax, rmin, rmax;
 };
@@ -291,164 +279,232 @@ __device__ __forceinline__ void broadcast_tri(int w, float4& v0, float4& v1, flo
 
 // RX x RY rays per lane: the packet is an (8 RX) x (8 RY)-pixel tile, lane (lx, ly) owns the RX x RY
 // pixel block at (lx RX, ly RY).  One tree walk, one node fetch and one vote serve all 64 RX RY rays.
+template <int R>
+struct packet_rays {
+    ray_t ray[R];
+    bool act[R];
+    float best_t[R], best_u[R], best_v[R];
+    uint32_t best_tri[R];
+};
+
+struct walk_counters { uint32_t pops, box, leaf, tri; };
+
+// Walk the tree for one packet; returns the number of steps (node fetches).
+template <bool STATS, int R>
+__device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict__ nodes, const lbvh_fast_tri* __restrict__ tris,
+                                                packet_rays<R>& P, walk_counters& C)
+{
+    const uint32_t lane = lane_id();
+    int stack = 0;            // wave-shared stack: slot k lives in lane k of this VGPR
+    uint32_t sp = 0;          // scalar
+    uint32_t steps = 0;
+    // root: its own box is never tested, both children are
+    int w_node = fetch_node_dword(nodes, 0, lane);
+    for (;;) {
+        const uniform_node nd = broadcast_node(w_node);
+        const uint32_t lref = __float_as_uint(nd.lmin.w), rref = __float_as_uint(nd.lmax.w);
+        const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
+        // both children are fetched NOW (node line or triangle line), before the box tests: whichever
+        // the packet goes to next is already in flight — one memory latency per step instead of two
+        const int w_l = leaf_l ? fetch_tri_dword(tris, lref & 0x7FFFFFFFu, lane) : fetch_node_dword(nodes, lref, lane);
+        const int w_r = leaf_r ? fetch_tri_dword(tris, rref & 0x7FFFFFFFu, lane) : fetch_node_dword(nodes, rref, lane);
+        if (STATS && lane == 0) C.pops++;
+        steps++;
+        float tl[R], tr[R];
+        bool hit_l[R], hit_r[R];
+        bool any_l = false, any_r = false;
+        int pref = 0;     // > 0: this lane's rays that want both children reach the left one first
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            hit_l[r] = P.act[r] && ray_box(nd.lmin, nd.lmax, P.ray[r], tl[r]);
+            hit_r[r] = P.act[r] && ray_box(nd.rmin, nd.rmax, P.ray[r], tr[r]);
+            if (STATS) C.box += (hit_l[r] ? 1u : 0u) + (hit_r[r] ? 1u : 0u);
+            // a box that starts beyond this ray's best hit cannot hold a nearer one
+            hit_l[r] = hit_l[r] && !(tl[r] > P.best_t[r]);
+            hit_r[r] = hit_r[r] && !(tr[r] > P.best_t[r]);
+            any_l |= hit_l[r];
+            any_r |= hit_r[r];
+        }
+        // leaves first: their hits tighten best_t before anything is entered
+        if (leaf_l && __any(any_l)) {
+            float4 v0, v1, v2;
+            broadcast_tri(w_l, v0, v1, v2);
+            if (STATS && lane == 0) C.leaf++;        // one 48-B triangle fetch for the packet
+            any_r = false;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (hit_l[r]) {
+                    if (STATS) C.tri++;
+                    float u = 0.0f, v = 0.0f;
+                    const float dist = ray_triangle(P.ray[r], v0, v1, v2, u, v);
+                    if (dist < P.best_t[r]) { P.best_t[r] = dist; P.best_tri[r] = __float_as_uint(v0.w); P.best_u[r] = u; P.best_v[r] = v; }
+                }
+                hit_r[r] = hit_r[r] && !(tr[r] > P.best_t[r]);
+                any_r |= hit_r[r];
+            }
+        }
+        if (leaf_r && __any(any_r)) {
+            float4 v0, v1, v2;
+            broadcast_tri(w_r, v0, v1, v2);
+            if (STATS && lane == 0) C.leaf++;
+            any_l = false;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (hit_r[r]) {
+                    if (STATS) C.tri++;
+                    float u = 0.0f, v = 0.0f;
+                    const float dist = ray_triangle(P.ray[r], v0, v1, v2, u, v);
+                    if (dist < P.best_t[r]) { P.best_t[r] = dist; P.best_tri[r] = __float_as_uint(v0.w); P.best_u[r] = u; P.best_v[r] = v; }
+                }
+                hit_l[r] = hit_l[r] && !(tl[r] > P.best_t[r]);
+                any_l |= hit_l[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (hit_l[r] && hit_r[r]) pref += tl[r] <= tr[r] ? 1 : -1;
+        const uint64_t ml = leaf_l ? 0ull : __ballot(any_l);
+        const uint64_t mr = leaf_r ? 0ull : __ballot(any_r);
+        if (ml != 0 && mr != 0) {
+            // both children wanted: the side most lanes reach first goes first
+            const int l_votes = __popcll(__ballot(pref > 0)), r_votes = __popcll(__ballot(pref < 0));
+            const bool l_near = l_votes == r_votes ? (__popcll(ml) >= __popcll(mr)) : (l_votes > r_votes);
+            const uint32_t far = l_near ? rref : lref;
+            w_node = l_near ? w_l : w_r;
+            stack = lane == (sp & 63u) ? (int)far : stack;      // v_cndmask: slot sp := far
+            sp++;
+        } else if (ml != 0) {
+            w_node = w_l;
+        } else if (mr != 0) {
+            w_node = w_r;
+        } else {
+            if (sp == 0) return steps;
+            sp--;
+            w_node = fetch_node_dword(nodes, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), lane);
+        }
+    }
+}
+
+template <int RX, int RY>
+__device__ __forceinline__ void tile_rays(const trace_args& a, uint32_t tile, uint32_t lane, packet_rays<RX * RY>& P,
+                                          uint32_t& px0, uint32_t& py0)
+{
+    const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    px0 = (uint32_t)a.x0 + tx * (8u * RX) + (lane & 7u) * RX;
+    py0 = (uint32_t)a.y0 + ty * (8u * RY) + (lane >> 3) * RY;
+#pragma unroll
+    for (int r = 0; r < RX * RY; r++) {
+        const uint32_t px = px0 + (uint32_t)(r % RX), py = py0 + (uint32_t)(r / RX);
+        P.act[r] = px < (uint32_t)a.x1 && py < (uint32_t)a.y1;
+        P.ray[r] = make_ray(a.cam, px, py);
+    }
+}
+
+// one wave per tile, 4 tiles per workgroup; the hardware dispatcher hands the workgroups out in index order, so
+// `order` (work items sorted by their step count in the previous trace, heaviest first) decides who starts first
 template <bool STATS, int RX, int RY>
 __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
-                                                           const lbvh_fast_tri* __restrict__ tris,
-                                                           uint32_t n_tiles, tile_queues* queues,
+                                                           const lbvh_fast_tri* __restrict__ tris, uint32_t n_work,
+                                                           const uint32_t* __restrict__ order, uint32_t* __restrict__ cost,
                                                            lbvh_hit* __restrict__ hits, lbvh_trace_stats* stats,
                                                            uint32_t* __restrict__ tile_cost)
 {
     constexpr int R = RX * RY;
     const uint32_t lane = lane_id();
-    const uint32_t home = xcc_id();
+    uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (w >= n_work) return;
+    if (order) w = order[w];
+    const uint32_t tile = shard_tile(w, a.shard_index, a.shard_count);
+    if (tile >= a.tiles_x * a.tiles_y) {                         // tail of the last group
+        if (lane == 0) cost[w] = 0;
+        return;
+    }
     const uint32_t rw = (uint32_t)(a.x1 - a.x0);
-
-    uint32_t n_pops = 0, n_box = 0, n_leaf = 0, n_tri = 0, n_hit = 0;
-    for (;;) {
-        const uint32_t work = next_tile(queues, n_tiles, home);      // n_tiles = this shard's work items
-        if (work == kNoTile) break;
-        const uint32_t tile = shard_tile(work, a.shard_index, a.shard_count);
-        if (tile >= a.tiles_x * a.tiles_y) continue;                 // tail of the last group
-        const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        const uint32_t px0 = (uint32_t)a.x0 + tx * (8u * RX) + (lane & 7u) * RX;
-        const uint32_t py0 = (uint32_t)a.y0 + ty * (8u * RY) + (lane >> 3) * RY;
-        ray_t ray[R];
-        bool act[R];
-        float best_t[R], best_u[R], best_v[R];
-        uint32_t best_tri[R];
+    packet_rays<R> P;
+    uint32_t px0, py0;
+    tile_rays<RX, RY>(a, tile, lane, P, px0, py0);
 #pragma unroll
-        for (int r = 0; r < R; r++) {
+    for (int r = 0; r < R; r++) { P.best_t[r] = LBVH_MAX_FLOAT; P.best_tri[r] = 0; P.best_u[r] = 0.0f; P.best_v[r] = 0.0f; }
+    walk_counters C = {0, 0, 0, 0};
+    const uint32_t steps = walk_packet<STATS, R>(nodes, tris, P, C);
+    if (lane == 0) cost[w] = steps;
+    if (STATS && tile_cost && lane == 0) tile_cost[tile] = steps;
+    uint32_t n_hit = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (P.act[r]) {
             const uint32_t px = px0 + (uint32_t)(r % RX), py = py0 + (uint32_t)(r / RX);
-            act[r] = px < (uint32_t)a.x1 && py < (uint32_t)a.y1;
-            ray[r] = make_ray(a.cam, px, py);
-            best_t[r] = LBVH_MAX_FLOAT;
-            best_tri[r] = 0;
-            best_u[r] = 0.0f;
-            best_v[r] = 0.0f;
-        }
-
-        int stack = 0;            // wave-shared stack: slot k lives in lane k of this VGPR
-        uint32_t sp = 0;          // scalar
-        uint32_t steps = 0;       // node fetches of this packet (profiling aid, only stored when asked for)
-        // root: its own box is never tested, both children are
-        int w_node = fetch_node_dword(nodes, 0, lane);
-        for (;;) {
-            const uniform_node nd = broadcast_node(w_node);
-            const uint32_t lref = __float_as_uint(nd.lmin.w), rref = __float_as_uint(nd.lmax.w);
-            const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
-            // both children are fetched NOW (node line or triangle line), before the box tests: whichever
-            // the packet goes to next is already in flight — one memory latency per step instead of two
-            const int w_l = leaf_l ? fetch_tri_dword(tris, lref & 0x7FFFFFFFu, lane) : fetch_node_dword(nodes, lref, lane);
-            const int w_r = leaf_r ? fetch_tri_dword(tris, rref & 0x7FFFFFFFu, lane) : fetch_node_dword(nodes, rref, lane);
-            if (STATS && lane == 0) n_pops++;
-            if (STATS) steps++;
-            float tl[R], tr[R];
-            bool hit_l[R], hit_r[R];
-            bool any_l = false, any_r = false;
-            int pref = 0;     // > 0: this lane's rays that want both children reach the left one first
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                hit_l[r] = act[r] && ray_box(nd.lmin, nd.lmax, ray[r], tl[r]);
-                hit_r[r] = act[r] && ray_box(nd.rmin, nd.rmax, ray[r], tr[r]);
-                if (STATS) n_box += (hit_l[r] ? 1u : 0u) + (hit_r[r] ? 1u : 0u);
-                // a box that starts beyond this ray's best hit cannot hold a nearer one
-                hit_l[r] = hit_l[r] && !(tl[r] > best_t[r]);
-                hit_r[r] = hit_r[r] && !(tr[r] > best_t[r]);
-                any_l |= hit_l[r];
-                any_r |= hit_r[r];
-            }
-            // leaves first: their hits tighten best_t before anything is entered
-            if (leaf_l && __any(any_l)) {
-                float4 v0, v1, v2;
-                broadcast_tri(w_l, v0, v1, v2);
-                if (STATS && lane == 0) n_leaf++;        // one 48-B triangle fetch for the packet
-                any_r = false;
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    if (hit_l[r]) {
-                        if (STATS) n_tri++;
-                        float u = 0.0f, v = 0.0f;
-                        const float dist = ray_triangle(ray[r], v0, v1, v2, u, v);
-                        if (dist < best_t[r]) { best_t[r] = dist; best_tri[r] = __float_as_uint(v0.w); best_u[r] = u; best_v[r] = v; }
-                    }
-                    hit_r[r] = hit_r[r] && !(tr[r] > best_t[r]);
-                    any_r |= hit_r[r];
-                }
-            }
-            if (leaf_r && __any(any_r)) {
-                float4 v0, v1, v2;
-                broadcast_tri(w_r, v0, v1, v2);
-                if (STATS && lane == 0) n_leaf++;
-                any_l = false;
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    if (hit_r[r]) {
-                        if (STATS) n_tri++;
-                        float u = 0.0f, v = 0.0f;
-                        const float dist = ray_triangle(ray[r], v0, v1, v2, u, v);
-                        if (dist < best_t[r]) { best_t[r] = dist; best_tri[r] = __float_as_uint(v0.w); best_u[r] = u; best_v[r] = v; }
-                    }
-                    hit_l[r] = hit_l[r] && !(tl[r] > best_t[r]);
-                    any_l |= hit_l[r];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; r++)
-                if (hit_l[r] && hit_r[r]) pref += tl[r] <= tr[r] ? 1 : -1;
-            const uint64_t ml = leaf_l ? 0ull : __ballot(any_l);
-            const uint64_t mr = leaf_r ? 0ull : __ballot(any_r);
-            if (ml != 0 && mr != 0) {
-                // both children wanted: the side most lanes reach first goes first
-                const int l_votes = __popcll(__ballot(pref > 0)), r_votes = __popcll(__ballot(pref < 0));
-                const bool l_near = l_votes == r_votes ? (__popcll(ml) >= __popcll(mr)) : (l_votes > r_votes);
-                const uint32_t far = l_near ? rref : lref;
-                w_node = l_near ? w_l : w_r;
-                stack = lane == (sp & 63u) ? (int)far : stack;      // v_cndmask: slot sp := far
-                sp++;
-            } else if (ml != 0) {
-                w_node = w_l;
-            } else if (mr != 0) {
-                w_node = w_r;
-            } else {
-                if (sp == 0) break;
-                sp--;
-                w_node = fetch_node_dword(nodes, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), lane);
-            }
-        }
-        if (STATS && tile_cost && lane == 0) tile_cost[tile] = steps;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            if (act[r]) {
-                const uint32_t px = px0 + (uint32_t)(r % RX), py = py0 + (uint32_t)(r / RX);
-                float4 out;
-                out.x = best_t[r];
-                out.y = __uint_as_float(best_tri[r]);
-                out.z = best_u[r];
-                out.w = best_v[r];
-                reinterpret_cast<float4*>(hits)[(size_t)(py - (uint32_t)a.y0) * rw + (px - (uint32_t)a.x0)] = out;
-                if (STATS && best_t[r] < LBVH_MAX_FLOAT) n_hit++;
-            }
+            float4 out;
+            out.x = P.best_t[r];
+            out.y = __uint_as_float(P.best_tri[r]);
+            out.z = P.best_u[r];
+            out.w = P.best_v[r];
+            reinterpret_cast<float4*>(hits)[(size_t)(py - (uint32_t)a.y0) * rw + (px - (uint32_t)a.x0)] = out;
+            if (STATS && P.best_t[r] < LBVH_MAX_FLOAT) n_hit++;
         }
     }
-    if (STATS) add_stats(stats, n_pops, n_box, n_leaf, n_tri, n_hit);
+    if (STATS) add_stats(stats, C.pops, C.box, C.leaf, C.tri, n_hit);
+}
+
+// order[] = the work items sorted by cost, heaviest first (counting sort over 256 cost classes, one workgroup;
+// the order inside a class is whatever the atomics give — it is only a dispatch hint)
+__global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t* __restrict__ cost, uint32_t n_work,
+                                                           uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t s_count[256], s_start[256];
+    const uint32_t t = threadIdx.x;
+    if (t < 256u) s_count[t] = 0;
+    __syncthreads();
+    for (uint32_t i = t; i < n_work; i += 1024u) atomicAdd(&s_count[min(cost[i] >> 2, 255u)], 1u);
+    __syncthreads();
+    // exclusive prefix over the classes in DESCENDING class order (thread t = class 255 - t)
+    __shared__ uint32_t s_wave[4];
+    uint32_t mine = 0, incl = 0;
+    if (t < 256u) {
+        mine = s_count[255u - t];
+        incl = wave_inclusive_sum(mine);
+        if ((t & 63u) == 63u) s_wave[t >> 6] = incl;
+    }
+    __syncthreads();
+    if (t < 256u) {
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < (t >> 6); k++) before += s_wave[k];
+        s_start[255u - t] = before + incl - mine;
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < n_work; i += 1024u) order[atomicAdd(&s_start[min(cost[i] >> 2, 255u)], 1u)] = i;
 }
 
 template <int RX, int RY>
-void launch_packets(lbvh_context* ctx, trace_args a, tile_queues* q, lbvh_hit* d_hits, lbvh_trace_stats* d_stats,
-                    uint32_t* d_tile_cost)
+int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_cost)
 {
     a.tiles_x = (uint32_t)(a.x1 - a.x0 + 8 * RX - 1) / (8 * RX);
     a.tiles_y = (uint32_t)(a.y1 - a.y0 + 8 * RY - 1) / (8 * RY);
-    const uint32_t n_tiles = shard_work(a.tiles_x * a.tiles_y, a.shard_index, a.shard_count);
-    if (n_tiles == 0) return;
-    uint32_t blocks = 256u * 8u;       // persistent 4-wave workgroups, no LDS
-    if (blocks * 4 > n_tiles) blocks = (n_tiles + 3) / 4;
+    const uint32_t n_work = shard_work(a.tiles_x * a.tiles_y, a.shard_index, a.shard_count);
+    if (n_work == 0) return LBVH_OK;
+    // [cost of each work item in the last trace | dispatch order]: valid for one frame layout
+    const size_t half = (((size_t)n_work * 4) + 255) & ~(size_t)255;
+    void* before = ctx->trace_queues;
+    int rc = lbvh_reserve(ctx, &ctx->trace_queues, &ctx->trace_queues_bytes, 2 * half);
+    if (rc != LBVH_OK) return rc;
+    if (ctx->trace_queues != before) ctx->trace_history = false;
+    uint32_t* cost = (uint32_t*)ctx->trace_queues;
+    uint32_t* order = (uint32_t*)((char*)ctx->trace_queues + half);
+    const uint64_t layout = ((uint64_t)a.tiles_x << 48) ^ ((uint64_t)a.tiles_y << 32) ^ ((uint64_t)a.shard_index << 16) ^
+                            (uint64_t)a.shard_count ^ ((uint64_t)(uint32_t)a.x0 << 8) ^ ((uint64_t)(uint32_t)a.y0 << 24);
+    const bool have_history = ctx->trace_layout == layout && ctx->trace_layout_work == n_work && ctx->trace_history;
+    if (have_history) LBVH_LAUNCH(ctx, order_tiles_kernel, dim3(1), dim3(1024), cost, n_work, order);
+    const uint32_t blocks = (n_work + 3) / 4;
     if (d_stats)
         LBVH_LAUNCH(ctx, (trace_packet_kernel<true, RX, RY>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris,
-                    n_tiles, q, d_hits, d_stats, d_tile_cost);
+                    n_work, have_history ? order : nullptr, cost, d_hits, d_stats, d_tile_cost);
     else
         LBVH_LAUNCH(ctx, (trace_packet_kernel<false, RX, RY>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris,
-                    n_tiles, q, d_hits, d_stats, d_tile_cost);
+                    n_work, have_history ? order : nullptr, cost, d_hits, d_stats, d_tile_cost);
+    ctx->trace_layout = layout;
+    ctx->trace_layout_work = n_work;
+    ctx->trace_history = true;
+    return LBVH_OK;
 }
 
 }  // namespace
@@ -603,13 +659,11 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
         if (!ctx->fast_nodes || ctx->fast_n != s.n)
             return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_trace_primary",
                                   "LBVH_TRACE_FAST needs lbvh_build_fast_scene on this scene first");
-        if (!ctx->trace_queues) LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->trace_queues, 256));
-        LBVH_HIP_TRY(ctx, hipMemsetAsync(ctx->trace_queues, 0, 32, ctx->cur_stream));
-        tile_queues* q = (tile_queues*)ctx->trace_queues;
         // 2 x 1 rays per lane = 16 x 8-pixel packets over 2-wide nodes: measured best of 1x1 / 2x1 / 1x2 / 3x1 /
         // 2x2 / 4x2 rays per lane (more rays cut node fetches per ray but the extra VGPRs cost occupancy) and of
         // 2-wide vs 4-wide (128-byte) nodes (half the steps, twice the work per step: 1.19 vs 1.12 ms)
-        launch_packets<2, 1>(ctx, a, q, d_hits, d_stats, d_tile_cost);
+        const int prc = launch_packets<2, 1>(ctx, a, d_hits, d_stats, d_tile_cost);
+        if (prc != LBVH_OK) return prc;
     }
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
