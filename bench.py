@@ -15,7 +15,7 @@ A step = one full pass of the hot path with the triangles already resident in HB
     primary-ray traversal of the frame (Update(), :76-84).
 Nothing is skipped or cached between steps (the tree is rebuilt from the triangles every step).
 With N GPUs the BVH is replicated (every rank builds the whole tree) and the 1080p frame is
-sharded across ranks in interleaved groups of 8 adjacent 16x8-pixel tiles (lbvh_trace_primary_shard,
+sharded across ranks in interleaved groups of 8 adjacent 8x8-pixel tiles (lbvh_trace_primary_shard,
 one launch per rank); no collective touches the data path.
 
 The JSON line carries both halves of the metric: `value` = primary Mrays/s = rays of the whole
@@ -60,7 +60,7 @@ def parse():
     return ap.parse_args()
 
 
-TILE_W, TILE_H, SHARD_GROUP = 16, 8, 8      # LBVH_TRACE_FAST packet size and the tile group lbvh_trace_primary_shard deals
+TILE_W, TILE_H, SHARD_GROUP = 8, 8, 8      # LBVH_TRACE_FAST packet size and the tile group lbvh_trace_primary_shard deals
 
 
 def shard_tiles(shard_index, shard_count, width, height, tile_w=TILE_W, tile_h=TILE_H, group=SHARD_GROUP):
@@ -156,7 +156,7 @@ def main():
     ccam = N.Camera.from_dict(cam)
 
     def trace_frame():
-        # this rank's share of the frame (every world-th group of 8 adjacent 16x8-pixel tiles), one launch
+        # this rank's share of the frame (every world-th group of 8 adjacent 8x8-pixel tiles), one launch
         s = drawer.container.scene()
         N.check(ctx.handle, N.lib.lbvh_trace_primary_shard(ctx.handle, C.byref(ccam), rank, world, C.byref(s), mode,
                                                            hit_buf.device, None))

@@ -114,13 +114,13 @@ typedef struct lbvh_camera {
 
 /* Traversal flavours of lbvh_trace_primary. */
 #define LBVH_TRACE_REFERENCE 0  /* the reference's visit order, no pruning, separate node arrays */
-#define LBVH_TRACE_FAST      1  /* 16x8 packets over fused 64-B nodes, near-first, t-pruned; same min-t */
+#define LBVH_TRACE_FAST      1  /* 8x8 packets over fused 64-B nodes, near-first, t-pruned; same min-t */
 
 /* Optional per-launch traversal statistics (sums over all rays of the launch), in the
  * reference's visit semantics for LBVH_TRACE_REFERENCE: P nodes popped, B internal boxes hit,
  * L leaf-AABB tests, T triangle tests.  Used for the algorithmic-bytes figure.
- * LBVH_TRACE_FAST walks one 16x8-pixel packet per wave: there `pops` = 64-byte node fetches and
- * `leaf_tests` = 48-byte triangle fetches per PACKET (each shared by the packet's 128 rays),
+ * LBVH_TRACE_FAST walks one 8x8-pixel packet per wave: there `pops` = 64-byte node fetches and
+ * `leaf_tests` = 48-byte triangle fetches per PACKET (each shared by the packet's 64 rays),
  * `box_hits` and `tri_tests` stay per ray. */
 typedef struct lbvh_trace_stats {
     uint64_t pops;
@@ -311,12 +311,11 @@ lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera,
                                lbvh_hit* d_hits, lbvh_trace_stats* d_stats);
 
 /* Ray sharding across GPUs in ONE launch per GPU: traces the pixels of shard `shard_index` of
- * `shard_count` of the FULL frame — every shard_count-th group of 8 adjacent pixel tiles (a 128x8-
- * or 64x8-pixel strip, by mode), so every shard samples the whole frame evenly — and writes them at
- * their full-frame positions d_hits[y * W + x]; pixels of other shards are not touched.  d_hits
- * holds W*H records on every GPU.  The BVH is replicated; no collective is involved.  The union over
- * all shards equals lbvh_trace_primary(0, 0, W, H).  Tile sizes differ by mode, so use ONE mode for
- * all shards of a frame. */
+ * `shard_count` of the FULL frame — every shard_count-th group of 8 adjacent 8x8-pixel tiles (a 64x8-
+ * pixel strip), so every shard samples the whole frame evenly — and writes them at their full-frame
+ * positions d_hits[y * W + x]; pixels of other shards are not touched.  d_hits holds W*H records on
+ * every GPU.  The BVH is replicated; no collective is involved.  The union over all shards equals
+ * lbvh_trace_primary(0, 0, W, H). */
 lbvh_status lbvh_trace_primary_shard(lbvh_context* ctx, const lbvh_camera* h_camera, uint32_t shard_index,
                                      uint32_t shard_count, const lbvh_scene* h_scene, int32_t mode,
                                      lbvh_hit* d_hits, lbvh_trace_stats* d_stats);
@@ -381,7 +380,7 @@ lbvh_status lbvh_path_scatter(lbvh_context* ctx, const lbvh_scene* h_scene, cons
 /* radiance (+ alpha) of the path states as RGBA16F, the reference's render-target format. */
 lbvh_status lbvh_path_resolve(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, uint16_t* d_rgba16f);
 
-/* Profiling aid: one LBVH_TRACE_FAST frame that also records, per 16x8-pixel tile (row-major,
+/* Profiling aid: one LBVH_TRACE_FAST frame that also records, per 8x8-pixel tile (row-major,
  * ceil(W/16) x ceil(H/8) entries), the number of node fetches its packet needed. */
 lbvh_status lbvh_trace_tile_costs(lbvh_context* ctx, const lbvh_camera* h_camera, const lbvh_scene* h_scene,
                                   lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_steps);

@@ -25,7 +25,7 @@ def test_shards_partition_the_frame(world, size):
         tiles = shard_tiles(r, world, width, height)
         counts.append(len(tiles))
         for x0, y0, x1, y1 in tiles:
-            assert 0 <= x0 < x1 <= width and 0 <= y0 < y1 <= height and x0 % 16 == 0 and y0 % 8 == 0
+            assert 0 <= x0 < x1 <= width and 0 <= y0 < y1 <= height and x0 % 8 == 0 and y0 % 8 == 0
             covered[y0:y1, x0:x1] += 1
     assert (covered == 1).all()
     assert max(counts) - min(counts) <= 8             # balanced to one group of tiles

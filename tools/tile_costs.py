@@ -20,7 +20,7 @@ ctx = Context(0)
 d = RaytracingMeshDrawer(ctx, tris).awake()
 hits = DataBuffer(ctx, W * H, L.HIT)
 stats = DataBuffer(ctx, 1, L.TRACE_STATS)
-tx, ty = (W + 15) // 16, (H + 7) // 8
+tx, ty = (W + 7) // 8, (H + 7) // 8
 costs = DataBuffer(ctx, tx * ty, np.uint32)
 s = d.container.scene()
 N.check(ctx.handle, N.lib.lbvh_trace_tile_costs(ctx.handle, C.byref(cam), C.byref(s), hits.device, stats.device, costs.device))

@@ -10,7 +10,7 @@ with Context(0) as ctx:
     cam = N.Camera.from_dict(scenes.camera(W, H, (0.0, 0.0, 250.0)))
     hits = DataBuffer(ctx, W * H, L.HIT)
     s = d.container.scene()
-    for _ in range(3):
+    for _ in range(6):
         N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(cam), 0, 0, W, H, C.byref(s), L.TRACE_FAST, hits.device, None))
     ctx.sync()
     ctx.profile_begin()

@@ -33,6 +33,7 @@ struct trace_args {
     uint32_t shard_index, shard_count;   // this launch traces every shard_count-th GROUP of tiles
 };
 
+constexpr int kOrderClasses = 16;         // cost classes of the packet dispatch order
 constexpr uint32_t kShardGroup = 8;      // adjacent tiles (one strip of the frame) that stay together
 
 // k-th work item of this shard -> tile of the rectangle (row-major); identity for shard_count == 1
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh
 // ---------------------------------------------------------------------------------------------
 // LBVH_TRACE_FAST — packet traversal
 //
-// The primary rays of a small pixel tile (16x8 pixels: 2 rays per lane) leave one pinhole and stay
+// The primary rays of a small pixel tile (8x8 pixels: one ray per lane) leave one pinhole and stay
 // together almost to the leaves, so the wave walks the tree ONCE for all of them:
 //   * the current node index is wave-uniform: the 64-byte fused node arrives as ONE coalesced line
 //     (lane k loads dword k, v_readlane broadcasts into SGPRs), not as 64 divergent vector gathers
@@ -237,6 +238,9 @@ __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh
 //     centre first 0.58): the run time is the tail of late-starting heavy tiles.  The kernel therefore records
 //     every tile's step count, and the next trace of the same frame layout dispatches in descending order of
 //     those counts (a scheduling hint only — any order gives the same hits; the first frame is row-major).
+//     Cheaper bookkeeping was tried and lost: a "heavy tiles" list built by the trace kernel + row-major for
+//     the rest leaves medium tiles in the tail (0.33 instead of 0.27 ms at 8x8 tiles); filing every tile under
+//     one of 8 cost classes with a returning atomic per tile: 0.48 ms (hot device-scope counters again).
 //   * cutting packets at a step budget and re-queueing their unfinished subtrees as (tile, subtree) items for
 //     further passes (results merged per pixel by compare-and-swap) was built and measured: no gain over
 //     heaviest-first (0.49 ms either way), so it is not in the code.
@@ -405,7 +409,8 @@ __device__ __forceinline__ void tile_rays(const trace_args& a, uint32_t tile, ui
 template <bool STATS, int RX, int RY>
 __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
                                                            const lbvh_fast_tri* __restrict__ tris, uint32_t n_work,
-                                                           const uint32_t* __restrict__ order, uint32_t* __restrict__ cost,
+                                                           const uint32_t* __restrict__ counts, const uint32_t* __restrict__ lists,
+                                                           uint32_t* __restrict__ cost,
                                                            lbvh_hit* __restrict__ hits, lbvh_trace_stats* stats,
                                                            uint32_t* __restrict__ tile_cost)
 {
@@ -413,7 +418,12 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
     const uint32_t lane = lane_id();
     uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (w >= n_work) return;
-    if (order) w = order[w];
+    if (counts) {        // the w-th item of the class lists, heaviest class first (they partition the work items)
+        uint32_t k = w;
+        int c = kOrderClasses - 1;
+        for (; c > 0 && k >= counts[c]; c--) k -= counts[c];
+        w = lists[(size_t)c * n_work + k];
+    }
     const uint32_t tile = shard_tile(w, a.shard_index, a.shard_count);
     if (tile >= a.tiles_x * a.tiles_y) {                         // tail of the last group
         if (lane == 0) cost[w] = 0;
@@ -446,33 +456,48 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
     if (STATS) add_stats(stats, C.pops, C.box, C.leaf, C.tri, n_hit);
 }
 
-// order[] = the work items sorted by cost, heaviest first (counting sort over 256 cost classes, one workgroup;
-// the order inside a class is whatever the atomics give — it is only a dispatch hint)
-__global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t* __restrict__ cost, uint32_t n_work,
-                                                           uint32_t* __restrict__ order)
+// Files every work item of the last trace under one of 16 cost classes (half-octave scale): lists[c][...] with
+// counts[c].  The next trace's wave w takes the w-th item of the concatenation, heaviest class first.  One
+// workgroup per 1024 items; a wave counts / ranks its 64 items per class with a ballot, a workgroup reserves its
+// run in each class list with ONE global atomic per class (per-item atomics on 16 hot counters measured 5x the
+// cost of the whole traversal's bookkeeping).  The order inside a class is arbitrary: it is a dispatch hint.
+__device__ __forceinline__ uint32_t order_class(uint32_t steps)
 {
-    __shared__ uint32_t s_count[256], s_start[256];
-    const uint32_t t = threadIdx.x;
-    if (t < 256u) s_count[t] = 0;
+    // 0: < 12, then [12,16) [16,24) [24,32) [32,48) ... : two classes per octave, 15: >= 1536
+    if (steps < 12u) return 0u;
+    const uint32_t e = 31u - (uint32_t)__builtin_clz(steps);          // >= 3
+    const uint32_t half = (steps >> (e - 1u)) & 1u;
+    const uint32_t c = 2u * (e - 3u) + half;                          // 12..15 -> 1, 16..23 -> 2, 24..31 -> 3, ...
+    return c > 15u ? 15u : c;
+}
+
+__global__ __launch_bounds__(1024) void file_tiles_kernel(const uint32_t* __restrict__ cost, uint32_t n_work,
+                                                          uint32_t* __restrict__ counts, uint32_t* __restrict__ lists)
+{
+    __shared__ uint32_t s_count[kOrderClasses], s_base[kOrderClasses];
+    const uint32_t t = threadIdx.x, lane = lane_id();
+    const uint32_t i = blockIdx.x * 1024u + t;
+    if (t < (uint32_t)kOrderClasses) s_count[t] = 0;
     __syncthreads();
-    for (uint32_t i = t; i < n_work; i += 1024u) atomicAdd(&s_count[min(cost[i] >> 2, 255u)], 1u);
-    __syncthreads();
-    // exclusive prefix over the classes in DESCENDING class order (thread t = class 255 - t)
-    __shared__ uint32_t s_wave[4];
-    uint32_t mine = 0, incl = 0;
-    if (t < 256u) {
-        mine = s_count[255u - t];
-        incl = wave_inclusive_sum(mine);
-        if ((t & 63u) == 63u) s_wave[t >> 6] = incl;
+    const uint32_t cls = i < n_work ? order_class(cost[i]) : 0xFFFFFFFFu;
+    uint64_t mine = 0;                                  // lanes of this wave in my class
+    uint32_t wave_n = 0;                                // lane c < 16: this wave's items of class c
+#pragma unroll
+    for (int c = 0; c < kOrderClasses; c++) {
+        const uint64_t m = __ballot(cls == (uint32_t)c);
+        if (cls == (uint32_t)c) mine = m;
+        if (lane == (uint32_t)c) wave_n = (uint32_t)__popcll(m);
     }
+    uint32_t wave_ofs = 0;                              // lane c: this wave's offset inside the workgroup's run of class c
+    if (lane < (uint32_t)kOrderClasses && wave_n) wave_ofs = atomicAdd(&s_count[lane], wave_n);
     __syncthreads();
-    if (t < 256u) {
-        uint32_t before = 0;
-        for (uint32_t k = 0; k < (t >> 6); k++) before += s_wave[k];
-        s_start[255u - t] = before + incl - mine;
+    if (t < (uint32_t)kOrderClasses && s_count[t])
+        s_base[t] = __hip_atomic_fetch_add(&counts[t], s_count[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (cls != 0xFFFFFFFFu) {
+        const uint32_t ofs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cls << 2), (int)wave_ofs);   // wave_ofs of lane `cls`
+        lists[(size_t)cls * n_work + s_base[cls] + ofs + mbcnt64(mine)] = i;
     }
-    __syncthreads();
-    for (uint32_t i = t; i < n_work; i += 1024u) order[atomicAdd(&s_start[min(cost[i] >> 2, 255u)], 1u)] = i;
 }
 
 template <int RX, int RY>
@@ -482,25 +507,29 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     a.tiles_y = (uint32_t)(a.y1 - a.y0 + 8 * RY - 1) / (8 * RY);
     const uint32_t n_work = shard_work(a.tiles_x * a.tiles_y, a.shard_index, a.shard_count);
     if (n_work == 0) return LBVH_OK;
-    // [cost of each work item in the last trace | dispatch order]: valid for one frame layout
-    const size_t half = (((size_t)n_work * 4) + 255) & ~(size_t)255;
+    // [class counts | cost of each work item in the last trace | 16 class lists]: valid for one frame layout
+    const size_t cost_bytes = (((size_t)n_work * 4) + 255) & ~(size_t)255;
     void* before = ctx->trace_queues;
-    int rc = lbvh_reserve(ctx, &ctx->trace_queues, &ctx->trace_queues_bytes, 2 * half);
+    int rc = lbvh_reserve(ctx, &ctx->trace_queues, &ctx->trace_queues_bytes, 256 + cost_bytes + (size_t)kOrderClasses * cost_bytes);
     if (rc != LBVH_OK) return rc;
     if (ctx->trace_queues != before) ctx->trace_history = false;
-    uint32_t* cost = (uint32_t*)ctx->trace_queues;
-    uint32_t* order = (uint32_t*)((char*)ctx->trace_queues + half);
+    uint32_t* counts = (uint32_t*)ctx->trace_queues;
+    uint32_t* cost = (uint32_t*)((char*)ctx->trace_queues + 256);
+    uint32_t* lists = (uint32_t*)((char*)ctx->trace_queues + 256 + cost_bytes);
     const uint64_t layout = ((uint64_t)a.tiles_x << 48) ^ ((uint64_t)a.tiles_y << 32) ^ ((uint64_t)a.shard_index << 16) ^
                             (uint64_t)a.shard_count ^ ((uint64_t)(uint32_t)a.x0 << 8) ^ ((uint64_t)(uint32_t)a.y0 << 24);
     const bool have_history = ctx->trace_layout == layout && ctx->trace_layout_work == n_work && ctx->trace_history;
-    if (have_history) LBVH_LAUNCH(ctx, order_tiles_kernel, dim3(1), dim3(1024), cost, n_work, order);
+    if (have_history) {
+        LBVH_HIP_TRY(ctx, hipMemsetAsync(counts, 0, 256, ctx->cur_stream));
+        LBVH_LAUNCH(ctx, file_tiles_kernel, dim3((n_work + 1023) / 1024), dim3(1024), cost, n_work, counts, lists);
+    }
     const uint32_t blocks = (n_work + 3) / 4;
     if (d_stats)
         LBVH_LAUNCH(ctx, (trace_packet_kernel<true, RX, RY>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris,
-                    n_work, have_history ? order : nullptr, cost, d_hits, d_stats, d_tile_cost);
+                    n_work, have_history ? counts : nullptr, lists, cost, d_hits, d_stats, d_tile_cost);
     else
         LBVH_LAUNCH(ctx, (trace_packet_kernel<false, RX, RY>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris,
-                    n_work, have_history ? order : nullptr, cost, d_hits, d_stats, d_tile_cost);
+                    n_work, have_history ? counts : nullptr, lists, cost, d_hits, d_stats, d_tile_cost);
     ctx->trace_layout = layout;
     ctx->trace_layout_work = n_work;
     ctx->trace_history = true;
@@ -659,10 +688,10 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
         if (!ctx->fast_nodes || ctx->fast_n != s.n)
             return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_trace_primary",
                                   "LBVH_TRACE_FAST needs lbvh_build_fast_scene on this scene first");
-        // 2 x 1 rays per lane = 16 x 8-pixel packets over 2-wide nodes: measured best of 1x1 / 2x1 / 1x2 / 3x1 /
-        // 2x2 / 4x2 rays per lane (more rays cut node fetches per ray but the extra VGPRs cost occupancy) and of
-        // 2-wide vs 4-wide (128-byte) nodes (half the steps, twice the work per step: 1.19 vs 1.12 ms)
-        const int prc = launch_packets<2, 1>(ctx, a, d_hits, d_stats, d_tile_cost);
+        // 1 ray per lane = 8 x 8-pixel packets: 0.27 ms; 1x2: 0.43, 2x1: 0.45, 3x1: 0.68, 4x1: 0.82, 2x2: 0.92 ms
+        // (more rays per lane cut node fetches per ray but lengthen every step and the per-tile critical path;
+        // while the tile queues still cost 0.7 ms per launch, 2x1 had looked best)
+        const int prc = launch_packets<1, 1>(ctx, a, d_hits, d_stats, d_tile_cost);
         if (prc != LBVH_OK) return prc;
     }
     LBVH_HIP_TRY(ctx, hipGetLastError());
