@@ -430,6 +430,36 @@ def test_shards_union_equals_the_full_frame(ctx, shards):
     d.on_destroy()
 
 
+def test_repeated_frames_cost_ordered_and_cooperative_tiles(ctx):
+    """From the second trace of a frame layout on, tiles are dispatched by their previous step counts and — when the
+    frame is small enough to leave the chip under-filled — heavy tiles are walked by several waves sharing their
+    best hits in LDS.  Every frame must still equal the reference order's result."""
+    tris = scenes.tiled_torus(nu=60, nv=40, grid=3)                 # 129 600 triangles
+    d = H().RaytracingMeshDrawer(ctx, tris).awake()
+    for cam_z, res in ((140.0, (640, 360)), (60.0, (512, 512))):     # 3 600 / 4 096 tiles: cooperative regime
+        cam = scenes.camera(res[0], res[1], (3.0, -2.0, cam_z))
+        d.update(cam, mode=L.TRACE_REFERENCE)
+        ref = d.hits()
+        costs = H().DataBuffer(ctx, (res[0] // 8) * (res[1] // 8), np.uint32)
+        for frame in range(4):
+            d.update(cam, mode=L.TRACE_FAST, stats=(frame == 3))
+            got = d.hits()
+            assert (got["t"] == ref["t"]).all()
+            same = got["tri"] == ref["tri"]
+            assert same.mean() > 0.9999                              # exact ties may pick the other triangle
+            assert (got["u"][same] == ref["u"][same]).all() and (got["v"][same] == ref["v"][same]).all()
+        assert int(d.stats()["hits"]) == int((ref["t"] < L.MAX_FLOAT).sum())
+        # the profiling entry point reports per-tile steps in both regimes
+        s = d.container.scene()
+        st = H().DataBuffer(ctx, 1, L.TRACE_STATS)
+        hb = H().DataBuffer(ctx, res[0] * res[1], L.HIT)
+        N().check(ctx.handle, N().lib.lbvh_trace_tile_costs(ctx.handle, C.byref(N().Camera.from_dict(cam)), C.byref(s), hb.device,
+                                                            st.device, costs.device))
+        c = costs.get_data()
+        assert c.max() >= 96 and int(c.sum()) == int(st.get_data()[0]["pops"])
+    d.on_destroy()
+
+
 def test_camera_inside_the_scene_and_negative_t(ctx):
     """The reference accepts t < 0 hits (no t > 0 test, Raytracing.compute:70) when the leaf box
     straddles the origin; both traversal modes must keep that."""

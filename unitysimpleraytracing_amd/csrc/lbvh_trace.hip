@@ -404,26 +404,257 @@ __device__ __forceinline__ void tile_rays(const trace_args& a, uint32_t tile, ui
     }
 }
 
+// ---- heavy tiles: one WORKGROUP per tile -------------------------------------------------------------------
+// With one wave per tile the run time of a frame (or of one GPU's share of it: 212 us at 1/8 of the frame against
+// 287 us for all of it) is the critical path of its heaviest tile — hundreds of dependent fetch -> test -> vote
+// steps.  Tiles the previous trace filed under the heavy cost classes are therefore walked by kCoopWaves waves
+// together: every wave walks its own chain with a private stack, the packet's 64 best hits live in LDS (64-bit
+// atomic min on (ordered t, sorted triangle position): pruning is shared by all waves), and a wave with spare
+// stack entries hands its OLDEST one (the largest unvisited subtree) to an idle wave through a small LDS list.
+constexpr int kCoopWaves = 8;
+constexpr int kHeavyClass = 7;             // cost classes >= this (>= 96 steps) are walked cooperatively
+constexpr uint32_t kCoopGrain = 32;        // steps of the last trace per cooperating wave
+constexpr uint32_t kCoopMaxWork = 12288;   // tiles per launch up to which heavy tiles are walked cooperatively
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+struct coop_params { uint32_t cap, first_class, grain; };
+
+__device__ __forceinline__ uint32_t heavy_items(const uint32_t* __restrict__ counts, coop_params cp)
+{
+    uint32_t h = 0;
+#pragma unroll
+    for (int c = 0; c < kOrderClasses; c++) h += (uint32_t)c >= cp.first_class ? counts[c] : 0u;
+    return min(h, cp.cap);
+}
+
+// floats <-> unsigned keys with the same order (t may be negative: the reference has no t > 0 test)
+__device__ __forceinline__ uint32_t ordered_key(float t)
+{
+    const uint32_t b = __float_as_uint(t);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float key_value(uint32_t k)
+{
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+struct coop_shared {
+    unsigned long long best[64];     // per ray: ordered t << 32 | sorted triangle position
+    uint32_t give[32];               // subtrees on offer
+    uint32_t give_n, lock, idle, steps;
+};
+
+__device__ __forceinline__ void coop_lock(coop_shared& S)
+{
+    while (atomicCAS(&S.lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void coop_unlock(coop_shared& S)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(&S.lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kCoopWaves * 64) void trace_heavy_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
+                                                                      const lbvh_fast_tri* __restrict__ tris, uint32_t n_work,
+                                                                      const uint32_t* __restrict__ counts,
+                                                                      const uint32_t* __restrict__ lists, coop_params heavy_cap,
+                                                                      uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits,
+                                                                      lbvh_trace_stats* stats, uint32_t* __restrict__ tile_cost)
+{
+    __shared__ coop_shared S;
+    if (blockIdx.x >= heavy_items(counts, heavy_cap)) return;        // uniform for the workgroup
+    uint32_t w;
+    {
+        uint32_t k = blockIdx.x;
+        int c = kOrderClasses - 1;
+        for (; c > 0 && k >= counts[c]; c--) k -= counts[c];
+        w = lists[(size_t)c * n_work + k];
+    }
+    const uint32_t tile = shard_tile(w, a.shard_index, a.shard_count);
+    if (w >= n_work || tile >= a.tiles_x * a.tiles_y) return;        // cannot happen for a heavy item
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    // as many waves as the tile's last step count is worth (about kCoopGrain steps each); the others leave now
+    const uint32_t n_waves = min(max((cost[w] + heavy_cap.grain / 2u) / heavy_cap.grain, 2u), (uint32_t)kCoopWaves);
+    if (wave >= n_waves) return;
+    packet_rays<1> P;
+    uint32_t px0, py0;
+    tile_rays<1, 1>(a, tile, lane, P, px0, py0);
+    if (threadIdx.x < 64u) S.best[threadIdx.x] = (unsigned long long)ordered_key(LBVH_MAX_FLOAT) << 32;
+    if (threadIdx.x == 0) { S.give_n = 0; S.lock = 0; S.idle = n_waves - 1u; S.steps = 0; }
+    __syncthreads();
+
+    volatile coop_shared& V = S;
+    int stack = 0;                  // private stack: entries [base, sp) live in lanes (index & 63) of this VGPR
+    uint32_t base = 0, sp = 0;
+    bool have = wave == 0;          // wave 0 starts at the root, the others wait for an offer
+    uint32_t cur = 0;
+    walk_counters C = {0, 0, 0, 0};
+    uint32_t steps = 0;
+    for (;;) {
+        if (!have) {
+            uint32_t got = kNone, all_idle = 0;
+            if (lane == 0) {
+                if (V.give_n > 0) {
+                    coop_lock(S);
+                    if (V.give_n > 0) {
+                        got = V.give[V.give_n - 1];
+                        V.give_n = V.give_n - 1;
+                        atomicSub(&S.idle, 1u);          // idle is also bumped outside the lock (atomically)
+                    }
+                    coop_unlock(S);
+                } else {
+                    all_idle = V.idle == n_waves ? 1u : 0u;
+                }
+            }
+            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            all_idle = (uint32_t)__builtin_amdgcn_readfirstlane((int)all_idle);
+            if (got == kNone) {
+                if (all_idle) break;
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
+            cur = got;
+            have = true;
+        }
+        int w_node = fetch_node_dword(nodes, cur, lane);
+        for (;;) {      // one chain: until this wave has nothing left
+            const uniform_node nd = broadcast_node(w_node);
+            const uint32_t lref = __float_as_uint(nd.lmin.w), rref = __float_as_uint(nd.lmax.w);
+            const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
+            const int w_l = leaf_l ? fetch_tri_dword(tris, lref & 0x7FFFFFFFu, lane) : fetch_node_dword(nodes, lref, lane);
+            const int w_r = leaf_r ? fetch_tri_dword(tris, rref & 0x7FFFFFFFu, lane) : fetch_node_dword(nodes, rref, lane);
+            if (STATS && lane == 0) C.pops++;
+            steps++;
+            float best_t = key_value((uint32_t)(V.best[lane] >> 32));      // everybody's hits so far
+            float tl, tr;
+            bool hit_l = P.act[0] && ray_box(nd.lmin, nd.lmax, P.ray[0], tl);
+            bool hit_r = P.act[0] && ray_box(nd.rmin, nd.rmax, P.ray[0], tr);
+            if (STATS) C.box += (hit_l ? 1u : 0u) + (hit_r ? 1u : 0u);
+            hit_l = hit_l && !(tl > best_t);
+            hit_r = hit_r && !(tr > best_t);
+            if (leaf_l && __any(hit_l)) {
+                float4 v0, v1, v2;
+                broadcast_tri(w_l, v0, v1, v2);
+                if (STATS && lane == 0) C.leaf++;
+                if (hit_l) {
+                    if (STATS) C.tri++;
+                    float u = 0.0f, v = 0.0f;
+                    const float dist = ray_triangle(P.ray[0], v0, v1, v2, u, v);
+                    if (dist < best_t) {
+                        best_t = dist;
+                        atomicMin(&S.best[lane], ((unsigned long long)ordered_key(dist) << 32) | (lref & 0x7FFFFFFFu));
+                    }
+                }
+                hit_r = hit_r && !(tr > best_t);
+            }
+            if (leaf_r && __any(hit_r)) {
+                float4 v0, v1, v2;
+                broadcast_tri(w_r, v0, v1, v2);
+                if (STATS && lane == 0) C.leaf++;
+                if (hit_r) {
+                    if (STATS) C.tri++;
+                    float u = 0.0f, v = 0.0f;
+                    const float dist = ray_triangle(P.ray[0], v0, v1, v2, u, v);
+                    if (dist < best_t) {
+                        best_t = dist;
+                        atomicMin(&S.best[lane], ((unsigned long long)ordered_key(dist) << 32) | (rref & 0x7FFFFFFFu));
+                    }
+                }
+                hit_l = hit_l && !(tl > best_t);
+            }
+            const int pref = (hit_l && hit_r) ? (tl <= tr ? 1 : -1) : 0;
+            const uint64_t ml = leaf_l ? 0ull : __ballot(hit_l);
+            const uint64_t mr = leaf_r ? 0ull : __ballot(hit_r);
+            bool more = true;
+            if (ml != 0 && mr != 0) {
+                const int l_votes = __popcll(__ballot(pref > 0)), r_votes = __popcll(__ballot(pref < 0));
+                const bool l_near = l_votes == r_votes ? (__popcll(ml) >= __popcll(mr)) : (l_votes > r_votes);
+                const uint32_t far = l_near ? rref : lref;
+                w_node = l_near ? w_l : w_r;
+                stack = lane == (sp & 63u) ? (int)far : stack;
+                sp++;
+            } else if (ml != 0) {
+                w_node = w_l;
+            } else if (mr != 0) {
+                w_node = w_r;
+            } else if (sp != base) {
+                sp--;
+                w_node = fetch_node_dword(nodes, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), lane);
+            } else {
+                more = false;
+            }
+            // an idle wave and a spare entry: offer my oldest one (the largest subtree I still hold)
+            if (sp != base) {
+                uint32_t offer = 0;
+                if (lane == 0) offer = (V.idle > V.give_n && V.give_n < 32u) ? 1u : 0u;
+                if (__builtin_amdgcn_readfirstlane((int)offer)) {
+                    const uint32_t node = (uint32_t)__builtin_amdgcn_readlane(stack, base & 63u);
+                    uint32_t given = 0;
+                    if (lane == 0) {
+                        coop_lock(S);
+                        if (V.give_n < 32u) { V.give[V.give_n] = node; V.give_n = V.give_n + 1; given = 1; }
+                        coop_unlock(S);
+                    }
+                    base += (uint32_t)__builtin_amdgcn_readfirstlane((int)given);
+                }
+            }
+            if (!more) break;
+        }
+        have = false;
+        if (lane == 0) atomicAdd(&S.idle, 1u);
+    }
+    if (lane == 0) atomicAdd(&S.steps, steps);
+    __syncthreads();
+    uint32_t n_hit = 0;
+    if (wave == 0) {
+        if (lane == 0) {
+            cost[w] = S.steps;
+            if (STATS && tile_cost) tile_cost[tile] = S.steps;
+        }
+        if (P.act[0]) {
+            const unsigned long long key = S.best[lane];
+            const float t = key_value((uint32_t)(key >> 32));
+            float4 out = make_float4(LBVH_MAX_FLOAT, __uint_as_float(0u), 0.0f, 0.0f);
+            if (t < LBVH_MAX_FLOAT) {
+                // barycentrics (and the original index) from the winning triangle: the same arithmetic as in the walk
+                const float4* tv = reinterpret_cast<const float4*>(&tris[(uint32_t)key]);
+                const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+                float u = 0.0f, v = 0.0f;
+                const float dist = ray_triangle(P.ray[0], v0, v1, v2, u, v);
+                out = make_float4(dist, v0.w, u, v);
+                if (STATS) n_hit++;
+            }
+            const uint32_t rw = (uint32_t)(a.x1 - a.x0);
+            reinterpret_cast<float4*>(hits)[(size_t)(py0 - (uint32_t)a.y0) * rw + (px0 - (uint32_t)a.x0)] = out;
+        }
+    }
+    if (STATS) add_stats(stats, C.pops, C.box, C.leaf, C.tri, n_hit);
+}
+
 // one wave per tile, 4 tiles per workgroup; the hardware dispatcher hands the workgroups out in index order, so
 // `order` (work items sorted by their step count in the previous trace, heaviest first) decides who starts first
 template <bool STATS, int RX, int RY>
 __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
                                                            const lbvh_fast_tri* __restrict__ tris, uint32_t n_work,
                                                            const uint32_t* __restrict__ counts, const uint32_t* __restrict__ lists,
-                                                           uint32_t* __restrict__ cost,
+                                                           coop_params heavy_cap, uint32_t* __restrict__ cost,
                                                            lbvh_hit* __restrict__ hits, lbvh_trace_stats* stats,
                                                            uint32_t* __restrict__ tile_cost)
 {
     constexpr int R = RX * RY;
     const uint32_t lane = lane_id();
     uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (w >= n_work) return;
     if (counts) {        // the w-th item of the class lists, heaviest class first (they partition the work items)
+        w += heavy_items(counts, heavy_cap);                 // those go to trace_heavy_kernel
+        if (w >= n_work) return;
         uint32_t k = w;
         int c = kOrderClasses - 1;
         for (; c > 0 && k >= counts[c]; c--) k -= counts[c];
         w = lists[(size_t)c * n_work + k];
     }
+    if (w >= n_work) return;
     const uint32_t tile = shard_tile(w, a.shard_index, a.shard_count);
     if (tile >= a.tiles_x * a.tiles_y) {                         // tail of the last group
         if (lane == 0) cost[w] = 0;
@@ -523,13 +754,38 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
         LBVH_HIP_TRY(ctx, hipMemsetAsync(counts, 0, 256, ctx->cur_stream));
         LBVH_LAUNCH(ctx, file_tiles_kernel, dim3((n_work + 1023) / 1024), dim3(1024), cost, n_work, counts, lists);
     }
+    // heavy tiles (known from the last trace) on the side stream, one workgroup each, concurrently with the rest
+    coop_params heavy_cap = {0u, (uint32_t)kHeavyClass, kCoopGrain};
+    // Cooperative walking costs ~25 % more steps (a subtree handed to another wave is walked before the near hits
+    // that would have pruned it are known), so it only pays when the chip is not full anyway: one GPU's share of a
+    // multi-GPU frame (1080p: 1/4 of the frame 226 -> 187 us, 1/8 212 -> 125 us; the whole frame 287 -> 570 us).
+    if (RX * RY == 1 && have_history && n_work <= kCoopMaxWork) heavy_cap.cap = n_work / 4u;
+    if (const char* e = getenv("LBVH_COOP_CLASS")) heavy_cap.first_class = (uint32_t)atoi(e);
+    if (const char* e = getenv("LBVH_COOP_GRAIN")) heavy_cap.grain = (uint32_t)atoi(e);
+    if (const char* e = getenv("LBVH_COOP_MAXWORK")) { if (n_work > (uint32_t)atoi(e)) heavy_cap.cap = 0; }
+    if (heavy_cap.cap) {
+        rc = lbvh_fork_side(ctx);
+        if (rc != LBVH_OK) return rc;
+        if (d_stats)
+            LBVH_LAUNCH(ctx, trace_heavy_kernel<true>, dim3(heavy_cap.cap), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris,
+                        n_work, counts, lists, heavy_cap, cost, d_hits, d_stats, d_tile_cost);
+        else
+            LBVH_LAUNCH(ctx, trace_heavy_kernel<false>, dim3(heavy_cap.cap), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris,
+                        n_work, counts, lists, heavy_cap, cost, d_hits, d_stats, d_tile_cost);
+        rc = lbvh_join_side(ctx, false);
+        if (rc != LBVH_OK) return rc;
+    }
     const uint32_t blocks = (n_work + 3) / 4;
     if (d_stats)
         LBVH_LAUNCH(ctx, (trace_packet_kernel<true, RX, RY>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris,
-                    n_work, have_history ? counts : nullptr, lists, cost, d_hits, d_stats, d_tile_cost);
+                    n_work, have_history ? counts : nullptr, lists, heavy_cap, cost, d_hits, d_stats, d_tile_cost);
     else
         LBVH_LAUNCH(ctx, (trace_packet_kernel<false, RX, RY>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris,
-                    n_work, have_history ? counts : nullptr, lists, cost, d_hits, d_stats, d_tile_cost);
+                    n_work, have_history ? counts : nullptr, lists, heavy_cap, cost, d_hits, d_stats, d_tile_cost);
+    if (heavy_cap.cap) {
+        rc = lbvh_join_side(ctx, true);
+        if (rc != LBVH_OK) return rc;
+    }
     ctx->trace_layout = layout;
     ctx->trace_layout_work = n_work;
     ctx->trace_history = true;
@@ -606,10 +862,9 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
     LBVH_REQUIRE(ctx, d_triangles && d_keys && d_indices && d_aabb && d_internal && d_leaf && d_bvh);
     LBVH_REQUIRE(ctx, ctx->lane == 0);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!ctx->side_stream) {
-        LBVH_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-        LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    {
+        const int src = lbvh_ensure_side(ctx);
+        if (src != LBVH_OK) return src;
     }
     lbvh_status rc;
     if (flags & LBVH_BUILD_RESET_NODES) {        // NullLeaf / uint.MaxValue fills, Sc/MeshBufferContainer.cs:114-115
