@@ -945,7 +945,9 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
                                   "LBVH_TRACE_FAST needs lbvh_build_fast_scene on this scene first");
         // 1 ray per lane = 8 x 8-pixel packets: 0.27 ms; 1x2: 0.43, 2x1: 0.45, 3x1: 0.68, 4x1: 0.82, 2x2: 0.92 ms
         // (more rays per lane cut node fetches per ray but lengthen every step and the per-tile critical path;
-        // while the tile queues still cost 0.7 ms per launch, 2x1 had looked best)
+        // while the tile queues still cost 0.7 ms per launch, 2x1 had looked best).  4-wide 128-byte nodes
+        // (the tree collapsed by one level, entries taken nearest first): 0.52x the steps but 0.37 ms, and
+        // 110 us more build — re-measured after the queues were gone, still a loss.
         const int prc = launch_packets<1, 1>(ctx, a, d_hits, d_stats, d_tile_cost);
         if (prc != LBVH_OK) return prc;
     }
