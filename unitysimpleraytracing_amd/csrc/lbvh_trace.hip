@@ -796,8 +796,11 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
 
 extern "C" {
 
-lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene, const float h_box_min[3],
-                                  const float h_box_max[3])
+}  // extern "C"
+
+// parts: 1 = traversal tree + fused nodes, 2 = sorted triangles (independent of the tree), 3 = both
+static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h_scene, const float h_box_min[3],
+                                          const float h_box_max[3], int parts)
 {
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     LBVH_REQUIRE(ctx, h_scene != nullptr && h_box_min != nullptr && h_box_max != nullptr);
@@ -832,23 +835,33 @@ lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene, 
     lbvh_aabb* t_bvh = (lbvh_aabb*)(p + keys_bytes + int_bytes + leaf_bytes);
     lbvh_aabb* t_leaf_box = (lbvh_aabb*)(p + keys_bytes + int_bytes + leaf_bytes + box_bytes);
     // the one random gather: triangle AABBs into sorted (leaf) order; everything after reads them in order
-    lbvh_launch_gather_aabb(ctx, s.n, s.triangle_aabb, s.sorted_indices, t_leaf_box);
-    rc = lbvh_launch_aligned_keys(ctx, s.n, t_leaf_box, nullptr, h_box_min, h_box_max, t_keys);
-    if (rc != LBVH_OK) return rc;
-    lbvh_launch_tree(ctx, s.n, t_keys, t_internal, t_leaf);
-    rc = lbvh_launch_refit(ctx, s.n, t_internal, t_leaf, t_leaf_box, nullptr, t_bvh);
-    if (rc != LBVH_OK) return rc;
-    lbvh_scene ts = s;
-    ts.internal_nodes = t_internal;
-    ts.leaf_nodes = t_leaf;
-    ts.bvh = t_bvh;
-    ts.triangle_aabb = t_leaf_box;
-    ts.sorted_indices = nullptr;
-    LBVH_LAUNCH(ctx, build_fast_nodes_kernel, dim3((s.n - 1 + 255) / 256), dim3(256), ts, ctx->fast_nodes);
-    LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((s.n + 255) / 256), dim3(256), s, ctx->fast_tris);
+    if (parts & 1) {
+        lbvh_launch_gather_aabb(ctx, s.n, s.triangle_aabb, s.sorted_indices, t_leaf_box);
+        rc = lbvh_launch_aligned_keys(ctx, s.n, t_leaf_box, nullptr, h_box_min, h_box_max, t_keys);
+        if (rc != LBVH_OK) return rc;
+        lbvh_launch_tree(ctx, s.n, t_keys, t_internal, t_leaf);
+        rc = lbvh_launch_refit(ctx, s.n, t_internal, t_leaf, t_leaf_box, nullptr, t_bvh);
+        if (rc != LBVH_OK) return rc;
+        lbvh_scene ts = s;
+        ts.internal_nodes = t_internal;
+        ts.leaf_nodes = t_leaf;
+        ts.bvh = t_bvh;
+        ts.triangle_aabb = t_leaf_box;
+        ts.sorted_indices = nullptr;
+        LBVH_LAUNCH(ctx, build_fast_nodes_kernel, dim3((s.n - 1 + 255) / 256), dim3(256), ts, ctx->fast_nodes);
+    }
+    if (parts & 2) LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((s.n + 255) / 256), dim3(256), s, ctx->fast_tris);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     ctx->fast_n = s.n;
     return LBVH_OK;
+}
+
+extern "C" {
+
+lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene, const float h_box_min[3],
+                                  const float h_box_max[3])
+{
+    return build_fast_scene_parts(ctx, h_scene, h_box_min, h_box_max, 3);
 }
 
 // RaytracingMeshDrawer.Awake()'s whole build chain in one call, as two concurrent lanes after the sort.
@@ -874,6 +887,7 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
     if ((rc = lbvh_morton_aabb(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb)) != LBVH_OK) return rc;
     if ((rc = lbvh_sort_pairs(ctx, d_keys, d_indices, capacity)) != LBVH_OK) return rc;
     const bool fast = (flags & LBVH_BUILD_FAST_SCENE) != 0;
+    lbvh_scene fast_scene = {};
     if (fast) {
         // lane 1: the derived traversal scene needs only the sorted indices and the triangle AABBs
         LBVH_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -888,7 +902,8 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
         s.triangles = d_triangles;
         ctx->lane = 1;
         ctx->cur_stream = ctx->side_stream;
-        rc = lbvh_build_fast_scene(ctx, &s, h_box_min, h_box_max);
+        fast_scene = s;
+        rc = build_fast_scene_parts(ctx, &s, h_box_min, h_box_max, 1);
         hipError_t e = hipEventRecord(ctx->ev_join, ctx->side_stream);
         ctx->lane = 0;
         ctx->cur_stream = ctx->stream;
@@ -899,7 +914,11 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
     if ((rc = lbvh_distribute_keys(ctx, d_keys, n)) != LBVH_OK) return rc;
     if ((rc = lbvh_build_tree(ctx, n, d_keys, d_internal, d_leaf)) != LBVH_OK) return rc;
     if ((rc = lbvh_refit(ctx, n, d_internal, d_leaf, d_aabb, d_indices, d_bvh)) != LBVH_OK) return rc;
-    if (fast) LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    if (fast) {
+        // the sorted triangles do not depend on the traversal tree: they ride on the shorter lane
+        if ((rc = build_fast_scene_parts(ctx, &fast_scene, h_box_min, h_box_max, 2)) != LBVH_OK) return rc;
+        LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    }
     return LBVH_OK;
 }
 
