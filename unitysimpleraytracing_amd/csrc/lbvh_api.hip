@@ -142,6 +142,7 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
         if (ctx->scan_scratch[l]) (void)hipFree(ctx->scan_scratch[l]);
         if (ctx->refit_scratch[l]) (void)hipFree(ctx->refit_scratch[l]);
     }
+    if (ctx->build_graph) (void)hipGraphExecDestroy(ctx->build_graph);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);

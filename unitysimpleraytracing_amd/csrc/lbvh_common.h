@@ -55,6 +55,12 @@ struct lbvh_context {
     hipStream_t cur_stream = nullptr;
     int lane = 0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // lbvh_build_scene replays a captured hipGraph when it is called again with the same arguments (per-frame
+    // rebuilds): ~20 short dependent kernels on two streams, launch gaps included, become one graph launch
+    hipGraphExec_t build_graph = nullptr;
+    uint64_t build_graph_key = 0;     // arguments the graph was captured for
+    uint64_t build_seen_key = 0;      // arguments of the last plain call (scratch is sized for them)
+    bool build_graph_off = false;     // capture failed once: stay on plain launches
     // distribute-keys / aligned-keys scan scratch
     void* scan_scratch[2] = {nullptr, nullptr};
     size_t scan_scratch_bytes[2] = {0, 0};

@@ -18,6 +18,7 @@
 // (bank-conflict-free, no scratch memory); no barriers anywhere.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include "lbvh_common.h"
 #include "lbvh_rt.h"
 
@@ -794,10 +795,6 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
 
 }  // namespace
 
-extern "C" {
-
-}  // extern "C"
-
 // parts: 1 = traversal tree + fused nodes, 2 = sorted triangles (independent of the tree), 3 = both
 static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h_scene, const float h_box_min[3],
                                           const float h_box_max[3], int parts)
@@ -864,17 +861,14 @@ lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene, 
     return build_fast_scene_parts(ctx, h_scene, h_box_min, h_box_max, 3);
 }
 
-// RaytracingMeshDrawer.Awake()'s whole build chain in one call, as two concurrent lanes after the sort.
-lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
-                             const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
-                             lbvh_aabb* d_aabb, lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh,
-                             uint32_t flags)
+}  // extern "C"
+
+// RaytracingMeshDrawer.Awake()'s whole build chain, as two concurrent lanes after the sort.
+static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
+                                       const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
+                                       lbvh_aabb* d_aabb, lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh,
+                                       uint32_t flags)
 {
-    if (!ctx) return LBVH_ERR_INVALID_ARG;
-    LBVH_REQUIRE(ctx, n >= 2 && capacity >= n);
-    LBVH_REQUIRE(ctx, d_triangles && d_keys && d_indices && d_aabb && d_internal && d_leaf && d_bvh);
-    LBVH_REQUIRE(ctx, ctx->lane == 0);
-    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     {
         const int src = lbvh_ensure_side(ctx);
         if (src != LBVH_OK) return src;
@@ -921,6 +915,79 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
     }
     return LBVH_OK;
 }
+
+extern "C" {
+
+lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
+                             const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
+                             lbvh_aabb* d_aabb, lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh,
+                             uint32_t flags)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, n >= 2 && capacity >= n);
+    LBVH_REQUIRE(ctx, h_box_min != nullptr && h_box_max != nullptr);
+    LBVH_REQUIRE(ctx, d_triangles && d_keys && d_indices && d_aabb && d_internal && d_leaf && d_bvh);
+    LBVH_REQUIRE(ctx, ctx->lane == 0);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // FNV-1a over every argument the enqueued work depends on
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { for (int i = 0; i < 8; i++) { key ^= (v >> (8 * i)) & 0xFFu; key *= 1099511628211ull; } };
+    mix((uint64_t)(uintptr_t)d_triangles); mix(n); mix(capacity); mix((uint64_t)(uintptr_t)d_keys); mix((uint64_t)(uintptr_t)d_indices);
+    mix((uint64_t)(uintptr_t)d_aabb); mix((uint64_t)(uintptr_t)d_internal); mix((uint64_t)(uintptr_t)d_leaf);
+    mix((uint64_t)(uintptr_t)d_bvh); mix(flags);
+    for (int k = 0; k < 3; k++) { uint32_t b; memcpy(&b, &h_box_min[k], 4); mix(b); memcpy(&b, &h_box_max[k], 4); mix(b); }
+    mix((uint64_t)(uintptr_t)ctx->fast_nodes); mix((uint64_t)(uintptr_t)ctx->fast_tree); mix((uint64_t)(uintptr_t)ctx->sort_scratch);
+    if (key == 0) key = 1;
+    const bool graphs = ctx->own_stream && !ctx->prof_enabled && !ctx->build_graph_off;
+    if (graphs && ctx->build_graph && ctx->build_graph_key == key) {
+        LBVH_HIP_TRY(ctx, hipGraphLaunch(ctx->build_graph, ctx->stream));
+        return LBVH_OK;
+    }
+    if (graphs && ctx->build_seen_key == key) {
+        // second call with these arguments: every scratch buffer has its final size, so nothing allocates or
+        // synchronises while the two lanes are recorded
+        if (ctx->build_graph) { (void)hipGraphExecDestroy(ctx->build_graph); ctx->build_graph = nullptr; }
+        int src = lbvh_ensure_side(ctx);
+        if (src != LBVH_OK) return src;
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const lbvh_status rc = build_scene_enqueue(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb,
+                                                       d_internal, d_leaf, d_bvh, flags);
+            const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+            if (rc == LBVH_OK && e == hipSuccess && graph &&
+                hipGraphInstantiate(&ctx->build_graph, graph, nullptr, nullptr, 0) == hipSuccess) {
+                (void)hipGraphDestroy(graph);
+                ctx->build_graph_key = key;
+                LBVH_HIP_TRY(ctx, hipGraphLaunch(ctx->build_graph, ctx->stream));
+                return LBVH_OK;
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        (void)hipGetLastError();
+        ctx->build_graph = nullptr;
+        ctx->build_graph_off = true;        // fall through to plain launches, now and from here on
+        ctx->lane = 0;
+        ctx->cur_stream = ctx->stream;
+    }
+    const lbvh_status rc = build_scene_enqueue(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb,
+                                               d_internal, d_leaf, d_bvh, flags);
+    // the key includes the scratch pointers as they are AFTER this call
+    uint64_t key2 = key;
+    {
+        uint64_t k2 = 1469598103934665603ull;
+        auto mix2 = [&](uint64_t v) { for (int i = 0; i < 8; i++) { k2 ^= (v >> (8 * i)) & 0xFFu; k2 *= 1099511628211ull; } };
+        mix2((uint64_t)(uintptr_t)d_triangles); mix2(n); mix2(capacity); mix2((uint64_t)(uintptr_t)d_keys); mix2((uint64_t)(uintptr_t)d_indices);
+        mix2((uint64_t)(uintptr_t)d_aabb); mix2((uint64_t)(uintptr_t)d_internal); mix2((uint64_t)(uintptr_t)d_leaf);
+        mix2((uint64_t)(uintptr_t)d_bvh); mix2(flags);
+        for (int k = 0; k < 3; k++) { uint32_t b; memcpy(&b, &h_box_min[k], 4); mix2(b); memcpy(&b, &h_box_max[k], 4); mix2(b); }
+        mix2((uint64_t)(uintptr_t)ctx->fast_nodes); mix2((uint64_t)(uintptr_t)ctx->fast_tree); mix2((uint64_t)(uintptr_t)ctx->sort_scratch);
+        key2 = k2 ? k2 : 1;
+    }
+    ctx->build_seen_key = rc == LBVH_OK ? key2 : 0;
+    return rc;
+}
+
+}  // extern "C"
 
 static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, int32_t x0, int32_t y0, int32_t x1,
                               int32_t y1, uint32_t shard_index, uint32_t shard_count, const lbvh_scene* h_scene,
@@ -973,6 +1040,8 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }
+
+extern "C" {
 
 lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera, int32_t x0, int32_t y0,
                                int32_t x1, int32_t y1, const lbvh_scene* h_scene, int32_t mode,
