@@ -150,6 +150,7 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
     if (ctx->fast_tris) (void)hipFree(ctx->fast_tris);
     if (ctx->trace_queues) (void)hipFree(ctx->trace_queues);
     if (ctx->fast_tree) (void)hipFree(ctx->fast_tree);
+    if (ctx->ray_scratch) (void)hipFree(ctx->ray_scratch);
     for (auto& s : ctx->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

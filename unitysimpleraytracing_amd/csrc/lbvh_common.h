@@ -82,6 +82,10 @@ struct lbvh_context {
     void* fast_tree = nullptr;
     size_t fast_tree_bytes = 0;
 
+    // lbvh_trace_rays: live-ray list
+    void* ray_scratch = nullptr;
+    size_t ray_scratch_bytes = 0;
+
     // per-kernel event profiling (lbvh_profile_begin / lbvh_profile_end)
     struct prof_span { const char* name; hipEvent_t a, b; };
     bool prof_enabled = false;

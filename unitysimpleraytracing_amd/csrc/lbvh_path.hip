@@ -56,14 +56,43 @@ __global__ __launch_bounds__(256) void path_begin_kernel(lbvh_camera cam, lbvh_p
 // [entry][lane].  One wave per workgroup, no barriers.
 constexpr int kRayStack = 34;
 
-__global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* __restrict__ states, size_t count, float t_min,
+// Live rays only: alive_rays_kernel writes the miss record of every dead ray and compacts the indices of the live
+// ones (after the first bounce more than half of a frame's paths have left the scene), so every lane of every wave
+// here has a ray.  (Sorting the live rays by direction octant + Morton code of the origin on top of this was
+// measured: the sort costs 0.15 ms per bounce and the walk does not get faster.)
+__global__ __launch_bounds__(256) void alive_rays_kernel(const lbvh_path_state* __restrict__ states, size_t count,
+                                                         uint32_t* __restrict__ n_alive, uint32_t* __restrict__ list,
+                                                         lbvh_hit* __restrict__ hits)
+{
+    __shared__ uint32_t s_n, s_base;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    bool alive = false;
+    if (i < count) {
+        alive = reinterpret_cast<const uint32_t*>(&states[i])[3] != 0u;
+        if (!alive) reinterpret_cast<float4*>(hits)[i] = make_float4(LBVH_MAX_FLOAT, __uint_as_float(0u), 0.0f, 0.0f);
+    }
+    const uint64_t m = __ballot(alive);
+    uint32_t wave_ofs = 0;
+    if (lane_id() == 0 && m) wave_ofs = atomicAdd(&s_n, (uint32_t)__popcll(m));
+    wave_ofs = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_ofs);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) s_base = __hip_atomic_fetch_add(n_alive, s_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (alive) list[s_base + wave_ofs + mbcnt64(m)] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* __restrict__ states, const uint32_t* __restrict__ n_alive,
+                                                        const uint32_t* __restrict__ list, float t_min,
                                                         const lbvh_fast_node* __restrict__ nodes,
                                                         const lbvh_fast_tri* __restrict__ tris, lbvh_hit* __restrict__ hits)
 {
     __shared__ uint32_t s_stack[kRayStack][LBVH_WAVE];
     const uint32_t lane = threadIdx.x;
-    const size_t i = (size_t)blockIdx.x * LBVH_WAVE + lane;
-    if (i >= count) return;
+    const uint32_t k = blockIdx.x * LBVH_WAVE + lane;
+    if (k >= *n_alive) return;
+    const size_t i = list[k];
     const float4* st = reinterpret_cast<const float4*>(&states[i]);
     const float4 o = st[0], d = st[1];
     float best_t = LBVH_MAX_FLOAT;
@@ -238,12 +267,20 @@ lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, 
     if (count == 0) return LBVH_OK;
     LBVH_REQUIRE(ctx, d_states != nullptr && h_scene != nullptr && d_hits != nullptr);
     LBVH_REQUIRE(ctx, ((uintptr_t)d_states & 15) == 0 && ((uintptr_t)d_hits & 15) == 0);
-    LBVH_REQUIRE(ctx, (count + LBVH_WAVE - 1) / LBVH_WAVE <= 0x7FFFFFFFu);
+    LBVH_REQUIRE(ctx, count <= 0xFFFFFFFFull);
     if (!ctx->fast_nodes || ctx->fast_n != h_scene->n)
         return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_trace_rays", "needs lbvh_build_fast_scene on this scene first");
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    LBVH_LAUNCH(ctx, trace_rays_kernel, dim3((unsigned)((count + LBVH_WAVE - 1) / LBVH_WAVE)), dim3(LBVH_WAVE), d_states, count,
-                t_min, ctx->fast_nodes, ctx->fast_tris, d_hits);
+    // scratch: [live-ray count (256 B) | indices of the live rays]
+    int rc = lbvh_reserve(ctx, &ctx->ray_scratch, &ctx->ray_scratch_bytes, 256 + count * 4);
+    if (rc != LBVH_OK) return rc;
+    uint32_t* n_alive = (uint32_t*)ctx->ray_scratch;
+    uint32_t* list = (uint32_t*)((char*)ctx->ray_scratch + 256);
+    LBVH_HIP_TRY(ctx, hipMemsetAsync(n_alive, 0, 4, ctx->cur_stream));
+    LBVH_LAUNCH(ctx, alive_rays_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), d_states, count, n_alive, list, d_hits);
+    // the launch covers every ray; waves beyond the live count leave at once
+    LBVH_LAUNCH(ctx, trace_rays_kernel, dim3((unsigned)((count + LBVH_WAVE - 1) / LBVH_WAVE)), dim3(LBVH_WAVE), d_states, n_alive,
+                list, t_min, ctx->fast_nodes, ctx->fast_tris, d_hits);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }

@@ -761,9 +761,6 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     // that would have pruned it are known), so it only pays when the chip is not full anyway: one GPU's share of a
     // multi-GPU frame (1080p: 1/4 of the frame 226 -> 187 us, 1/8 212 -> 125 us; the whole frame 287 -> 570 us).
     if (RX * RY == 1 && have_history && n_work <= kCoopMaxWork) heavy_cap.cap = n_work / 4u;
-    if (const char* e = getenv("LBVH_COOP_CLASS")) heavy_cap.first_class = (uint32_t)atoi(e);
-    if (const char* e = getenv("LBVH_COOP_GRAIN")) heavy_cap.grain = (uint32_t)atoi(e);
-    if (const char* e = getenv("LBVH_COOP_MAXWORK")) { if (n_work > (uint32_t)atoi(e)) heavy_cap.cap = 0; }
     if (heavy_cap.cap) {
         rc = lbvh_fork_side(ctx);
         if (rc != LBVH_OK) return rc;
