@@ -492,19 +492,6 @@ __global__ __launch_bounds__(256) void refit_frontier_kernel(uint32_t n, const l
     }
 }
 
-// out[i] = in[index[i]] for 32-byte boxes: the one random gather of the traversal-tree build
-__global__ __launch_bounds__(256) void gather_aabb_kernel(const lbvh_aabb* __restrict__ in, const uint32_t* __restrict__ index,
-                                                          uint32_t n, lbvh_aabb* __restrict__ out)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4* src = reinterpret_cast<const float4*>(&in[index[i]]);
-    const float4 a = src[0], b = src[1];
-    float4* dst = reinterpret_cast<float4*>(&out[i]);
-    dst[0] = a;
-    dst[1] = b;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Aligned keys for the DERIVED traversal tree (no reference counterpart).  DistributeKeys makes the
 // reference's keys unique by accumulating max(diff, 1), which shifts every later key and so cuts the
@@ -513,24 +500,6 @@ __global__ __launch_bounds__(256) void gather_aabb_kernel(const lbvh_aabb* __res
 // uniqueness needs: k'_i = i + max_{j<=i}(k_j - j)  (68 fetches per packet, same hit results).
 // The raw code of sorted position i is recomputed from the triangle AABB exactly as a-1 does.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int32_t aligned_term(const lbvh_aabb* __restrict__ tri_aabb,
-                                                const uint32_t* __restrict__ sorted_indices, uint32_t i, const box3& scene)
-{
-    const float4* b = reinterpret_cast<const float4*>(&tri_aabb[sorted_indices ? sorted_indices[i] : i]);
-    const float4 mn = b[0], mx = b[1];
-    const float bmn[3] = {mn.x, mn.y, mn.z}, bmx[3] = {mx.x, mx.y, mx.z};
-    uint32_t q[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        float cen = (bmn[k] + bmx[k]) * 0.5f;
-        cen = cen - scene.mn[k];
-        cen = cen / (scene.mx[k] - scene.mn[k]);
-        q[k] = quantize(cen);
-    }
-    const uint32_t code = expand_bits(q[0]) * 4u + expand_bits(q[1]) * 2u + expand_bits(q[2]);
-    return (int32_t)code - (int32_t)i;          // code < 2^30, i < 2^31
-}
-
 __device__ __forceinline__ int32_t wave_inclusive_max(int32_t v)
 {
 #pragma unroll
@@ -561,15 +530,44 @@ __device__ __forceinline__ int32_t block_inclusive_max(int32_t v, int32_t* s_wav
     return max(incl, prefix);
 }
 
-__global__ __launch_bounds__(kAkThreads) void aligned_keys_reduce_kernel(const lbvh_aabb* __restrict__ tri_aabb,
-                                                                         const uint32_t* __restrict__ sorted_indices,
-                                                                         uint32_t n, box3 scene, int32_t* __restrict__ chunk_max)
+// One pass over the sorted order does both jobs of the derived build's start: the triangle AABBs are gathered into
+// leaf order (the one random gather; everything after reads them in order) and the aligned-key terms code_i - i are
+// written where the keys will be, with the maximum of every 1024-term chunk.
+constexpr int kAkItems = 4;
+constexpr uint32_t kAkChunk = kAkThreads * kAkItems;
+
+__global__ __launch_bounds__(kAkThreads) void gather_terms_kernel(const lbvh_aabb* __restrict__ tri_aabb,
+                                                                  const uint32_t* __restrict__ sorted_indices, uint32_t n,
+                                                                  box3 scene, lbvh_aabb* __restrict__ leaf_box,
+                                                                  int32_t* __restrict__ terms, int32_t* __restrict__ chunk_max)
 {
     __shared__ int32_t s_wave[kAkThreads / LBVH_WAVE];
-    const uint32_t i = blockIdx.x * kAkThreads + threadIdx.x;
-    const int32_t v = i < n ? aligned_term(tri_aabb, sorted_indices, i, scene) : INT32_MIN;
+    int32_t mine = INT32_MIN;
+#pragma unroll
+    for (int k = 0; k < kAkItems; k++) {
+        const uint32_t i = blockIdx.x * kAkChunk + (uint32_t)k * kAkThreads + threadIdx.x;
+        if (i < n) {
+            const float4* src = reinterpret_cast<const float4*>(&tri_aabb[sorted_indices[i]]);
+            const float4 mn = src[0], mx = src[1];
+            float4* dst = reinterpret_cast<float4*>(&leaf_box[i]);
+            dst[0] = mn;
+            dst[1] = mx;
+            const float bmn[3] = {mn.x, mn.y, mn.z}, bmx[3] = {mx.x, mx.y, mx.z};
+            uint32_t q[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                float cen = (bmn[d] + bmx[d]) * 0.5f;
+                cen = cen - scene.mn[d];
+                cen = cen / (scene.mx[d] - scene.mn[d]);
+                q[d] = quantize(cen);
+            }
+            const int32_t term = (int32_t)(expand_bits(q[0]) * 4u + expand_bits(q[1]) * 2u + expand_bits(q[2])) - (int32_t)i;
+            terms[i] = term;
+            mine = max(mine, term);
+        }
+    }
     int32_t all;
-    (void)block_inclusive_max(v, s_wave, &all);
+    (void)block_inclusive_max(mine, s_wave, &all);
     if (threadIdx.x == 0) chunk_max[blockIdx.x] = all;
 }
 
@@ -592,18 +590,22 @@ __global__ __launch_bounds__(kAkThreads) void aligned_keys_scan_kernel(int32_t* 
     }
 }
 
-__global__ __launch_bounds__(kAkThreads) void aligned_keys_apply_kernel(const lbvh_aabb* __restrict__ tri_aabb,
-                                                                        const uint32_t* __restrict__ sorted_indices,
-                                                                        uint32_t n, box3 scene,
-                                                                        const int32_t* __restrict__ chunk_excl,
-                                                                        uint32_t* __restrict__ keys_out)
+// keys[i] = i + max_{j <= i} term_j, in place over the terms
+__global__ __launch_bounds__(kAkThreads) void aligned_keys_apply_kernel(uint32_t n, const int32_t* __restrict__ chunk_excl,
+                                                                        uint32_t* keys)
 {
     __shared__ int32_t s_wave[kAkThreads / LBVH_WAVE];
-    const uint32_t i = blockIdx.x * kAkThreads + threadIdx.x;
-    const int32_t v = i < n ? aligned_term(tri_aabb, sorted_indices, i, scene) : INT32_MIN;
-    int32_t all;
-    const int32_t incl = block_inclusive_max(v, s_wave, &all);
-    if (i < n) keys_out[i] = (uint32_t)((int32_t)i + max(incl, chunk_excl[blockIdx.x]));
+    int32_t carry = chunk_excl[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kAkItems; k++) {
+        const uint32_t i = blockIdx.x * kAkChunk + (uint32_t)k * kAkThreads + threadIdx.x;
+        const int32_t v = i < n ? (int32_t)keys[i] : INT32_MIN;
+        int32_t all;
+        const int32_t incl = block_inclusive_max(v, s_wave, &all);
+        if (i < n) keys[i] = (uint32_t)((int32_t)i + max(incl, carry));
+        carry = max(carry, all);
+        __syncthreads();           // s_wave is reused by the next sub-chunk
+    }
 }
 
 }  // namespace
@@ -671,27 +673,20 @@ int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d
     return LBVH_OK;
 }
 
-int lbvh_launch_gather_aabb(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_in, const uint32_t* d_index, lbvh_aabb* d_out)
-{
-    LBVH_LAUNCH(ctx, gather_aabb_kernel, dim3((n + 255) / 256), dim3(256), d_in, d_index, n, d_out);
-    return LBVH_OK;
-}
-
-int lbvh_launch_aligned_keys(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_triangle_aabb,
-                             const uint32_t* d_sorted_indices, const float box_min[3], const float box_max[3],
-                             uint32_t* d_keys_out)
+int lbvh_launch_gather_aligned_keys(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_triangle_aabb,
+                                    const uint32_t* d_sorted_indices, const float box_min[3], const float box_max[3],
+                                    lbvh_aabb* d_leaf_box_out, uint32_t* d_keys_out)
 {
     box3 scene;
     for (int k = 0; k < 3; k++) { scene.mn[k] = box_min[k]; scene.mx[k] = box_max[k]; }
-    const uint32_t chunks = (n + kAkThreads - 1) / kAkThreads;
+    const uint32_t chunks = (n + kAkChunk - 1) / kAkChunk;
     int rc = lbvh_reserve(ctx, &ctx->scan_scratch[ctx->lane], &ctx->scan_scratch_bytes[ctx->lane], (size_t)chunks * 8);
     if (rc != LBVH_OK) return rc;
     int32_t* chunk_max = (int32_t*)ctx->scan_scratch[ctx->lane];
-    LBVH_LAUNCH(ctx, aligned_keys_reduce_kernel, dim3(chunks), dim3(kAkThreads), d_triangle_aabb, d_sorted_indices, n, scene,
-                chunk_max);
+    LBVH_LAUNCH(ctx, gather_terms_kernel, dim3(chunks), dim3(kAkThreads), d_triangle_aabb, d_sorted_indices, n, scene,
+                d_leaf_box_out, (int32_t*)d_keys_out, chunk_max);
     LBVH_LAUNCH(ctx, aligned_keys_scan_kernel, dim3(1), dim3(kAkThreads), chunk_max, chunks);
-    LBVH_LAUNCH(ctx, aligned_keys_apply_kernel, dim3(chunks), dim3(kAkThreads), d_triangle_aabb, d_sorted_indices, n, scene,
-                chunk_max, d_keys_out);
+    LBVH_LAUNCH(ctx, aligned_keys_apply_kernel, dim3(chunks), dim3(kAkThreads), n, chunk_max, d_keys_out);
     return LBVH_OK;
 }
 

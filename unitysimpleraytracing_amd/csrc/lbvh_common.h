@@ -134,12 +134,12 @@ int lbvh_launch_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, lbvh
                      lbvh_leaf_node* d_leaf);
 int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d_internal, const lbvh_leaf_node* d_leaf,
                       const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh);
-// d_sorted_indices may be nullptr in lbvh_launch_refit / lbvh_launch_aligned_keys: boxes already in leaf order
-int lbvh_launch_gather_aabb(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_in, const uint32_t* d_index, lbvh_aabb* d_out);
-// aligned traversal keys: k'_i = i + max_{j<=i}(morton(centre of aabb[sorted[j]]) - j), strictly increasing
-int lbvh_launch_aligned_keys(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_triangle_aabb,
-                             const uint32_t* d_sorted_indices, const float box_min[3], const float box_max[3],
-                             uint32_t* d_keys_out);
+// d_sorted_indices may be nullptr in lbvh_launch_refit: boxes already in leaf order.
+// The start of the derived build: leaf_box[i] = aabb[sorted[i]] and the aligned traversal keys
+// k'_i = i + max_{j<=i}(morton(centre of leaf_box[j]) - j), strictly increasing.
+int lbvh_launch_gather_aligned_keys(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_triangle_aabb,
+                                    const uint32_t* d_sorted_indices, const float box_min[3], const float box_max[3],
+                                    lbvh_aabb* d_leaf_box_out, uint32_t* d_keys_out);
 
 // Side lane: lbvh_fork_side makes the side stream wait for everything enqueued on the context's stream so far and
 // routes the following launches to it; lbvh_join_side(ctx, false) routes launches back to the context's stream

@@ -830,8 +830,7 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
     lbvh_aabb* t_leaf_box = (lbvh_aabb*)(p + keys_bytes + int_bytes + leaf_bytes + box_bytes);
     // the one random gather: triangle AABBs into sorted (leaf) order; everything after reads them in order
     if (parts & 1) {
-        lbvh_launch_gather_aabb(ctx, s.n, s.triangle_aabb, s.sorted_indices, t_leaf_box);
-        rc = lbvh_launch_aligned_keys(ctx, s.n, t_leaf_box, nullptr, h_box_min, h_box_max, t_keys);
+        rc = lbvh_launch_gather_aligned_keys(ctx, s.n, s.triangle_aabb, s.sorted_indices, h_box_min, h_box_max, t_leaf_box, t_keys);
         if (rc != LBVH_OK) return rc;
         lbvh_launch_tree(ctx, s.n, t_keys, t_internal, t_leaf);
         rc = lbvh_launch_refit(ctx, s.n, t_internal, t_leaf, t_leaf_box, nullptr, t_bvh);
