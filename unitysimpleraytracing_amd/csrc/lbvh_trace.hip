@@ -228,17 +228,17 @@ __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh
 // Each lane still sees every node it would visit alone (it votes for it), the leaf's own AABB slab
 // test gates the triangle test per lane, and the accept rule is the reference's strict t < best —
 // so per-ray results equal the reference order's min t.
-// Persistent waves pull tiles from eight per-XCD queues (contiguous screen regions per XCD for L2
-// locality; HW_REG_XCC_ID picks the home queue, other queues are stolen from when it is empty).
 // ---------------------------------------------------------------------------------------------
-// Work distribution (measured, 1 M triangles / 1080p; per-tile steps: median 48, p99 323, max 594):
+// Work distribution (measured, 1 M triangles / 1080p; per-tile steps at 16x8 pixels: median 48, p99 323, max 594):
 //   * persistent waves pulling tiles from per-XCD atomic queues: 1.13 ms — 0.70 ms of it with the traversal
 //     switched off (two dependent device-scope round trips per tile on eight hot counters);
 //   * one tile per wave, handed out by the hardware dispatcher in row-major order: 0.65 ms;
 //   * the same with the tiles dispatched HEAVIEST FIRST: 0.49 ms (lightest first 0.67, random 0.66, screen
 //     centre first 0.58): the run time is the tail of late-starting heavy tiles.  The kernel therefore records
 //     every tile's step count, and the next trace of the same frame layout dispatches in descending order of
-//     those counts (a scheduling hint only — any order gives the same hits; the first frame is row-major).
+//     those counts (a scheduling hint only — any order gives the same hits; the first frame is row-major):
+//     file_tiles_kernel files the tiles under 16 half-octave cost classes (6 us), wave w takes the w-th tile
+//     of the class lists, heaviest class first.
 //     Cheaper bookkeeping was tried and lost: a "heavy tiles" list built by the trace kernel + row-major for
 //     the rest leaves medium tiles in the tail (0.33 instead of 0.27 ms at 8x8 tiles); filing every tile under
 //     one of 8 cost classes with a returning atomic per tile: 0.48 ms (hot device-scope counters again).
