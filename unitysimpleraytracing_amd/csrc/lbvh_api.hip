@@ -41,27 +41,6 @@ int lbvh_ensure_side(lbvh_context* ctx)
     return LBVH_OK;
 }
 
-int lbvh_fork_side(lbvh_context* ctx)
-{
-    int rc = lbvh_ensure_side(ctx);
-    if (rc != LBVH_OK) return rc;
-    LBVH_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-    LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
-    ctx->cur_stream = ctx->side_stream;
-    return LBVH_OK;
-}
-
-int lbvh_join_side(lbvh_context* ctx, bool wait)
-{
-    if (!wait) {
-        LBVH_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
-        ctx->cur_stream = ctx->stream;
-    } else {
-        LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-    }
-    return LBVH_OK;
-}
-
 hipEvent_t lbvh_prof_event(lbvh_context* ctx)
 {
     hipEvent_t e = nullptr;

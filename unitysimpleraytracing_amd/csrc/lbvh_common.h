@@ -141,12 +141,8 @@ int lbvh_launch_gather_aligned_keys(lbvh_context* ctx, uint32_t n, const lbvh_aa
                                     const uint32_t* d_sorted_indices, const float box_min[3], const float box_max[3],
                                     lbvh_aabb* d_leaf_box_out, uint32_t* d_keys_out);
 
-// Side lane: lbvh_fork_side makes the side stream wait for everything enqueued on the context's stream so far and
-// routes the following launches to it; lbvh_join_side(ctx, false) routes launches back to the context's stream
-// (both streams now run concurrently); lbvh_join_side(ctx, true) makes the context's stream wait for the side work.
+// Creates the side stream and its fork / join events on first use.
 int lbvh_ensure_side(lbvh_context* ctx);
-int lbvh_fork_side(lbvh_context* ctx);
-int lbvh_join_side(lbvh_context* ctx, bool wait);
 
 // Grow-only scratch helper: (re)allocates *ptr to at least `bytes`.
 int lbvh_reserve(lbvh_context* ctx, void** ptr, size_t* have, size_t bytes);

@@ -415,7 +415,12 @@ __device__ __forceinline__ void tile_rays(const trace_args& a, uint32_t tile, ui
 constexpr int kCoopWaves = 8;
 constexpr int kHeavyClass = 7;             // cost classes >= this (>= 96 steps) are walked cooperatively
 constexpr uint32_t kCoopGrain = 32;        // steps of the last trace per cooperating wave
-constexpr uint32_t kCoopMaxWork = 12288;   // tiles per launch up to which heavy tiles are walked cooperatively
+constexpr uint32_t kCoopMaxWork = 12288;   // tiles per launch up to which every heavy class is walked cooperatively
+constexpr uint32_t kSharedMaxWork = 24576; // ... and up to which the very heaviest are (beyond: one wave per tile only)
+#ifndef LBVH_HEAVY_CLASS_FULL
+#define LBVH_HEAVY_CLASS_FULL 10
+#endif
+constexpr uint32_t kHeavyClassFull = LBVH_HEAVY_CLASS_FULL;   // above that: only classes >= this (>= 256 steps)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 struct coop_params { uint32_t cap, first_class, grain; };
@@ -456,23 +461,13 @@ __device__ __forceinline__ void coop_unlock(coop_shared& S)
     __hip_atomic_store(&S.lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// one heavy tile (work item w) walked by the waves of this workgroup
 template <bool STATS>
-__global__ __launch_bounds__(kCoopWaves * 64) void trace_heavy_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
-                                                                      const lbvh_fast_tri* __restrict__ tris, uint32_t n_work,
-                                                                      const uint32_t* __restrict__ counts,
-                                                                      const uint32_t* __restrict__ lists, coop_params heavy_cap,
-                                                                      uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits,
-                                                                      lbvh_trace_stats* stats, uint32_t* __restrict__ tile_cost)
+__device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, const lbvh_fast_node* __restrict__ nodes,
+                                          const lbvh_fast_tri* __restrict__ tris, uint32_t n_work, uint32_t w,
+                                          coop_params heavy_cap, uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits,
+                                          lbvh_trace_stats* stats, uint32_t* __restrict__ tile_cost)
 {
-    __shared__ coop_shared S;
-    if (blockIdx.x >= heavy_items(counts, heavy_cap)) return;        // uniform for the workgroup
-    uint32_t w;
-    {
-        uint32_t k = blockIdx.x;
-        int c = kOrderClasses - 1;
-        for (; c > 0 && k >= counts[c]; c--) k -= counts[c];
-        w = lists[(size_t)c * n_work + k];
-    }
     const uint32_t tile = shard_tile(w, a.shard_index, a.shard_count);
     if (w >= n_work || tile >= a.tiles_x * a.tiles_y) return;        // cannot happen for a heavy item
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
@@ -634,58 +629,97 @@ __global__ __launch_bounds__(kCoopWaves * 64) void trace_heavy_kernel(trace_args
     if (STATS) add_stats(stats, C.pops, C.box, C.leaf, C.tri, n_hit);
 }
 
-// one wave per tile, 4 tiles per workgroup; the hardware dispatcher hands the workgroups out in index order, so
-// `order` (work items sorted by their step count in the previous trace, heaviest first) decides who starts first
-template <bool STATS, int RX, int RY>
-__global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
-                                                           const lbvh_fast_tri* __restrict__ tris, uint32_t n_work,
-                                                           const uint32_t* __restrict__ counts, const uint32_t* __restrict__ lists,
-                                                           coop_params heavy_cap, uint32_t* __restrict__ cost,
-                                                           lbvh_hit* __restrict__ hits, lbvh_trace_stats* stats,
-                                                           uint32_t* __restrict__ tile_cost)
+// one tile (work item w) walked by one wave
+template <bool STATS>
+__device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_node* __restrict__ nodes,
+                                           const lbvh_fast_tri* __restrict__ tris, uint32_t w, uint32_t lane,
+                                           uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits, lbvh_trace_stats* stats,
+                                           uint32_t* __restrict__ tile_cost)
 {
-    constexpr int R = RX * RY;
-    const uint32_t lane = lane_id();
-    uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (counts) {        // the w-th item of the class lists, heaviest class first (they partition the work items)
-        w += heavy_items(counts, heavy_cap);                 // those go to trace_heavy_kernel
-        if (w >= n_work) return;
-        uint32_t k = w;
-        int c = kOrderClasses - 1;
-        for (; c > 0 && k >= counts[c]; c--) k -= counts[c];
-        w = lists[(size_t)c * n_work + k];
-    }
-    if (w >= n_work) return;
     const uint32_t tile = shard_tile(w, a.shard_index, a.shard_count);
     if (tile >= a.tiles_x * a.tiles_y) {                         // tail of the last group
         if (lane == 0) cost[w] = 0;
         return;
     }
     const uint32_t rw = (uint32_t)(a.x1 - a.x0);
-    packet_rays<R> P;
+    packet_rays<1> P;
     uint32_t px0, py0;
-    tile_rays<RX, RY>(a, tile, lane, P, px0, py0);
-#pragma unroll
-    for (int r = 0; r < R; r++) { P.best_t[r] = LBVH_MAX_FLOAT; P.best_tri[r] = 0; P.best_u[r] = 0.0f; P.best_v[r] = 0.0f; }
+    tile_rays<1, 1>(a, tile, lane, P, px0, py0);
+    P.best_t[0] = LBVH_MAX_FLOAT; P.best_tri[0] = 0; P.best_u[0] = 0.0f; P.best_v[0] = 0.0f;
     walk_counters C = {0, 0, 0, 0};
-    const uint32_t steps = walk_packet<STATS, R>(nodes, tris, P, C);
+    const uint32_t steps = walk_packet<STATS, 1>(nodes, tris, P, C);
     if (lane == 0) cost[w] = steps;
     if (STATS && tile_cost && lane == 0) tile_cost[tile] = steps;
     uint32_t n_hit = 0;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        if (P.act[r]) {
-            const uint32_t px = px0 + (uint32_t)(r % RX), py = py0 + (uint32_t)(r / RX);
-            float4 out;
-            out.x = P.best_t[r];
-            out.y = __uint_as_float(P.best_tri[r]);
-            out.z = P.best_u[r];
-            out.w = P.best_v[r];
-            reinterpret_cast<float4*>(hits)[(size_t)(py - (uint32_t)a.y0) * rw + (px - (uint32_t)a.x0)] = out;
-            if (STATS && P.best_t[r] < LBVH_MAX_FLOAT) n_hit++;
-        }
+    if (P.act[0]) {
+        float4 out;
+        out.x = P.best_t[0];
+        out.y = __uint_as_float(P.best_tri[0]);
+        out.z = P.best_u[0];
+        out.w = P.best_v[0];
+        reinterpret_cast<float4*>(hits)[(size_t)(py0 - (uint32_t)a.y0) * rw + (px0 - (uint32_t)a.x0)] = out;
+        if (STATS && P.best_t[0] < LBVH_MAX_FLOAT) n_hit++;
     }
     if (STATS) add_stats(stats, C.pops, C.box, C.leaf, C.tri, n_hit);
+}
+
+// A full chip (a whole frame on one GPU): one wave per tile, 4 tiles per workgroup, the w-th tile of the class
+// lists, heaviest class first.  No cooperative tiles: with every wave slot taken they do not pay (287 -> 304 us).
+template <bool STATS>
+__global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
+                                                           const lbvh_fast_tri* __restrict__ tris, uint32_t n_work,
+                                                           const uint32_t* __restrict__ counts, const uint32_t* __restrict__ lists,
+                                                           uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits,
+                                                           lbvh_trace_stats* stats, uint32_t* __restrict__ tile_cost)
+{
+    const uint32_t lane = lane_id();
+    uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (w >= n_work) return;
+    if (counts) {        // the w-th item of the class lists, heaviest class first (they partition the work items)
+        uint32_t k = w;
+        int c = kOrderClasses - 1;
+        for (; c > 0 && k >= counts[c]; c--) k -= counts[c];
+        w = lists[(size_t)c * n_work + k];
+    }
+    light_tile<STATS>(a, nodes, tris, w, lane, cost, hits, stats, tile_cost);
+}
+
+// One launch per frame share.  Workgroups of 8 waves; the hardware dispatcher hands them out in index order:
+//   * workgroups [0, cap): the heavy tiles of the previous trace, one per workgroup, walked cooperatively
+//     (workgroups beyond the actual number of heavy tiles leave at once) — at the FRONT of the grid, so they start
+//     first (as a second kernel on another stream they were starved by the light tiles' workgroups);
+//   * the rest: one tile per wave, the w-th tile of the class lists after the heavy ones, heaviest class first.
+template <bool STATS>
+__global__ __launch_bounds__(kCoopWaves * 64) void trace_shared_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
+                                                                       const lbvh_fast_tri* __restrict__ tris, uint32_t n_work,
+                                                                       const uint32_t* __restrict__ counts,
+                                                                       const uint32_t* __restrict__ lists, coop_params heavy_cap,
+                                                                       uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits,
+                                                                       lbvh_trace_stats* stats, uint32_t* __restrict__ tile_cost)
+{
+    __shared__ coop_shared S;
+    const uint32_t lane = lane_id();
+    const uint32_t heavy = counts ? heavy_items(counts, heavy_cap) : 0u;
+    uint32_t w;
+    if (blockIdx.x < heavy_cap.cap) {
+        if (blockIdx.x >= heavy) return;                         // uniform for the workgroup
+        w = blockIdx.x;
+    } else {
+        w = (blockIdx.x - heavy_cap.cap) * (uint32_t)kCoopWaves + (threadIdx.x >> 6) + heavy;
+        if (w >= n_work) return;
+    }
+    if (counts) {        // the w-th item of the class lists, heaviest class first (they partition the work items)
+        uint32_t k = w;
+        int c = kOrderClasses - 1;
+        for (; c > 0 && k >= counts[c]; c--) k -= counts[c];
+        w = lists[(size_t)c * n_work + k];
+    }
+    if (blockIdx.x < heavy_cap.cap) {
+        coop_tile<STATS>(S, a, nodes, tris, n_work, w, heavy_cap, cost, hits, stats, tile_cost);
+        return;
+    }
+    if (w >= n_work) return;
+    light_tile<STATS>(a, nodes, tris, w, lane, cost, hits, stats, tile_cost);
 }
 
 // Files every work item of the last trace under one of 16 cost classes (half-octave scale): lists[c][...] with
@@ -732,11 +766,10 @@ __global__ __launch_bounds__(1024) void file_tiles_kernel(const uint32_t* __rest
     }
 }
 
-template <int RX, int RY>
 int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_cost)
 {
-    a.tiles_x = (uint32_t)(a.x1 - a.x0 + 8 * RX - 1) / (8 * RX);
-    a.tiles_y = (uint32_t)(a.y1 - a.y0 + 8 * RY - 1) / (8 * RY);
+    a.tiles_x = (uint32_t)(a.x1 - a.x0 + 7) / 8;
+    a.tiles_y = (uint32_t)(a.y1 - a.y0 + 7) / 8;
     const uint32_t n_work = shard_work(a.tiles_x * a.tiles_y, a.shard_index, a.shard_count);
     if (n_work == 0) return LBVH_OK;
     // [class counts | cost of each work item in the last trace | 16 class lists]: valid for one frame layout
@@ -755,34 +788,28 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
         LBVH_HIP_TRY(ctx, hipMemsetAsync(counts, 0, 256, ctx->cur_stream));
         LBVH_LAUNCH(ctx, file_tiles_kernel, dim3((n_work + 1023) / 1024), dim3(1024), cost, n_work, counts, lists);
     }
-    // heavy tiles (known from the last trace) on the side stream, one workgroup each, concurrently with the rest
-    coop_params heavy_cap = {0u, (uint32_t)kHeavyClass, kCoopGrain};
-    // Cooperative walking costs ~25 % more steps (a subtree handed to another wave is walked before the near hits
-    // that would have pruned it are known), so it only pays when the chip is not full anyway: one GPU's share of a
-    // multi-GPU frame (1080p: 1/4 of the frame 226 -> 187 us, 1/8 212 -> 125 us; the whole frame 287 -> 570 us).
-    if (RX * RY == 1 && have_history && n_work <= kCoopMaxWork) heavy_cap.cap = n_work / 4u;
-    if (heavy_cap.cap) {
-        rc = lbvh_fork_side(ctx);
-        if (rc != LBVH_OK) return rc;
+    // Which tiles are walked cooperatively (known from the last trace).  It costs ~50 % more steps on those tiles (a
+    // subtree handed to another wave is walked before the near hits that would have pruned it are known), so it is
+    // for under-filled launches — one GPU's share of a multi-GPU frame: every tile of 96 steps or more up to
+    // 12 288 tiles, only those of 256 steps or more up to 24 576, none beyond (1080p whole / half / quarter /
+    // eighth of the frame: 287 -> 275, 234 -> 190, 226 -> 170, 212 -> 103 us).
+    if (have_history && n_work <= kSharedMaxWork) {
+        coop_params hp = {n_work / 4u, n_work <= kCoopMaxWork ? (uint32_t)kHeavyClass : kHeavyClassFull, kCoopGrain};
+        const uint32_t blocks = hp.cap + (n_work + kCoopWaves - 1) / kCoopWaves;
         if (d_stats)
-            LBVH_LAUNCH(ctx, trace_heavy_kernel<true>, dim3(heavy_cap.cap), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris,
-                        n_work, counts, lists, heavy_cap, cost, d_hits, d_stats, d_tile_cost);
+            LBVH_LAUNCH(ctx, trace_shared_kernel<true>, dim3(blocks), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris, n_work,
+                        counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
         else
-            LBVH_LAUNCH(ctx, trace_heavy_kernel<false>, dim3(heavy_cap.cap), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris,
-                        n_work, counts, lists, heavy_cap, cost, d_hits, d_stats, d_tile_cost);
-        rc = lbvh_join_side(ctx, false);
-        if (rc != LBVH_OK) return rc;
-    }
-    const uint32_t blocks = (n_work + 3) / 4;
-    if (d_stats)
-        LBVH_LAUNCH(ctx, (trace_packet_kernel<true, RX, RY>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris,
-                    n_work, have_history ? counts : nullptr, lists, heavy_cap, cost, d_hits, d_stats, d_tile_cost);
-    else
-        LBVH_LAUNCH(ctx, (trace_packet_kernel<false, RX, RY>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris,
-                    n_work, have_history ? counts : nullptr, lists, heavy_cap, cost, d_hits, d_stats, d_tile_cost);
-    if (heavy_cap.cap) {
-        rc = lbvh_join_side(ctx, true);
-        if (rc != LBVH_OK) return rc;
+            LBVH_LAUNCH(ctx, trace_shared_kernel<false>, dim3(blocks), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris, n_work,
+                        counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
+    } else {
+        const uint32_t blocks = (n_work + 3) / 4;
+        if (d_stats)
+            LBVH_LAUNCH(ctx, trace_packet_kernel<true>, dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris, n_work,
+                        have_history ? counts : nullptr, lists, cost, d_hits, d_stats, d_tile_cost);
+        else
+            LBVH_LAUNCH(ctx, trace_packet_kernel<false>, dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris, n_work,
+                        have_history ? counts : nullptr, lists, cost, d_hits, d_stats, d_tile_cost);
     }
     ctx->trace_layout = layout;
     ctx->trace_layout_work = n_work;
@@ -1030,7 +1057,7 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
         // while the tile queues still cost 0.7 ms per launch, 2x1 had looked best).  4-wide 128-byte nodes
         // (the tree collapsed by one level, entries taken nearest first): 0.52x the steps but 0.37 ms, and
         // 110 us more build — re-measured after the queues were gone, still a loss.
-        const int prc = launch_packets<1, 1>(ctx, a, d_hits, d_stats, d_tile_cost);
+        const int prc = launch_packets(ctx, a, d_hits, d_stats, d_tile_cost);
         if (prc != LBVH_OK) return prc;
     }
     LBVH_HIP_TRY(ctx, hipGetLastError());
