@@ -272,6 +272,34 @@ def test_build_scene_one_call_equals_the_staged_chain(ctx, scene):
     d.on_destroy()
 
 
+def test_build_scene_graph_replay_survives_other_scenes_and_scratch_growth(ctx):
+    """lbvh_build_scene replays a captured graph for repeated arguments; a bigger scene in between regrows the
+    context's scratch, so the first scene's graph must be re-captured, not replayed with stale pointers."""
+    small = scenes.random_triangles(20_000, seed=31, extent=80.0, edge=4.0)
+    big = scenes.random_triangles(1_500_000, seed=32, extent=115.0, edge=1.0)
+    ds, cs, bs = build_both(ctx, small)
+    for _ in range(3):
+        ds.rebuild()
+    assert_build_equal(cs, bs)
+    db, cb, bb = build_both(ctx, big)                 # every scratch buffer grows
+    for _ in range(3):
+        db.rebuild()
+    assert_build_equal(cb, bb)
+    cam = scenes.camera(160, 120, (0.0, 0.0, 240.0))
+    for _ in range(3):
+        cs.bvh_data.fill_u32(0x7FC00000, mirror=False)
+        ds.rebuild()
+    assert_build_equal(cs, bs)
+    ds.update(cam, mode=L.TRACE_FAST)
+    fast = ds.hits()
+    ds.update(cam, mode=L.TRACE_REFERENCE)
+    assert (fast["t"] == ds.hits()["t"]).all()
+    db.rebuild()
+    assert_build_equal(cb, bb)
+    ds.on_destroy()
+    db.on_destroy()
+
+
 def test_refit_race_stress(ctx):
     """Many small trees, repeated: the flag hand-off must never read a stale sibling box."""
     for rep in range(30):

@@ -959,7 +959,13 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
     mix((uint64_t)(uintptr_t)d_aabb); mix((uint64_t)(uintptr_t)d_internal); mix((uint64_t)(uintptr_t)d_leaf);
     mix((uint64_t)(uintptr_t)d_bvh); mix(flags);
     for (int k = 0; k < 3; k++) { uint32_t b; memcpy(&b, &h_box_min[k], 4); mix(b); memcpy(&b, &h_box_max[k], 4); mix(b); }
-    mix((uint64_t)(uintptr_t)ctx->fast_nodes); mix((uint64_t)(uintptr_t)ctx->fast_tree); mix((uint64_t)(uintptr_t)ctx->sort_scratch);
+    auto mix_scratch = [&](decltype(mix)& m) {      // every context-owned buffer the captured kernels point into
+        m((uint64_t)(uintptr_t)ctx->fast_nodes); m((uint64_t)(uintptr_t)ctx->fast_tris); m((uint64_t)(uintptr_t)ctx->fast_tree);
+        m((uint64_t)(uintptr_t)ctx->sort_scratch);
+        for (int l = 0; l < 2; l++) { m((uint64_t)(uintptr_t)ctx->scan_scratch[l]); m((uint64_t)(uintptr_t)ctx->refit_scratch[l]); }
+    };
+    const uint64_t args_key = key;
+    mix_scratch(mix);
     if (key == 0) key = 1;
     const bool graphs = ctx->own_stream && !ctx->prof_enabled && !ctx->build_graph_off;
     if (graphs && ctx->build_graph && ctx->build_graph_key == key) {
@@ -995,17 +1001,9 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
     const lbvh_status rc = build_scene_enqueue(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb,
                                                d_internal, d_leaf, d_bvh, flags);
     // the key includes the scratch pointers as they are AFTER this call
-    uint64_t key2 = key;
-    {
-        uint64_t k2 = 1469598103934665603ull;
-        auto mix2 = [&](uint64_t v) { for (int i = 0; i < 8; i++) { k2 ^= (v >> (8 * i)) & 0xFFu; k2 *= 1099511628211ull; } };
-        mix2((uint64_t)(uintptr_t)d_triangles); mix2(n); mix2(capacity); mix2((uint64_t)(uintptr_t)d_keys); mix2((uint64_t)(uintptr_t)d_indices);
-        mix2((uint64_t)(uintptr_t)d_aabb); mix2((uint64_t)(uintptr_t)d_internal); mix2((uint64_t)(uintptr_t)d_leaf);
-        mix2((uint64_t)(uintptr_t)d_bvh); mix2(flags);
-        for (int k = 0; k < 3; k++) { uint32_t b; memcpy(&b, &h_box_min[k], 4); mix2(b); memcpy(&b, &h_box_max[k], 4); mix2(b); }
-        mix2((uint64_t)(uintptr_t)ctx->fast_nodes); mix2((uint64_t)(uintptr_t)ctx->fast_tree); mix2((uint64_t)(uintptr_t)ctx->sort_scratch);
-        key2 = k2 ? k2 : 1;
-    }
+    key = args_key;
+    mix_scratch(mix);
+    const uint64_t key2 = key ? key : 1;
     ctx->build_seen_key = rc == LBVH_OK ? key2 : 0;
     return rc;
 }
