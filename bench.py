@@ -242,6 +242,18 @@ def main():
             drawer.rebuild(fast=(mode == L.TRACE_FAST))      # single-GPU build (no collective: the other ranks are past this)
         prof_build = {k: round(v[1] / 5.0, 4) for k, v in ctx.profile_end().items()}
 
+        # the reference's own stages alone (a-1 .. a-8: Morton, sort, DistributeKeys, tree, refit — SURVEY 8d's
+        # build_Mtri_s formula), without the derived traversal scene that `build_ms` also contains
+        for _ in range(2):
+            drawer.rebuild(fast=False)
+        e0, e1 = ctx.event(), ctx.event()
+        ctx.record(e0)
+        for _ in range(10):
+            drawer.rebuild(fast=False)
+        ctx.record(e1)
+        ref_build_ms = ctx.elapsed_ms(e0, e1) / 10.0
+        drawer.rebuild(fast=(mode == L.TRACE_FAST))
+
         # measured HBM copy rate of this box (float4 copy, 1 GiB)
         nbytes = 1 << 30
         a = DataBuffer(ctx, nbytes // 4, np.uint32)
@@ -293,6 +305,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall_ms, 4),
             "build_ms": round(build_ms_max, 4), "trace_ms": round(trace_ms_max, 4),
+            "build_reference_stages_ms": round(ref_build_ms, 4),
+            "build_reference_stages_Mtri_s": round(n_tris / (ref_build_ms * 1e-3) / 1e6, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32+u32", "data": "synthetic",
             "config": {"workload": ("cfg4: 16,000,000-triangle tiled bumpy torus (400x160 quads x 125 tiles, seed 2), sort "
