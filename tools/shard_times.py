@@ -5,7 +5,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unitysimpleraytracing_amd import _native as N, layouts as L, scenes
 from unitysimpleraytracing_amd.host import Context, DataBuffer, RaytracingMeshDrawer
-W, H = 1920, 1080
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 with Context(0) as ctx:
     d = RaytracingMeshDrawer(ctx, scenes.tiled_torus()).awake()
     cam = N.Camera.from_dict(scenes.camera(W, H, (0.0, 0.0, 250.0)))
