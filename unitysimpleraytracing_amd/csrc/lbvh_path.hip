@@ -2,6 +2,7 @@
 // step of a 1-spp path tracer (BASELINE configs[4]).  No reference counterpart: the reference traces
 // primary rays of a static mesh only.  Definitions: include/lbvh.h; bit-exact checker: oracle/.
 // Strict fp32 (-ffp-contract=off), no device trig, counter-based RNG.
+#include <algorithm>
 #include "lbvh_common.h"
 #include "lbvh_rt.h"
 
@@ -54,11 +55,13 @@ __global__ __launch_bounds__(256) void path_begin_kernel(lbvh_camera cam, lbvh_p
 // Secondary rays are incoherent, so the packet walk of lbvh_trace.hip does not apply: every lane walks on its
 // own (64-byte fused nodes, near child first, boxes beyond the best hit skipped) with its stack in LDS as
 // [entry][lane].  One wave per workgroup, no barriers.
-constexpr int kRayStack = 34;
+#ifndef LBVH_RAY_STACK
+#define LBVH_RAY_STACK 34
+#endif
+constexpr int kRayStack = LBVH_RAY_STACK;
 
 // Live rays only: alive_rays_kernel writes the miss record of every dead ray and compacts the indices of the live
-// ones (after the first bounce more than half of a frame's paths have left the scene), so every lane of every wave
-// here has a ray.  (Sorting the live rays by direction octant + Morton code of the origin on top of this was
+// ones (after the first bounce more than half of a frame's paths have left the scene).  (Sorting the live rays by direction octant + Morton code of the origin on top of this was
 // measured: the sort costs 0.15 ms per bounce and the walk does not get faster.)
 __global__ __launch_bounds__(256) void alive_rays_kernel(const lbvh_path_state* __restrict__ states, size_t count,
                                                          uint32_t* __restrict__ n_alive, uint32_t* __restrict__ list,
@@ -83,6 +86,17 @@ __global__ __launch_bounds__(256) void alive_rays_kernel(const lbvh_path_state* 
     if (alive) list[s_base + wave_ofs + mbcnt64(m)] = (uint32_t)i;
 }
 
+// One ray per lane; a wave owns a run of consecutive entries of the live-ray list and REFILLS a lane from it as
+// soon as that lane's ray is finished, so a wave's run time is the sum of its rays' steps / 64 and not the step
+// count of its longest ray (incoherent rays: mean ~100 steps, maxima of several hundred).  The grid is a fixed
+// number of waves (every wave slot of the chip once) and the live rays are dealt out evenly: at least 64 per wave.
+// Measured per frame of 4 bounces: no refill 3.75 ms; fixed runs of 128 / 256 / 512 rays 1.83 / 2.62 / 4.44 ms
+// (long runs leave most of the chip empty).
+#ifndef LBVH_RAY_WAVES
+#define LBVH_RAY_WAVES 8192
+#endif
+constexpr uint32_t kRayWaves = LBVH_RAY_WAVES;
+
 __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* __restrict__ states, const uint32_t* __restrict__ n_alive,
                                                         const uint32_t* __restrict__ list, float t_min,
                                                         const lbvh_fast_node* __restrict__ nodes,
@@ -90,21 +104,39 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* _
 {
     __shared__ uint32_t s_stack[kRayStack][LBVH_WAVE];
     const uint32_t lane = threadIdx.x;
-    const uint32_t k = blockIdx.x * LBVH_WAVE + lane;
-    if (k >= *n_alive) return;
-    const size_t i = list[k];
-    const float4* st = reinterpret_cast<const float4*>(&states[i]);
-    const float4 o = st[0], d = st[1];
-    float best_t = LBVH_MAX_FLOAT;
-    uint32_t best_tri = 0;
-    float best_u = 0.0f, best_v = 0.0f;
-    if (__float_as_uint(o.w) != 0u) {
-        ray_t ray;
-        ray.ox = o.x; ray.oy = o.y; ray.oz = o.z;
-        ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
-        ray.ix = 1.0f / d.x; ray.iy = 1.0f / d.y; ray.iz = 1.0f / d.z;
-        uint32_t sp = 0, node = 0;
-        for (;;) {
+    const uint32_t total = *n_alive;
+    const uint32_t run = max((total + gridDim.x - 1) / gridDim.x, (uint32_t)LBVH_WAVE);
+    uint32_t next = blockIdx.x * run;                      // scalar: next unclaimed entry of this wave's run
+    if (next >= total) return;
+    const uint32_t end = min(next + run, total);
+
+    bool active = false;
+    size_t i = 0;
+    ray_t ray = {};
+    float best_t = LBVH_MAX_FLOAT, best_u = 0.0f, best_v = 0.0f;
+    uint32_t best_tri = 0, sp = 0, node = 0;
+    for (;;) {
+        // refill idle lanes from the chunk
+        const uint64_t idle = __ballot(!active);
+        if (idle != 0 && next < end) {
+            if (!active) {
+                const uint32_t k = next + mbcnt64(idle);
+                if (k < end) {
+                    i = list[k];
+                    const float4* st = reinterpret_cast<const float4*>(&states[i]);
+                    const float4 o = st[0], d = st[1];
+                    ray.ox = o.x; ray.oy = o.y; ray.oz = o.z;
+                    ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
+                    ray.ix = 1.0f / d.x; ray.iy = 1.0f / d.y; ray.iz = 1.0f / d.z;
+                    best_t = LBVH_MAX_FLOAT; best_tri = 0; best_u = 0.0f; best_v = 0.0f;
+                    sp = 0; node = 0;
+                    active = true;
+                }
+            }
+            next += (uint32_t)__popcll(idle);
+        }
+        if (!__any(active)) break;
+        if (active) {
             const float4* nb = reinterpret_cast<const float4*>(&nodes[node]);
             const float4 lmin = nb[0], lmax = nb[1], rmin = nb[2], rmax = nb[3];
             const uint32_t lref = __float_as_uint(lmin.w), rref = __float_as_uint(lmax.w);
@@ -133,19 +165,20 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* _
                 node = lref;
             } else if (go_r) {
                 node = rref;
-            } else {
-                if (sp == 0) break;
+            } else if (sp != 0) {
                 sp--;
                 node = s_stack[sp][lane];
+            } else {
+                float4 out;
+                out.x = best_t;
+                out.y = __uint_as_float(best_tri);
+                out.z = best_u;
+                out.w = best_v;
+                reinterpret_cast<float4*>(hits)[i] = out;
+                active = false;
             }
         }
     }
-    float4 out;
-    out.x = best_t;
-    out.y = __uint_as_float(best_tri);
-    out.z = best_u;
-    out.w = best_v;
-    reinterpret_cast<float4*>(hits)[i] = out;
 }
 
 // ---- bounce ----------------------------------------------------------------------------------------------
@@ -278,8 +311,8 @@ lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, 
     uint32_t* list = (uint32_t*)((char*)ctx->ray_scratch + 256);
     LBVH_HIP_TRY(ctx, hipMemsetAsync(n_alive, 0, 4, ctx->cur_stream));
     LBVH_LAUNCH(ctx, alive_rays_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), d_states, count, n_alive, list, d_hits);
-    // the launch covers every ray; waves beyond the live count leave at once
-    LBVH_LAUNCH(ctx, trace_rays_kernel, dim3((unsigned)((count + LBVH_WAVE - 1) / LBVH_WAVE)), dim3(LBVH_WAVE), d_states, n_alive,
+    const uint32_t ray_waves = (uint32_t)std::min<size_t>(kRayWaves, (count + LBVH_WAVE - 1) / LBVH_WAVE);
+    LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive,
                 list, t_min, ctx->fast_nodes, ctx->fast_tris, d_hits);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
