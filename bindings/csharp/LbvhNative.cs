@@ -73,6 +73,8 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern int lbvh_trace_rays(IntPtr ctx, IntPtr dStates, UIntPtr count, float tMin, ref Scene scene, IntPtr dHits);
     [DllImport(Lib)] public static extern int lbvh_path_scatter(IntPtr ctx, ref Scene scene, IntPtr dHits, UIntPtr count, uint bounce, uint seed,
         float albedo, IntPtr dStates);
+    [DllImport(Lib)] public static extern int lbvh_path_bounce(IntPtr ctx, ref Scene scene, IntPtr dStates, IntPtr dHits, UIntPtr count,
+        uint bounce, uint seed, float albedo, float tMin);
     [DllImport(Lib)] public static extern int lbvh_path_resolve(IntPtr ctx, IntPtr dStates, UIntPtr count, IntPtr dRgba16f);
 
     // local kernels of the multi-GPU key-range sharded sort (BASELINE configs[3])

@@ -377,6 +377,14 @@ lbvh_status lbvh_path_begin(lbvh_context* ctx, const lbvh_camera* h_camera, lbvh
 lbvh_status lbvh_path_scatter(lbvh_context* ctx, const lbvh_scene* h_scene, const lbvh_hit* d_hits, size_t count,
                               uint32_t bounce, uint32_t seed, float albedo, lbvh_path_state* d_states);
 
+/* lbvh_path_scatter for bounce `bounce` followed by lbvh_trace_rays for the next segment of the paths that go on,
+ * as one call: the scatter kernel itself lists those paths, so no pass over all path states is needed before the
+ * trace.  d_hits holds the hit records of the segment just traced on entry and those of the next segment on
+ * return; records of finished paths are left as they are (a path ends on a miss, so they already read "miss").
+ * Same results as the two calls. */
+lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_path_state* d_states, lbvh_hit* d_hits,
+                             size_t count, uint32_t bounce, uint32_t seed, float albedo, float t_min);
+
 /* radiance (+ alpha) of the path states as RGBA16F, the reference's render-target format. */
 lbvh_status lbvh_path_resolve(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, uint16_t* d_rgba16f);
 

@@ -85,6 +85,7 @@ SIGNATURES = {
     "lbvh_trace_rays": (_I32, [_P, _P, _SZ, C.c_float, C.POINTER(Scene), _P]),
     "lbvh_path_begin": (_I32, [_P, C.POINTER(Camera), _P]),
     "lbvh_path_scatter": (_I32, [_P, C.POINTER(Scene), _P, _SZ, _U32, _U32, C.c_float, _P]),
+    "lbvh_path_bounce": (_I32, [_P, C.POINTER(Scene), _P, _P, _SZ, _U32, _U32, C.c_float, C.c_float]),
     "lbvh_path_resolve": (_I32, [_P, _P, _SZ, _P]),
     "lbvh_trace_tile_costs": (_I32, [_P, C.POINTER(Camera), C.POINTER(Scene), _P, _P, _P]),
     "lbvh_shade": (_I32, [_P, _P, _SZ, _P, _P, _I32, _I32, _P]),

@@ -195,15 +195,43 @@ __device__ __forceinline__ float path_rnd(uint32_t seed, uint32_t index, uint32_
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
+// one path's bounce; returns true when the path goes on
+__device__ __forceinline__ bool scatter_path(const lbvh_triangle* __restrict__ triangles, const lbvh_hit* __restrict__ hits, size_t i,
+                                             uint32_t bounce, uint32_t seed, float albedo, lbvh_path_state* __restrict__ states);
+
+// LIST: also append the indices of the paths that go on (one global atomic per workgroup), so that the next
+// segment is traced without a separate pass over all path states
+template <bool LIST>
 __global__ __launch_bounds__(256) void path_scatter_kernel(const lbvh_triangle* __restrict__ triangles,
                                                            const lbvh_hit* __restrict__ hits, size_t count, uint32_t bounce,
-                                                           uint32_t seed, float albedo, lbvh_path_state* __restrict__ states)
+                                                           uint32_t seed, float albedo, lbvh_path_state* __restrict__ states,
+                                                           uint32_t* __restrict__ n_alive, uint32_t* __restrict__ list)
 {
+    __shared__ uint32_t s_n, s_base;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+    if (LIST) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+    }
+    const bool on = i < count && scatter_path(triangles, hits, i, bounce, seed, albedo, states);
+    if (LIST) {
+        const uint64_t m = __ballot(on);
+        uint32_t wave_ofs = 0;
+        if (lane_id() == 0 && m) wave_ofs = atomicAdd(&s_n, (uint32_t)__popcll(m));
+        wave_ofs = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_ofs);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_n) s_base = __hip_atomic_fetch_add(n_alive, s_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (on) list[s_base + wave_ofs + mbcnt64(m)] = (uint32_t)i;
+    }
+}
+
+__device__ __forceinline__ bool scatter_path(const lbvh_triangle* __restrict__ triangles, const lbvh_hit* __restrict__ hits, size_t i,
+                                             uint32_t bounce, uint32_t seed, float albedo, lbvh_path_state* __restrict__ states)
+{
     float4* st = reinterpret_cast<float4*>(&states[i]);
     float4 o = st[0], d = st[1], thr = st[2], rad = st[3];
-    if (__float_as_uint(o.w) == 0u) return;
+    if (__float_as_uint(o.w) == 0u) return false;
     const float4 h = reinterpret_cast<const float4*>(hits)[i];
     if (!(h.x < LBVH_MAX_FLOAT)) {
         const float sk = 0.5f * (d.y + 1.0f);
@@ -213,7 +241,7 @@ __global__ __launch_bounds__(256) void path_scatter_kernel(const lbvh_triangle* 
         o.w = __uint_as_float(0u);
         st[0] = o;
         st[3] = rad;
-        return;
+        return false;
     }
     if (bounce == 0) rad.w = 1.0f;
     const float4* tp = reinterpret_cast<const float4*>(&triangles[__float_as_uint(h.y)]);
@@ -243,6 +271,7 @@ __global__ __launch_bounds__(256) void path_scatter_kernel(const lbvh_triangle* 
     if (dl > 1e-6f) { vx = vx / dl; vy = vy / dl; vz = vz / dl; } else { vx = nx; vy = ny; vz = nz; }
     d.x = vx; d.y = vy; d.z = vz;
     st[0] = o; st[1] = d; st[2] = thr; st[3] = rad;
+    return true;
 }
 
 __global__ __launch_bounds__(256) void path_resolve_kernel(const lbvh_path_state* __restrict__ states, size_t count,
@@ -325,8 +354,32 @@ lbvh_status lbvh_path_scatter(lbvh_context* ctx, const lbvh_scene* h_scene, cons
     if (count == 0) return LBVH_OK;
     LBVH_REQUIRE(ctx, h_scene != nullptr && h_scene->triangles != nullptr && d_hits != nullptr && d_states != nullptr);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    LBVH_LAUNCH(ctx, path_scatter_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), h_scene->triangles, d_hits, count,
-                bounce, seed, albedo, d_states);
+    LBVH_LAUNCH(ctx, path_scatter_kernel<false>, dim3((unsigned)((count + 255) / 256)), dim3(256), h_scene->triangles, d_hits, count,
+                bounce, seed, albedo, d_states, nullptr, nullptr);
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_path_state* d_states, lbvh_hit* d_hits,
+                             size_t count, uint32_t bounce, uint32_t seed, float albedo, float t_min)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    if (count == 0) return LBVH_OK;
+    LBVH_REQUIRE(ctx, h_scene != nullptr && h_scene->triangles != nullptr && d_hits != nullptr && d_states != nullptr);
+    LBVH_REQUIRE(ctx, ((uintptr_t)d_states & 15) == 0 && ((uintptr_t)d_hits & 15) == 0 && count <= 0xFFFFFFFFull);
+    if (!ctx->fast_nodes || ctx->fast_n != h_scene->n)
+        return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_path_bounce", "needs lbvh_build_fast_scene on this scene first");
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = lbvh_reserve(ctx, &ctx->ray_scratch, &ctx->ray_scratch_bytes, 256 + count * 4);
+    if (rc != LBVH_OK) return rc;
+    uint32_t* n_alive = (uint32_t*)ctx->ray_scratch;
+    uint32_t* list = (uint32_t*)((char*)ctx->ray_scratch + 256);
+    LBVH_HIP_TRY(ctx, hipMemsetAsync(n_alive, 0, 4, ctx->cur_stream));
+    LBVH_LAUNCH(ctx, path_scatter_kernel<true>, dim3((unsigned)((count + 255) / 256)), dim3(256), h_scene->triangles, d_hits, count,
+                bounce, seed, albedo, d_states, n_alive, list);
+    const uint32_t ray_waves = (uint32_t)std::min<size_t>(kRayWaves, (count + LBVH_WAVE - 1) / LBVH_WAVE);
+    LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, ctx->fast_nodes,
+                ctx->fast_tris, d_hits);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }

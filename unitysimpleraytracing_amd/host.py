@@ -400,11 +400,12 @@ class DynamicPathTracer:
         # primary rays: the coherent packet kernel
         N.check(h, N.lib.lbvh_trace_primary(h, C.byref(cam), 0, 0, cam.screen_width, cam.screen_height, C.byref(s),
                                             L.TRACE_FAST, self.hits.device, None))
-        N.check(h, N.lib.lbvh_path_scatter(h, C.byref(s), self.hits.device, count, 0, self.seed, self.albedo, self.states.device))
-        for b in range(1, bounces + 1):
-            N.check(h, N.lib.lbvh_trace_rays(h, self.states.device, count, self.t_min, C.byref(s), self.hits.device))
-            N.check(h, N.lib.lbvh_path_scatter(h, C.byref(s), self.hits.device, count, b, self.seed, self.albedo,
-                                               self.states.device))
+        # bounce b = scatter at the hits of segment b + trace of segment b + 1 (one call); the last bounce only scatters
+        for b in range(bounces):
+            N.check(h, N.lib.lbvh_path_bounce(h, C.byref(s), self.states.device, self.hits.device, count, b, self.seed,
+                                              self.albedo, self.t_min))
+        N.check(h, N.lib.lbvh_path_scatter(h, C.byref(s), self.hits.device, count, bounces, self.seed, self.albedo,
+                                           self.states.device))
         N.check(h, N.lib.lbvh_path_resolve(h, self.states.device, count, self.image_buf.device))
         self._shape = (cam.screen_height, cam.screen_width)
         return self.image_buf

@@ -319,11 +319,9 @@ public:
         lbvh_path_state* st = (lbvh_path_state*)states_->DeviceBuffer();
         lbvh_hit* hits = (lbvh_hit*)drawer_.Hits().DeviceBuffer();
         check(ctx_.get(), lbvh_path_begin(ctx_.get(), &cam, st));
-        check(ctx_.get(), lbvh_path_scatter(ctx_.get(), &s, hits, rays, 0, seed_, albedo_, st));
-        for (uint32_t b = 1; b <= bounces; ++b) {
-            check(ctx_.get(), lbvh_trace_rays(ctx_.get(), st, rays, t_min_, &s, hits));
-            check(ctx_.get(), lbvh_path_scatter(ctx_.get(), &s, hits, rays, b, seed_, albedo_, st));
-        }
+        for (uint32_t b = 0; b < bounces; ++b)          // scatter at segment b's hits + trace of segment b + 1
+            check(ctx_.get(), lbvh_path_bounce(ctx_.get(), &s, st, hits, rays, b, seed_, albedo_, t_min_));
+        check(ctx_.get(), lbvh_path_scatter(ctx_.get(), &s, hits, rays, bounces, seed_, albedo_, st));
         check(ctx_.get(), lbvh_path_resolve(ctx_.get(), st, rays, (uint16_t*)image_->DeviceBuffer()));
     }
     DataBuffer<uint64_t>& Image() { return *image_; }
