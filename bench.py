@@ -15,7 +15,7 @@ A step = one full pass of the hot path with the triangles already resident in HB
     primary-ray traversal of the frame (Update(), :76-84).
 Nothing is skipped or cached between steps (the tree is rebuilt from the triangles every step).
 With N GPUs the BVH is replicated (every rank builds the whole tree) and the 1080p frame is
-sharded across ranks in 64x64-pixel (64x16 beyond 2 ranks) blocks dealt round-robin (lbvh_trace_primary_shard,
+sharded across ranks in interleaved groups of 8 adjacent 8x8-pixel tiles (lbvh_trace_primary_shard,
 one launch per rank); no collective touches the data path.
 
 The JSON line carries both halves of the metric: `value` = primary Mrays/s = rays of the whole
@@ -60,26 +60,21 @@ def parse():
     return ap.parse_args()
 
 
-TILE_W, TILE_H, GROUP_W = 8, 8, 8      # LBVH_TRACE_FAST packet size; tiles per shard group in x
+TILE_W, TILE_H, SHARD_GROUP = 8, 8, 8      # LBVH_TRACE_FAST packet size and the tile group lbvh_trace_primary_shard deals
 
 
-def shard_tiles(shard_index, shard_count, width, height, tile_w=TILE_W, tile_h=TILE_H, group_w=GROUP_W, group_h=None):
-    """Python mirror of lbvh_trace_primary_shard's ownership rule (csrc/lbvh_trace.hip shard_tile): groups of
-    group_w x group_h tiles (group_h = 8 up to 2 shards, 2 beyond), numbered row-major over the frame, dealt
-    round-robin to the shards.  Returns the (x0, y0, x1, y1) pixel rectangles of the shard's tiles."""
-    if group_h is None:
-        group_h = 8 if shard_count <= 2 else 2
+def shard_tiles(shard_index, shard_count, width, height, tile_w=TILE_W, tile_h=TILE_H, group=SHARD_GROUP):
+    """Python mirror of lbvh_trace_primary_shard's ownership rule (csrc/lbvh_trace.hip shard_tile):
+    tiles of the full frame in row-major order, dealt to shards in groups of `group` adjacent tiles.
+    Returns the (x0, y0, x1, y1) pixel rectangles of the shard's tiles."""
     tiles_x = (width + tile_w - 1) // tile_w
     tiles_y = (height + tile_h - 1) // tile_h
-    groups_x = (tiles_x + group_w - 1) // group_w
-    groups_y = (tiles_y + group_h - 1) // group_h
+    n_tiles = tiles_x * tiles_y
     out = []
-    for g in range(shard_index, groups_x * groups_y, shard_count):
-        gy, gx = divmod(g, groups_x)
-        for j in range(group_w * group_h):
-            tx, ty = gx * group_w + j % group_w, gy * group_h + j // group_w
-            if tx < tiles_x and ty < tiles_y:
-                out.append((tx * tile_w, ty * tile_h, min((tx + 1) * tile_w, width), min((ty + 1) * tile_h, height)))
+    for g in range(shard_index, (n_tiles + group - 1) // group, shard_count):
+        for t in range(g * group, min((g + 1) * group, n_tiles)):
+            ty, tx = divmod(t, tiles_x)
+            out.append((tx * tile_w, ty * tile_h, min((tx + 1) * tile_w, width), min((ty + 1) * tile_h, height)))
     return out
 
 
@@ -161,7 +156,7 @@ def main():
     ccam = N.Camera.from_dict(cam)
 
     def trace_frame():
-        # this rank's share of the frame (every world-th block of tiles), one launch
+        # this rank's share of the frame (every world-th group of 8 adjacent 8x8-pixel tiles), one launch
         s = drawer.container.scene()
         N.check(ctx.handle, N.lib.lbvh_trace_primary_shard(ctx.handle, C.byref(ccam), rank, world, C.byref(s), mode,
                                                            hit_buf.device, None))
@@ -226,6 +221,9 @@ def main():
         N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s),
                                                      L.TRACE_REFERENCE, full.device, stats_buf.device))
         rs = stats_buf.get_data()[0]
+        # guard: the fast mode (after the timed steps: cost-ordered dispatch, history) found exactly the reference's hits
+        if int(rs["hits"]) != int(st["hits"]):
+            raise SystemExit(f"fast-mode hit count {int(st['hits'])} != reference-mode hit count {int(rs['hits'])}")
         bytes_per_ray = (32.0 * float(rs["pops"]) + 24.0 * float(rs["box_hits"]) + 44.0 * float(rs["leaf_tests"])
                          + 48.0 * float(rs["tri_tests"])) / (W * H) + 8.0
         ref_counts = {k: round(float(rs[k]) / (W * H), 3) for k in ("pops", "box_hits", "leaf_tests", "tri_tests")}
@@ -321,7 +319,7 @@ def main():
                                    "cfg2: 1,000,000-triangle tiled bumpy torus (seed 2), 1920x1080 primary rays, "
                                    "camera (0,0,250) fov 60; full LBVH rebuild + frame trace per step",
                        "triangles": n_tris, "rays": W * H, "trace_mode": args.mode,
-                       "sharding": f"rays in blocks of 8x8 (8x2 beyond 2 GPUs) tiles dealt round-robin over {world} GPU(s) (one launch per GPU), BVH replicated, "
+                       "sharding": f"rays in interleaved groups of 8 tiles over {world} GPU(s) (one launch per GPU), BVH replicated, "
                                    "no collective",
                        "hit_fraction": round(hit_fraction, 4)},
             "roofline": roofline,

@@ -311,9 +311,8 @@ lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera,
                                lbvh_hit* d_hits, lbvh_trace_stats* d_stats);
 
 /* Ray sharding across GPUs in ONE launch per GPU: traces the pixels of shard `shard_index` of
- * `shard_count` of the FULL frame — every shard_count-th block of 8 x 8 packets (64 x 64 pixels;
- * 8 x 2 packets beyond 2 shards; blocks numbered row-major), so every shard samples the whole frame evenly —
- * and writes them at their full-frame
+ * `shard_count` of the FULL frame — every shard_count-th group of 8 adjacent 8x8-pixel tiles (a 64x8-
+ * pixel strip), so every shard samples the whole frame evenly — and writes them at their full-frame
  * positions d_hits[y * W + x]; pixels of other shards are not touched.  d_hits holds W*H records on
  * every GPU.  The BVH is replicated; no collective is involved.  The union over all shards equals
  * lbvh_trace_primary(0, 0, W, H). */

@@ -464,7 +464,8 @@ def test_repeated_frames_cost_ordered_and_cooperative_tiles(ctx):
     best hits in LDS.  Every frame must still equal the reference order's result."""
     tris = scenes.tiled_torus(nu=60, nv=40, grid=3)                 # 129 600 triangles
     d = H().RaytracingMeshDrawer(ctx, tris).awake()
-    for cam_z, res in ((140.0, (640, 360)), (60.0, (512, 512))):     # 3 600 / 4 096 tiles: cooperative regime
+    # 3 600 / 4 096 tiles: the cooperative regime; 32 400 tiles: a full chip (XCD regions)
+    for cam_z, res in ((140.0, (640, 360)), (60.0, (512, 512)), (150.0, (1920, 1080))):
         cam = scenes.camera(res[0], res[1], (3.0, -2.0, cam_z))
         d.update(cam, mode=L.TRACE_REFERENCE)
         ref = d.hits()

@@ -35,37 +35,20 @@ struct trace_args {
 };
 
 constexpr int kOrderClasses = 16;         // cost classes of the packet dispatch order
-// Work items are tiles in GROUP-major order: a group is a block of 8 x group_h tiles, groups are numbered row-major
-// over the frame and dealt round-robin to the shards (GPUs).  Neighbouring tiles walk the same part of the tree,
-// so keeping them together in the work order — and, through the XCD regions below, on one L2 — matters more than
-// anything else in this kernel; the round-robin over the groups balances the shards.  Up to 2 shards the groups
-// are 64 x 64 pixels; with more shards a GPU's share is small enough for its heaviest tiles to decide its run
-// time, and flatter groups (64 x 16 pixels) spread those more evenly (1/8 of a 1080p frame: 129 -> 105 us).
-constexpr uint32_t kGroupW = 8;
-constexpr uint32_t kNoTile = 0xFFFFFFFFu;
+constexpr uint32_t kShardGroup = 8;      // adjacent tiles (one strip of the frame) that stay together
 
-__device__ __host__ __forceinline__ uint32_t group_height(uint32_t shard_count) { return shard_count <= 2u ? 8u : 2u; }
-
-// k-th work item of this shard -> tile of the rectangle (row-major index), or kNoTile for the part of an edge group
-// that lies outside the frame
-__device__ __host__ __forceinline__ uint32_t shard_tile(uint32_t k, uint32_t tiles_x, uint32_t tiles_y, uint32_t shard_index,
-                                                        uint32_t shard_count)
+// k-th work item of this shard -> tile of the rectangle (row-major); identity for shard_count == 1
+__device__ __host__ __forceinline__ uint32_t shard_tile(uint32_t k, uint32_t shard_index, uint32_t shard_count)
 {
-    const uint32_t gh = group_height(shard_count), gt = kGroupW * gh;
-    const uint32_t groups_x = (tiles_x + kGroupW - 1) / kGroupW;
-    const uint32_t g = (k / gt) * shard_count + shard_index;
-    const uint32_t gy = g / groups_x, gx = g - gy * groups_x;
-    const uint32_t j = k % gt, tx = gx * kGroupW + j % kGroupW, ty = gy * gh + j / kGroupW;
-    return (tx < tiles_x && ty < tiles_y) ? ty * tiles_x + tx : kNoTile;
+    return ((k / kShardGroup) * shard_count + shard_index) * kShardGroup + k % kShardGroup;
 }
 
-// number of work items (tile slots of the owned groups) of a shard
-static inline uint32_t shard_work(uint32_t tiles_x, uint32_t tiles_y, uint32_t shard_index, uint32_t shard_count)
+// number of work items (tile slots, the last group may run past n_tiles) owned by a shard
+static inline uint32_t shard_work(uint32_t n_tiles, uint32_t shard_index, uint32_t shard_count)
 {
-    const uint32_t gh = group_height(shard_count);
-    const uint32_t groups = ((tiles_x + kGroupW - 1) / kGroupW) * ((tiles_y + gh - 1) / gh);
+    const uint32_t groups = (n_tiles + kShardGroup - 1) / kShardGroup;
     const uint32_t owned = groups > shard_index ? (groups - shard_index + shard_count - 1) / shard_count : 0;
-    return owned * kGroupW * gh;
+    return owned * kShardGroup;
 }
 
 // Workgroup id -> 8x8 pixel tile.  Workgroups are dealt round-robin over the 8 XCDs, so ids
@@ -119,7 +102,7 @@ __global__ __launch_bounds__(64) void trace_reference_kernel(trace_args a, lbvh_
 {
     __shared__ uint32_t s_stack[kStackDepth][LBVH_WAVE];
     const uint32_t lane = threadIdx.x;
-    const uint32_t tile = shard_tile(blockIdx.x, a.tiles_x, a.tiles_y, a.shard_index, a.shard_count);
+    const uint32_t tile = shard_tile(blockIdx.x, a.shard_index, a.shard_count);
     uint32_t px, py;
     const bool active = tile < a.tiles_x * a.tiles_y && tile_pixel(a, tile, lane, px, py);
 
@@ -263,46 +246,6 @@ __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh
 //     further passes (results merged per pixel by compare-and-swap) was built and measured: no gain over
 //     heaviest-first (0.49 ms either way), so it is not in the code.
 // ---------------------------------------------------------------------------------------------
-// XCD regions.  Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch), and each XCD has its own 4-MiB
-// L2: if the tiles an XCD walks come from all over the frame, every L2 sees the whole scene (112 MB of nodes and
-// triangles at 1 M triangles) and most fetches below the top levels miss it.  So the work items (row-major tiles)
-// are cut into 8 * kBandsPerXcd bands of consecutive items, band j belongs to region j % 8, and workgroup b only
-// takes tiles of region b % 8: the same kernel, 276 -> 137 us for the 1080p frame.  Each region has its own 16
-// class lists; the order inside a region is heaviest class first, as before.
-#ifndef LBVH_BANDS_PER_XCD
-#define LBVH_BANDS_PER_XCD 1
-#endif
-constexpr uint32_t kBandsPerXcd = LBVH_BANDS_PER_XCD;
-
-struct region_map {
-    uint32_t regions;      // 8 (one per XCD) or 1 (no regions: small launches, see launch_packets)
-    uint32_t band_len;     // work items per band
-    uint32_t cap;          // capacity of one class list of one region (= items per region, upper bound)
-};
-
-__host__ __device__ inline region_map make_region_map(uint32_t n_work, uint32_t regions)
-{
-    region_map m;
-    m.regions = regions;
-    const uint32_t bands = regions * (regions > 1 ? kBandsPerXcd : 1u);
-    m.band_len = (n_work + bands - 1u) / bands;
-    if (m.band_len == 0) m.band_len = 1;
-    m.cap = m.band_len * (bands / regions);
-    return m;
-}
-
-// the k-th tile of a region in dispatch order (heaviest class first), or kNoItem beyond its last one
-constexpr uint32_t kNoItem = 0xFFFFFFFFu;
-__device__ __forceinline__ uint32_t region_item(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ lists,
-                                                region_map rm, uint32_t region, uint32_t k)
-{
-    const uint32_t* rc = counts + region * kOrderClasses;
-    int c = kOrderClasses - 1;
-    for (; c > 0 && k >= rc[c]; c--) k -= rc[c];
-    if (k >= rc[c]) return kNoItem;
-    return lists[((size_t)region * kOrderClasses + c) * rm.cap + k];
-}
-
 struct uniform_node {        // one fused node, wave-uniform (lives in SGPRs)
     float4 lmin, lmax, rmin, rmax;
 };
@@ -472,7 +415,12 @@ __device__ __forceinline__ void tile_rays(const trace_args& a, uint32_t tile, ui
 constexpr int kCoopWaves = 8;
 constexpr int kHeavyClass = 7;             // cost classes >= this (>= 96 steps) are walked cooperatively
 constexpr uint32_t kCoopGrain = 32;        // steps of the last trace per cooperating wave
-constexpr uint32_t kCoopMaxWork = 12288;   // tiles per launch up to which heavy tiles are walked cooperatively (above: XCD regions)
+constexpr uint32_t kCoopMaxWork = 12288;   // tiles per launch up to which every heavy class is walked cooperatively
+constexpr uint32_t kSharedMaxWork = 24576; // ... and up to which the very heaviest are (beyond: one wave per tile only)
+#ifndef LBVH_HEAVY_CLASS_FULL
+#define LBVH_HEAVY_CLASS_FULL 10
+#endif
+constexpr uint32_t kHeavyClassFull = LBVH_HEAVY_CLASS_FULL;   // above that: only classes >= this (>= 256 steps)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 struct coop_params { uint32_t cap, first_class, grain; };
@@ -520,7 +468,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                                           coop_params heavy_cap, uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits,
                                           lbvh_trace_stats* stats, uint32_t* __restrict__ tile_cost)
 {
-    const uint32_t tile = shard_tile(w, a.tiles_x, a.tiles_y, a.shard_index, a.shard_count);
+    const uint32_t tile = shard_tile(w, a.shard_index, a.shard_count);
     if (w >= n_work || tile >= a.tiles_x * a.tiles_y) return;        // cannot happen for a heavy item
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     // as many waves as the tile's last step count is worth (about kCoopGrain steps each); the others leave now
@@ -688,7 +636,7 @@ __device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_
                                            uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits, lbvh_trace_stats* stats,
                                            uint32_t* __restrict__ tile_cost)
 {
-    const uint32_t tile = shard_tile(w, a.tiles_x, a.tiles_y, a.shard_index, a.shard_count);
+    const uint32_t tile = shard_tile(w, a.shard_index, a.shard_count);
     if (tile >= a.tiles_x * a.tiles_y) {                         // tail of the last group
         if (lane == 0) cost[w] = 0;
         return;
@@ -721,7 +669,7 @@ template <bool STATS>
 __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
                                                            const lbvh_fast_tri* __restrict__ tris, uint32_t n_work,
                                                            const uint32_t* __restrict__ counts, const uint32_t* __restrict__ lists,
-                                                           region_map rm, uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits,
+                                                           uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits,
                                                            lbvh_trace_stats* stats, uint32_t* __restrict__ tile_cost)
 {
     const uint32_t lane = lane_id();
@@ -737,35 +685,40 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
 }
 
 // One launch per frame share.  Workgroups of 8 waves; the hardware dispatcher hands them out in index order:
-//   * workgroups [0, 8 cap): the heavy tiles of the previous trace, one per workgroup, walked cooperatively
-//     (workgroup b: the (b / 8)-th heavy tile of region b % 8; workgroups beyond a region's heavy tiles leave at
-//     once) — at the FRONT of the grid, so they start first (as a second kernel on another stream they were
-//     starved by the light tiles' workgroups);
-//   * the rest: one tile per wave, the tiles of region b % 8 after its heavy ones, heaviest class first.
+//   * workgroups [0, cap): the heavy tiles of the previous trace, one per workgroup, walked cooperatively
+//     (workgroups beyond the actual number of heavy tiles leave at once) — at the FRONT of the grid, so they start
+//     first (as a second kernel on another stream they were starved by the light tiles' workgroups);
+//   * the rest: one tile per wave, the w-th tile of the class lists after the heavy ones, heaviest class first.
 template <bool STATS>
 __global__ __launch_bounds__(kCoopWaves * 64) void trace_shared_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
                                                                        const lbvh_fast_tri* __restrict__ tris, uint32_t n_work,
                                                                        const uint32_t* __restrict__ counts,
-                                                                       const uint32_t* __restrict__ lists, region_map rm,
-                                                                       coop_params heavy_cap, uint32_t* __restrict__ cost,
-                                                                       lbvh_hit* __restrict__ hits, lbvh_trace_stats* stats,
-                                                                       uint32_t* __restrict__ tile_cost)
+                                                                       const uint32_t* __restrict__ lists, coop_params heavy_cap,
+                                                                       uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits,
+                                                                       lbvh_trace_stats* stats, uint32_t* __restrict__ tile_cost)
 {
     __shared__ coop_shared S;
     const uint32_t lane = lane_id();
-    const uint32_t region = blockIdx.x % rm.regions;                 // = the XCD this workgroup runs on (8 regions)
-    const uint32_t heavy = heavy_items(counts + region * kOrderClasses, heavy_cap);    // heavy tiles of my region
-    if (blockIdx.x < rm.regions * heavy_cap.cap) {
-        const uint32_t k = blockIdx.x / rm.regions;
-        if (k >= heavy) return;                                      // uniform for the workgroup
-        const uint32_t w = region_item(counts, lists, rm, region, k);
-        if (w == kNoItem) return;
+    const uint32_t heavy = counts ? heavy_items(counts, heavy_cap) : 0u;
+    uint32_t w;
+    if (blockIdx.x < heavy_cap.cap) {
+        if (blockIdx.x >= heavy) return;                         // uniform for the workgroup
+        w = blockIdx.x;
+    } else {
+        w = (blockIdx.x - heavy_cap.cap) * (uint32_t)kCoopWaves + (threadIdx.x >> 6) + heavy;
+        if (w >= n_work) return;
+    }
+    if (counts) {        // the w-th item of the class lists, heaviest class first (they partition the work items)
+        uint32_t k = w;
+        int c = kOrderClasses - 1;
+        for (; c > 0 && k >= counts[c]; c--) k -= counts[c];
+        w = lists[(size_t)c * n_work + k];
+    }
+    if (blockIdx.x < heavy_cap.cap) {
         coop_tile<STATS>(S, a, nodes, tris, n_work, w, heavy_cap, cost, hits, stats, tile_cost);
         return;
     }
-    const uint32_t k = ((blockIdx.x - rm.regions * heavy_cap.cap) / rm.regions) * (uint32_t)kCoopWaves + (threadIdx.x >> 6) + heavy;
-    const uint32_t w = region_item(counts, lists, rm, region, k);
-    if (w == kNoItem) return;
+    if (w >= n_work) return;
     light_tile<STATS>(a, nodes, tris, w, lane, cost, hits, stats, tile_cost);
 }
 
@@ -784,22 +737,15 @@ __device__ __forceinline__ uint32_t order_class(uint32_t steps)
     return c > 15u ? 15u : c;
 }
 
-// One workgroup per 1024 consecutive work items of ONE band (bands are padded to a multiple of 1024 in the grid).
-__global__ __launch_bounds__(1024) void file_tiles_kernel(const uint32_t* __restrict__ cost, uint32_t n_work, region_map rm,
+__global__ __launch_bounds__(1024) void file_tiles_kernel(const uint32_t* __restrict__ cost, uint32_t n_work,
                                                           uint32_t* __restrict__ counts, uint32_t* __restrict__ lists)
 {
     __shared__ uint32_t s_count[kOrderClasses], s_base[kOrderClasses];
     const uint32_t t = threadIdx.x, lane = lane_id();
-    const uint32_t bpb = (rm.band_len + 1023u) / 1024u;          // workgroups per band
-    const uint32_t band = blockIdx.x / bpb;
-    const uint32_t i = band * rm.band_len + (blockIdx.x % bpb) * 1024u + t;
-    const bool valid = i < min((band + 1u) * rm.band_len, n_work);
-    const uint32_t region = band % rm.regions;
-    counts += region * kOrderClasses;
-    lists += (size_t)region * kOrderClasses * rm.cap;
+    const uint32_t i = blockIdx.x * 1024u + t;
     if (t < (uint32_t)kOrderClasses) s_count[t] = 0;
     __syncthreads();
-    const uint32_t cls = valid ? order_class(cost[i]) : 0xFFFFFFFFu;
+    const uint32_t cls = i < n_work ? order_class(cost[i]) : 0xFFFFFFFFu;
     uint64_t mine = 0;                                  // lanes of this wave in my class
     uint32_t wave_n = 0;                                // lane c < 16: this wave's items of class c
 #pragma unroll
@@ -816,7 +762,7 @@ __global__ __launch_bounds__(1024) void file_tiles_kernel(const uint32_t* __rest
     __syncthreads();
     if (cls != 0xFFFFFFFFu) {
         const uint32_t ofs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cls << 2), (int)wave_ofs);   // wave_ofs of lane `cls`
-        lists[(size_t)cls * rm.cap + s_base[cls] + ofs + mbcnt64(mine)] = i;
+        lists[(size_t)cls * n_work + s_base[cls] + ofs + mbcnt64(mine)] = i;
     }
 }
 
@@ -824,53 +770,46 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
 {
     a.tiles_x = (uint32_t)(a.x1 - a.x0 + 7) / 8;
     a.tiles_y = (uint32_t)(a.y1 - a.y0 + 7) / 8;
-    const uint32_t n_work = shard_work(a.tiles_x, a.tiles_y, a.shard_index, a.shard_count);
+    const uint32_t n_work = shard_work(a.tiles_x * a.tiles_y, a.shard_index, a.shard_count);
     if (n_work == 0) return LBVH_OK;
-    // [class counts of the 8 regions (1 KB) | cost of each work item in the last trace | 8 x 16 class lists]:
-    // valid for one frame layout
-    // XCD regions pay when the launch fills the chip (a whole 1080p frame: 276 -> 137 us); a small launch (one GPU's
-    // share of a multi-GPU frame) is better off with one global heaviest-first order and cooperative heavy tiles
-    // (1/8 of the frame: 103 us against 146 us with regions)
-    const bool full_chip = n_work > kCoopMaxWork;
-    const region_map rm = make_region_map(n_work, full_chip ? 8u : 1u);
+    // [class counts | cost of each work item in the last trace | 16 class lists]: valid for one frame layout
     const size_t cost_bytes = (((size_t)n_work * 4) + 255) & ~(size_t)255;
-    const size_t lists_bytes = (size_t)rm.regions * kOrderClasses * rm.cap * 4;
     void* before = ctx->trace_queues;
-    int rc = lbvh_reserve(ctx, &ctx->trace_queues, &ctx->trace_queues_bytes, 1024 + cost_bytes + lists_bytes);
+    int rc = lbvh_reserve(ctx, &ctx->trace_queues, &ctx->trace_queues_bytes, 256 + cost_bytes + (size_t)kOrderClasses * cost_bytes);
     if (rc != LBVH_OK) return rc;
     if (ctx->trace_queues != before) ctx->trace_history = false;
     uint32_t* counts = (uint32_t*)ctx->trace_queues;
-    uint32_t* cost = (uint32_t*)((char*)ctx->trace_queues + 1024);
-    uint32_t* lists = (uint32_t*)((char*)ctx->trace_queues + 1024 + cost_bytes);
+    uint32_t* cost = (uint32_t*)((char*)ctx->trace_queues + 256);
+    uint32_t* lists = (uint32_t*)((char*)ctx->trace_queues + 256 + cost_bytes);
     const uint64_t layout = ((uint64_t)a.tiles_x << 48) ^ ((uint64_t)a.tiles_y << 32) ^ ((uint64_t)a.shard_index << 16) ^
                             (uint64_t)a.shard_count ^ ((uint64_t)(uint32_t)a.x0 << 8) ^ ((uint64_t)(uint32_t)a.y0 << 24);
     const bool have_history = ctx->trace_layout == layout && ctx->trace_layout_work == n_work && ctx->trace_history;
     if (have_history) {
-        LBVH_HIP_TRY(ctx, hipMemsetAsync(counts, 0, 1024, ctx->cur_stream));
-        const uint32_t bpb = (rm.band_len + 1023u) / 1024u;
-        LBVH_LAUNCH(ctx, file_tiles_kernel, dim3(((n_work + rm.band_len - 1u) / rm.band_len) * bpb), dim3(1024), cost, n_work, rm,
-                    counts, lists);
+        LBVH_HIP_TRY(ctx, hipMemsetAsync(counts, 0, 256, ctx->cur_stream));
+        LBVH_LAUNCH(ctx, file_tiles_kernel, dim3((n_work + 1023) / 1024), dim3(1024), cost, n_work, counts, lists);
     }
-    // Cooperative walking costs ~50 % more steps on the tiles it is used for (a subtree handed to another wave is
-    // walked before the near hits that would have pruned it are known), so it is for launches that do not fill
-    // the chip: every tile of 96 steps or more.
-    if (have_history && !full_chip) {
-        coop_params hp = {rm.cap / 4u + 1u, (uint32_t)kHeavyClass, kCoopGrain};
-        const uint32_t blocks = rm.regions * hp.cap + rm.regions * ((rm.cap + kCoopWaves - 1) / kCoopWaves);
+    // Which tiles are walked cooperatively (known from the last trace).  It costs ~50 % more steps on those tiles (a
+    // subtree handed to another wave is walked before the near hits that would have pruned it are known), so it is
+    // for under-filled launches — one GPU's share of a multi-GPU frame: every tile of 96 steps or more up to
+    // 12 288 tiles, only those of 256 steps or more up to 24 576, none beyond (1080p whole / half / quarter /
+    // eighth of the frame: 287 -> 275, 234 -> 190, 226 -> 170, 212 -> 103 us).
+    if (have_history && n_work <= kSharedMaxWork) {
+        coop_params hp = {n_work / 4u, n_work <= kCoopMaxWork ? (uint32_t)kHeavyClass : kHeavyClassFull, kCoopGrain};
+        const uint32_t blocks = hp.cap + (n_work + kCoopWaves - 1) / kCoopWaves;
         if (d_stats)
             LBVH_LAUNCH(ctx, trace_shared_kernel<true>, dim3(blocks), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris, n_work,
-                        counts, lists, rm, hp, cost, d_hits, d_stats, d_tile_cost);
+                        counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
         else
             LBVH_LAUNCH(ctx, trace_shared_kernel<false>, dim3(blocks), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris, n_work,
-                        counts, lists, rm, hp, cost, d_hits, d_stats, d_tile_cost);
+                        counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
     } else {
-        const uint32_t blocks = rm.regions * ((rm.cap + 3u) / 4u);
+        const uint32_t blocks = (n_work + 3) / 4;
         if (d_stats)
             LBVH_LAUNCH(ctx, trace_packet_kernel<true>, dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris, n_work,
-                        have_history ? counts : nullptr, lists, rm, cost, d_hits, d_stats, d_tile_cost);
+                        have_history ? counts : nullptr, lists, cost, d_hits, d_stats, d_tile_cost);
         else
             LBVH_LAUNCH(ctx, trace_packet_kernel<false>, dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris, n_work,
-                        have_history ? counts : nullptr, lists, rm, cost, d_hits, d_stats, d_tile_cost);
+                        have_history ? counts : nullptr, lists, cost, d_hits, d_stats, d_tile_cost);
     }
     ctx->trace_layout = layout;
     ctx->trace_layout_work = n_work;
@@ -1094,7 +1033,7 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
     a.shard_index = shard_index; a.shard_count = shard_count;
     a.tiles_x = (uint32_t)(x1 - x0 + 7) / 8;
     a.tiles_y = (uint32_t)(y1 - y0 + 7) / 8;
-    const uint32_t n_tiles = shard_work(a.tiles_x, a.tiles_y, shard_index, shard_count);
+    const uint32_t n_tiles = shard_work(a.tiles_x * a.tiles_y, shard_index, shard_count);
     if (d_stats) LBVH_HIP_TRY(ctx, hipMemsetAsync(d_stats, 0, sizeof(lbvh_trace_stats), ctx->cur_stream));
 
     if (n_tiles == 0) return LBVH_OK;
