@@ -34,6 +34,7 @@ if args.no_check:
     ctx.close()
     sys.exit(0)
 stats = DataBuffer(ctx, 1, L.TRACE_STATS)
+hits.fill_u32(0x7FC00000, mirror=False)          # a tile left untraced must not pass on an earlier frame's values
 N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(cam), 0, 0, W, H, C.byref(s), mode, hits.device, stats.device))
 st = stats.get_data()[0]
 print("stats", {k: int(st[k]) for k in st.dtype.names}, "visits/ray", float(st["pops"]) / (W * H))
