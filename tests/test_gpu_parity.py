@@ -437,13 +437,15 @@ def test_shards_union_equals_the_full_frame(ctx, shards):
     full = d.hits()
     stitched = np.zeros_like(full)
     for r in range(shards):
-        d._hits.fill_u32(0xFFFFFFFF)
-        d.update_shard(cam, r, shards, mode=L.TRACE_FAST)
-        part = d.hits()
         owned = np.zeros(full.shape, dtype=bool)
         for x0, y0, x1, y1 in shard_tiles(r, shards, 250, 131):
             owned[y0:y1, x0:x1] = True
-        assert (part.view(np.uint32).reshape(131, 250, 4)[~owned] == 0xFFFFFFFF).all()     # other shards' pixels untouched
+        for frame in range(3):        # frames 2, 3 of a shard use its dispatch history (and cooperative tiles)
+            d._hits.fill_u32(0xFFFFFFFF)
+            d.update_shard(cam, r, shards, mode=L.TRACE_FAST)
+            part = d.hits()
+            assert (part.view(np.uint32).reshape(131, 250, 4)[~owned] == 0xFFFFFFFF).all()     # other shards' pixels untouched
+            assert (part[owned] == full[owned]).all()
         stitched[owned] = part[owned]
     assert (stitched == full).all()
     # reference mode shards too (8x8 tiles): union equals its full frame
