@@ -193,6 +193,18 @@ def main():
 
     # ---- untimed extras (rank 0 prints them) ---------------------------------------------------
     out = None
+    # every rank: hits found in its own share of the frame (one more launch of the timed trace, with counters);
+    # summed over the ranks they must equal the whole frame's hit count in reference order (checked on rank 0)
+    share_stats = DataBuffer(ctx, 1, L.TRACE_STATS)
+    s_all = drawer.container.scene()
+    N.check(ctx.handle, N.lib.lbvh_trace_primary_shard(ctx.handle, C.byref(ccam), rank, world, C.byref(s_all), mode,
+                                                       hit_buf.device, share_stats.device))
+    share_hits = int(share_stats.get_data()[0]["hits"])
+    if dist is not None:
+        import torch
+        t_h = torch.tensor([float(share_hits)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t_h)
+        share_hits = int(t_h.item())
     sharded_sort_check = None
     if sorter is not None and rank == 0:
         # the timed steps left the sharded sort's result in the container: compare it with the one-GPU sort
@@ -222,8 +234,8 @@ def main():
                                                      L.TRACE_REFERENCE, full.device, stats_buf.device))
         rs = stats_buf.get_data()[0]
         # guard: the fast mode (after the timed steps: cost-ordered dispatch, history) found exactly the reference's hits
-        if int(rs["hits"]) != int(st["hits"]):
-            raise SystemExit(f"fast-mode hit count {int(st['hits'])} != reference-mode hit count {int(rs['hits'])}")
+        if int(rs["hits"]) != int(st["hits"]) or int(rs["hits"]) != share_hits:
+            raise SystemExit(f"hit counts differ: fast {int(st['hits'])}, all shards {share_hits}, reference {int(rs['hits'])}")
         bytes_per_ray = (32.0 * float(rs["pops"]) + 24.0 * float(rs["box_hits"]) + 44.0 * float(rs["leaf_tests"])
                          + 48.0 * float(rs["tri_tests"])) / (W * H) + 8.0
         ref_counts = {k: round(float(rs[k]) / (W * H), 3) for k in ("pops", "box_hits", "leaf_tests", "tri_tests")}
