@@ -491,6 +491,27 @@ def test_repeated_frames_cost_ordered_and_cooperative_tiles(ctx):
     d.on_destroy()
 
 
+def test_odd_frame_sizes_repeated(ctx):
+    """Frame sizes around the tile / group / wave-count boundaries, each traced three times into a poisoned buffer
+    (the second and third frame run the cost-ordered / cooperative scheduling): every pixel equals reference order."""
+    tris = scenes.tiled_torus(nu=30, nv=20, grid=3)
+    d = H().RaytracingMeshDrawer(ctx, tris).awake()
+    rng = np.random.default_rng(77)
+    sizes = [(1, 1), (7, 9), (8, 8), (9, 8), (64, 64), (65, 63), (257, 129), (511, 3), (3, 400)]
+    sizes += [(int(rng.integers(1, 400)), int(rng.integers(1, 300))) for _ in range(6)]
+    for w, h in sizes:
+        cam = scenes.camera(w, h, (2.0, 1.0, 130.0))
+        d.update(cam, mode=L.TRACE_REFERENCE)
+        ref = d.hits()
+        for frame in range(3):
+            d.update(cam, mode=L.TRACE_FAST)
+            got = d.hits()
+            assert (got["t"] == ref["t"]).all(), (w, h, frame)
+            same = got["tri"] == ref["tri"]
+            assert (got["u"][same] == ref["u"][same]).all() and (got["v"][same] == ref["v"][same]).all()
+    d.on_destroy()
+
+
 def test_camera_inside_the_scene_and_negative_t(ctx):
     """The reference accepts t < 0 hits (no t > 0 test, Raytracing.compute:70) when the leaf box
     straddles the origin; both traversal modes must keep that."""

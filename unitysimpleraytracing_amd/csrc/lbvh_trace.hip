@@ -760,10 +760,10 @@ __global__ __launch_bounds__(1024) void file_tiles_kernel(const uint32_t* __rest
     if (t < (uint32_t)kOrderClasses && s_count[t])
         s_base[t] = __hip_atomic_fetch_add(&counts[t], s_count[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (cls != 0xFFFFFFFFu) {
-        const uint32_t ofs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cls << 2), (int)wave_ofs);   // wave_ofs of lane `cls`
-        lists[(size_t)cls * n_work + s_base[cls] + ofs + mbcnt64(mine)] = i;
-    }
+    // wave_ofs of lane `cls` — read with EVERY lane active: ds_bpermute returns 0 for a disabled source lane, and in the
+    // ragged last wave the lanes holding the offsets of the higher classes have no item of their own
+    const uint32_t ofs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((cls & 15u) << 2), (int)wave_ofs);
+    if (cls != 0xFFFFFFFFu) lists[(size_t)cls * n_work + s_base[cls] + ofs + mbcnt64(mine)] = i;
 }
 
 int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_cost)
