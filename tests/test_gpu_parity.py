@@ -712,3 +712,23 @@ def test_secondary_rays_and_path_trace_bit_exact(ctx):
     assert (gh["t"] == oh["t"]).all()
     assert ((gh["tri"] == oh["tri"]) | (gh["t"] == oh["t"])).all()
     pt.drawer.on_destroy()
+
+
+@pytest.mark.parametrize("res", [(1, 1), (5, 3), (63, 1), (65, 9)])
+def test_path_trace_tiny_frames(ctx, res):
+    """Ray counts below / around one wave: live-ray compaction, lane refill and lbvh_path_bounce at the edges."""
+    tris, body, centres = scenes.tiled_torus(nu=16, nv=10, grid=2, with_bodies=True)
+    pt = H().DynamicPathTracer(ctx, tris, body, centres, t_min=1e-3, albedo=0.7, seed=9)
+    pt.animate(0.2)
+    moved = O.animate(tris, body, centres, 0.2)
+    b = O.Built(moved, capacity=pt.drawer.container.capacity, threads=4)
+    cam = scenes.camera(res[0], res[1], (0.0, 0.0, 70.0))
+    for frame in range(2):
+        pt.render(cam, bounces=3)
+        img = pt.image()
+        oimg, ost = O.path_trace(b, cam, bounces=3, t_min=1e-3, albedo=0.7, seed=9, threads=4)
+        gst = pt.states.get_data()[: res[0] * res[1]]
+        same = (gst["origin"] == ost["origin"]).all(axis=1) & (gst["dir"] == ost["dir"]).all(axis=1)
+        assert same.mean() > 0.98 or same.size < 64
+        assert (img.view(np.uint16).reshape(-1, 4)[same] == oimg.view(np.uint16).reshape(-1, 4)[same]).all()
+    pt.drawer.on_destroy()
