@@ -68,7 +68,8 @@ def gpu_sort(ctx, keys, vals):
 
 
 @pytest.mark.parametrize("count", [1, 2, 63, 64, 65, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 12289, 100003,
-                                   524288, 1000000 + 37])
+                                   524288, 1000000 + 37, (1 << 21) - 1, 1 << 21, (1 << 21) + 1, 8192 * 129 - 5,
+                                   4096 * 1024 + 4095, 3 * 8192 * 16 * 8 + 1])
 def test_sort_random_sizes(ctx, count):
     keys, vals = sort_inputs(count, count, "random")
     gk, gv = gpu_sort(ctx, keys, vals)
@@ -298,6 +299,27 @@ def test_build_scene_graph_replay_survives_other_scenes_and_scratch_growth(ctx):
     assert_build_equal(cb, bb)
     ds.on_destroy()
     db.on_destroy()
+
+
+@pytest.mark.parametrize("n", [2, 3, 63, 64, 65, 1023, 1024, 1025, 2047, 2048, 2049, 4097, 16383, 16385, 65537, 131071])
+def test_build_at_boundary_sizes(ctx, n):
+    """Triangle counts around the wave / workgroup / refit-block / range-level boundaries, through the staged calls
+    and twice through lbvh_build_scene (second call = graph replay), every array compared with the oracle."""
+    tris = scenes.random_triangles(n, seed=1000 + n, extent=100.0, edge=2.5)
+    d, c, b = build_both(ctx, tris)
+    assert_build_equal(c, b)
+    for _ in range(2):
+        c.bvh_data.fill_u32(0x7FC00000, mirror=False)
+        c.keys.fill_u32(0, mirror=False)
+        d.rebuild()
+        assert_build_equal(c, b)
+    cam = scenes.camera(96, 64, (0.0, 0.0, 260.0))
+    d.update(cam, mode=L.TRACE_REFERENCE)
+    ref = d.hits()
+    for _ in range(2):
+        d.update(cam, mode=L.TRACE_FAST)
+        assert (d.hits()["t"] == ref["t"]).all()
+    d.on_destroy()
 
 
 def test_refit_race_stress(ctx):
