@@ -312,29 +312,42 @@ struct refit_levels_t {
     int levels;
 };
 
-// sorted_indices == nullptr: tri_aabb is already in sorted (leaf) order
+// sorted_indices == nullptr: tri_aabb is already in sorted (leaf) order.
+// FUSED (the derived traversal tree): every node finished here is written as the 64-byte traversal node holding
+// its two CHILDREN's boxes — both are in the merging thread's hands — instead of its own box; own boxes go to bvh[]
+// only where a frontier node will need them as a child box (fuse_frontier_kernel).
+template <bool FUSED>
 __global__ __launch_bounds__(kRefitThreads) void refit_kernel(uint32_t n, const lbvh_internal_node* __restrict__ internal,
                                                               const lbvh_leaf_node* __restrict__ leaf,
                                                               const lbvh_aabb* __restrict__ tri_aabb,
                                                               const uint32_t* __restrict__ sorted_indices,
                                                               lbvh_aabb* bvh, refit_levels_t lv,
                                                               uint32_t* __restrict__ frontier_count,
-                                                              uint32_t* __restrict__ frontier_list)
+                                                              uint32_t* __restrict__ frontier_list,
+                                                              lbvh_fast_node* __restrict__ fused)
 {
-    __shared__ float s_box[2][6][kRefitThreads];        // [side][min xyz, max xyz][slot]: 48 KB
-    __shared__ uint32_t s_range[2][kRefitThreads];      // first | last << 16, relative to the workgroup: 8 KB
+    // parked child boxes, [side][slot] = {min xyz, range word | max xyz, -}: two 16-byte LDS accesses per box.
+    // range word: first | last << 16 relative to the workgroup, bit 31 = the parked child is a leaf.   64 KB
+    __shared__ float4 s_box[2][kRefitThreads][2];
     __shared__ uint32_t s_flag[kRefitThreads];          // +1 = left child arrived, +0x10000 = right child
     __shared__ float s_wave[6][kRefitThreads / LBVH_WAVE];
+    __shared__ uint2 s_node[kRefitThreads];             // {leftNode (= split), parent} of this index block's nodes: 8 KB
     __shared__ uint32_t s_front_n, s_front_base;
     const uint32_t t = threadIdx.x;
     const uint32_t b0 = blockIdx.x * (uint32_t)kRefitThreads;
+    const uint32_t j = b0 + t;
     s_flag[t] = 0;
     if (t == 0) s_front_n = 0;
+    // the climb below only ever reads nodes of this index block: stage their two words once, coalesced, so that
+    // the dependent chain (one node per level) runs on LDS latency instead of one L2 / HBM round trip per level
+    if (j < n - 1) {
+        const uint32_t* nd = reinterpret_cast<const uint32_t*>(&internal[j]);
+        s_node[t] = make_uint2(nd[0], nd[4]);
+    }
     __syncthreads();
 
-    const uint32_t j = b0 + t;
     uint32_t q = 0xFFFFFFFFu, child_id = j, first = j, last = j;
-    bool child_internal = false;
+    uint32_t child_leaf = 0x80000000u;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (j < n) {                                                                           // :179
         load_box_plain(&tri_aabb[sorted_indices ? sorted_indices[j] : j], mn, mx);
@@ -360,53 +373,131 @@ __global__ __launch_bounds__(kRefitThreads) void refit_kernel(uint32_t n, const 
             if (t == 0 && lv.levels >= 2) store_box_plain(&lv.box[2][blockIdx.x], bmn, bmx);
         }
     }
+#ifdef LBVH_EXPERIMENT_REFIT_NOCLIMB
+    if (false) {
+#else
     if (j < n) {
+#endif
+        bool stranded = false;      // FUSED: the carried box belongs to a finished node whose parent is not local
         for (int guard = 0; q != 0xFFFFFFFFu && guard < 64; guard++) {
+            stranded = true;
             if (q >= n - 1) break;
             // LOCAL arrival: q's index and the carried range lie inside the workgroup's 1024 indices.  Anything
             // else is a frontier node (refit_frontier computes it from the range levels).
             const bool local = q >= b0 && q - b0 < (uint32_t)kRefitThreads && first >= b0 &&
                                last - b0 < (uint32_t)kRefitThreads;
             if (!local) break;
+            stranded = false;
             const uint32_t slot = q - b0;
-            const uint32_t* nd = reinterpret_cast<const uint32_t*>(&internal[q]);
-            const uint2 l = *reinterpret_cast<const uint2*>(nd + 0);
-            const uint32_t next = nd[4];
-            const uint32_t side = (l.x == child_id && (l.y == LBVH_INTERNAL_NODE) == child_internal) ? 0u : 1u;
+            const uint2 nd = s_node[slot];
+            const uint32_t next = nd.y;
+            // Karras numbering: the children of q are indices split and split + 1, so a child (leaf or internal)
+            // is the left one iff its index is the split
+            const uint32_t side = nd.x == child_id ? 0u : 1u;
             // park my box and range, THEN arrive (LDS executes in issue order: the sibling that draws
             // the second ticket finds them)
-#pragma unroll
-            for (int k = 0; k < 3; k++) { s_box[side][k][slot] = mn[k]; s_box[side][3 + k][slot] = mx[k]; }
-            s_range[side][slot] = (first - b0) | ((last - b0) << 16);
+            s_box[side][slot][0] = make_float4(mn[0], mn[1], mn[2],
+                                               __uint_as_float((first - b0) | ((last - b0) << 16) | child_leaf));
+            s_box[side][slot][1] = make_float4(mx[0], mx[1], mx[2], 0.0f);
             const uint32_t old = atomicAdd(&s_flag[slot], side == 0 ? 1u : 0x10000u);      // :185 (LDS)
             if (old == 0) break;                                                           // first arrival :186-189
+            // second arrival: merge and carry on.  Nothing is stored here: both children's boxes stay parked in this
+            // slot, and the node is written from them, coalesced by node index, after the climb.
             const uint32_t o = side ^ 1u;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                mn[k] = fminf(mn[k], s_box[o][k][slot]);                                   // MergeAABB :152-170
-                mx[k] = fmaxf(mx[k], s_box[o][3 + k][slot]);
-            }
-            const uint32_t orange = s_range[o][slot];
+            const float4 omn = s_box[o][slot][0], omx = s_box[o][slot][1];
+            const uint32_t orange = __float_as_uint(omn.w);
+            mn[0] = fminf(mn[0], omn.x); mn[1] = fminf(mn[1], omn.y); mn[2] = fminf(mn[2], omn.z);   // MergeAABB :152-170
+            mx[0] = fmaxf(mx[0], omx.x); mx[1] = fmaxf(mx[1], omx.y); mx[2] = fmaxf(mx[2], omx.z);
             first = min(first, b0 + (orange & 0xFFFFu));
-            last = max(last, b0 + (orange >> 16));
-            store_box_plain(&bvh[q], mn, mx);                                              // :215
+            last = max(last, b0 + ((orange >> 16) & 0x7FFFu));
             if (q == 0) break;                          // the root: its parent word is whatever the caller's buffer held
             child_id = q;
-            child_internal = true;
+            child_leaf = 0u;
             q = next;                                                                      // :217
         }
+        if (FUSED && stranded && child_leaf == 0u) store_box_plain(&bvh[child_id], mn, mx);
     }
     // internal nodes of this index block that did not see both children arrive through LDS are the frontier
     // (one global atomic per workgroup: the list order is irrelevant)
     __syncthreads();
+#ifdef LBVH_EXPERIMENT_REFIT_NOCLIMB
+    const bool is_front = false;
+#else
     const bool is_front = j < n - 1 && s_flag[t] != 0x10001u;
+#endif
     uint32_t my = 0;
     if (is_front) my = atomicAdd(&s_front_n, 1u);
+    if (j < n - 1) {
+        const uint32_t f = s_flag[t];
+        if (f == 0x10001u) {
+            // finished node: its children's boxes are the two parked entries of its slot
+            const float4 lmn = s_box[0][t][0], lmx = s_box[0][t][1], rmn = s_box[1][t][0], rmx = s_box[1][t][1];
+            if (FUSED) {
+                const uint32_t split = s_node[t].x;
+                float4* out = reinterpret_cast<float4*>(&fused[j]);
+                out[0] = make_float4(lmn.x, lmn.y, lmn.z, __uint_as_float((__float_as_uint(lmn.w) & 0x80000000u) | split));
+                out[1] = make_float4(lmx.x, lmx.y, lmx.z, __uint_as_float((__float_as_uint(rmn.w) & 0x80000000u) | (split + 1u)));
+                out[2] = make_float4(rmn.x, rmn.y, rmn.z, 0.0f);
+                out[3] = make_float4(rmx.x, rmx.y, rmx.z, 0.0f);
+            } else {
+                float4* out = reinterpret_cast<float4*>(&bvh[j]);                          // :215
+                out[0] = make_float4(fminf(lmn.x, rmn.x), fminf(lmn.y, rmn.y), fminf(lmn.z, rmn.z), 0.0f);
+                out[1] = make_float4(fmaxf(lmx.x, rmx.x), fmaxf(lmx.y, rmx.y), fmaxf(lmx.z, rmx.z), 0.0f);
+            }
+        } else if (FUSED && f != 0) {
+            // frontier node with one finished child parked here and nowhere else: fuse_frontier_kernel needs its box
+            const uint32_t side = (f & 1u) ? 0u : 1u;
+            const float4 pmn = s_box[side][t][0], pmx = s_box[side][t][1];
+            if (!(__float_as_uint(pmn.w) & 0x80000000u)) {
+                float4* o = reinterpret_cast<float4*>(&bvh[s_node[t].x + side]);
+                o[0] = make_float4(pmn.x, pmn.y, pmn.z, 0.0f);
+                o[1] = make_float4(pmx.x, pmx.y, pmx.z, 0.0f);
+            }
+        }
+    }
     __syncthreads();
     if (t == 0 && s_front_n)
         s_front_base = __hip_atomic_fetch_add(frontier_count, s_front_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (is_front) frontier_list[s_front_base + my] = j;
+}
+
+// FUSED: the traversal nodes of the frontier, after refit_frontier_kernel has written the frontier's own boxes.  A
+// child of a frontier node is a leaf, another frontier node, or a finished node whose box refit_kernel stored.
+__global__ __launch_bounds__(256) void fuse_frontier_kernel(uint32_t n, const lbvh_internal_node* __restrict__ internal,
+                                                            const uint32_t* __restrict__ count, const uint32_t* __restrict__ list,
+                                                            const lbvh_aabb* __restrict__ tri_aabb,
+                                                            const uint32_t* __restrict__ sorted_indices,
+                                                            const lbvh_aabb* __restrict__ bvh, lbvh_fast_node* __restrict__ fused)
+{
+    const uint32_t total = *count;
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+        const uint32_t node = list[e];
+        const uint32_t* nd = reinterpret_cast<const uint32_t*>(&internal[node]);
+        const uint2 lc = *reinterpret_cast<const uint2*>(nd + 0);
+        const uint2 rc = *reinterpret_cast<const uint2*>(nd + 2);
+        float4 b[4];
+        uint32_t ref[2];
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const uint2 c = side == 0 ? lc : rc;
+            const float4* src;
+            if (c.y == LBVH_INTERNAL_NODE) {
+                src = reinterpret_cast<const float4*>(&bvh[c.x]);
+                ref[side] = c.x;
+            } else {
+                src = reinterpret_cast<const float4*>(&tri_aabb[sorted_indices ? sorted_indices[c.x] : c.x]);
+                ref[side] = 0x80000000u | c.x;          // leaf c sits at sorted position c (tree_kernel)
+            }
+            b[2 * side + 0] = src[0];
+            b[2 * side + 1] = src[1];
+        }
+        float4* o = reinterpret_cast<float4*>(&fused[node]);
+        o[0] = make_float4(b[0].x, b[0].y, b[0].z, __uint_as_float(ref[0]));
+        o[1] = make_float4(b[1].x, b[1].y, b[1].z, __uint_as_float(ref[1]));
+        o[2] = make_float4(b[2].x, b[2].y, b[2].z, 0.0f);
+        o[3] = make_float4(b[3].x, b[3].y, b[3].z, 0.0f);
+    }
 }
 
 // range level k >= 3 from level k - 1 (only built when level 2 alone would leave the top nodes with thousands of
@@ -619,7 +710,8 @@ int lbvh_launch_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, lbvh
 }
 
 int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d_internal, const lbvh_leaf_node* d_leaf,
-                      const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh)
+                      const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh,
+                      lbvh_fast_node* d_fused)
 {
     // scratch: [frontier count (256 B) | frontier list, one u32 per internal node (every node could be one) | range levels]
     refit_levels_t lv = {};
@@ -660,8 +752,12 @@ int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d
     }
     LBVH_HIP_TRY(ctx, hipMemsetAsync(count, 0, 256, ctx->cur_stream));
     const uint32_t blocks = (n + kRefitThreads - 1) / kRefitThreads;
-    LBVH_LAUNCH(ctx, refit_kernel, dim3(blocks), dim3(kRefitThreads), n, d_internal, d_leaf, d_triangle_aabb,
-                d_sorted_indices, d_bvh, lv, count, list);
+    if (d_fused)
+        LBVH_LAUNCH(ctx, refit_kernel<true>, dim3(blocks), dim3(kRefitThreads), n, d_internal, d_leaf, d_triangle_aabb,
+                    d_sorted_indices, d_bvh, lv, count, list, d_fused);
+    else
+        LBVH_LAUNCH(ctx, refit_kernel<false>, dim3(blocks), dim3(kRefitThreads), n, d_internal, d_leaf, d_triangle_aabb,
+                    d_sorted_indices, d_bvh, lv, count, list, d_fused);
     if (blocks > 1) {       // a single workgroup finishes the whole tree in LDS
         for (int k = 3; k <= lv.levels; k++)
             LBVH_LAUNCH(ctx, refit_level_kernel, dim3((lv.count[k] + 255) / 256), dim3(256), lv, k);
@@ -669,6 +765,9 @@ int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d
         if (fblocks > 2048u) fblocks = 2048u;
         LBVH_LAUNCH(ctx, refit_frontier_kernel, dim3(fblocks), dim3(256), n, d_internal, count, list, d_triangle_aabb,
                     d_sorted_indices, d_bvh, lv);
+        if (d_fused)
+            LBVH_LAUNCH(ctx, fuse_frontier_kernel, dim3(blocks < 64u ? blocks : 64u), dim3(256), n, d_internal, count, list,
+                        d_triangle_aabb, d_sorted_indices, d_bvh, d_fused);
     }
     return LBVH_OK;
 }
@@ -759,7 +858,7 @@ lbvh_status lbvh_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* 
     LBVH_REQUIRE(ctx, ((uintptr_t)d_internal & 7) == 0 && ((uintptr_t)d_triangle_aabb & 15) == 0 &&
                           ((uintptr_t)d_bvh & 15) == 0);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = lbvh_launch_refit(ctx, n, d_internal, d_leaf, d_triangle_aabb, d_sorted_indices, d_bvh);
+    int rc = lbvh_launch_refit(ctx, n, d_internal, d_leaf, d_triangle_aabb, d_sorted_indices, d_bvh, nullptr);
     if (rc != LBVH_OK) return rc;
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;

@@ -133,8 +133,11 @@ int lbvh_set_error(lbvh_context* ctx, int code, const char* what, const char* de
 int lbvh_launch_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, lbvh_internal_node* d_internal,
                      lbvh_leaf_node* d_leaf);
 int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d_internal, const lbvh_leaf_node* d_leaf,
-                      const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh);
-// d_sorted_indices may be nullptr in lbvh_launch_refit: boxes already in leaf order.
+                      const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh,
+                      lbvh_fast_node* d_fused);
+// d_sorted_indices may be nullptr in lbvh_launch_refit: boxes already in leaf order.  d_fused != nullptr (a tree made
+// by lbvh_launch_tree only): write the 64-byte traversal nodes instead of d_bvh, which then only holds the few
+// boxes the frontier needs.
 // The start of the derived build: leaf_box[i] = aabb[sorted[i]] and the aligned traversal keys
 // k'_i = i + max_{j<=i}(morton(centre of leaf_box[j]) - j), strictly increasing.
 int lbvh_launch_gather_aligned_keys(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_triangle_aabb,

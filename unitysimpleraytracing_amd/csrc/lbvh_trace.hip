@@ -166,37 +166,6 @@ __global__ __launch_bounds__(64) void trace_reference_kernel(trace_args a, lbvh_
 // ---------------------------------------------------------------------------------------------
 // derived fast-traversal scene
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void build_fast_nodes_kernel(lbvh_scene s, lbvh_fast_node* __restrict__ nodes)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= s.n - 1) return;
-    const uint32_t* nd = reinterpret_cast<const uint32_t*>(&s.internal_nodes[i]);
-    const uint2 lc = *reinterpret_cast<const uint2*>(nd + 0);
-    const uint2 rc = *reinterpret_cast<const uint2*>(nd + 2);
-    float4 b[4];
-    uint32_t ref[2];
-#pragma unroll
-    for (int side = 0; side < 2; side++) {
-        const uint2 c = side == 0 ? lc : rc;
-        const float4* src;
-        if (c.y == LBVH_INTERNAL_NODE) {
-            src = reinterpret_cast<const float4*>(&s.bvh[c.x]);
-            ref[side] = c.x;
-        } else {
-            const uint32_t pos = s.leaf_nodes[c.x].index;                 // sorted position
-            src = reinterpret_cast<const float4*>(&s.triangle_aabb[s.sorted_indices ? s.sorted_indices[pos] : pos]);
-            ref[side] = 0x80000000u | pos;
-        }
-        b[2 * side + 0] = src[0];
-        b[2 * side + 1] = src[1];
-    }
-    float4* o = reinterpret_cast<float4*>(&nodes[i]);
-    o[0] = make_float4(b[0].x, b[0].y, b[0].z, __uint_as_float(ref[0]));
-    o[1] = make_float4(b[1].x, b[1].y, b[1].z, __uint_as_float(ref[1]));
-    o[2] = make_float4(b[2].x, b[2].y, b[2].z, 0.0f);
-    o[3] = make_float4(b[3].x, b[3].y, b[3].z, 0.0f);
-}
-
 __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh_fast_tri* __restrict__ tris)
 {
     const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
@@ -860,15 +829,9 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
         rc = lbvh_launch_gather_aligned_keys(ctx, s.n, s.triangle_aabb, s.sorted_indices, h_box_min, h_box_max, t_leaf_box, t_keys);
         if (rc != LBVH_OK) return rc;
         lbvh_launch_tree(ctx, s.n, t_keys, t_internal, t_leaf);
-        rc = lbvh_launch_refit(ctx, s.n, t_internal, t_leaf, t_leaf_box, nullptr, t_bvh);
+        // the refit writes the 64-byte traversal nodes (both child boxes + child references) directly
+        rc = lbvh_launch_refit(ctx, s.n, t_internal, t_leaf, t_leaf_box, nullptr, t_bvh, ctx->fast_nodes);
         if (rc != LBVH_OK) return rc;
-        lbvh_scene ts = s;
-        ts.internal_nodes = t_internal;
-        ts.leaf_nodes = t_leaf;
-        ts.bvh = t_bvh;
-        ts.triangle_aabb = t_leaf_box;
-        ts.sorted_indices = nullptr;
-        LBVH_LAUNCH(ctx, build_fast_nodes_kernel, dim3((s.n - 1 + 255) / 256), dim3(256), ts, ctx->fast_nodes);
     }
     if (parts & 2) LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((s.n + 255) / 256), dim3(256), s, ctx->fast_tris);
     LBVH_HIP_TRY(ctx, hipGetLastError());
