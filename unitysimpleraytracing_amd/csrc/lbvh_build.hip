@@ -32,9 +32,13 @@ __global__ __launch_bounds__(256) void morton_aabb_kernel(const lbvh_triangle* _
                                                           uint32_t n, uint32_t capacity, box3 scene,
                                                           uint32_t* __restrict__ keys,
                                                           uint32_t* __restrict__ indices,
-                                                          lbvh_aabb* __restrict__ aabb)
+                                                          lbvh_aabb* __restrict__ aabb,
+                                                          uint32_t* __restrict__ zero, uint32_t zero_words)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // lbvh_build_scene: the sort that follows wants its counters and look-back words cleared; doing it here saves
+    // a fill kernel in the chain
+    for (uint32_t w = i; w < zero_words; w += gridDim.x * blockDim.x) zero[w] = 0u;
     if (i >= capacity) return;
     if (i >= n) {   // DataBuffer<uint>(.., uint.MaxValue)  MeshBufferContainer.cs:108-109
         keys[i] = 0xFFFFFFFFu;
@@ -185,9 +189,10 @@ __device__ __forceinline__ int delta(const uint32_t* __restrict__ codes, int x_c
 
 __global__ __launch_bounds__(256) void tree_kernel(const uint32_t* __restrict__ codes, uint32_t n,
                                                    lbvh_internal_node* __restrict__ internal,
-                                                   lbvh_leaf_node* __restrict__ leaf)
+                                                   lbvh_leaf_node* __restrict__ leaf, uint32_t* __restrict__ zero_word)
 {
     const uint32_t thread_id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (thread_id == 0 && zero_word) *zero_word = 0u;      // the refit's frontier counter (lbvh_build_scene)
     if (thread_id >= n - 1) return;                                                        // :101
     const int num = (int)n;
     const int idx = (int)thread_id;
@@ -702,18 +707,37 @@ __global__ __launch_bounds__(kAkThreads) void aligned_keys_apply_kernel(uint32_t
 }  // namespace
 
 int lbvh_launch_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, lbvh_internal_node* d_internal,
-                     lbvh_leaf_node* d_leaf)
+                     lbvh_leaf_node* d_leaf, uint32_t* d_zero_word)
 {
     const uint32_t blocks = (n - 1 + 255) / 256;
-    LBVH_LAUNCH(ctx, tree_kernel, dim3(blocks), dim3(256), d_keys, n, d_internal, d_leaf);
+    LBVH_LAUNCH(ctx, tree_kernel, dim3(blocks), dim3(256), d_keys, n, d_internal, d_leaf, d_zero_word);
     return LBVH_OK;
 }
 
-int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d_internal, const lbvh_leaf_node* d_leaf,
-                      const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh,
-                      lbvh_fast_node* d_fused)
+int lbvh_launch_morton(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
+                       const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
+                       lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words)
 {
-    // scratch: [frontier count (256 B) | frontier list, one u32 per internal node (every node could be one) | range levels]
+    box3 scene;
+    for (int k = 0; k < 3; k++) { scene.mn[k] = h_box_min[k]; scene.mx[k] = h_box_max[k]; }
+    const uint32_t blocks = (capacity + 255) / 256;
+    LBVH_LAUNCH(ctx, morton_aabb_kernel, dim3(blocks), dim3(256), d_triangles, n, capacity, scene, d_keys, d_indices, d_aabb,
+                d_zero, zero_words);
+    return LBVH_OK;
+}
+
+namespace {
+struct refit_plan {
+    refit_levels_t lv;
+    uint32_t* count;
+    uint32_t* list;
+};
+}
+
+// scratch of the current lane: [frontier count (256 B) | frontier list, one u32 per internal node (every node could
+// be one) | range levels]
+static int refit_prepare(lbvh_context* ctx, uint32_t n, refit_plan* plan)
+{
     refit_levels_t lv = {};
     size_t level_bytes = 0;
     {
@@ -744,13 +768,38 @@ int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d
         if (rc != LBVH_OK) return rc;
     }
     char* base = (char*)ctx->refit_scratch[L];
-    uint32_t* count = (uint32_t*)base;
-    uint32_t* list = (uint32_t*)(base + 256);
+    plan->count = (uint32_t*)base;
+    plan->list = (uint32_t*)(base + 256);
     {
         char* p = base + 256 + list_bytes;
         for (int k = 1; k <= lv.levels; k++) { lv.box[k] = (lbvh_aabb*)p; p += (size_t)lv.count[k] * sizeof(lbvh_aabb); }
     }
-    LBVH_HIP_TRY(ctx, hipMemsetAsync(count, 0, 256, ctx->cur_stream));
+    plan->lv = lv;
+    return LBVH_OK;
+}
+
+int lbvh_refit_counter(lbvh_context* ctx, uint32_t n, uint32_t** d_counter)
+{
+    refit_plan plan;
+    const int rc = refit_prepare(ctx, n, &plan);
+    if (rc != LBVH_OK) return rc;
+    *d_counter = plan.count;
+    return LBVH_OK;
+}
+
+int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d_internal, const lbvh_leaf_node* d_leaf,
+                      const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh,
+                      lbvh_fast_node* d_fused, bool counter_cleared)
+{
+    refit_plan plan;
+    {
+        const int rc = refit_prepare(ctx, n, &plan);
+        if (rc != LBVH_OK) return rc;
+    }
+    const refit_levels_t lv = plan.lv;
+    uint32_t* count = plan.count;
+    uint32_t* list = plan.list;
+    if (!counter_cleared) LBVH_HIP_TRY(ctx, hipMemsetAsync(count, 0, 256, ctx->cur_stream));
     const uint32_t blocks = (n + kRefitThreads - 1) / kRefitThreads;
     if (d_fused)
         LBVH_LAUNCH(ctx, refit_kernel<true>, dim3(blocks), dim3(kRefitThreads), n, d_internal, d_leaf, d_triangle_aabb,
@@ -803,11 +852,7 @@ lbvh_status lbvh_morton_aabb(lbvh_context* ctx, const lbvh_triangle* d_triangles
     LBVH_REQUIRE(ctx, n == 0 || (d_triangles != nullptr && d_aabb != nullptr));
     LBVH_REQUIRE(ctx, ((uintptr_t)d_triangles & 15) == 0 && ((uintptr_t)d_aabb & 15) == 0);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    box3 scene;
-    for (int k = 0; k < 3; k++) { scene.mn[k] = h_box_min[k]; scene.mx[k] = h_box_max[k]; }
-    const uint32_t blocks = (capacity + 255) / 256;
-    LBVH_LAUNCH(ctx, morton_aabb_kernel, dim3(blocks), dim3(256), d_triangles, n,
-                       capacity, scene, d_keys, d_indices, d_aabb);
+    lbvh_launch_morton(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, nullptr, 0);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }
@@ -842,7 +887,7 @@ lbvh_status lbvh_build_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_sor
     LBVH_REQUIRE(ctx, d_sorted_keys != nullptr && d_internal != nullptr && d_leaf != nullptr);
     LBVH_REQUIRE(ctx, ((uintptr_t)d_internal & 7) == 0 && ((uintptr_t)d_leaf & 7) == 0);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    lbvh_launch_tree(ctx, n, d_sorted_keys, d_internal, d_leaf);
+    lbvh_launch_tree(ctx, n, d_sorted_keys, d_internal, d_leaf, nullptr);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }
@@ -858,7 +903,7 @@ lbvh_status lbvh_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* 
     LBVH_REQUIRE(ctx, ((uintptr_t)d_internal & 7) == 0 && ((uintptr_t)d_triangle_aabb & 15) == 0 &&
                           ((uintptr_t)d_bvh & 15) == 0);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = lbvh_launch_refit(ctx, n, d_internal, d_leaf, d_triangle_aabb, d_sorted_indices, d_bvh, nullptr);
+    int rc = lbvh_launch_refit(ctx, n, d_internal, d_leaf, d_triangle_aabb, d_sorted_indices, d_bvh, nullptr, false);
     if (rc != LBVH_OK) return rc;
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;

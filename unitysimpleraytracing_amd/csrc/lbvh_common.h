@@ -130,11 +130,21 @@ int lbvh_set_error(lbvh_context* ctx, int code, const char* what, const char* de
 
 // Stage launchers shared between translation units (validated arguments, no error reporting of
 // their own beyond hipGetLastError at the caller).
+// d_zero_word (may be nullptr): a word the tree kernel clears on the way — the counter of the refit that follows
 int lbvh_launch_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, lbvh_internal_node* d_internal,
-                     lbvh_leaf_node* d_leaf);
+                     lbvh_leaf_node* d_leaf, uint32_t* d_zero_word);
+// Morton / AABB kernel that also clears d_zero[0 .. zero_words) (the scratch of the sort that follows)
+int lbvh_launch_morton(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
+                       const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
+                       lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words);
+// the sort with its scratch described / already cleared by the caller
+int lbvh_sort_scratch(lbvh_context* ctx, uint32_t count, uint32_t** d_zero, uint32_t* zero_words);
+int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t count, bool scratch_cleared);
+// the frontier counter lbvh_launch_refit(n) will use on the current lane (sizes the scratch)
+int lbvh_refit_counter(lbvh_context* ctx, uint32_t n, uint32_t** d_counter);
 int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d_internal, const lbvh_leaf_node* d_leaf,
                       const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh,
-                      lbvh_fast_node* d_fused);
+                      lbvh_fast_node* d_fused, bool counter_cleared);
 // d_sorted_indices may be nullptr in lbvh_launch_refit: boxes already in leaf order.  d_fused != nullptr (a tree made
 // by lbvh_launch_tree only): write the 64-byte traversal nodes instead of d_bvh, which then only holds the few
 // boxes the frontier needs.

@@ -436,16 +436,17 @@ void launch_passes(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint
 
 }  // namespace
 
-extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values,
-                                       uint32_t count)
-{
-    if (!ctx) return LBVH_ERR_INVALID_ARG;
-    if (count == 0) return LBVH_OK;
-    LBVH_REQUIRE(ctx, d_keys != nullptr && d_values != nullptr);
-    LBVH_REQUIRE(ctx, count <= kValueMask);       // status words carry 30-bit counts
-    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (count == 1) return LBVH_OK;
+namespace {
+struct sort_plan {
+    int items;
+    uint32_t tiles, groups;
+    uint32_t *alt_keys, *alt_vals, *ghist, *tickets, *status, *gstatus;
+    size_t zero_bytes;
+};
+}
 
+static int sort_prepare(lbvh_context* ctx, uint32_t count, sort_plan* pl)
+{
     // tile = 512 threads x 16 keys (8192) for big inputs: long digit runs = fuller cache lines in the
     // scatter and short look-back chains (measured best of 256..1024 threads x 4..16 keys at 2^24..2^28);
     // 512 x 8 below 2 M keys so every CU still gets tiles
@@ -460,13 +461,46 @@ extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint
     int rc = lbvh_reserve(ctx, &ctx->sort_scratch, &ctx->sort_scratch_bytes, 2 * pair_bytes + head_bytes + status_bytes);
     if (rc != LBVH_OK) return rc;
     char* p = (char*)ctx->sort_scratch;
-    uint32_t* alt_keys = (uint32_t*)p;
-    uint32_t* alt_vals = (uint32_t*)(p + pair_bytes);
-    uint32_t* ghist = (uint32_t*)(p + 2 * pair_bytes);
-    uint32_t* tickets = ghist + kPasses * kRadix;
-    uint32_t* status = (uint32_t*)(p + 2 * pair_bytes + head_bytes);
-    uint32_t* gstatus = status + (size_t)kPasses * tiles * kRadix;
-    LBVH_HIP_TRY(ctx, hipMemsetAsync(ghist, 0, head_bytes + status_bytes, ctx->cur_stream));
+    pl->items = items;
+    pl->tiles = tiles;
+    pl->groups = groups;
+    pl->alt_keys = (uint32_t*)p;
+    pl->alt_vals = (uint32_t*)(p + pair_bytes);
+    pl->ghist = (uint32_t*)(p + 2 * pair_bytes);
+    pl->tickets = pl->ghist + kPasses * kRadix;
+    pl->status = (uint32_t*)(p + 2 * pair_bytes + head_bytes);
+    pl->gstatus = pl->status + (size_t)kPasses * tiles * kRadix;
+    pl->zero_bytes = head_bytes + status_bytes;
+    return LBVH_OK;
+}
+
+int lbvh_sort_scratch(lbvh_context* ctx, uint32_t count, uint32_t** d_zero, uint32_t* zero_words)
+{
+    *d_zero = nullptr;
+    *zero_words = 0;
+    if (count < 2) return LBVH_OK;
+    sort_plan pl;
+    const int rc = sort_prepare(ctx, count, &pl);
+    if (rc != LBVH_OK) return rc;
+    if (pl.zero_bytes / 4 > 0xFFFFFFFFull) return LBVH_OK;      // the caller's sort clears it itself
+    *d_zero = pl.ghist;
+    *zero_words = (uint32_t)(pl.zero_bytes / 4);
+    return LBVH_OK;
+}
+
+int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t count, bool scratch_cleared)
+{
+    if (count < 2) return LBVH_OK;
+    sort_plan pl;
+    {
+        const int rc = sort_prepare(ctx, count, &pl);
+        if (rc != LBVH_OK) return rc;
+    }
+    const int items = pl.items;
+    const uint32_t tiles = pl.tiles, groups = pl.groups;
+    uint32_t *alt_keys = pl.alt_keys, *alt_vals = pl.alt_vals, *ghist = pl.ghist, *tickets = pl.tickets, *status = pl.status,
+             *gstatus = pl.gstatus;
+    if (!scratch_cleared) LBVH_HIP_TRY(ctx, hipMemsetAsync(ghist, 0, pl.zero_bytes, ctx->cur_stream));
 
     // 4 K keys per block up to 2048 blocks: enough blocks to hide the load latency, few enough that the
     // 1024 global atomics each block ends with do not pile up on the same counters
@@ -485,6 +519,17 @@ extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint
         launch_passes<512, 8>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;   // 4 passes: the result is back in d_keys / d_values
+}
+
+extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values,
+                                       uint32_t count)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    if (count == 0) return LBVH_OK;
+    LBVH_REQUIRE(ctx, d_keys != nullptr && d_values != nullptr);
+    LBVH_REQUIRE(ctx, count <= kValueMask);       // status words carry 30-bit counts
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return (lbvh_status)lbvh_launch_sort(ctx, d_keys, d_values, count, false);
 }
 
 

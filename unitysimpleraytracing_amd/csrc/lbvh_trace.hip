@@ -828,9 +828,11 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
     if (parts & 1) {
         rc = lbvh_launch_gather_aligned_keys(ctx, s.n, s.triangle_aabb, s.sorted_indices, h_box_min, h_box_max, t_leaf_box, t_keys);
         if (rc != LBVH_OK) return rc;
-        lbvh_launch_tree(ctx, s.n, t_keys, t_internal, t_leaf);
+        uint32_t* counter = nullptr;
+        if ((rc = lbvh_refit_counter(ctx, s.n, &counter)) != LBVH_OK) return rc;
+        lbvh_launch_tree(ctx, s.n, t_keys, t_internal, t_leaf, counter);
         // the refit writes the 64-byte traversal nodes (both child boxes + child references) directly
-        rc = lbvh_launch_refit(ctx, s.n, t_internal, t_leaf, t_leaf_box, nullptr, t_bvh, ctx->fast_nodes);
+        rc = lbvh_launch_refit(ctx, s.n, t_internal, t_leaf, t_leaf_box, nullptr, t_bvh, ctx->fast_nodes, true);
         if (rc != LBVH_OK) return rc;
     }
     if (parts & 2) LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((s.n + 255) / 256), dim3(256), s, ctx->fast_tris);
@@ -864,8 +866,19 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
         LBVH_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_internal, 0xFFFFFFFFu, (size_t)capacity * 6, ctx->stream));
         LBVH_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_leaf, 0xFFFFFFFFu, (size_t)capacity * 2, ctx->stream));
     }
-    if ((rc = lbvh_morton_aabb(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb)) != LBVH_OK) return rc;
-    if ((rc = lbvh_sort_pairs(ctx, d_keys, d_indices, capacity)) != LBVH_OK) return rc;
+    // (argument checks of the public stage functions are repeated here only where lbvh_build_scene's own do not cover them)
+    LBVH_REQUIRE(ctx, ((uintptr_t)d_triangles & 15) == 0 && ((uintptr_t)d_aabb & 15) == 0);
+    LBVH_REQUIRE(ctx, ((uintptr_t)d_internal & 7) == 0 && ((uintptr_t)d_leaf & 7) == 0 && ((uintptr_t)d_bvh & 15) == 0);
+    LBVH_REQUIRE(ctx, n <= 0x7FFFFFFFu && capacity <= 0x3FFFFFFFu);
+    {
+        // the Morton kernel clears the sort's counters and look-back words, the tree kernels the refit counters:
+        // three fill kernels less in the chain
+        uint32_t* zero = nullptr;
+        uint32_t zero_words = 0;
+        if ((rc = (lbvh_status)lbvh_sort_scratch(ctx, capacity, &zero, &zero_words)) != LBVH_OK) return rc;
+        lbvh_launch_morton(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, zero, zero_words);
+        if ((rc = (lbvh_status)lbvh_launch_sort(ctx, d_keys, d_indices, capacity, zero != nullptr)) != LBVH_OK) return rc;
+    }
     const bool fast = (flags & LBVH_BUILD_FAST_SCENE) != 0;
     lbvh_scene fast_scene = {};
     if (fast) {
@@ -892,8 +905,14 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
     }
     // lane 0: the reference's arrays
     if ((rc = lbvh_distribute_keys(ctx, d_keys, n)) != LBVH_OK) return rc;
-    if ((rc = lbvh_build_tree(ctx, n, d_keys, d_internal, d_leaf)) != LBVH_OK) return rc;
-    if ((rc = lbvh_refit(ctx, n, d_internal, d_leaf, d_aabb, d_indices, d_bvh)) != LBVH_OK) return rc;
+    {
+        uint32_t* counter = nullptr;
+        if ((rc = (lbvh_status)lbvh_refit_counter(ctx, n, &counter)) != LBVH_OK) return rc;
+        lbvh_launch_tree(ctx, n, d_keys, d_internal, d_leaf, counter);
+        if ((rc = (lbvh_status)lbvh_launch_refit(ctx, n, d_internal, d_leaf, d_aabb, d_indices, d_bvh, nullptr, true)) != LBVH_OK)
+            return rc;
+        LBVH_HIP_TRY(ctx, hipGetLastError());
+    }
     if (fast) {
         // the sorted triangles do not depend on the traversal tree: they ride on the shorter lane
         if ((rc = build_fast_scene_parts(ctx, &fast_scene, h_box_min, h_box_max, 2)) != LBVH_OK) return rc;
