@@ -237,6 +237,9 @@ __global__ __launch_bounds__(256) void tree_kernel(const uint32_t* __restrict__ 
     }
     if (split < 0 || (uint32_t)split + 1u >= n) return;   // only reachable with non-unique keys
 
+#ifdef LBVH_EXPERIMENT_TREE_NOSTORE
+    if (split != 0x12345678) { if (split == -7) internal[thread_id].index = (uint32_t)split; return; }
+#endif
     const bool left_leaf = split == first;                                                 // :114
     const bool right_leaf = split + 1 == last;                                             // :132
     uint32_t* node = reinterpret_cast<uint32_t*>(&internal[thread_id]);
