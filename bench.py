@@ -294,7 +294,7 @@ def main():
                     round(own_bytes_per_ray * W * H / (trace_kernel_ms * 1e-3) / 1e9, 1),
                     "kernel_ms": round(trace_kernel_ms, 4),
                     "note": "achieved/frac price the kernel at the bytes of the reference's per-ray walk it replaces (SURVEY 8d); the "
-                            "packet kernel itself moves own_bytes_per_ray and is bounded by the dependent fetch chain of its heaviest "
+                            "packet kernel itself moves own_bytes_per_ray and is bounded by the dependent instruction chain of its heaviest "
                             "tile, not by HBM (DESIGN.md section 7)",
                     "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
 
