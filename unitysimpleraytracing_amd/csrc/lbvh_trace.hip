@@ -228,10 +228,17 @@ __device__ __forceinline__ int fetch_node_dword(const lbvh_fast_node* __restrict
 {
     return reinterpret_cast<const int*>(&nodes[nidx])[lane & 15u];
 }
-__device__ __forceinline__ int fetch_tri_dword(const lbvh_fast_tri* __restrict__ tris, uint32_t pos, uint32_t lane)
+// child line (node, or triangle + the first 16 bytes after it: the array is padded) by reference: the address is
+// computed on the scalar unit, the load takes it as an SGPR base + the lane's constant byte offset (no vector
+// address arithmetic in the walk)
+__device__ __forceinline__ int fetch_line_dword(const lbvh_fast_node* __restrict__ nodes, const lbvh_fast_tri* __restrict__ tris,
+                                                uint32_t ref, uint32_t lane_bytes)
 {
-    const uint32_t k = lane & 15u;
-    return reinterpret_cast<const int*>(&tris[pos])[k < 12u ? k : 11u];
+    const uint32_t i = ref & 0x7FFFFFFFu;
+    const bool leaf = (ref & 0x80000000u) != 0;
+    const char* array = leaf ? reinterpret_cast<const char*>(tris) : reinterpret_cast<const char*>(nodes);
+    const uint32_t stride = leaf ? (uint32_t)sizeof(lbvh_fast_tri) : (uint32_t)sizeof(lbvh_fast_node);
+    return *reinterpret_cast<const int*>(array + (size_t)i * stride + lane_bytes);
 }
 __device__ __forceinline__ uniform_node broadcast_node(int w)
 {
@@ -272,6 +279,7 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
     int stack = 0;            // wave-shared stack: slot k lives in lane k of this VGPR
     uint32_t sp = 0;          // scalar
     uint32_t steps = 0;
+    const uint32_t lane_bytes = (lane & 15u) * 4u;
     // root: its own box is never tested, both children are
     int w_node = fetch_node_dword(nodes, 0, lane);
     for (;;) {
@@ -280,8 +288,8 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
         const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
         // both children are fetched NOW (node line or triangle line), before the box tests: whichever
         // the packet goes to next is already in flight — one memory latency per step instead of two
-        const int w_l = leaf_l ? fetch_tri_dword(tris, lref & 0x7FFFFFFFu, lane) : fetch_node_dword(nodes, lref, lane);
-        const int w_r = leaf_r ? fetch_tri_dword(tris, rref & 0x7FFFFFFFu, lane) : fetch_node_dword(nodes, rref, lane);
+        const int w_l = fetch_line_dword(nodes, tris, lref, lane_bytes);
+        const int w_r = fetch_line_dword(nodes, tris, rref, lane_bytes);
         if (STATS && lane == 0) C.pops++;
         steps++;
         float tl[R], tr[R];
@@ -354,7 +362,7 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
         } else {
             if (sp == 0) return steps;
             sp--;
-            w_node = fetch_node_dword(nodes, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), lane);
+            w_node = fetch_line_dword(nodes, tris, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), lane_bytes);
         }
     }
 }
@@ -440,6 +448,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
     const uint32_t tile = shard_tile(w, a.shard_index, a.shard_count);
     if (w >= n_work || tile >= a.tiles_x * a.tiles_y) return;        // cannot happen for a heavy item
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t lane_bytes = (lane & 15u) * 4u;
     // as many waves as the tile's last step count is worth (about kCoopGrain steps each); the others leave now
     const uint32_t n_waves = min(max((cost[w] + heavy_cap.grain / 2u) / heavy_cap.grain, 2u), (uint32_t)kCoopWaves);
     if (wave >= n_waves) return;
@@ -483,13 +492,13 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
             cur = got;
             have = true;
         }
-        int w_node = fetch_node_dword(nodes, cur, lane);
+        int w_node = fetch_line_dword(nodes, tris, cur, lane_bytes);
         for (;;) {      // one chain: until this wave has nothing left
             const uniform_node nd = broadcast_node(w_node);
             const uint32_t lref = __float_as_uint(nd.lmin.w), rref = __float_as_uint(nd.lmax.w);
             const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
-            const int w_l = leaf_l ? fetch_tri_dword(tris, lref & 0x7FFFFFFFu, lane) : fetch_node_dword(nodes, lref, lane);
-            const int w_r = leaf_r ? fetch_tri_dword(tris, rref & 0x7FFFFFFFu, lane) : fetch_node_dword(nodes, rref, lane);
+            const int w_l = fetch_line_dword(nodes, tris, lref, lane_bytes);
+            const int w_r = fetch_line_dword(nodes, tris, rref, lane_bytes);
             if (STATS && lane == 0) C.pops++;
             steps++;
             float best_t = key_value((uint32_t)(V.best[lane] >> 32));      // everybody's hits so far
@@ -546,7 +555,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                 w_node = w_r;
             } else if (sp != base) {
                 sp--;
-                w_node = fetch_node_dword(nodes, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), lane);
+                w_node = fetch_line_dword(nodes, tris, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), lane_bytes);
             } else {
                 more = false;
             }
@@ -806,7 +815,7 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
         if (ctx->fast_tris) { LBVH_HIP_TRY(ctx, hipFree(ctx->fast_tris)); ctx->fast_tris = nullptr; }
         ctx->fast_capacity = 0;
         LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->fast_nodes, (size_t)s.n * sizeof(lbvh_fast_node)));
-        LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->fast_tris, (size_t)s.n * sizeof(lbvh_fast_tri)));
+        LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->fast_tris, (size_t)s.n * sizeof(lbvh_fast_tri) + 64));
         ctx->fast_capacity = s.n;
     }
     // The traversal tree: same sorted triangle order as the scene, its own topology over aligned keys
