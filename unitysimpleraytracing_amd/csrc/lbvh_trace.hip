@@ -271,25 +271,58 @@ struct packet_rays {
 struct walk_counters { uint32_t pops, box, leaf, tri; };
 
 // Walk the tree for one packet; returns the number of steps (node fetches).
-template <bool STATS, int R>
+// Do all active rays of the packet agree on the sign of every direction component, with finite non-zero inverse
+// directions (every tile but those on the image's centre lines)?  neg: bit k = component k is negative.
+__device__ __forceinline__ bool packet_signs(const packet_rays<1>& P, uint32_t& neg)
+{
+    const ray_t& r = P.ray[0];
+    const uint64_t act = __ballot(P.act[0]);
+    const float inv[3] = {r.ix, r.iy, r.iz};
+    bool ordered = true;
+    neg = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint64_t finite = __ballot(P.act[0] && fabsf(inv[k]) < INFINITY && inv[k] != 0.0f);
+        const uint64_t negative = __ballot(P.act[0] && inv[k] < 0.0f);
+        ordered = ordered && finite == act && (negative == 0 || negative == act);
+        neg |= negative != 0 ? 1u << k : 0u;
+    }
+    return ordered;
+}
+
+// which dword of a NODE line a lane fetches: with ordered signs the min and max plane of every axis whose direction
+// component is negative change places, so that dwords 0-2 / 8-10 of the line in the register are the planes the
+// rays meet first and 4-6 / 12-14 the ones they leave through — the ordering costs nothing per step
+__device__ __forceinline__ uint32_t node_line_bytes(uint32_t lane, bool ordered, uint32_t neg)
+{
+    const uint32_t d = lane & 15u, axis = d & 3u;
+    const bool flip = ordered && axis < 3u && ((neg >> axis) & 1u) != 0;
+    return (flip ? d ^ 4u : d) * 4u;
+}
+
+// SIGNS: all active rays of the packet share the sign of each direction component (and have finite non-zero
+// inverse directions): bit i of `neg` = component i is negative.  The near / far planes of both child boxes are
+// then picked on the scalar unit and the box tests lose their six min / max each (ray_box_ordered).
+template <bool STATS, int R, bool SIGNS>
 __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict__ nodes, const lbvh_fast_tri* __restrict__ tris,
-                                                packet_rays<R>& P, walk_counters& C)
+                                                packet_rays<R>& P, walk_counters& C, uint32_t neg)
 {
     const uint32_t lane = lane_id();
     int stack = 0;            // wave-shared stack: slot k lives in lane k of this VGPR
     uint32_t sp = 0;          // scalar
     uint32_t steps = 0;
-    const uint32_t lane_bytes = (lane & 15u) * 4u;
+    const uint32_t tri_bytes = (lane & 15u) * 4u, node_bytes = node_line_bytes(lane, SIGNS, neg);
     // root: its own box is never tested, both children are
-    int w_node = fetch_node_dword(nodes, 0, lane);
+    int w_node = fetch_line_dword(nodes, tris, 0u, node_bytes);
     for (;;) {
+        // SIGNS: node lines arrive with their planes already ordered (node_bytes above): *min = near, *max = far
         const uniform_node nd = broadcast_node(w_node);
         const uint32_t lref = __float_as_uint(nd.lmin.w), rref = __float_as_uint(nd.lmax.w);
         const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
         // both children are fetched NOW (node line or triangle line), before the box tests: whichever
         // the packet goes to next is already in flight — one memory latency per step instead of two
-        const int w_l = fetch_line_dword(nodes, tris, lref, lane_bytes);
-        const int w_r = fetch_line_dword(nodes, tris, rref, lane_bytes);
+        const int w_l = fetch_line_dword(nodes, tris, lref, leaf_l ? tri_bytes : node_bytes);
+        const int w_r = fetch_line_dword(nodes, tris, rref, leaf_r ? tri_bytes : node_bytes);
         if (STATS && lane == 0) C.pops++;
         steps++;
         float tl[R], tr[R];
@@ -298,8 +331,14 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
         int pref = 0;     // > 0: this lane's rays that want both children reach the left one first
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            hit_l[r] = P.act[r] && ray_box(nd.lmin, nd.lmax, P.ray[r], tl[r]);
-            hit_r[r] = P.act[r] && ray_box(nd.rmin, nd.rmax, P.ray[r], tr[r]);
+            if (SIGNS) {
+                // nd.*min hold the near planes, nd.*max the far ones (picked at the broadcast)
+                hit_l[r] = P.act[r] && ray_box_ordered(nd.lmin.x, nd.lmin.y, nd.lmin.z, nd.lmax.x, nd.lmax.y, nd.lmax.z, P.ray[r], tl[r]);
+                hit_r[r] = P.act[r] && ray_box_ordered(nd.rmin.x, nd.rmin.y, nd.rmin.z, nd.rmax.x, nd.rmax.y, nd.rmax.z, P.ray[r], tr[r]);
+            } else {
+                hit_l[r] = P.act[r] && ray_box(nd.lmin, nd.lmax, P.ray[r], tl[r]);
+                hit_r[r] = P.act[r] && ray_box(nd.rmin, nd.rmax, P.ray[r], tr[r]);
+            }
             if (STATS) C.box += (hit_l[r] ? 1u : 0u) + (hit_r[r] ? 1u : 0u);
             // a box that starts beyond this ray's best hit cannot hold a nearer one
             hit_l[r] = hit_l[r] && !(tl[r] > P.best_t[r]);
@@ -362,7 +401,7 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
         } else {
             if (sp == 0) return steps;
             sp--;
-            w_node = fetch_line_dword(nodes, tris, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), lane_bytes);
+            w_node = fetch_line_dword(nodes, tris, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), node_bytes);
         }
     }
 }
@@ -448,13 +487,15 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
     const uint32_t tile = shard_tile(w, a.shard_index, a.shard_count);
     if (w >= n_work || tile >= a.tiles_x * a.tiles_y) return;        // cannot happen for a heavy item
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    const uint32_t lane_bytes = (lane & 15u) * 4u;
     // as many waves as the tile's last step count is worth (about kCoopGrain steps each); the others leave now
     const uint32_t n_waves = min(max((cost[w] + heavy_cap.grain / 2u) / heavy_cap.grain, 2u), (uint32_t)kCoopWaves);
     if (wave >= n_waves) return;
     packet_rays<1> P;
     uint32_t px0, py0;
     tile_rays<1, 1>(a, tile, lane, P, px0, py0);
+    uint32_t neg = 0;
+    const bool ordered = packet_signs(P, neg);      // see walk_packet
+    const uint32_t tri_bytes = (lane & 15u) * 4u, node_bytes = node_line_bytes(lane, ordered, neg);
     if (threadIdx.x < 64u) S.best[threadIdx.x] = (unsigned long long)ordered_key(LBVH_MAX_FLOAT) << 32;
     if (threadIdx.x == 0) { S.give_n = 0; S.lock = 0; S.idle = n_waves - 1u; S.steps = 0; }
     __syncthreads();
@@ -492,19 +533,25 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
             cur = got;
             have = true;
         }
-        int w_node = fetch_line_dword(nodes, tris, cur, lane_bytes);
+        int w_node = fetch_line_dword(nodes, tris, cur, node_bytes);
         for (;;) {      // one chain: until this wave has nothing left
             const uniform_node nd = broadcast_node(w_node);
             const uint32_t lref = __float_as_uint(nd.lmin.w), rref = __float_as_uint(nd.lmax.w);
             const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
-            const int w_l = fetch_line_dword(nodes, tris, lref, lane_bytes);
-            const int w_r = fetch_line_dword(nodes, tris, rref, lane_bytes);
+            const int w_l = fetch_line_dword(nodes, tris, lref, leaf_l ? tri_bytes : node_bytes);
+            const int w_r = fetch_line_dword(nodes, tris, rref, leaf_r ? tri_bytes : node_bytes);
             if (STATS && lane == 0) C.pops++;
             steps++;
             float best_t = key_value((uint32_t)(V.best[lane] >> 32));      // everybody's hits so far
             float tl, tr;
-            bool hit_l = P.act[0] && ray_box(nd.lmin, nd.lmax, P.ray[0], tl);
-            bool hit_r = P.act[0] && ray_box(nd.rmin, nd.rmax, P.ray[0], tr);
+            bool hit_l, hit_r;
+            if (ordered) {
+                hit_l = P.act[0] && ray_box_ordered(nd.lmin.x, nd.lmin.y, nd.lmin.z, nd.lmax.x, nd.lmax.y, nd.lmax.z, P.ray[0], tl);
+                hit_r = P.act[0] && ray_box_ordered(nd.rmin.x, nd.rmin.y, nd.rmin.z, nd.rmax.x, nd.rmax.y, nd.rmax.z, P.ray[0], tr);
+            } else {
+                hit_l = P.act[0] && ray_box(nd.lmin, nd.lmax, P.ray[0], tl);
+                hit_r = P.act[0] && ray_box(nd.rmin, nd.rmax, P.ray[0], tr);
+            }
             if (STATS) C.box += (hit_l ? 1u : 0u) + (hit_r ? 1u : 0u);
             hit_l = hit_l && !(tl > best_t);
             hit_r = hit_r && !(tr > best_t);
@@ -555,7 +602,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                 w_node = w_r;
             } else if (sp != base) {
                 sp--;
-                w_node = fetch_line_dword(nodes, tris, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), lane_bytes);
+                w_node = fetch_line_dword(nodes, tris, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), node_bytes);
             } else {
                 more = false;
             }
@@ -625,7 +672,10 @@ __device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_
     tile_rays<1, 1>(a, tile, lane, P, px0, py0);
     P.best_t[0] = LBVH_MAX_FLOAT; P.best_tri[0] = 0; P.best_u[0] = 0.0f; P.best_v[0] = 0.0f;
     walk_counters C = {0, 0, 0, 0};
-    const uint32_t steps = walk_packet<STATS, 1>(nodes, tris, P, C);
+    uint32_t neg = 0;
+    const bool ordered = packet_signs(P, neg);
+    const uint32_t steps = ordered ? walk_packet<STATS, 1, true>(nodes, tris, P, C, neg)
+                                   : walk_packet<STATS, 1, false>(nodes, tris, P, C, 0u);
     if (lane == 0) cost[w] = steps;
     if (STATS && tile_cost && lane == 0) tile_cost[tile] = steps;
     uint32_t n_hit = 0;
