@@ -30,12 +30,13 @@ struct alignas(64) lbvh_fast_node {
 };
 static_assert(sizeof(lbvh_fast_node) == 64, "fast node must be 64 bytes");
 
-// Positions-only triangle in SORTED order for LBVH_TRACE_FAST, 48 bytes (3 x float4).
-// The .w lanes carry the original triangle index (a.w) so the hit record needs no extra gather.
+// Triangle in SORTED order for LBVH_TRACE_FAST, 48 bytes (3 x float4): first vertex and the two edge vectors
+// e1 = b - a, e2 = c - a (the fp32 differences the intersection test starts with, Raytracing.compute:41-42, taken
+// once at build time).  The .w of the first carries the original triangle index: no extra gather for the hit record.
 struct alignas(16) lbvh_fast_tri {
     float a[3]; uint32_t orig_index;
-    float b[3]; uint32_t pad0;
-    float c[3]; uint32_t pad1;
+    float e1[3]; uint32_t pad0;
+    float e2[3]; uint32_t pad1;
 };
 static_assert(sizeof(lbvh_fast_tri) == 48, "fast triangle must be 48 bytes");
 

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* _
                     const float4* tv = reinterpret_cast<const float4*>(&tris[ref & 0x7FFFFFFFu]);
                     const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
                     float u = 0.0f, v = 0.0f;
-                    const float dist = ray_triangle(ray, v0, v1, v2, u, v);
+                    const float dist = ray_fast_triangle(ray, v0, v1, v2, u, v);
                     if (dist > t_min && dist < best_t) { best_t = dist; best_tri = __float_as_uint(v0.w); best_u = u; best_v = v; }
                 }
             }

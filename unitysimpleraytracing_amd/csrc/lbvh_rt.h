@@ -72,12 +72,11 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
     return (ax * bx + ay * by) + az * bz;
 }
 
-// RayTriangleIntersection, Raytracing.compute:37-73.  Returns distance (LBVH_MAX_FLOAT = miss).
-__device__ __forceinline__ float ray_triangle(const ray_t& r, const float4 v0, const float4 v1,
-                                              const float4 v2, float& u_out, float& v_out)
+// RayTriangleIntersection, Raytracing.compute:37-73, from the first vertex and the two edge vectors
+// e1 = v1 - v0, e2 = v2 - v0 (:41-42).  Returns distance (LBVH_MAX_FLOAT = miss).
+__device__ __forceinline__ float ray_triangle_edges(const ray_t& r, const float4 v0, const float e1x, const float e1y, const float e1z,
+                                                    const float e2x, const float e2y, const float e2z, float& u_out, float& v_out)
 {
-    const float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
-    const float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
     // pvec = cross(dir, e2)
     const float px = r.dy * e2z - r.dz * e2y;
     const float py = r.dz * e2x - r.dx * e2z;
@@ -97,6 +96,20 @@ __device__ __forceinline__ float ray_triangle(const ray_t& r, const float4 v0, c
     u_out = u;
     v_out = v;
     return dot3(e2x, e2y, e2z, qx, qy, qz) * inv_det;
+}
+
+__device__ __forceinline__ float ray_triangle(const ray_t& r, const float4 v0, const float4 v1,
+                                              const float4 v2, float& u_out, float& v_out)
+{
+    return ray_triangle_edges(r, v0, v1.x - v0.x, v1.y - v0.y, v1.z - v0.z, v2.x - v0.x, v2.y - v0.y, v2.z - v0.z, u_out, v_out);
+}
+
+// the sorted-triangle record of the derived scene: {v0, original index | e1 | e2} — the edges are the same fp32
+// differences the reference forms per test, taken once at build time
+__device__ __forceinline__ float ray_fast_triangle(const ray_t& r, const float4 t0, const float4 t1, const float4 t2,
+                                                   float& u_out, float& v_out)
+{
+    return ray_triangle_edges(r, t0, t1.x, t1.y, t1.z, t2.x, t2.y, t2.z, u_out, v_out);
 }
 
 }  // namespace

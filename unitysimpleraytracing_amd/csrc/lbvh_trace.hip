@@ -175,8 +175,8 @@ __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh
     const float4 a = tv[0], b = tv[1], c = tv[2];
     float4* o = reinterpret_cast<float4*>(&tris[pos]);
     o[0] = make_float4(a.x, a.y, a.z, __uint_as_float(tri));
-    o[1] = make_float4(b.x, b.y, b.z, 0.0f);
-    o[2] = make_float4(c.x, c.y, c.z, 0.0f);
+    o[1] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, 0.0f);
+    o[2] = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, 0.0f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -357,7 +357,7 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
                 if (hit_l[r]) {
                     if (STATS) C.tri++;
                     float u = 0.0f, v = 0.0f;
-                    const float dist = ray_triangle(P.ray[r], v0, v1, v2, u, v);
+                    const float dist = ray_fast_triangle(P.ray[r], v0, v1, v2, u, v);
                     if (dist < P.best_t[r]) { P.best_t[r] = dist; P.best_tri[r] = __float_as_uint(v0.w); P.best_u[r] = u; P.best_v[r] = v; }
                 }
                 hit_r[r] = hit_r[r] && !(tr[r] > P.best_t[r]);
@@ -374,7 +374,7 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
                 if (hit_r[r]) {
                     if (STATS) C.tri++;
                     float u = 0.0f, v = 0.0f;
-                    const float dist = ray_triangle(P.ray[r], v0, v1, v2, u, v);
+                    const float dist = ray_fast_triangle(P.ray[r], v0, v1, v2, u, v);
                     if (dist < P.best_t[r]) { P.best_t[r] = dist; P.best_tri[r] = __float_as_uint(v0.w); P.best_u[r] = u; P.best_v[r] = v; }
                 }
                 hit_l[r] = hit_l[r] && !(tl[r] > P.best_t[r]);
@@ -562,7 +562,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                 if (hit_l) {
                     if (STATS) C.tri++;
                     float u = 0.0f, v = 0.0f;
-                    const float dist = ray_triangle(P.ray[0], v0, v1, v2, u, v);
+                    const float dist = ray_fast_triangle(P.ray[0], v0, v1, v2, u, v);
                     if (dist < best_t) {
                         best_t = dist;
                         atomicMin(&S.best[lane], ((unsigned long long)ordered_key(dist) << 32) | (lref & 0x7FFFFFFFu));
@@ -577,7 +577,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                 if (hit_r) {
                     if (STATS) C.tri++;
                     float u = 0.0f, v = 0.0f;
-                    const float dist = ray_triangle(P.ray[0], v0, v1, v2, u, v);
+                    const float dist = ray_fast_triangle(P.ray[0], v0, v1, v2, u, v);
                     if (dist < best_t) {
                         best_t = dist;
                         atomicMin(&S.best[lane], ((unsigned long long)ordered_key(dist) << 32) | (rref & 0x7FFFFFFFu));
@@ -643,7 +643,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                 const float4* tv = reinterpret_cast<const float4*>(&tris[(uint32_t)key]);
                 const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
                 float u = 0.0f, v = 0.0f;
-                const float dist = ray_triangle(P.ray[0], v0, v1, v2, u, v);
+                const float dist = ray_fast_triangle(P.ray[0], v0, v1, v2, u, v);
                 out = make_float4(dist, v0.w, u, v);
                 if (STATS) n_hit++;
             }
