@@ -79,6 +79,7 @@ struct lbvh_context {
     uint64_t trace_layout = 0;      // frame layout (tiles, shard, origin) the history belongs to
     uint32_t trace_layout_work = 0;
     bool trace_history = false;
+    uint32_t trace_counts_turn = 0;  // which of the two class-counter sets the next filing counts into
     // the traversal tree of the derived scene (aligned keys, own topology and boxes)
     void* fast_tree = nullptr;
     size_t fast_tree_bytes = 0;

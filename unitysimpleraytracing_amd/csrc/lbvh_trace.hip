@@ -240,6 +240,18 @@ __device__ __forceinline__ int fetch_line_dword(const lbvh_fast_node* __restrict
     const uint32_t stride = leaf ? (uint32_t)sizeof(lbvh_fast_tri) : (uint32_t)sizeof(lbvh_fast_node);
     return *reinterpret_cast<const int*>(array + (size_t)i * stride + lane_bytes);
 }
+// dword K of the line held by every 16-lane row of w, in all lanes (DPP row_newbcast:K, gfx90a+; folds into the
+// consuming vector instruction)
+template <int K>
+__device__ __forceinline__ float row_dword(int w)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, w, 0x150 + K, 0xf, 0xf, true));
+}
+template <int K>
+__device__ __forceinline__ float4 row_box(int w)     // dwords K, K + 1, K + 2 as a box corner
+{
+    return make_float4(row_dword<K>(w), row_dword<K + 1>(w), row_dword<K + 2>(w), 0.0f);
+}
 __device__ __forceinline__ uniform_node broadcast_node(int w)
 {
     uniform_node nd;
@@ -332,12 +344,20 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (SIGNS) {
-                // nd.*min hold the near planes, nd.*max the far ones (picked at the broadcast)
-                hit_l[r] = P.act[r] && ray_box_ordered(nd.lmin.x, nd.lmin.y, nd.lmin.z, nd.lmax.x, nd.lmax.y, nd.lmax.z, P.ray[r], tl[r]);
-                hit_r[r] = P.act[r] && ray_box_ordered(nd.rmin.x, nd.rmin.y, nd.rmin.z, nd.rmax.x, nd.rmax.y, nd.rmax.z, P.ray[r], tr[r]);
+                // the planes come straight out of the line register: every 16-lane row holds the whole line, and a DPP
+                // row broadcast feeds dword k to the subtraction as its operand — no v_readlane, no SGPR
+                // (evaluated by every lane, inactive ones too: a DPP operand must not sit behind a lane-dependent branch)
+                const bool box_l = ray_box_ordered(row_dword<0>(w_node), row_dword<1>(w_node), row_dword<2>(w_node),
+                                                   row_dword<4>(w_node), row_dword<5>(w_node), row_dword<6>(w_node), P.ray[r], tl[r]);
+                const bool box_r = ray_box_ordered(row_dword<8>(w_node), row_dword<9>(w_node), row_dword<10>(w_node),
+                                                   row_dword<12>(w_node), row_dword<13>(w_node), row_dword<14>(w_node), P.ray[r], tr[r]);
+                hit_l[r] = P.act[r] & box_l;
+                hit_r[r] = P.act[r] & box_r;
             } else {
-                hit_l[r] = P.act[r] && ray_box(nd.lmin, nd.lmax, P.ray[r], tl[r]);
-                hit_r[r] = P.act[r] && ray_box(nd.rmin, nd.rmax, P.ray[r], tr[r]);
+                const bool box_l = ray_box(row_box<0>(w_node), row_box<4>(w_node), P.ray[r], tl[r]);
+                const bool box_r = ray_box(row_box<8>(w_node), row_box<12>(w_node), P.ray[r], tr[r]);
+                hit_l[r] = P.act[r] & box_l;
+                hit_r[r] = P.act[r] & box_r;
             }
             if (STATS) C.box += (hit_l[r] ? 1u : 0u) + (hit_r[r] ? 1u : 0u);
             // a box that starts beyond this ray's best hit cannot hold a nearer one
@@ -546,12 +566,16 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
             float tl, tr;
             bool hit_l, hit_r;
             if (ordered) {
-                hit_l = P.act[0] && ray_box_ordered(nd.lmin.x, nd.lmin.y, nd.lmin.z, nd.lmax.x, nd.lmax.y, nd.lmax.z, P.ray[0], tl);
-                hit_r = P.act[0] && ray_box_ordered(nd.rmin.x, nd.rmin.y, nd.rmin.z, nd.rmax.x, nd.rmax.y, nd.rmax.z, P.ray[0], tr);
+                hit_l = ray_box_ordered(row_dword<0>(w_node), row_dword<1>(w_node), row_dword<2>(w_node),
+                                        row_dword<4>(w_node), row_dword<5>(w_node), row_dword<6>(w_node), P.ray[0], tl);
+                hit_r = ray_box_ordered(row_dword<8>(w_node), row_dword<9>(w_node), row_dword<10>(w_node),
+                                        row_dword<12>(w_node), row_dword<13>(w_node), row_dword<14>(w_node), P.ray[0], tr);
             } else {
-                hit_l = P.act[0] && ray_box(nd.lmin, nd.lmax, P.ray[0], tl);
-                hit_r = P.act[0] && ray_box(nd.rmin, nd.rmax, P.ray[0], tr);
+                hit_l = ray_box(row_box<0>(w_node), row_box<4>(w_node), P.ray[0], tl);
+                hit_r = ray_box(row_box<8>(w_node), row_box<12>(w_node), P.ray[0], tr);
             }
+            hit_l = P.act[0] & hit_l;
+            hit_r = P.act[0] & hit_r;
             if (STATS) C.box += (hit_l ? 1u : 0u) + (hit_r ? 1u : 0u);
             hit_l = hit_l && !(tl > best_t);
             hit_r = hit_r && !(tr > best_t);
@@ -766,11 +790,15 @@ __device__ __forceinline__ uint32_t order_class(uint32_t steps)
 }
 
 __global__ __launch_bounds__(1024) void file_tiles_kernel(const uint32_t* __restrict__ cost, uint32_t n_work,
-                                                          uint32_t* __restrict__ counts, uint32_t* __restrict__ lists)
+                                                          uint32_t* __restrict__ counts, uint32_t* __restrict__ lists,
+                                                          uint32_t* __restrict__ next_counts)
 {
     __shared__ uint32_t s_count[kOrderClasses], s_base[kOrderClasses];
     const uint32_t t = threadIdx.x, lane = lane_id();
     const uint32_t i = blockIdx.x * 1024u + t;
+    // the class counters take turns: this launch clears the set the NEXT filing will count into (the trace that
+    // read it has finished), so no fill kernel sits between the rebuild and the trace
+    if (blockIdx.x == 0 && t < (uint32_t)kOrderClasses) next_counts[t] = 0;
     if (t < (uint32_t)kOrderClasses) s_count[t] = 0;
     __syncthreads();
     const uint32_t cls = i < n_work ? order_class(cost[i]) : 0xFFFFFFFFu;
@@ -805,16 +833,22 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     void* before = ctx->trace_queues;
     int rc = lbvh_reserve(ctx, &ctx->trace_queues, &ctx->trace_queues_bytes, 256 + cost_bytes + (size_t)kOrderClasses * cost_bytes);
     if (rc != LBVH_OK) return rc;
-    if (ctx->trace_queues != before) ctx->trace_history = false;
-    uint32_t* counts = (uint32_t*)ctx->trace_queues;
+    if (ctx->trace_queues != before) {
+        ctx->trace_history = false;
+        ctx->trace_counts_turn = 0;
+        LBVH_HIP_TRY(ctx, hipMemsetAsync(ctx->trace_queues, 0, 256, ctx->cur_stream));
+    }
+    // two sets of 16 class counters in the first 256 bytes
+    uint32_t* counts = (uint32_t*)ctx->trace_queues + 32u * ctx->trace_counts_turn;
+    uint32_t* next_counts = (uint32_t*)ctx->trace_queues + 32u * (ctx->trace_counts_turn ^ 1u);
     uint32_t* cost = (uint32_t*)((char*)ctx->trace_queues + 256);
     uint32_t* lists = (uint32_t*)((char*)ctx->trace_queues + 256 + cost_bytes);
     const uint64_t layout = ((uint64_t)a.tiles_x << 48) ^ ((uint64_t)a.tiles_y << 32) ^ ((uint64_t)a.shard_index << 16) ^
                             (uint64_t)a.shard_count ^ ((uint64_t)(uint32_t)a.x0 << 8) ^ ((uint64_t)(uint32_t)a.y0 << 24);
     const bool have_history = ctx->trace_layout == layout && ctx->trace_layout_work == n_work && ctx->trace_history;
     if (have_history) {
-        LBVH_HIP_TRY(ctx, hipMemsetAsync(counts, 0, 256, ctx->cur_stream));
-        LBVH_LAUNCH(ctx, file_tiles_kernel, dim3((n_work + 1023) / 1024), dim3(1024), cost, n_work, counts, lists);
+        LBVH_LAUNCH(ctx, file_tiles_kernel, dim3((n_work + 1023) / 1024), dim3(1024), cost, n_work, counts, lists, next_counts);
+        ctx->trace_counts_turn ^= 1u;
     }
     // Which tiles are walked cooperatively (known from the last trace).  It costs ~50 % more steps on those tiles (a
     // subtree handed to another wave is walked before the near hits that would have pruned it are known), so it is
