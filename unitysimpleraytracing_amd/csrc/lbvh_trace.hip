@@ -241,7 +241,8 @@ __device__ __forceinline__ int fetch_line_dword(const lbvh_fast_node* __restrict
     return *reinterpret_cast<const int*>(array + (size_t)i * stride + lane_bytes);
 }
 // dword K of the line held by every 16-lane row of w, in all lanes (DPP row_newbcast:K, gfx90a+; folds into the
-// consuming vector instruction)
+// consuming vector instruction).  ONLY where every lane is active: a DPP read of a disabled source lane yields 0
+// (the triangle test under `if (hit)` tried it and lost the triangle indices)
 template <int K>
 __device__ __forceinline__ float row_dword(int w)
 {
