@@ -294,9 +294,10 @@ def main():
                     round(own_bytes_per_ray * W * H / (trace_kernel_ms * 1e-3) / 1e9, 1),
                     "kernel_ms": round(trace_kernel_ms, 4),
                     "note": "achieved/frac price the kernel at the bytes of the reference's per-ray walk it replaces (SURVEY 8d); the "
-                            "packet kernel itself moves own_bytes_per_ray and is bounded by the dependent instruction chain of its heaviest "
-                            "tile, not by HBM (DESIGN.md section 7)",
-                    "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4)}
+                            "packet kernel itself moves own_bytes_per_ray and is bound by vector / scalar instruction issue "
+                            "(instruction_issue; DESIGN.md section 7), not by HBM",
+                    "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
+                    "instruction_issue": None if cfg4 else issue_counters(trace_kernel_ms)}
 
         sort_roofline = None
         if not args.no_sort_bench:
@@ -371,6 +372,23 @@ def measured_traffic(kernel_substr, largest_grid=True):
     v = rows[-1][1] if largest_grid else rows[0][1]
     return {"bytes": round(v["fetch_bytes_x2"] + v["write_bytes"]), "fetch_bytes_x2": round(v["fetch_bytes_x2"]),
             "write_bytes": round(v["write_bytes"]), "source": os.path.relpath(files[-1], ROOT)}
+
+
+def issue_counters(kernel_ms, clock_ghz=2.4):
+    """What actually bounds the packet kernel: the committed SQ instruction counters of the same frame
+    (tools/pmc_packet.sh) priced at the issue rates — one wave64 vector instruction per 4 cycles per SIMD
+    (1024 SIMDs), one scalar instruction per cycle per CU (256) — against this run's live kernel duration."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*packet_counters.json")))
+    if not files:
+        return None
+    c = json.load(open(files[-1]))
+    cycles = kernel_ms * 1e-3 * clock_ghz * 1e9
+    return {"valu_per_step": c["valu_per_step"], "salu_per_step": c["salu_per_step"], "steps": c["steps"],
+            "lane_utilisation": c["lane_utilisation"],
+            "valu_issue_frac": round(c["valu_issue_cycles_per_simd"] / cycles, 3),
+            "salu_issue_frac": round(c["salu_issue_cycles_per_cu"] / cycles, 3),
+            "clock_GHz": clock_ghz, "source": os.path.relpath(files[-1], ROOT)}
 
 
 def sort_microbench(ctx, log2n, copy_gbs):
