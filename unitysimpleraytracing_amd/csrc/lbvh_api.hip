@@ -49,7 +49,7 @@ hipEvent_t lbvh_prof_event(lbvh_context* ctx)
         ctx->prof_pool.pop_back();
         return e;
     }
-    (void)hipEventCreate(&e);
+    (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
     return e;
 }
 
@@ -209,8 +209,10 @@ lbvh_status lbvh_event_create(lbvh_context* ctx, void** out_event)
 {
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     LBVH_REQUIRE(ctx, out_event != nullptr);
+    // timing-only events: no system-scope fence at the record (HIP: "avoids the cost of cache writeback and
+    // invalidation, and the performance impact of those actions on the execution of following work")
     hipEvent_t ev;
-    LBVH_HIP_TRY(ctx, hipEventCreate(&ev));
+    LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
     *out_event = (void*)ev;
     return LBVH_OK;
 }
