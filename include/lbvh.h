@@ -120,7 +120,7 @@ typedef struct lbvh_camera {
  * reference's visit semantics for LBVH_TRACE_REFERENCE: P nodes popped, B internal boxes hit,
  * L leaf-AABB tests, T triangle tests.  Used for the algorithmic-bytes figure.
  * LBVH_TRACE_FAST walks one 8x8-pixel packet per wave: there `pops` = 64-byte node fetches and
- * `leaf_tests` = 48-byte triangle fetches per PACKET (each shared by the packet's 64 rays),
+ * `leaf_tests` = triangle-line fetches per PACKET (each shared by the packet's 64 rays),
  * `box_hits` and `tri_tests` stay per ray. */
 typedef struct lbvh_trace_stats {
     uint64_t pops;
@@ -287,8 +287,9 @@ typedef struct lbvh_scene {
 /* Build the derived traversal structure used by LBVH_TRACE_FAST for `scene`: its own "traversal
  * tree" over the scene's SORTED triangle order (Karras topology over minimally perturbed Morton
  * keys k'_i = i + max_{j<=i}(k_j - j) instead of DistributeKeys' shifted ones — tighter boxes — and
- * its own refit), flattened to fused 64-B nodes (both child boxes + child references) plus 48-B
- * positions-only triangles in sorted order.  h_box_min/max = the scene box given to
+ * its own refit), flattened to fused 64-B nodes (both child boxes + child references) plus the sorted
+ * triangles as 64-B lines (first vertex, two edge vectors, original index) in the same array.  At most 2^30 - 1
+ * triangles.  h_box_min/max = the scene box given to
  * lbvh_morton_aabb (the raw Morton code of a sorted position is recomputed from its triangle AABB).
  * Owned by the context, rebuilt on each call; call it after lbvh_sort_pairs (+ lbvh_morton_aabb) and
  * before the first LBVH_TRACE_FAST launch.  The scene's internalNodes / leafNodes / bvhData are not

@@ -126,7 +126,6 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->fast_nodes) (void)hipFree(ctx->fast_nodes);
-    if (ctx->fast_tris) (void)hipFree(ctx->fast_tris);
     if (ctx->trace_queues) (void)hipFree(ctx->trace_queues);
     if (ctx->fast_tree) (void)hipFree(ctx->fast_tree);
     if (ctx->ray_scratch) (void)hipFree(ctx->ray_scratch);

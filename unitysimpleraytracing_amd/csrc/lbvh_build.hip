@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kRefitThreads) void refit_kernel(uint32_t n, const 
                                                               lbvh_aabb* bvh, refit_levels_t lv,
                                                               uint32_t* __restrict__ frontier_count,
                                                               uint32_t* __restrict__ frontier_list,
-                                                              lbvh_fast_node* __restrict__ fused)
+                                                              lbvh_fast_node* __restrict__ fused, uint32_t leaf_base)
 {
     // parked child boxes, [side][slot] = {min xyz, range word | max xyz, -}: two 16-byte LDS accesses per box.
     // range word: first | last << 16 relative to the workgroup, bit 31 = the parked child is a leaf.   64 KB
@@ -443,8 +443,9 @@ __global__ __launch_bounds__(kRefitThreads) void refit_kernel(uint32_t n, const 
             if (FUSED) {
                 const uint32_t split = s_node[t].x;
                 float4* out = reinterpret_cast<float4*>(&fused[j]);
-                out[0] = make_float4(lmn.x, lmn.y, lmn.z, __uint_as_float((__float_as_uint(lmn.w) & 0x80000000u) | split));
-                out[1] = make_float4(lmx.x, lmx.y, lmx.z, __uint_as_float((__float_as_uint(rmn.w) & 0x80000000u) | (split + 1u)));
+                const uint32_t l_leaf = __float_as_uint(lmn.w) & 0x80000000u, r_leaf = __float_as_uint(rmn.w) & 0x80000000u;
+                out[0] = make_float4(lmn.x, lmn.y, lmn.z, __uint_as_float(l_leaf | (split + (l_leaf ? leaf_base : 0u))));
+                out[1] = make_float4(lmx.x, lmx.y, lmx.z, __uint_as_float(r_leaf | (split + 1u + (r_leaf ? leaf_base : 0u))));
                 out[2] = make_float4(rmn.x, rmn.y, rmn.z, 0.0f);
                 out[3] = make_float4(rmx.x, rmx.y, rmx.z, 0.0f);
             } else {
@@ -476,7 +477,8 @@ __global__ __launch_bounds__(256) void fuse_frontier_kernel(uint32_t n, const lb
                                                             const uint32_t* __restrict__ count, const uint32_t* __restrict__ list,
                                                             const lbvh_aabb* __restrict__ tri_aabb,
                                                             const uint32_t* __restrict__ sorted_indices,
-                                                            const lbvh_aabb* __restrict__ bvh, lbvh_fast_node* __restrict__ fused)
+                                                            const lbvh_aabb* __restrict__ bvh, lbvh_fast_node* __restrict__ fused,
+                                                            uint32_t leaf_base)
 {
     const uint32_t total = *count;
     for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(256) void fuse_frontier_kernel(uint32_t n, const lb
                 ref[side] = c.x;
             } else {
                 src = reinterpret_cast<const float4*>(&tri_aabb[sorted_indices ? sorted_indices[c.x] : c.x]);
-                ref[side] = 0x80000000u | c.x;          // leaf c sits at sorted position c (tree_kernel)
+                ref[side] = 0x80000000u | (leaf_base + c.x);   // leaf c sits at sorted position c (tree_kernel)
             }
             b[2 * side + 0] = src[0];
             b[2 * side + 1] = src[1];
@@ -792,7 +794,7 @@ int lbvh_refit_counter(lbvh_context* ctx, uint32_t n, uint32_t** d_counter)
 
 int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d_internal, const lbvh_leaf_node* d_leaf,
                       const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh,
-                      lbvh_fast_node* d_fused, bool counter_cleared)
+                      lbvh_fast_node* d_fused, uint32_t fused_leaf_base, bool counter_cleared)
 {
     refit_plan plan;
     {
@@ -806,10 +808,10 @@ int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d
     const uint32_t blocks = (n + kRefitThreads - 1) / kRefitThreads;
     if (d_fused)
         LBVH_LAUNCH(ctx, refit_kernel<true>, dim3(blocks), dim3(kRefitThreads), n, d_internal, d_leaf, d_triangle_aabb,
-                    d_sorted_indices, d_bvh, lv, count, list, d_fused);
+                    d_sorted_indices, d_bvh, lv, count, list, d_fused, fused_leaf_base);
     else
         LBVH_LAUNCH(ctx, refit_kernel<false>, dim3(blocks), dim3(kRefitThreads), n, d_internal, d_leaf, d_triangle_aabb,
-                    d_sorted_indices, d_bvh, lv, count, list, d_fused);
+                    d_sorted_indices, d_bvh, lv, count, list, d_fused, 0u);
     if (blocks > 1) {       // a single workgroup finishes the whole tree in LDS
         for (int k = 3; k <= lv.levels; k++)
             LBVH_LAUNCH(ctx, refit_level_kernel, dim3((lv.count[k] + 255) / 256), dim3(256), lv, k);
@@ -819,7 +821,7 @@ int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d
                     d_sorted_indices, d_bvh, lv);
         if (d_fused)
             LBVH_LAUNCH(ctx, fuse_frontier_kernel, dim3(blocks < 64u ? blocks : 64u), dim3(256), n, d_internal, count, list,
-                        d_triangle_aabb, d_sorted_indices, d_bvh, d_fused);
+                        d_triangle_aabb, d_sorted_indices, d_bvh, d_fused, fused_leaf_base);
     }
     return LBVH_OK;
 }
@@ -906,7 +908,7 @@ lbvh_status lbvh_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* 
     LBVH_REQUIRE(ctx, ((uintptr_t)d_internal & 7) == 0 && ((uintptr_t)d_triangle_aabb & 15) == 0 &&
                           ((uintptr_t)d_bvh & 15) == 0);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = lbvh_launch_refit(ctx, n, d_internal, d_leaf, d_triangle_aabb, d_sorted_indices, d_bvh, nullptr, false);
+    int rc = lbvh_launch_refit(ctx, n, d_internal, d_leaf, d_triangle_aabb, d_sorted_indices, d_bvh, nullptr, 0u, false);
     if (rc != LBVH_OK) return rc;
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;

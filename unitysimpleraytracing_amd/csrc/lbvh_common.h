@@ -20,8 +20,8 @@ static_assert(sizeof(lbvh_hit) == 16, "hit record must be 16 bytes");
 #define LBVH_WAVE 64
 
 // Derived traversal node for LBVH_TRACE_FAST: both child boxes + child references, 64 bytes,
-// one 64-B aligned fetch per traversal step.  Child reference: bit 31 set = leaf, low bits =
-// SORTED leaf position (index into fast_tris); bit 31 clear = internal node index.
+// one 64-B aligned fetch per traversal step.  Child reference: an index into the array of 64-byte lines that
+// holds the nodes and, from index fast_leaf_base on, the sorted triangles; bit 31 set = leaf.
 struct alignas(64) lbvh_fast_node {
     float lmin[3]; uint32_t left;
     float lmax[3]; uint32_t right;
@@ -30,15 +30,19 @@ struct alignas(64) lbvh_fast_node {
 };
 static_assert(sizeof(lbvh_fast_node) == 64, "fast node must be 64 bytes");
 
-// Triangle in SORTED order for LBVH_TRACE_FAST, 48 bytes (3 x float4): first vertex and the two edge vectors
+// Triangle in SORTED order for LBVH_TRACE_FAST (3 x float4 used): first vertex and the two edge vectors
 // e1 = b - a, e2 = c - a (the fp32 differences the intersection test starts with, Raytracing.compute:41-42, taken
 // once at build time).  The .w of the first carries the original triangle index: no extra gather for the hit record.
-struct alignas(16) lbvh_fast_tri {
+// Padded to the traversal node's 64 bytes and kept in the SAME allocation, right behind the nodes: a child reference
+// (node index, or LEAF | leaf_base + sorted position) is one index into one array of 64-byte lines, and a line fetch
+// is base + (index << 6) whatever it points at.
+struct alignas(64) lbvh_fast_tri {
     float a[3]; uint32_t orig_index;
     float e1[3]; uint32_t pad0;
     float e2[3]; uint32_t pad1;
+    uint32_t pad2[4];
 };
-static_assert(sizeof(lbvh_fast_tri) == 48, "fast triangle must be 48 bytes");
+static_assert(sizeof(lbvh_fast_tri) == 64, "fast triangle must be 64 bytes");
 
 struct lbvh_context {
     int device = 0;
@@ -70,8 +74,8 @@ struct lbvh_context {
     size_t refit_scratch_words[2] = {0, 0};
     // derived fast-traversal scene
     lbvh_fast_node* fast_nodes = nullptr;
-    lbvh_fast_tri* fast_tris = nullptr;
-    uint32_t fast_capacity = 0;
+    lbvh_fast_tri* fast_tris = nullptr;    // = fast_nodes + fast_capacity (same allocation)
+    uint32_t fast_capacity = 0;            // = the line index of sorted triangle 0 (leaf base)
     uint32_t fast_n = 0;
     // packet traversal scheduling: step count of every tile in the last trace + the dispatch order made from it
     void* trace_queues = nullptr;
@@ -146,10 +150,10 @@ int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, ui
 int lbvh_refit_counter(lbvh_context* ctx, uint32_t n, uint32_t** d_counter);
 int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d_internal, const lbvh_leaf_node* d_leaf,
                       const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh,
-                      lbvh_fast_node* d_fused, bool counter_cleared);
+                      lbvh_fast_node* d_fused, uint32_t fused_leaf_base, bool counter_cleared);
 // d_sorted_indices may be nullptr in lbvh_launch_refit: boxes already in leaf order.  d_fused != nullptr (a tree made
 // by lbvh_launch_tree only): write the 64-byte traversal nodes instead of d_bvh, which then only holds the few
-// boxes the frontier needs.
+// boxes the frontier needs; leaf references are LEAF | fused_leaf_base + sorted position.
 // The start of the derived build: leaf_box[i] = aabb[sorted[i]] and the aligned traversal keys
 // k'_i = i + max_{j<=i}(morton(centre of leaf_box[j]) - j), strictly increasing.
 int lbvh_launch_gather_aligned_keys(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_triangle_aabb,

@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh
     o[0] = make_float4(a.x, a.y, a.z, __uint_as_float(tri));
     o[1] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, 0.0f);
     o[2] = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, 0.0f);
+    o[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);             // whole 64-byte lines: no partial-line writes
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -224,21 +225,12 @@ struct uniform_node {        // one fused node, wave-uniform (lives in SGPRs)
 // i.e. one coalesced 64-byte line through the CU's vector L1, and v_readlane broadcasts the 16
 // dwords into SGPRs.
 #define LBVH_RL(v, k) __int_as_float(__builtin_amdgcn_readlane((v), (k)))
-__device__ __forceinline__ int fetch_node_dword(const lbvh_fast_node* __restrict__ nodes, uint32_t nidx, uint32_t lane)
+// a 64-byte line (node or sorted triangle) by reference: the address is base + (index << 6), computed on the scalar
+// unit; the load takes it as an SGPR base + the lane's constant byte offset (no vector address arithmetic in the walk)
+__device__ __forceinline__ int fetch_line_dword(const lbvh_fast_node* __restrict__ lines, uint32_t ref, uint32_t lane_bytes)
 {
-    return reinterpret_cast<const int*>(&nodes[nidx])[lane & 15u];
-}
-// child line (node, or triangle + the first 16 bytes after it: the array is padded) by reference: the address is
-// computed on the scalar unit, the load takes it as an SGPR base + the lane's constant byte offset (no vector
-// address arithmetic in the walk)
-__device__ __forceinline__ int fetch_line_dword(const lbvh_fast_node* __restrict__ nodes, const lbvh_fast_tri* __restrict__ tris,
-                                                uint32_t ref, uint32_t lane_bytes)
-{
-    const uint32_t i = ref & 0x7FFFFFFFu;
-    const bool leaf = (ref & 0x80000000u) != 0;
-    const char* array = leaf ? reinterpret_cast<const char*>(tris) : reinterpret_cast<const char*>(nodes);
-    const uint32_t stride = leaf ? (uint32_t)sizeof(lbvh_fast_tri) : (uint32_t)sizeof(lbvh_fast_node);
-    return *reinterpret_cast<const int*>(array + (size_t)i * stride + lane_bytes);
+    const char* base = reinterpret_cast<const char*>(lines) + ((size_t)(ref & 0x7FFFFFFFu) << 6);
+    return *reinterpret_cast<const int*>(base + lane_bytes);
 }
 // dword K of the line held by every 16-lane row of w, in all lanes (DPP row_newbcast:K, gfx90a+; folds into the
 // consuming vector instruction).  ONLY where every lane is active: a DPP read of a disabled source lane yields 0
@@ -326,7 +318,7 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
     uint32_t steps = 0;
     const uint32_t tri_bytes = (lane & 15u) * 4u, node_bytes = node_line_bytes(lane, SIGNS, neg);
     // root: its own box is never tested, both children are
-    int w_node = fetch_line_dword(nodes, tris, 0u, node_bytes);
+    int w_node = fetch_line_dword(nodes, 0u, node_bytes);
     for (;;) {
         // SIGNS: node lines arrive with their planes already ordered (node_bytes above): *min = near, *max = far
         const uniform_node nd = broadcast_node(w_node);
@@ -334,8 +326,8 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
         const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
         // both children are fetched NOW (node line or triangle line), before the box tests: whichever
         // the packet goes to next is already in flight — one memory latency per step instead of two
-        const int w_l = fetch_line_dword(nodes, tris, lref, leaf_l ? tri_bytes : node_bytes);
-        const int w_r = fetch_line_dword(nodes, tris, rref, leaf_r ? tri_bytes : node_bytes);
+        const int w_l = fetch_line_dword(nodes, lref, leaf_l ? tri_bytes : node_bytes);
+        const int w_r = fetch_line_dword(nodes, rref, leaf_r ? tri_bytes : node_bytes);
         if (STATS && lane == 0) C.pops++;
         steps++;
         float tl[R], tr[R];
@@ -422,7 +414,7 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
         } else {
             if (sp == 0) return steps;
             sp--;
-            w_node = fetch_line_dword(nodes, tris, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), node_bytes);
+            w_node = fetch_line_dword(nodes, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), node_bytes);
         }
     }
 }
@@ -554,13 +546,13 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
             cur = got;
             have = true;
         }
-        int w_node = fetch_line_dword(nodes, tris, cur, node_bytes);
+        int w_node = fetch_line_dword(nodes, cur, node_bytes);
         for (;;) {      // one chain: until this wave has nothing left
             const uniform_node nd = broadcast_node(w_node);
             const uint32_t lref = __float_as_uint(nd.lmin.w), rref = __float_as_uint(nd.lmax.w);
             const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
-            const int w_l = fetch_line_dword(nodes, tris, lref, leaf_l ? tri_bytes : node_bytes);
-            const int w_r = fetch_line_dword(nodes, tris, rref, leaf_r ? tri_bytes : node_bytes);
+            const int w_l = fetch_line_dword(nodes, lref, leaf_l ? tri_bytes : node_bytes);
+            const int w_r = fetch_line_dword(nodes, rref, leaf_r ? tri_bytes : node_bytes);
             if (STATS && lane == 0) C.pops++;
             steps++;
             float best_t = key_value((uint32_t)(V.best[lane] >> 32));      // everybody's hits so far
@@ -627,7 +619,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                 w_node = w_r;
             } else if (sp != base) {
                 sp--;
-                w_node = fetch_line_dword(nodes, tris, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), node_bytes);
+                w_node = fetch_line_dword(nodes, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), node_bytes);
             } else {
                 more = false;
             }
@@ -665,7 +657,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
             float4 out = make_float4(LBVH_MAX_FLOAT, __uint_as_float(0u), 0.0f, 0.0f);
             if (t < LBVH_MAX_FLOAT) {
                 // barycentrics (and the original index) from the winning triangle: the same arithmetic as in the walk
-                const float4* tv = reinterpret_cast<const float4*>(&tris[(uint32_t)key]);
+                const float4* tv = reinterpret_cast<const float4*>(&nodes[(uint32_t)key]);    // a triangle line
                 const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
                 float u = 0.0f, v = 0.0f;
                 const float dist = ray_fast_triangle(P.ray[0], v0, v1, v2, u, v);
@@ -889,7 +881,7 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     LBVH_REQUIRE(ctx, h_scene != nullptr && h_box_min != nullptr && h_box_max != nullptr);
     const lbvh_scene s = *h_scene;
-    LBVH_REQUIRE(ctx, s.n >= 2 && s.n <= 0x7FFFFFFFu);
+    LBVH_REQUIRE(ctx, s.n >= 2 && s.n <= 0x3FFFFFFFu);     // nodes and triangles share one 31-bit line index
     LBVH_REQUIRE(ctx, s.sorted_indices && s.triangle_aabb && s.internal_nodes && s.leaf_nodes && s.bvh &&
                           s.triangles);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -897,10 +889,11 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
         LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->side_stream) LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->side_stream));
         if (ctx->fast_nodes) { LBVH_HIP_TRY(ctx, hipFree(ctx->fast_nodes)); ctx->fast_nodes = nullptr; }
-        if (ctx->fast_tris) { LBVH_HIP_TRY(ctx, hipFree(ctx->fast_tris)); ctx->fast_tris = nullptr; }
+        ctx->fast_tris = nullptr;
         ctx->fast_capacity = 0;
-        LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->fast_nodes, (size_t)s.n * sizeof(lbvh_fast_node)));
-        LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->fast_tris, (size_t)s.n * sizeof(lbvh_fast_tri) + 64));
+        // one array of 64-byte lines: [capacity traversal nodes | capacity sorted triangles]
+        LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->fast_nodes, (size_t)s.n * (sizeof(lbvh_fast_node) + sizeof(lbvh_fast_tri))));
+        ctx->fast_tris = reinterpret_cast<lbvh_fast_tri*>(ctx->fast_nodes + s.n);
         ctx->fast_capacity = s.n;
     }
     // The traversal tree: same sorted triangle order as the scene, its own topology over aligned keys
@@ -926,7 +919,7 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
         if ((rc = lbvh_refit_counter(ctx, s.n, &counter)) != LBVH_OK) return rc;
         lbvh_launch_tree(ctx, s.n, t_keys, t_internal, t_leaf, counter);
         // the refit writes the 64-byte traversal nodes (both child boxes + child references) directly
-        rc = lbvh_launch_refit(ctx, s.n, t_internal, t_leaf, t_leaf_box, nullptr, t_bvh, ctx->fast_nodes, true);
+        rc = lbvh_launch_refit(ctx, s.n, t_internal, t_leaf, t_leaf_box, nullptr, t_bvh, ctx->fast_nodes, ctx->fast_capacity, true);
         if (rc != LBVH_OK) return rc;
     }
     if (parts & 2) LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((s.n + 255) / 256), dim3(256), s, ctx->fast_tris);
@@ -1003,7 +996,7 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
         uint32_t* counter = nullptr;
         if ((rc = (lbvh_status)lbvh_refit_counter(ctx, n, &counter)) != LBVH_OK) return rc;
         lbvh_launch_tree(ctx, n, d_keys, d_internal, d_leaf, counter);
-        if ((rc = (lbvh_status)lbvh_launch_refit(ctx, n, d_internal, d_leaf, d_aabb, d_indices, d_bvh, nullptr, true)) != LBVH_OK)
+        if ((rc = (lbvh_status)lbvh_launch_refit(ctx, n, d_internal, d_leaf, d_aabb, d_indices, d_bvh, nullptr, 0u, true)) != LBVH_OK)
             return rc;
         LBVH_HIP_TRY(ctx, hipGetLastError());
     }
