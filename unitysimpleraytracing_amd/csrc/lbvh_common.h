@@ -30,17 +30,20 @@ struct alignas(64) lbvh_fast_node {
 };
 static_assert(sizeof(lbvh_fast_node) == 64, "fast node must be 64 bytes");
 
-// Triangle in SORTED order for LBVH_TRACE_FAST (3 x float4 used): first vertex and the two edge vectors
-// e1 = b - a, e2 = c - a (the fp32 differences the intersection test starts with, Raytracing.compute:41-42, taken
-// once at build time).  The .w of the first carries the original triangle index: no extra gather for the hit record.
-// Padded to the traversal node's 64 bytes and kept in the SAME allocation, right behind the nodes: a child reference
-// (node index, or LEAF | leaf_base + sorted position) is one index into one array of 64-byte lines, and a line fetch
-// is base + (index << 6) whatever it points at.
+// Triangle in SORTED order for LBVH_TRACE_FAST: first vertex and the two edge vectors e1 = b - a, e2 = c - a (the
+// fp32 differences the intersection test starts with, Raytracing.compute:41-42, taken once at build time) and the
+// original triangle index (no extra gather for the hit record).  A 64-byte line in the SAME allocation as the
+// traversal nodes, right behind them: a child reference (node index, or LEAF | leaf_base + sorted position) is one
+// index into one array of 64-byte lines, and a line fetch is base + (index << 6) whatever it points at.
+// Layout: the packet walk fetches node lines with dwords k and k + 4 (k = 0, 1, 2 and 8, 9, 10) swapped for the axes
+// its rays travel down (lbvh_trace.hip), and fetches a child's line before it knows — per lane — what the child
+// is; so the triangle line reads the same under any such swap: a and e1 are stored twice, e2 and the index sit in
+// the four dwords 3, 7, 11, 15 the swap never touches.
 struct alignas(64) lbvh_fast_tri {
     float a[3]; uint32_t orig_index;
-    float e1[3]; uint32_t pad0;
-    float e2[3]; uint32_t pad1;
-    uint32_t pad2[4];
+    float a_again[3]; float e2x;
+    float e1[3]; float e2y;
+    float e1_again[3]; float e2z;
 };
 static_assert(sizeof(lbvh_fast_tri) == 64, "fast triangle must be 64 bytes");
 

@@ -148,8 +148,8 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* _
                 const bool h = side == 0 ? hit_l : hit_r;
                 const uint32_t ref = side == 0 ? lref : rref;
                 if (h && (ref & 0x80000000u)) {
-                    const float4* tv = reinterpret_cast<const float4*>(&nodes[ref & 0x7FFFFFFFu]);     // a triangle line
-                    const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+                    float4 v0, v1, v2;
+                    unpack_fast_triangle(reinterpret_cast<const float4*>(&nodes[ref & 0x7FFFFFFFu]), v0, v1, v2);   // a triangle line
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_fast_triangle(ray, v0, v1, v2, u, v);
                     if (dist > t_min && dist < best_t) { best_t = dist; best_tri = __float_as_uint(v0.w); best_u = u; best_v = v; }

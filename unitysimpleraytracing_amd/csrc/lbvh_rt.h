@@ -104,6 +104,16 @@ __device__ __forceinline__ float ray_triangle(const ray_t& r, const float4 v0, c
     return ray_triangle_edges(r, v0, v1.x - v0.x, v1.y - v0.y, v1.z - v0.z, v2.x - v0.x, v2.y - v0.y, v2.z - v0.z, u_out, v_out);
 }
 
+// a sorted-triangle line of the derived scene (lbvh_fast_tri) as the three float4 ray_fast_triangle takes:
+// {v0, original index}, e1, e2
+__device__ __forceinline__ void unpack_fast_triangle(const float4* line, float4& t0, float4& t1, float4& t2)
+{
+    const float4 q0 = line[0], q1 = line[1], q2 = line[2], q3 = line[3];
+    t0 = q0;
+    t1 = make_float4(q2.x, q2.y, q2.z, 0.0f);
+    t2 = make_float4(q1.w, q2.w, q3.w, 0.0f);
+}
+
 // the sorted-triangle record of the derived scene: {v0, original index | e1 | e2} — the edges are the same fp32
 // differences the reference forms per test, taken once at build time
 __device__ __forceinline__ float ray_fast_triangle(const ray_t& r, const float4 t0, const float4 t1, const float4 t2,

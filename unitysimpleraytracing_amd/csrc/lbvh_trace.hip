@@ -174,10 +174,12 @@ __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh
     const float4* tv = reinterpret_cast<const float4*>(&s.triangles[tri]);
     const float4 a = tv[0], b = tv[1], c = tv[2];
     float4* o = reinterpret_cast<float4*>(&tris[pos]);
-    o[0] = make_float4(a.x, a.y, a.z, __uint_as_float(tri));
-    o[1] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, 0.0f);
-    o[2] = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, 0.0f);
-    o[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);             // whole 64-byte lines: no partial-line writes
+    const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
+    const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+    o[0] = make_float4(a.x, a.y, a.z, __uint_as_float(tri));      // layout: lbvh_common.h
+    o[1] = make_float4(a.x, a.y, a.z, e2x);
+    o[2] = make_float4(e1x, e1y, e1z, e2y);
+    o[3] = make_float4(e1x, e1y, e1z, e2z);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -255,12 +257,12 @@ __device__ __forceinline__ uniform_node broadcast_node(int w)
     return nd;
 }
 
-// same for a 48-byte sorted triangle (12 dwords)
+// same for a sorted-triangle line (lbvh_fast_tri: v0 and index in dwords 0-3, e1 in 8-10, e2 in 7, 11, 15)
 __device__ __forceinline__ void broadcast_tri(int w, float4& v0, float4& v1, float4& v2)
 {
     v0 = make_float4(LBVH_RL(w, 0), LBVH_RL(w, 1), LBVH_RL(w, 2), LBVH_RL(w, 3));
-    v1 = make_float4(LBVH_RL(w, 4), LBVH_RL(w, 5), LBVH_RL(w, 6), 0.0f);
-    v2 = make_float4(LBVH_RL(w, 8), LBVH_RL(w, 9), LBVH_RL(w, 10), 0.0f);
+    v1 = make_float4(LBVH_RL(w, 8), LBVH_RL(w, 9), LBVH_RL(w, 10), 0.0f);
+    v2 = make_float4(LBVH_RL(w, 7), LBVH_RL(w, 11), LBVH_RL(w, 15), 0.0f);
 }
 
 // RX x RY rays per lane: the packet is an (8 RX) x (8 RY)-pixel tile, lane (lx, ly) owns the RX x RY
@@ -316,7 +318,7 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
     int stack = 0;            // wave-shared stack: slot k lives in lane k of this VGPR
     uint32_t sp = 0;          // scalar
     uint32_t steps = 0;
-    const uint32_t tri_bytes = (lane & 15u) * 4u, node_bytes = node_line_bytes(lane, SIGNS, neg);
+    const uint32_t node_bytes = node_line_bytes(lane, SIGNS, neg);      // triangle lines read the same under it
     // root: its own box is never tested, both children are
     int w_node = fetch_line_dword(nodes, 0u, node_bytes);
     for (;;) {
@@ -326,8 +328,8 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
         const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
         // both children are fetched NOW (node line or triangle line), before the box tests: whichever
         // the packet goes to next is already in flight — one memory latency per step instead of two
-        const int w_l = fetch_line_dword(nodes, lref, leaf_l ? tri_bytes : node_bytes);
-        const int w_r = fetch_line_dword(nodes, rref, leaf_r ? tri_bytes : node_bytes);
+        const int w_l = fetch_line_dword(nodes, lref, node_bytes);
+        const int w_r = fetch_line_dword(nodes, rref, node_bytes);
         if (STATS && lane == 0) C.pops++;
         steps++;
         float tl[R], tr[R];
@@ -508,7 +510,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
     tile_rays<1, 1>(a, tile, lane, P, px0, py0);
     uint32_t neg = 0;
     const bool ordered = packet_signs(P, neg);      // see walk_packet
-    const uint32_t tri_bytes = (lane & 15u) * 4u, node_bytes = node_line_bytes(lane, ordered, neg);
+    const uint32_t node_bytes = node_line_bytes(lane, ordered, neg);
     if (threadIdx.x < 64u) S.best[threadIdx.x] = (unsigned long long)ordered_key(LBVH_MAX_FLOAT) << 32;
     if (threadIdx.x == 0) { S.give_n = 0; S.lock = 0; S.idle = n_waves - 1u; S.steps = 0; }
     __syncthreads();
@@ -551,8 +553,8 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
             const uniform_node nd = broadcast_node(w_node);
             const uint32_t lref = __float_as_uint(nd.lmin.w), rref = __float_as_uint(nd.lmax.w);
             const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
-            const int w_l = fetch_line_dword(nodes, lref, leaf_l ? tri_bytes : node_bytes);
-            const int w_r = fetch_line_dword(nodes, rref, leaf_r ? tri_bytes : node_bytes);
+            const int w_l = fetch_line_dword(nodes, lref, node_bytes);
+            const int w_r = fetch_line_dword(nodes, rref, node_bytes);
             if (STATS && lane == 0) C.pops++;
             steps++;
             float best_t = key_value((uint32_t)(V.best[lane] >> 32));      // everybody's hits so far
@@ -657,8 +659,8 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
             float4 out = make_float4(LBVH_MAX_FLOAT, __uint_as_float(0u), 0.0f, 0.0f);
             if (t < LBVH_MAX_FLOAT) {
                 // barycentrics (and the original index) from the winning triangle: the same arithmetic as in the walk
-                const float4* tv = reinterpret_cast<const float4*>(&nodes[(uint32_t)key]);    // a triangle line
-                const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2];
+                float4 v0, v1, v2;
+                unpack_fast_triangle(reinterpret_cast<const float4*>(&nodes[(uint32_t)key]), v0, v1, v2);   // a triangle line
                 float u = 0.0f, v = 0.0f;
                 const float dist = ray_fast_triangle(P.ray[0], v0, v1, v2, u, v);
                 out = make_float4(dist, v0.w, u, v);
