@@ -200,6 +200,14 @@ def test_stage_argument_errors(ctx):
     assert n_.lib.lbvh_morton_aabb(ctx.handle, None, 10, 5, f3, f3, kb.device, kb.device, None) == -1  # n > capacity
     with pytest.raises(n_.LbvhError):
         n_.check(ctx.handle, n_.lib.lbvh_refit(ctx.handle, 0, None, None, None, None, None))
+    # the derived traversal scene indexes nodes and triangles with one 31-bit line index: 2^30 triangles are refused
+    # before anything is allocated or launched
+    d = H().RaytracingMeshDrawer(ctx, scenes.random_triangles(64, seed=1)).awake()
+    s = d.container.scene()
+    s.n = 1 << 30
+    assert n_.lib.lbvh_build_fast_scene(ctx.handle, C.byref(s), f3, f3) == -1
+    assert b"s.n" in n_.lib.lbvh_last_error(ctx.handle)
+    d.on_destroy()
 
 
 def build_both(ctx, tris, cap=None):
