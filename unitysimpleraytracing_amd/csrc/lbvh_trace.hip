@@ -166,20 +166,34 @@ __global__ __launch_bounds__(64) void trace_reference_kernel(trace_args a, lbvh_
 // ---------------------------------------------------------------------------------------------
 // derived fast-traversal scene
 // ---------------------------------------------------------------------------------------------
+// Four lanes per triangle: lane q of a quad reads float4 q of the 128-byte reference triangle (a, b, c: the 48
+// contiguous bytes of its positions) and writes float4 q of the 64-byte line, so a wave's one store covers 16
+// whole lines (1 KB contiguous) instead of 64 quarter lines; a / b / c travel inside the quad by DPP quad_perm.
 __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh_fast_tri* __restrict__ tris)
 {
-    const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= s.n) return;
-    const uint32_t tri = s.sorted_indices[pos];
-    const float4* tv = reinterpret_cast<const float4*>(&s.triangles[tri]);
-    const float4 a = tv[0], b = tv[1], c = tv[2];
-    float4* o = reinterpret_cast<float4*>(&tris[pos]);
-    const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
-    const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
-    o[0] = make_float4(a.x, a.y, a.z, __uint_as_float(tri));      // layout: lbvh_common.h
-    o[1] = make_float4(a.x, a.y, a.z, e2x);
-    o[2] = make_float4(e1x, e1y, e1z, e2y);
-    o[3] = make_float4(e1x, e1y, e1z, e2z);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t pos = t >> 2, q = t & 3u;
+    const bool live = pos < s.n;
+    const uint32_t tri = live ? s.sorted_indices[pos] : 0u;
+    float4 mine = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (live && q < 3u) mine = reinterpret_cast<const float4*>(&s.triangles[tri])[q];
+    // quad_perm:[k,k,k,k] = 0x00 / 0x55 / 0xAA: every lane of the quad reads lane k's value (all lanes active here)
+#define LBVH_QUAD(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true))
+#define LBVH_QUAD3(name, ctrl) \
+    const float name##x = LBVH_QUAD(mine.x, ctrl), name##y = LBVH_QUAD(mine.y, ctrl), name##z = LBVH_QUAD(mine.z, ctrl)
+    LBVH_QUAD3(a, 0x00);
+    LBVH_QUAD3(b, 0x55);
+    LBVH_QUAD3(c, 0xAA);
+#undef LBVH_QUAD3
+#undef LBVH_QUAD
+    const float e1x = bx - ax, e1y = by - ay, e1z = bz - az;
+    const float e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
+    // layout: lbvh_common.h — {a, index | a, e2.x | e1, e2.y | e1, e2.z}
+    const float4 out = q == 0u ? make_float4(ax, ay, az, __uint_as_float(tri))
+                     : q == 1u ? make_float4(ax, ay, az, e2x)
+                     : q == 2u ? make_float4(e1x, e1y, e1z, e2y)
+                               : make_float4(e1x, e1y, e1z, e2z);
+    if (live) reinterpret_cast<float4*>(&tris[pos])[q] = out;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -924,7 +938,7 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
         rc = lbvh_launch_refit(ctx, s.n, t_internal, t_leaf, t_leaf_box, nullptr, t_bvh, ctx->fast_nodes, ctx->fast_capacity, true);
         if (rc != LBVH_OK) return rc;
     }
-    if (parts & 2) LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((s.n + 255) / 256), dim3(256), s, ctx->fast_tris);
+    if (parts & 2) LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((s.n + 63) / 64), dim3(256), s, ctx->fast_tris);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     ctx->fast_n = s.n;
     return LBVH_OK;
