@@ -435,25 +435,38 @@ __global__ __launch_bounds__(kRefitThreads) void refit_kernel(uint32_t n, const 
 #endif
     uint32_t my = 0;
     if (is_front) my = atomicAdd(&s_front_n, 1u);
-    if (j < n - 1) {
-        const uint32_t f = s_flag[t];
-        if (f == 0x10001u) {
-            // finished node: its children's boxes are the two parked entries of its slot
-            const float4 lmn = s_box[0][t][0], lmx = s_box[0][t][1], rmn = s_box[1][t][0], rmx = s_box[1][t][1];
-            if (FUSED) {
-                const uint32_t split = s_node[t].x;
-                float4* out = reinterpret_cast<float4*>(&fused[j]);
-                const uint32_t l_leaf = __float_as_uint(lmn.w) & 0x80000000u, r_leaf = __float_as_uint(rmn.w) & 0x80000000u;
-                out[0] = make_float4(lmn.x, lmn.y, lmn.z, __uint_as_float(l_leaf | (split + (l_leaf ? leaf_base : 0u))));
-                out[1] = make_float4(lmx.x, lmx.y, lmx.z, __uint_as_float(r_leaf | (split + 1u + (r_leaf ? leaf_base : 0u))));
-                out[2] = make_float4(rmn.x, rmn.y, rmn.z, 0.0f);
-                out[3] = make_float4(rmx.x, rmx.y, rmx.z, 0.0f);
+    // finished nodes (both children arrived): their children's boxes are the two parked entries of their slot.  Written
+    // with 4 (traversal node) or 2 (box) threads per node — thread t takes float4 (t & 3) of node (t >> 2) + 256 k — so
+    // that a wave's store covers whole consecutive records instead of 64 quarter / half lines
+    if (FUSED) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t slot = (t >> 2) + 256u * k, q = t & 3u, node = b0 + slot;
+            if (node >= n - 1 || s_flag[slot] != 0x10001u) continue;
+            float4 v = s_box[q >> 1][slot][q & 1u];
+            if (q < 2u) {
+                // .w of float4 0 / 1: the left / right child reference (line index; LEAF | leaf_base + sorted position)
+                const uint32_t leaf = __float_as_uint(s_box[q][slot][0].w) & 0x80000000u;
+                v.w = __uint_as_float(leaf | (s_node[slot].x + q + (leaf ? leaf_base : 0u)));
             } else {
-                float4* out = reinterpret_cast<float4*>(&bvh[j]);                          // :215
-                out[0] = make_float4(fminf(lmn.x, rmn.x), fminf(lmn.y, rmn.y), fminf(lmn.z, rmn.z), 0.0f);
-                out[1] = make_float4(fmaxf(lmx.x, rmx.x), fmaxf(lmx.y, rmx.y), fmaxf(lmx.z, rmx.z), 0.0f);
+                v.w = 0.0f;
             }
-        } else if (FUSED && f != 0) {
+            reinterpret_cast<float4*>(&fused[node])[q] = v;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 2; k++) {
+            const uint32_t slot = (t >> 1) + 512u * k, h = t & 1u, node = b0 + slot;
+            if (node >= n - 1 || s_flag[slot] != 0x10001u) continue;
+            const float4 l = s_box[0][slot][h], r = s_box[1][slot][h];
+            reinterpret_cast<float4*>(&bvh[node])[h] =                                     // :215
+                h == 0u ? make_float4(fminf(l.x, r.x), fminf(l.y, r.y), fminf(l.z, r.z), 0.0f)
+                        : make_float4(fmaxf(l.x, r.x), fmaxf(l.y, r.y), fmaxf(l.z, r.z), 0.0f);
+        }
+    }
+    if (FUSED && j < n - 1) {
+        const uint32_t f = s_flag[t];
+        if (f != 0x10001u && f != 0) {
             // frontier node with one finished child parked here and nowhere else: fuse_frontier_kernel needs its box
             const uint32_t side = (f & 1u) ? 0u : 1u;
             const float4 pmn = s_box[side][t][0], pmx = s_box[side][t][1];
