@@ -450,7 +450,11 @@ static int sort_prepare(lbvh_context* ctx, uint32_t count, sort_plan* pl)
     // tile = 512 threads x 16 keys (8192) for big inputs: long digit runs = fuller cache lines in the
     // scatter and short look-back chains (measured best of 256..1024 threads x 4..16 keys at 2^24..2^28);
     // 512 x 8 below 2 M keys so every CU still gets tiles
+#ifdef LBVH_EXPERIMENT_SMALL_ITEMS
+    const int threads = 512, items = count >= (1u << 21) ? 16 : LBVH_EXPERIMENT_SMALL_ITEMS;
+#else
     const int threads = 512, items = count >= (1u << 21) ? 16 : 8;
+#endif
     const uint32_t tile = (uint32_t)threads * (uint32_t)items;
     const uint32_t tiles = (uint32_t)(((uint64_t)count + tile - 1) / tile);
     const size_t pair_bytes = (((size_t)count * 4) + 255) & ~(size_t)255;
@@ -515,6 +519,10 @@ int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, ui
 #endif
     if (items == 16)
         launch_passes<512, 16>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
+#ifdef LBVH_EXPERIMENT_SMALL_ITEMS
+    else if (items == 4)
+        launch_passes<512, 4>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
+#endif
     else
         launch_passes<512, 8>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     LBVH_HIP_TRY(ctx, hipGetLastError());
