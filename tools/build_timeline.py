@@ -20,6 +20,25 @@ def run():
         d.on_destroy()
 
 
+def run_steps():
+    """rebuild + frame trace per step, as bench.py's timed loop does"""
+    import ctypes as C
+    from unitysimpleraytracing_amd import _native as N, layouts as L, scenes
+    from unitysimpleraytracing_amd.host import Context, DataBuffer, RaytracingMeshDrawer
+    W, H = 1920, 1080
+    tris = scenes.tiled_torus(nu=80, nv=50)
+    cam = N.Camera.from_dict(scenes.camera(W, H, (0.0, 0.0, 250.0)))
+    with Context(0) as ctx:
+        d = RaytracingMeshDrawer(ctx, tris).awake()
+        hits = DataBuffer(ctx, W * H, L.HIT)
+        for _ in range(8):
+            d.rebuild()
+            s = d.container.scene()
+            N.check(ctx.handle, N.lib.lbvh_trace_primary_shard(ctx.handle, C.byref(cam), 0, 1, C.byref(s), L.TRACE_FAST, hits.device, None))
+            ctx.sync()
+        d.on_destroy()
+
+
 def show(root):
     rows = []
     for f in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
@@ -37,5 +56,7 @@ def show(root):
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run()
+    elif sys.argv[1] == "steps":
+        run_steps()
     else:
         show(sys.argv[2])
