@@ -292,6 +292,23 @@ struct packet_rays {
 struct walk_counters { uint32_t pops, box, leaf, tri; };
 
 // Walk the tree for one packet; returns the number of steps (node fetches).
+// stack[slot] := value, both wave-uniform: one v_writelane_b32 (the lane select goes through M0: a vector instruction
+// takes one SGPR operand; both operands come from the scalar unit, so there is no lane-select hazard)
+__device__ __forceinline__ void push_slot(int& stack, uint32_t value, uint32_t slot)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(stack) : "s"(value), "s"(slot) : "m0");
+#pragma clang diagnostic pop
+}
+
+// population count of a lane mask as a 32-bit scalar (two s_bcnt1_i32_b32: the 64-bit form comes back as a 64-bit
+// value, and ordered 64-bit compares only exist on the vector unit)
+__device__ __forceinline__ int mask_count(uint64_t m)
+{
+    return __builtin_popcount((uint32_t)m) + __builtin_popcount((uint32_t)(m >> 32));
+}
+
 // Do all active rays of the packet agree on the sign of every direction component, with finite non-zero inverse
 // directions (every tile but those on the image's centre lines)?  neg: bit k = component k is negative.
 __device__ __forceinline__ bool packet_signs(const packet_rays<1>& P, uint32_t& neg)
@@ -410,18 +427,33 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
                 any_l |= hit_l[r];
             }
         }
+        if (R != 1) {
 #pragma unroll
-        for (int r = 0; r < R; r++)
-            if (hit_l[r] && hit_r[r]) pref += tl[r] <= tr[r] ? 1 : -1;
+            for (int r = 0; r < R; r++)
+                if (hit_l[r] && hit_r[r]) pref += tl[r] <= tr[r] ? 1 : -1;
+        }
         const uint64_t ml = leaf_l ? 0ull : __ballot(any_l);
         const uint64_t mr = leaf_r ? 0ull : __ballot(any_r);
         if (ml != 0 && mr != 0) {
-            // both children wanted: the side most lanes reach first goes first
-            const int l_votes = __popcll(__ballot(pref > 0)), r_votes = __popcll(__ballot(pref < 0));
-            const bool l_near = l_votes == r_votes ? (__popcll(ml) >= __popcll(mr)) : (l_votes > r_votes);
+            // both children wanted: the side most lanes reach first goes first.  One ray per lane: the votes are
+            // population counts of scalar masks (one vector compare, the rest on the scalar unit)
+            int l_votes, r_votes;
+            if (R == 1) {
+                const uint64_t both = ml & mr, le = __ballot(tl[0] <= tr[0]);
+                l_votes = mask_count(both & le);
+                r_votes = mask_count(both & ~le);
+            } else {
+                l_votes = __popcll(__ballot(pref > 0));
+                r_votes = __popcll(__ballot(pref < 0));
+            }
+            const int l_lanes = mask_count(ml), r_lanes = mask_count(mr);
+            // more votes, or on a tie more lanes (an integer select: a select between two conditions would be
+            // materialised in vector registers)
+            const int by_votes = l_votes - r_votes, by_lanes = l_lanes - r_lanes;
+            const bool l_near = (by_votes != 0 ? by_votes : by_lanes) >= 0;
             const uint32_t far = l_near ? rref : lref;
             w_node = l_near ? w_l : w_r;
-            stack = lane == (sp & 63u) ? (int)far : stack;      // v_cndmask: slot sp := far
+            push_slot(stack, far, sp & 63u);            // slot sp := far
             sp++;
         } else if (ml != 0) {
             w_node = w_l;
@@ -618,16 +650,18 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                 }
                 hit_l = hit_l && !(tl > best_t);
             }
-            const int pref = (hit_l && hit_r) ? (tl <= tr ? 1 : -1) : 0;
             const uint64_t ml = leaf_l ? 0ull : __ballot(hit_l);
             const uint64_t mr = leaf_r ? 0ull : __ballot(hit_r);
             bool more = true;
             if (ml != 0 && mr != 0) {
-                const int l_votes = __popcll(__ballot(pref > 0)), r_votes = __popcll(__ballot(pref < 0));
-                const bool l_near = l_votes == r_votes ? (__popcll(ml) >= __popcll(mr)) : (l_votes > r_votes);
+                const uint64_t both = ml & mr, le = __ballot(tl <= tr);       // votes as in walk_packet
+                const int by_votes = mask_count(both & le) - mask_count(both & ~le), by_lanes = mask_count(ml) - mask_count(mr);
+                const bool l_near = (by_votes != 0 ? by_votes : by_lanes) >= 0;
                 const uint32_t far = l_near ? rref : lref;
                 w_node = l_near ? w_l : w_r;
-                stack = lane == (sp & 63u) ? (int)far : stack;
+                // (this walker's stack pointer lives in a vector register: hand the asm scalar copies)
+                push_slot(stack, (uint32_t)__builtin_amdgcn_readfirstlane((int)far),
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(sp & 63u)));
                 sp++;
             } else if (ml != 0) {
                 w_node = w_l;
