@@ -201,16 +201,19 @@ __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh
 //
 // The primary rays of a small pixel tile (8x8 pixels: one ray per lane) leave one pinhole and stay
 // together almost to the leaves, so the wave walks the tree ONCE for all of them:
-//   * the current node index is wave-uniform: the 64-byte fused node arrives as ONE coalesced line
-//     (lane k loads dword k, v_readlane broadcasts into SGPRs), not as 64 divergent vector gathers
-//     (the per-lane form measured 22 % lane utilisation and an L1 pipe stalled on pending misses;
-//     more waves per CU made it slower);
+//   * the current node index is wave-uniform: the 64-byte fused node arrives as ONE coalesced line in every
+//     16-lane row (lane k loads dword k & 15; address arithmetic on the scalar unit), not as 64 divergent vector
+//     gathers (the per-lane form measured 22 % lane utilisation and an L1 pipe stalled on pending misses; more
+//     waves per CU made it slower).  The box planes go into the tests as DPP row-broadcast operands straight from
+//     that register, only the two child references (and a triangle's values) are moved to SGPRs by v_readlane;
 //   * every lane tests ITS ray against the node's two child boxes; a child is entered when any lane
 //     hits it (ballot) and its entry t is not beyond that lane's best hit; order = majority vote of
 //     the lanes that hit both;
-//   * the traversal stack is shared by the wave: one VGPR used as a 64-slot array written by
-//     a lane-select and read by v_readlane with a scalar stack pointer — no LDS, no scratch;
+//   * the traversal stack is shared by the wave: one VGPR used as a 64-slot array written by v_writelane and read
+//     by v_readlane with a scalar stack pointer — no LDS, no scratch;
 //   * all control flow is scalar (conditions come from ballots).
+// The kernel is bound by instruction issue (73 vector + 48 scalar instructions per step, vector
+// issue 87 % busy over the frame), so the step is written for instruction count: see walk_packet's SIGNS form.
 // Each lane still sees every node it would visit alone (it votes for it), the leaf's own AABB slab
 // test gates the triangle test per lane, and the accept rule is the reference's strict t < best —
 // so per-ray results equal the reference order's min t.
@@ -236,10 +239,9 @@ struct uniform_node {        // one fused node, wave-uniform (lives in SGPRs)
     float4 lmin, lmax, rmin, rmax;
 };
 
-// Wave-uniform fetch of a 64-byte node WITHOUT the scalar cache (s_load of a ~100 MB working set
-// serialises on the scalar cache's miss path, which several CUs share): lane k loads dword k & 15,
-// i.e. one coalesced 64-byte line through the CU's vector L1, and v_readlane broadcasts the 16
-// dwords into SGPRs.
+// Wave-uniform fetch of a 64-byte line WITHOUT the scalar cache (s_load of a ~100 MB working set serialises on
+// the scalar cache's miss path, which several CUs share — measured again at the end of round 1: 0.315 vs 0.285 ms):
+// lane k loads dword k & 15, i.e. one coalesced 64-byte line per 16-lane row through the CU's vector L1.
 #define LBVH_RL(v, k) __int_as_float(__builtin_amdgcn_readlane((v), (k)))
 // a 64-byte line (node or sorted triangle) by reference: the address is base + (index << 6), computed on the scalar
 // unit; the load takes it as an SGPR base + the lane's constant byte offset (no vector address arithmetic in the walk)
