@@ -492,7 +492,10 @@ __device__ __forceinline__ void tile_rays(const trace_args& a, uint32_t tile, ui
 // atomic min on (ordered t, sorted triangle position): pruning is shared by all waves), and a wave with spare
 // stack entries hands its OLDEST one (the largest unvisited subtree) to an idle wave through a small LDS list.
 constexpr int kCoopWaves = 8;
-constexpr int kHeavyClass = 7;             // cost classes >= this (>= 96 steps) are walked cooperatively
+#ifndef LBVH_HEAVY_CLASS
+#define LBVH_HEAVY_CLASS 7
+#endif
+constexpr int kHeavyClass = LBVH_HEAVY_CLASS;   // cost classes >= this (>= 96 steps) are walked cooperatively
 constexpr uint32_t kCoopGrain = 32;        // steps of the last trace per cooperating wave
 constexpr uint32_t kCoopMaxWork = 12288;   // tiles per launch up to which every heavy class is walked cooperatively
 constexpr uint32_t kSharedMaxWork = 24576; // ... and up to which the very heaviest are (beyond: one wave per tile only)
@@ -898,10 +901,15 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     // Which tiles are walked cooperatively (known from the last trace).  It costs ~50 % more steps on those tiles (a
     // subtree handed to another wave is walked before the near hits that would have pruned it are known), so it is
     // for under-filled launches — one GPU's share of a multi-GPU frame: every tile of 96 steps or more up to
-    // 12 288 tiles, only those of 256 steps or more up to 24 576, none beyond (1080p whole / half / quarter /
-    // eighth of the frame: 287 -> 275, 234 -> 190, 226 -> 170, 212 -> 103 us).
+    // 6 144 tiles, of 128 or more up to 12 288, only those of 256 steps or more up to 24 576, none beyond (1080p
+    // whole / half / quarter / eighth of the frame at the time: 287 -> 275, 234 -> 190, 226 -> 170, 212 -> 103 us).
     if (have_history && n_work <= kSharedMaxWork) {
-        coop_params hp = {n_work / 4u, n_work <= kCoopMaxWork ? (uint32_t)kHeavyClass : kHeavyClassFull, kCoopGrain};
+        // (re-measured after the walk's instruction diet: 1/8 frame 90 us with class 7 against 94 / 109 with 8 / 9;
+        // 1/4 frame 139 us with 7 against 117 / 121 with 8 / 9)
+        const uint32_t first_class = n_work <= kCoopMaxWork / 2u ? (uint32_t)kHeavyClass
+                                     : n_work <= kCoopMaxWork   ? (uint32_t)kHeavyClass + 1u
+                                                                : kHeavyClassFull;
+        coop_params hp = {n_work / 4u, first_class, kCoopGrain};
         const uint32_t blocks = hp.cap + (n_work + kCoopWaves - 1) / kCoopWaves;
         if (d_stats)
             LBVH_LAUNCH(ctx, trace_shared_kernel<true>, dim3(blocks), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris, n_work,
