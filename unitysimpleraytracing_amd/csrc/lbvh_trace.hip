@@ -498,11 +498,14 @@ constexpr int kCoopWaves = 8;
 constexpr int kHeavyClass = LBVH_HEAVY_CLASS;   // cost classes >= this (>= 96 steps) are walked cooperatively
 constexpr uint32_t kCoopGrain = 32;        // steps of the last trace per cooperating wave
 constexpr uint32_t kCoopMaxWork = 12288;   // tiles per launch up to which every heavy class is walked cooperatively
-constexpr uint32_t kSharedMaxWork = 24576; // ... and up to which the very heaviest are (beyond: one wave per tile only)
-#ifndef LBVH_HEAVY_CLASS_FULL
-#define LBVH_HEAVY_CLASS_FULL 10
+#ifndef LBVH_SHARED_MAX_WORK
+#define LBVH_SHARED_MAX_WORK 24576
 #endif
-constexpr uint32_t kHeavyClassFull = LBVH_HEAVY_CLASS_FULL;   // above that: only classes >= this (>= 256 steps)
+constexpr uint32_t kSharedMaxWork = LBVH_SHARED_MAX_WORK; // ... and up to which the very heaviest are (beyond: one wave per tile only)
+#ifndef LBVH_HEAVY_CLASS_FULL
+#define LBVH_HEAVY_CLASS_FULL 9
+#endif
+constexpr uint32_t kHeavyClassFull = LBVH_HEAVY_CLASS_FULL;   // above that: only classes >= this (>= 192 steps; half frame: 152 us against 184 / 160 / 193 with 8 / 10 / 11)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 struct coop_params { uint32_t cap, first_class, grain; };
@@ -901,7 +904,8 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     // Which tiles are walked cooperatively (known from the last trace).  It costs ~50 % more steps on those tiles (a
     // subtree handed to another wave is walked before the near hits that would have pruned it are known), so it is
     // for under-filled launches — one GPU's share of a multi-GPU frame: every tile of 96 steps or more up to
-    // 6 144 tiles, of 128 or more up to 12 288, only those of 256 steps or more up to 24 576, none beyond (1080p
+    // 6 144 tiles, of 128 or more up to 12 288, only those of 192 steps or more up to 24 576, none beyond — a whole
+    // 1080p frame runs the plain kernel: 225 us against 234 / 225 with the heaviest classes cooperative (1080p
     // whole / half / quarter / eighth of the frame at the time: 287 -> 275, 234 -> 190, 226 -> 170, 212 -> 103 us).
     if (have_history && n_work <= kSharedMaxWork) {
         // (re-measured after the walk's instruction diet: 1/8 frame 90 us with class 7 against 94 / 109 with 8 / 9;
