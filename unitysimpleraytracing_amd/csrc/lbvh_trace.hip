@@ -496,7 +496,10 @@ constexpr int kCoopWaves = 8;
 #define LBVH_HEAVY_CLASS 7
 #endif
 constexpr int kHeavyClass = LBVH_HEAVY_CLASS;   // cost classes >= this (>= 96 steps) are walked cooperatively
-constexpr uint32_t kCoopGrain = 32;        // steps of the last trace per cooperating wave
+#ifndef LBVH_COOP_GRAIN
+#define LBVH_COOP_GRAIN 32
+#endif
+constexpr uint32_t kCoopGrain = LBVH_COOP_GRAIN;   // steps of the last trace per cooperating wave
 constexpr uint32_t kCoopMaxWork = 12288;   // tiles per launch up to which every heavy class is walked cooperatively
 #ifndef LBVH_SHARED_MAX_WORK
 #define LBVH_SHARED_MAX_WORK 24576
