@@ -149,11 +149,25 @@ __global__ __launch_bounds__(kDistThreads) void distribute_scan_kernel(uint32_t*
     }
 }
 
+// SELF: chunk_sums still holds the raw per-chunk sums (no scan kernel ran): the block adds up its predecessors' itself —
+// a few loads per thread up to kSelfScanChunks chunks, and one dependent single-workgroup kernel less in the chain
+constexpr uint32_t kSelfScanChunks = 2048;
+
+template <bool SELF>
 __global__ __launch_bounds__(kDistThreads) void distribute_apply_kernel(
     uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ chunk_sums,
     const uint32_t* __restrict__ boundary)
 {
     __shared__ uint32_t s_wave[kDistThreads / LBVH_WAVE];
+    __shared__ uint32_t s_before[kDistThreads / LBVH_WAVE];
+    uint32_t before = 0;
+    if (SELF) {
+        uint32_t part = 0;
+        for (uint32_t c = threadIdx.x; c < blockIdx.x; c += kDistThreads) part += chunk_sums[c];
+        (void)block_exclusive_sum(part, s_before, &before);
+    } else {
+        before = chunk_sums[blockIdx.x];
+    }
     const uint32_t base = blockIdx.x * (uint32_t)kDistChunk;
     const uint32_t j0 = base + threadIdx.x * (uint32_t)kDistItems;
     uint32_t prev = 0;
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(kDistThreads) void distribute_apply_kernel(
     for (int c = 0; c < kDistItems; c++) { s += f[c]; f[c] = s; }   // thread-local inclusive
     uint32_t total;
     const uint32_t excl = block_exclusive_sum(s, s_wave, &total);  // barrier inside: every old key
-    const uint32_t carry = chunk_sums[blockIdx.x] + excl;          // of the chunk is loaded by now
+    const uint32_t carry = before + excl;                          // of the chunk is loaded by now
 #pragma unroll
     for (int c = 0; c < kDistItems; c++) {
         const uint32_t j = j0 + (uint32_t)c;
@@ -705,11 +719,21 @@ __global__ __launch_bounds__(kAkThreads) void aligned_keys_scan_kernel(int32_t* 
 }
 
 // keys[i] = i + max_{j <= i} term_j, in place over the terms
+// SELF: chunk_excl still holds the raw per-chunk maxima (see distribute_apply_kernel)
+template <bool SELF>
 __global__ __launch_bounds__(kAkThreads) void aligned_keys_apply_kernel(uint32_t n, const int32_t* __restrict__ chunk_excl,
                                                                         uint32_t* keys)
 {
     __shared__ int32_t s_wave[kAkThreads / LBVH_WAVE];
-    int32_t carry = chunk_excl[blockIdx.x];
+    __shared__ int32_t s_before[kAkThreads / LBVH_WAVE];
+    int32_t carry;
+    if (SELF) {
+        int32_t part = INT32_MIN;
+        for (uint32_t c = threadIdx.x; c < blockIdx.x; c += kAkThreads) part = max(part, chunk_excl[c]);
+        (void)block_inclusive_max(part, s_before, &carry);
+    } else {
+        carry = chunk_excl[blockIdx.x];
+    }
 #pragma unroll
     for (int k = 0; k < kAkItems; k++) {
         const uint32_t i = blockIdx.x * kAkChunk + (uint32_t)k * kAkThreads + threadIdx.x;
@@ -851,8 +875,12 @@ int lbvh_launch_gather_aligned_keys(lbvh_context* ctx, uint32_t n, const lbvh_aa
     int32_t* chunk_max = (int32_t*)ctx->scan_scratch[ctx->lane];
     LBVH_LAUNCH(ctx, gather_terms_kernel, dim3(chunks), dim3(kAkThreads), d_triangle_aabb, d_sorted_indices, n, scene,
                 d_leaf_box_out, (int32_t*)d_keys_out, chunk_max);
-    LBVH_LAUNCH(ctx, aligned_keys_scan_kernel, dim3(1), dim3(kAkThreads), chunk_max, chunks);
-    LBVH_LAUNCH(ctx, aligned_keys_apply_kernel, dim3(chunks), dim3(kAkThreads), n, chunk_max, d_keys_out);
+    if (chunks <= kSelfScanChunks) {
+        LBVH_LAUNCH(ctx, aligned_keys_apply_kernel<true>, dim3(chunks), dim3(kAkThreads), n, chunk_max, d_keys_out);
+    } else {
+        LBVH_LAUNCH(ctx, aligned_keys_scan_kernel, dim3(1), dim3(kAkThreads), chunk_max, chunks);
+        LBVH_LAUNCH(ctx, aligned_keys_apply_kernel<false>, dim3(chunks), dim3(kAkThreads), n, chunk_max, d_keys_out);
+    }
     return LBVH_OK;
 }
 
@@ -888,10 +916,12 @@ lbvh_status lbvh_distribute_keys(lbvh_context* ctx, uint32_t* d_keys, uint32_t n
     uint32_t* boundary = chunk_sums + chunks;
     LBVH_LAUNCH(ctx, distribute_reduce_kernel, dim3(chunks), dim3(kDistThreads),
                        d_keys, n, chunk_sums, boundary);
-    LBVH_LAUNCH(ctx, distribute_scan_kernel, dim3(1), dim3(kDistThreads), chunk_sums,
-                       chunks);
-    LBVH_LAUNCH(ctx, distribute_apply_kernel, dim3(chunks), dim3(kDistThreads),
-                       d_keys, n, chunk_sums, boundary);
+    if (chunks <= kSelfScanChunks) {
+        LBVH_LAUNCH(ctx, distribute_apply_kernel<true>, dim3(chunks), dim3(kDistThreads), d_keys, n, chunk_sums, boundary);
+    } else {
+        LBVH_LAUNCH(ctx, distribute_scan_kernel, dim3(1), dim3(kDistThreads), chunk_sums, chunks);
+        LBVH_LAUNCH(ctx, distribute_apply_kernel<false>, dim3(chunks), dim3(kDistThreads), d_keys, n, chunk_sums, boundary);
+    }
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }
