@@ -61,6 +61,8 @@ public static class LbvhNative
 
     [DllImport(Lib)] public static extern int lbvh_shade(IntPtr ctx, IntPtr dHits, UIntPtr count, IntPtr dTriangles,
         IntPtr dTextureRgba8, int texW, int texH, IntPtr dRgba16f);
+    [DllImport(Lib)] public static extern int lbvh_compose(IntPtr ctx, IntPtr dBackgroundRgba16f, IntPtr dObjectRgba16f, UIntPtr count,
+                                                            IntPtr dOutRgba16f);
 
     // the whole Awake() build chain in one call (per-frame rebuilds); flags: 1 = fast scene, 2 = reset node arrays
     [DllImport(Lib)] public static extern int lbvh_build_scene(IntPtr ctx, IntPtr dTriangles, uint n, uint capacity, float[] boxMin,

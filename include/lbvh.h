@@ -336,6 +336,14 @@ lbvh_status lbvh_trace_primary_shard(lbvh_context* ctx, const lbvh_camera* h_cam
 lbvh_status lbvh_shade(lbvh_context* ctx, const lbvh_hit* d_hits, size_t count, const lbvh_triangle* d_triangles,
                        const uint8_t* d_texture_rgba8, int32_t tex_w, int32_t tex_h, uint16_t* d_rgba16f);
 
+/* Replaces the full-screen pass of Hidden/ImageComposer (Sh/ImageComposer.shader:44-52, driven by
+ * RaytracingMeshDrawer.OnRenderImage, Sc/RaytracingMeshDrawer.cs:86-90): the traced image is laid over the camera's
+ * own rendering, one texel over the same pixel:  out.rgb = lerp(background.rgb, object.rgb, object.a)
+ * = background + object.a * (object - background)  in fp32, out.a = 1.  All three images: count x 4 IEEE halfs
+ * (RGBA16F, the format of lbvh_shade's output).  d_out may alias d_background. */
+lbvh_status lbvh_compose(lbvh_context* ctx, const uint16_t* d_background_rgba16f, const uint16_t* d_object_rgba16f,
+                         size_t count, uint16_t* d_out_rgba16f);
+
 /* ---- dynamic scenes and secondary rays (extension; no reference counterpart) ----
  * The reference traces primary rays of a static mesh only (Sh/Raytracing/Raytracing.compute has no
  * secondary rays and no RNG; Sc/BVHConstructor.cs:41 zeroes the refit flags once, so it cannot even

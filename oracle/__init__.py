@@ -74,6 +74,19 @@ def shade(hits, triangles, texture_rgba8):
     return out.view(np.float16)
 
 
+_lib.orc_compose.argtypes = [_P, _P, C.c_size_t, _P]
+_lib.orc_compose.restype = None
+
+
+def compose(background, obj):
+    """ImageComposer: float16 arrays (..., 4) -> float16 (..., 4)."""
+    b = np.ascontiguousarray(background, dtype=np.float16)
+    o = np.ascontiguousarray(obj, dtype=np.float16)
+    out = np.zeros(b.shape, dtype=np.uint16)
+    _lib.orc_compose(_ptr(b), _ptr(o), b.size // 4, _ptr(out))
+    return out.view(np.float16)
+
+
 _lib.orc_animate.argtypes = [_P, _U32, _P, _P, C.c_float, C.c_float, _P]
 _lib.orc_animate.restype = None
 _lib.orc_path_begin.argtypes = [C.POINTER(_Camera), _P]

@@ -685,6 +685,42 @@ void orc_shade(const lbvh_hit* hits, size_t count, const lbvh_triangle* tris, co
     }
 }
 
+/* IEEE half -> float (exact) */
+static float half_to_float(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+    uint32_t bits;
+    if (e == 0) {
+        if (m == 0) bits = sign;
+        else {                                               /* subnormal half: normalise */
+            int shift = 0;
+            uint32_t mm = m;
+            while (!(mm & 0x400u)) { mm <<= 1; shift++; }
+            bits = sign | ((uint32_t)(113 - shift) << 23) | ((mm & 0x3FFu) << 13);
+        }
+    } else if (e == 31) bits = sign | 0x7F800000u | (m << 13);
+    else bits = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+/* Hidden/ImageComposer, Assets/_Shaders/ImageComposer.shader:44-52: ret = lerp(col.rgb, colObject.rgb, colObject.a),
+ * alpha 1; lerp(a, b, t) = a + t * (b - a), each operation rounded to fp32; RGBA16F in and out. */
+void orc_compose(const uint16_t* background, const uint16_t* object, size_t count, uint16_t* out)
+{
+    for (size_t i = 0; i < count; i++) {
+        const float a = half_to_float(object[4 * i + 3]);
+        for (int k = 0; k < 3; k++) {
+            const float bg = half_to_float(background[4 * i + k]), ob = half_to_float(object[4 * i + k]);
+            const float d = ob - bg;
+            const float t = a * d;
+            out[4 * i + k] = float_to_half(bg + t);
+        }
+        out[4 * i + 3] = float_to_half(1.0f);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* dynamic scene + secondary rays.  NOT in the reference (it has neither); these  */
 /* restate include/lbvh.h's definitions so the GPU kernels have a bit-exact checker.                  */

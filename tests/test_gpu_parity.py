@@ -693,6 +693,15 @@ def test_shade_bit_exact(ctx):
     d.shade()
     same = fh["tri"] == oh["tri"]
     assert (d.image().view(np.uint16)[same] == oimg.view(np.uint16)[same]).all() and same.mean() > 0.999
+    # OnRenderImage: the image composed over the camera's own rendering (ImageComposer.shader:44-52), in place
+    d.update(cam, mode=L.TRACE_REFERENCE)
+    d.shade()
+    src = rng.uniform(0.0, 1.0, (120, 200, 4)).astype(np.float16)
+    dest = d.on_render_image(src)
+    odest = O.compose(src, oimg)
+    assert (dest.view(np.uint16) == odest.view(np.uint16)).all()
+    miss = oh["t"] >= L.MAX_FLOAT
+    assert (dest[miss][:, :3] == src[miss][:, :3]).all() and (dest[..., 3] == 1).all()     # alpha 0 keeps the background
     d.on_destroy()
 
 

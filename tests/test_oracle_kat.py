@@ -335,3 +335,15 @@ def test_path_trace_is_deterministic_and_energy_bounded():
     h2 = O.trace_rays(b, st, 1e-3)
     assert (h2["t"][alive & (h2["t"] < L.MAX_FLOAT)] > 1e-3).all()
     assert (h2["t"][~alive] == L.MAX_FLOAT).all()
+
+
+def test_compose_known_answers():
+    """ImageComposer.shader:49: lerp(col.rgb, colObject.rgb, colObject.a), alpha 1 — halves in, halves out."""
+    bg = np.array([[0.25, 0.5, 1.0, 0.3], [0.125, 0.75, 0.0, 1.0], [1.0, 1.0, 1.0, 1.0]], np.float16)
+    ob = np.array([[1.0, 0.0, 0.5, 0.5], [0.5, 0.5, 0.5, 0.0], [0.0, 0.25, 0.5, 1.0]], np.float16)
+    out = O.compose(bg, ob)
+    assert out.tolist() == [[0.625, 0.25, 0.75, 1.0], [0.125, 0.75, 0.0, 1.0], [0.0, 0.25, 0.5, 1.0]]
+    # subnormal and large halves survive the half -> float -> half trip
+    x = np.array([[6e-8, 65504.0, -2.0, 1.0]], np.float16)
+    assert (O.compose(x, np.zeros((1, 4), np.float16))[0, :3] == x[0, :3]).all()
+

@@ -89,6 +89,7 @@ SIGNATURES = {
     "lbvh_path_resolve": (_I32, [_P, _P, _SZ, _P]),
     "lbvh_trace_tile_costs": (_I32, [_P, C.POINTER(Camera), C.POINTER(Scene), _P, _P, _P]),
     "lbvh_shade": (_I32, [_P, _P, _SZ, _P, _P, _I32, _I32, _P]),
+    "lbvh_compose": (_I32, [_P, _P, _P, _SZ, _P]),
     "lbvh_event_create": (_I32, [_P, C.POINTER(_P)]),
     "lbvh_event_destroy": (_I32, [_P, _P]),
     "lbvh_event_record": (_I32, [_P, _P]),

@@ -82,3 +82,46 @@ extern "C" lbvh_status lbvh_shade(lbvh_context* ctx, const lbvh_hit* d_hits, siz
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }
+
+// ---- Hidden/ImageComposer (Assets/_Shaders/ImageComposer.shader:44-52) ------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void compose_kernel(const uint2* __restrict__ background, const uint2* __restrict__ object,
+                                                      size_t count, uint2* out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint2 b = background[i], o = object[i];       // 4 halfs each
+    const __half2 b01 = *reinterpret_cast<const __half2*>(&b.x), b23 = *reinterpret_cast<const __half2*>(&b.y);
+    const __half2 o01 = *reinterpret_cast<const __half2*>(&o.x), o23 = *reinterpret_cast<const __half2*>(&o.y);
+    const float bg[3] = {__low2float(b01), __high2float(b01), __low2float(b23)};
+    const float ob[3] = {__low2float(o01), __high2float(o01), __low2float(o23)};
+    const float a = __high2float(o23);
+    float r[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) r[k] = bg[k] + a * (ob[k] - bg[k]);                         // lerp, :49
+    const __half h0 = __float2half_rn(r[0]), h1 = __float2half_rn(r[1]), h2 = __float2half_rn(r[2]),
+                 h3 = __float2half_rn(1.0f);                                                // fixed4(ret, 1), :52
+    uint2 w;
+    w.x = (uint32_t)__half_as_ushort(h0) | ((uint32_t)__half_as_ushort(h1) << 16);
+    w.y = (uint32_t)__half_as_ushort(h2) | ((uint32_t)__half_as_ushort(h3) << 16);
+    out[i] = w;
+}
+
+}  // namespace
+
+extern "C" lbvh_status lbvh_compose(lbvh_context* ctx, const uint16_t* d_background_rgba16f, const uint16_t* d_object_rgba16f,
+                                    size_t count, uint16_t* d_out_rgba16f)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    if (count == 0) return LBVH_OK;
+    LBVH_REQUIRE(ctx, d_background_rgba16f != nullptr && d_object_rgba16f != nullptr && d_out_rgba16f != nullptr);
+    LBVH_REQUIRE(ctx, ((uintptr_t)d_background_rgba16f & 7) == 0 && ((uintptr_t)d_object_rgba16f & 7) == 0 &&
+                          ((uintptr_t)d_out_rgba16f & 7) == 0);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t blocks = (count + 255) / 256;
+    LBVH_LAUNCH(ctx, compose_kernel, dim3((unsigned)blocks), dim3(256), reinterpret_cast<const uint2*>(d_background_rgba16f),
+                reinterpret_cast<const uint2*>(d_object_rgba16f), count, reinterpret_cast<uint2*>(d_out_rgba16f));
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
+}

@@ -342,6 +342,21 @@ class RaytracingMeshDrawer:
             self._tex_shape[1], self._tex_shape[0], self._image.device))
         return self._image
 
+    def on_render_image(self, src):
+        """OnRenderImage (Assets/_Scripts/RaytracingMeshDrawer.cs:86-90): Graphics.Blit(src, dest, _imageComposerMaterial) —
+        the shaded image laid over the camera's own rendering `src` ((h, w, 4) float16); returns dest as float16."""
+        x0, y0, x1, y1 = self._rect
+        count = (x1 - x0) * (y1 - y0)
+        bg = np.ascontiguousarray(src, dtype=np.float16)
+        assert bg.shape == (y1 - y0, x1 - x0, 4)
+        buf = DataBuffer(self.ctx, count, np.uint64)
+        buf.local[:] = bg.reshape(-1, 4).view(np.uint64).reshape(-1)
+        buf.sync()
+        N.check(self.ctx.handle, N.lib.lbvh_compose(self.ctx.handle, buf.device, self._image.device, count, buf.device))
+        out = buf.get_data()[:count].view(np.float16).reshape(y1 - y0, x1 - x0, 4).copy()
+        buf.dispose()
+        return out
+
     def image(self):
         x0, y0, x1, y1 = self._rect
         n = (x1 - x0) * (y1 - y0)
