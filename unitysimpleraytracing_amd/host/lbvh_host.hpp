@@ -258,6 +258,13 @@ public:
                                      (const lbvh_triangle*)container_->TriangleData().DeviceBuffer(),
                                      (const uint8_t*)tex_->DeviceBuffer(), tex_w_, tex_h_, (uint16_t*)image_->DeviceBuffer()));
     }
+    // OnRenderImage :86-90 — Graphics.Blit(src, dest, _imageComposerMaterial): the shaded image over the camera's own
+    // rendering (RGBA16F, 4 halves per pixel), in place in `src_dest`
+    void OnRenderImage(DataBuffer<uint64_t>& src_dest)
+    {
+        check(ctx_.get(), lbvh_compose(ctx_.get(), (const uint16_t*)src_dest.DeviceBuffer(), (const uint16_t*)image_->DeviceBuffer(),
+                                       hits_->Size(), (uint16_t*)src_dest.DeviceBuffer()));
+    }
     // per-frame rebuild on the same buffers (dynamic scenes): the whole Awake() chain in one call
     void Rebuild()
     {
