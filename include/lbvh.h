@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LBVH_ABI_VERSION 3
+#define LBVH_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------------- */
 typedef int32_t lbvh_status;
