@@ -205,6 +205,28 @@ def main():
         t_h = torch.tensor([float(share_hits)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t_h)
         share_hits = int(t_h.item())
+    # untimed extra for N > 1: every rank traces the WHOLE frame (N frames in flight on N GPUs) — the weak-scaling
+    # counterpart of the strong-scaling `value`, reported beside it, never instead of it
+    weak = None
+    if dist is not None and not cfg4:
+        whole = DataBuffer(ctx, W * H, L.HIT)
+        s_w = drawer.container.scene()
+
+        def whole_frame():
+            N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s_w), mode, whole.device, None))
+        for _ in range(3):
+            whole_frame()
+        ctx.sync()
+        barrier()
+        t0w = time.perf_counter()
+        for _ in range(args.steps):
+            whole_frame()
+        ctx.sync()
+        barrier()
+        ms_w = reduce_max((time.perf_counter() - t0w) * 1e3 / args.steps)
+        weak = {"Mrays_s": round(world * W * H / (ms_w * 1e-3) / 1e6, 2), "ms_per_frame_per_gpu": round(ms_w, 4),
+                "workload": "every GPU traces the whole 1080p frame, %d frames in flight" % world}
+        whole.dispose()
     sharded_sort_check = None
     if sorter is not None and rank == 0:
         # the timed steps left the sharded sort's result in the container: compare it with the one-GPU sort
@@ -343,6 +365,8 @@ def main():
         }
         if sharded_sort_check is not None:
             out["sharded_sort_matches_single_gpu"] = sharded_sort_check
+        if weak is not None:
+            out["weak_scaling_extra"] = weak
     for e in events:
         for x in e:
             ctx.destroy_event(x)
