@@ -1103,7 +1103,8 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
     const uint64_t args_key = key;
     mix_scratch(mix);
     if (key == 0) key = 1;
-    const bool graphs = ctx->own_stream && !ctx->prof_enabled && !ctx->build_graph_off;
+    static const bool env_no_graph = getenv("LBVH_NO_GRAPH") != nullptr;     // debugging / measurement switch
+    const bool graphs = ctx->own_stream && !ctx->prof_enabled && !ctx->build_graph_off && !env_no_graph;
     if (graphs && ctx->build_graph && ctx->build_graph_key == key) {
         LBVH_HIP_TRY(ctx, hipGraphLaunch(ctx->build_graph, ctx->stream));
         return LBVH_OK;
