@@ -169,11 +169,12 @@ __global__ __launch_bounds__(64) void trace_reference_kernel(trace_args a, lbvh_
 // Four lanes per triangle: lane q of a quad reads float4 q of the 128-byte reference triangle (a, b, c: the 48
 // contiguous bytes of its positions) and writes float4 q of the 64-byte line, so a wave's one store covers 16
 // whole lines (1 KB contiguous) instead of 64 quarter lines; a / b / c travel inside the quad by DPP quad_perm.
-__global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh_fast_tri* __restrict__ tris)
+__global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh_fast_tri* __restrict__ tris, uint32_t begin,
+                                                              uint32_t end)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t pos = t >> 2, q = t & 3u;
-    const bool live = pos < s.n;
+    const uint32_t pos = begin + (t >> 2), q = t & 3u;
+    const bool live = pos < end;
     const uint32_t tri = live ? s.sorted_indices[pos] : 0u;
     float4 mine = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (live && q < 3u) mine = reinterpret_cast<const float4*>(&s.triangles[tri])[q];
@@ -989,7 +990,13 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
         rc = lbvh_launch_refit(ctx, s.n, t_internal, t_leaf, t_leaf_box, nullptr, t_bvh, ctx->fast_nodes, ctx->fast_capacity, true);
         if (rc != LBVH_OK) return rc;
     }
-    if (parts & 2) LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((s.n + 63) / 64), dim3(256), s, ctx->fast_tris);
+    // parts 2 / 4 / 8: all / the first half / the second half of the sorted triangles
+    if (parts & 14) {
+        const uint32_t half = (s.n / 2u) & ~15u;
+        const uint32_t begin = (parts & 8) ? half : 0u, end = (parts & 4) ? half : s.n;
+        if (end > begin)
+            LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((end - begin + 63) / 64), dim3(256), s, ctx->fast_tris, begin, end);
+    }
     LBVH_HIP_TRY(ctx, hipGetLastError());
     ctx->fast_n = s.n;
     return LBVH_OK;
@@ -1050,7 +1057,11 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
         ctx->lane = 1;
         ctx->cur_stream = ctx->side_stream;
         fast_scene = s;
+#ifdef LBVH_EXPERIMENT_SPLIT_TRIS
+        rc = build_fast_scene_parts(ctx, &s, h_box_min, h_box_max, 1 | 4);
+#else
         rc = build_fast_scene_parts(ctx, &s, h_box_min, h_box_max, 1);
+#endif
         hipError_t e = hipEventRecord(ctx->ev_join, ctx->side_stream);
         ctx->lane = 0;
         ctx->cur_stream = ctx->stream;
@@ -1069,7 +1080,11 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
     }
     if (fast) {
         // the sorted triangles do not depend on the traversal tree: they ride on the shorter lane
+#ifdef LBVH_EXPERIMENT_SPLIT_TRIS
+        if ((rc = build_fast_scene_parts(ctx, &fast_scene, h_box_min, h_box_max, 8)) != LBVH_OK) return rc;
+#else
         if ((rc = build_fast_scene_parts(ctx, &fast_scene, h_box_min, h_box_max, 2)) != LBVH_OK) return rc;
+#endif
         LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     return LBVH_OK;
