@@ -559,6 +559,9 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
 {
     const uint32_t tile = shard_tile(w, a.shard_index, a.shard_count);
     if (w >= n_work || tile >= a.tiles_x * a.tiles_y) return;        // cannot happen for a heavy item
+#ifdef LBVH_EXPERIMENT_SKIP_HEAVY
+    return;                                                           // timing floor of the rest of the launch (wrong hits)
+#endif
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     // as many waves as the tile's last step count is worth (about kCoopGrain steps each); the others leave now
     const uint32_t n_waves = min(max((cost[w] + heavy_cap.grain / 2u) / heavy_cap.grain, 2u), (uint32_t)kCoopWaves);
