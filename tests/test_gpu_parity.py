@@ -455,6 +455,39 @@ def test_trace_rectangles_stitch_to_the_full_frame(ctx):
     d.on_destroy()
 
 
+def _rotated(cam, yaw_deg, pitch_deg):
+    """the camera dict with its orientation turned (camera_to_world's 3x3 block replaced, position kept)"""
+    import math
+    cy, sy = math.cos(math.radians(yaw_deg)), math.sin(math.radians(yaw_deg))
+    cp, sp = math.cos(math.radians(pitch_deg)), math.sin(math.radians(pitch_deg))
+    yaw = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=np.float64)
+    pitch = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]], dtype=np.float64)
+    m = np.array(cam["camera_to_world"], dtype=np.float32).reshape(4, 4).copy()
+    m[:3, :3] = (yaw @ pitch @ m[:3, :3].astype(np.float64)).astype(np.float32)
+    out = dict(cam)
+    out["camera_to_world"] = m.reshape(-1).copy()
+    return out
+
+
+@pytest.mark.parametrize("pos,yaw,pitch", [((3.0, 2.0, 1.0), 0.0, 0.0), ((3.0, 2.0, 1.0), 90.0, 0.0), ((-20.0, 5.0, 40.0), 37.0, -23.0),
+                                           ((0.0, 0.0, 0.0), 180.0, 45.0), ((60.0, -70.0, 10.0), -120.0, 60.0)])
+def test_trace_fast_from_inside_the_scene(ctx, pos, yaw, pitch):
+    """Cameras inside the mesh, turned every way: tiles whose rays agree on the direction signs in all eight octants and
+    tiles that do not, rays parallel to an axis, hits behind the origin (the reference has no t > 0 test) — the packet
+    walk's ordered box tests and DPP operands against the oracle's reference-order walk, three frames each."""
+    tris = scenes.tiled_torus(nu=24, nv=16, grid=3)                 # 20 736 triangles around the origin
+    d, c, b = build_both(ctx, tris)
+    cam = _rotated(scenes.camera(161, 97, pos), yaw, pitch)
+    oh, _ = O.trace_primary(b, cam, threads=8)
+    for frame in range(3):
+        d.update(cam, mode=L.TRACE_FAST)
+        fh = d.hits()
+        assert (fh["t"] == oh["t"]).all()
+        same = fh["tri"] == oh["tri"]
+        assert same.mean() > 0.999 and (fh["u"][same] == oh["u"][same]).all() and (fh["v"][same] == oh["v"][same]).all()
+    d.on_destroy()
+
+
 @pytest.mark.parametrize("shards", [2, 3, 8])
 def test_shards_union_equals_the_full_frame(ctx, shards):
     """lbvh_trace_primary_shard: one launch per GPU; the shards partition the frame exactly as bench.shard_tiles
