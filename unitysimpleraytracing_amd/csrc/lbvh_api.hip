@@ -37,6 +37,7 @@ int lbvh_ensure_side(lbvh_context* ctx)
         LBVH_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
         LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_leaf_boxes, hipEventDisableTiming));
     }
     return LBVH_OK;
 }
@@ -124,6 +125,7 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
     if (ctx->build_graph) (void)hipGraphExecDestroy(ctx->build_graph);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_leaf_boxes) (void)hipEventDestroy(ctx->ev_leaf_boxes);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->fast_nodes) (void)hipFree(ctx->fast_nodes);
     if (ctx->trace_queues) (void)hipFree(ctx->trace_queues);

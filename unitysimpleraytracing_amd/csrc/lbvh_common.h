@@ -63,6 +63,8 @@ struct lbvh_context {
     hipStream_t cur_stream = nullptr;
     int lane = 0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_leaf_boxes = nullptr;    // lane 1 has gathered the triangle AABBs into leaf order (fast_leaf_boxes)
+    lbvh_aabb* fast_leaf_boxes = nullptr;  // inside fast_tree; valid for the build in flight
     // lbvh_build_scene replays a captured hipGraph when it is called again with the same arguments (per-frame
     // rebuilds): ~20 short dependent kernels on two streams, launch gaps included, become one graph launch
     hipGraphExec_t build_graph = nullptr;

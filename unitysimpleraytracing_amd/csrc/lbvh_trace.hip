@@ -986,6 +986,9 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
     if (parts & 1) {
         rc = lbvh_launch_gather_aligned_keys(ctx, s.n, s.triangle_aabb, s.sorted_indices, h_box_min, h_box_max, t_leaf_box, t_keys);
         if (rc != LBVH_OK) return rc;
+        // lbvh_build_scene: the reference lane's refit reads these leaf-ordered boxes instead of gathering them again
+        ctx->fast_leaf_boxes = t_leaf_box;
+        if (ctx->lane == 1 && ctx->ev_leaf_boxes) LBVH_HIP_TRY(ctx, hipEventRecord(ctx->ev_leaf_boxes, ctx->cur_stream));
         uint32_t* counter = nullptr;
         if ((rc = lbvh_refit_counter(ctx, s.n, &counter)) != LBVH_OK) return rc;
         lbvh_launch_tree(ctx, s.n, t_keys, t_internal, t_leaf, counter);
@@ -1077,7 +1080,16 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
         uint32_t* counter = nullptr;
         if ((rc = (lbvh_status)lbvh_refit_counter(ctx, n, &counter)) != LBVH_OK) return rc;
         lbvh_launch_tree(ctx, n, d_keys, d_internal, d_leaf, counter);
-        if ((rc = (lbvh_status)lbvh_launch_refit(ctx, n, d_internal, d_leaf, d_aabb, d_indices, d_bvh, nullptr, 0u, true)) != LBVH_OK)
+        // the boxes in leaf order: lane 1 gathered them long ago (an exact copy of aabb[sortedTriangleIndices[i]],
+        // BVH.compute:196-205) — a stream-ordered read instead of a second random gather
+        const lbvh_aabb* leaf_boxes = d_aabb;
+        const uint32_t* leaf_order = d_indices;
+        if (fast && ctx->fast_leaf_boxes) {
+            LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_leaf_boxes, 0));
+            leaf_boxes = ctx->fast_leaf_boxes;
+            leaf_order = nullptr;
+        }
+        if ((rc = (lbvh_status)lbvh_launch_refit(ctx, n, d_internal, d_leaf, leaf_boxes, leaf_order, d_bvh, nullptr, 0u, true)) != LBVH_OK)
             return rc;
         LBVH_HIP_TRY(ctx, hipGetLastError());
     }
