@@ -32,6 +32,7 @@ struct trace_args {
     int32_t x0, y0, x1, y1;
     uint32_t tiles_x, tiles_y;
     uint32_t shard_index, shard_count;   // this launch traces every shard_count-th GROUP of tiles
+    uint32_t line_bytes;                 // size of the node + triangle line array if it is below 4 GB, else 0
 };
 
 constexpr int kOrderClasses = 16;         // cost classes of the packet dispatch order
@@ -251,6 +252,19 @@ __device__ __forceinline__ int fetch_line_dword(const lbvh_fast_node* __restrict
     const char* base = reinterpret_cast<const char*>(lines) + ((size_t)(ref & 0x7FFFFFFFu) << 6);
     return *reinterpret_cast<const int*>(base + lane_bytes);
 }
+// the same through a buffer resource over the line array (below 4 GB): the line's byte offset is the instruction's
+// scalar offset operand and the lane's constant its vector offset — no address arithmetic on the vector unit at all
+struct line_source {
+    const lbvh_fast_node* lines;
+    __amdgpu_buffer_rsrc_t rsrc;
+};
+template <bool BUF>
+__device__ __forceinline__ int fetch_line(const line_source& src, uint32_t ref, uint32_t lane_bytes)
+{
+    if (BUF) return (int)__builtin_amdgcn_raw_buffer_load_b32(src.rsrc, (int)lane_bytes, (int)((ref & 0x7FFFFFFFu) << 6), 0);
+    return fetch_line_dword(src.lines, ref, lane_bytes);
+}
+
 // dword K of the line held by every 16-lane row of w, in all lanes (DPP row_newbcast:K, gfx90a+; folds into the
 // consuming vector instruction).  ONLY where every lane is active: a DPP read of a disabled source lane yields 0
 // (the triangle test under `if (hit)` tried it and lost the triangle indices)
@@ -344,9 +358,8 @@ __device__ __forceinline__ uint32_t node_line_bytes(uint32_t lane, bool ordered,
 // SIGNS: all active rays of the packet share the sign of each direction component (and have finite non-zero
 // inverse directions): bit i of `neg` = component i is negative.  The near / far planes of both child boxes are
 // then picked on the scalar unit and the box tests lose their six min / max each (ray_box_ordered).
-template <bool STATS, int R, bool SIGNS>
-__device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict__ nodes, const lbvh_fast_tri* __restrict__ tris,
-                                                packet_rays<R>& P, walk_counters& C, uint32_t neg)
+template <bool STATS, int R, bool SIGNS, bool BUF>
+__device__ __forceinline__ uint32_t walk_packet(const line_source& src, packet_rays<R>& P, walk_counters& C, uint32_t neg)
 {
     const uint32_t lane = lane_id();
     int stack = 0;            // wave-shared stack: slot k lives in lane k of this VGPR
@@ -354,7 +367,7 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
     uint32_t steps = 0;
     const uint32_t node_bytes = node_line_bytes(lane, SIGNS, neg);      // triangle lines read the same under it
     // root: its own box is never tested, both children are
-    int w_node = fetch_line_dword(nodes, 0u, node_bytes);
+    int w_node = fetch_line<BUF>(src, 0u, node_bytes);
     for (;;) {
         // SIGNS: node lines arrive with their planes already ordered (node_bytes above): *min = near, *max = far
         const uniform_node nd = broadcast_node(w_node);
@@ -362,8 +375,8 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
         const bool leaf_l = (lref & 0x80000000u) != 0, leaf_r = (rref & 0x80000000u) != 0;
         // both children are fetched NOW (node line or triangle line), before the box tests: whichever
         // the packet goes to next is already in flight — one memory latency per step instead of two
-        const int w_l = fetch_line_dword(nodes, lref, node_bytes);
-        const int w_r = fetch_line_dword(nodes, rref, node_bytes);
+        const int w_l = fetch_line<BUF>(src, lref, node_bytes);
+        const int w_r = fetch_line<BUF>(src, rref, node_bytes);
         if (STATS && lane == 0) C.pops++;
         steps++;
         float tl[R], tr[R];
@@ -465,7 +478,7 @@ __device__ __forceinline__ uint32_t walk_packet(const lbvh_fast_node* __restrict
         } else {
             if (sp == 0) return steps;
             sp--;
-            w_node = fetch_line_dword(nodes, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), node_bytes);
+            w_node = fetch_line<BUF>(src, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), node_bytes);
         }
     }
 }
@@ -756,8 +769,14 @@ __device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_
     walk_counters C = {0, 0, 0, 0};
     uint32_t neg = 0;
     const bool ordered = packet_signs(P, neg);
-    const uint32_t steps = ordered ? walk_packet<STATS, 1, true>(nodes, tris, P, C, neg)
-                                   : walk_packet<STATS, 1, false>(nodes, tris, P, C, 0u);
+    line_source src;
+    src.lines = nodes;
+    src.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<lbvh_fast_node*>(nodes), 0, (int)a.line_bytes, 0x00020000);
+    uint32_t steps;
+    if (a.line_bytes != 0)
+        steps = ordered ? walk_packet<STATS, 1, true, true>(src, P, C, neg) : walk_packet<STATS, 1, false, true>(src, P, C, 0u);
+    else
+        steps = ordered ? walk_packet<STATS, 1, true, false>(src, P, C, neg) : walk_packet<STATS, 1, false, false>(src, P, C, 0u);
     if (lane == 0) cost[w] = steps;
     if (STATS && tile_cost && lane == 0) tile_cost[tile] = steps;
     uint32_t n_hit = 0;
@@ -884,6 +903,10 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
 {
     a.tiles_x = (uint32_t)(a.x1 - a.x0 + 7) / 8;
     a.tiles_y = (uint32_t)(a.y1 - a.y0 + 7) / 8;
+    {
+        const uint64_t bytes = (uint64_t)ctx->fast_capacity * (sizeof(lbvh_fast_node) + sizeof(lbvh_fast_tri));
+        a.line_bytes = bytes < 0xFFFFFFFFull ? (uint32_t)bytes : 0u;
+    }
     const uint32_t n_work = shard_work(a.tiles_x * a.tiles_y, a.shard_index, a.shard_count);
     if (n_work == 0) return LBVH_OK;
     // [class counts | cost of each work item in the last trace | 16 class lists]: valid for one frame layout
