@@ -214,8 +214,8 @@ __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh
 //   * the traversal stack is shared by the wave: one VGPR used as a 64-slot array written by v_writelane and read
 //     by v_readlane with a scalar stack pointer — no LDS, no scratch;
 //   * all control flow is scalar (conditions come from ballots).
-// The kernel is bound by instruction issue (70 vector + 50 scalar instructions per step, vector
-// issue 85 % busy over the frame), so the step is written for instruction count: see walk_packet's SIGNS form.
+// The kernel is bound by instruction issue (68 vector + 49 scalar instructions per step, vector
+// issue 84 % busy over the frame), so the step is written for instruction count: see walk_packet's SIGNS form.
 // Each lane still sees every node it would visit alone (it votes for it), the leaf's own AABB slab
 // test gates the triangle test per lane, and the accept rule is the reference's strict t < best —
 // so per-ray results equal the reference order's min t.
