@@ -32,14 +32,15 @@
 extern "C" {
 #endif
 
-#define LBVH_ABI_VERSION 4
+#define LBVH_ABI_VERSION 5
 
 /* ---- status codes ------------------------------------------------------------------------- */
 typedef int32_t lbvh_status;
 #define LBVH_OK                 0
 #define LBVH_ERR_INVALID_ARG   -1   /* null pointer, n < 2, n > capacity, bad tile rectangle ...   */
 #define LBVH_ERR_OUT_OF_MEMORY -2
-#define LBVH_ERR_HIP           -3   /* a HIP runtime call failed; see lbvh_last_error              */
+#define LBVH_ERR_HIP           -3   /* a HIP runtime call failed, or a device-side wait gave up (lbvh_sync /
+                                       lbvh_buffer_download report it); see lbvh_last_error           */
 #define LBVH_ERR_NO_DEVICE     -4   /* no usable gfx950 device                                     */
 
 /* ---- scene structs: the reference's buffer element layouts --------------------------------- */
@@ -200,6 +201,13 @@ lbvh_status lbvh_morton_aabb(lbvh_context* ctx, const lbvh_triangle* d_triangles
 lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values,
                             uint32_t count);
 
+/* Host-side view of the sort's tile hand-out order (pure function, no GPU): the tile that the k-th ticket of queue x
+ * stands for.  A pass kernel takes its tile from atomic tickets; on the full 8-XCD device there are 8 queues (one per
+ * XCD, `group` consecutive tiles each in turn: neighbouring tiles meet in one L2), on anything else a single queue
+ * (tile = ticket).  Exposed so the order invariant the decoupled look-back relies on — every tile below a handed-out
+ * tile has been handed out or is the next ticket of some queue — can be model-checked without a GPU. */
+uint32_t lbvh_debug_sort_ticket_tile(uint32_t k, uint32_t x, uint32_t group, uint32_t queues);
+
 /* ---- cfg4: building blocks of the multi-GPU (key-range sharded) sort, SURVEY 8(e) ------------- *
  * The reference has no multi-GPU path; these are the local kernels of the sharded sort that
  * unitysimpleraytracing_amd/sharded_sort.py drives (one process per GPU): every rank sorts its own
@@ -284,7 +292,15 @@ typedef struct lbvh_scene {
     const lbvh_triangle*      triangles;         /* triangleData (original order)                  */
 } lbvh_scene;
 
-/* Build the derived traversal structure used by LBVH_TRACE_FAST for `scene`: its own "traversal
+/* LBVH_TRACE_FAST and the secondary-ray calls work from a derived traversal scene the context caches.  The cache is
+ * keyed: it answers only for the scene it was built from — same triangles / sorted_indices / triangle_aabb pointers and
+ * n — and only while no library call has written into those buffers since (lbvh_morton_aabb, lbvh_sort_pairs,
+ * lbvh_buffer_upload / fill_u32, lbvh_animate, lbvh_build_scene without LBVH_BUILD_FAST_SCENE ...).  Otherwise the
+ * trace returns LBVH_ERR_INVALID_ARG ("stale") instead of hits from old geometry: the reference's Dispatch has no hidden
+ * state (Sc/RaytracingMeshDrawer.cs:65-70).  Writes the library cannot see (the caller's own kernels on those buffers)
+ * are the caller's to follow with lbvh_build_fast_scene.
+ *
+ * Build the derived traversal structure used by LBVH_TRACE_FAST for `scene`: its own "traversal
  * tree" over the scene's SORTED triangle order (Karras topology over minimally perturbed Morton
  * keys k'_i = i + max_{j<=i}(k_j - j) instead of DistributeKeys' shifted ones — tighter boxes — and
  * its own refit), flattened to fused 64-B nodes (both child boxes + child references) plus the sorted
@@ -398,7 +414,7 @@ lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_
 lbvh_status lbvh_path_resolve(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, uint16_t* d_rgba16f);
 
 /* Profiling aid: one LBVH_TRACE_FAST frame that also records, per 8x8-pixel tile (row-major,
- * ceil(W/16) x ceil(H/8) entries), the number of node fetches its packet needed. */
+ * ceil(W/8) x ceil(H/8) entries), the number of node fetches its packet needed. */
 lbvh_status lbvh_trace_tile_costs(lbvh_context* ctx, const lbvh_camera* h_camera, const lbvh_scene* h_scene,
                                   lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_steps);
 

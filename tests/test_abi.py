@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(N.lib, name), f"liblbvh.so does not export {name}"
     assert set(N.SIGNATURES) == set(declared_functions())
-    assert N.lib.lbvh_abi_version() == N.ABI_VERSION == 4
+    assert N.lib.lbvh_abi_version() == N.ABI_VERSION == 5
 
 
 def test_struct_layouts_match_the_reference():
@@ -63,3 +63,75 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in text and "from oracle" not in text and "liblbvh_oracle" not in text, f
+
+
+@pytest.mark.parametrize("queues,group,tiles", [(1, 1, 1), (1, 16, 1000), (8, 1, 7), (8, 8, 130), (8, 8, 1000), (8, 16, 8192),
+                                                (8, 16, 2049)])
+def test_sort_ticket_order_model(queues, group, tiles):
+    """CPU model of the sort's tile hand-out (lbvh_sort.hip): the decoupled look-back of tile T spins on
+    every lower tile, so a lower tile must never be stranded behind workgroups that wait for it.
+      * the ticket -> tile map is a bijection onto a superset of [0, tiles): every tile is handed out exactly once;
+      * one queue (what every context but the full 8-XCD device uses): tiles are handed out in increasing order, so
+        whatever order workgroups start in, everything a tile waits for is already running;
+      * eight queues, workgroups dealt round-robin over the XCDs (the layout lbvh_create selects them for: workgroup
+        b belongs to XCD b % 8, every XCD starts its own workgroups as its slots free up): with any number R of
+        resident workgroups per XCD, the lowest tile not yet handed out is always the next ticket of an XCD whose
+        residents can all finish — simulated with the worst case where a tile finishes only when every lower tile
+        has been handed out."""
+    from unitysimpleraytracing_amd import _native as N
+    f = N.lib.lbvh_debug_sort_ticket_tile
+    per_queue = []
+    for x in range(queues):
+        ks, k = [], 0
+        while True:
+            t = f(k, x, group, queues)
+            if t >= tiles and k % group == 0:
+                break
+            ks.append(t)
+            k += 1
+        assert ks == sorted(ks)
+        per_queue.append([t for t in ks if t < tiles])
+    everything = sorted(t for q in per_queue for t in q)
+    assert everything == list(range(tiles))                              # bijection
+    if queues == 1:
+        assert per_queue[0] == list(range(tiles))
+        return
+    # round-robin placement: workgroup b runs on XCD b % 8 and takes its home queue first, then the others in turn
+    for resident in (1, 3):
+        nxt = [0] * queues                                               # next ticket per queue
+        handed = set()
+        running = [[] for _ in range(queues)]                            # tiles resident per XCD
+        quota = [len(range(x, tiles, queues)) for x in range(queues)]    # workgroups of the grid that belong to XCD x
+        started = [0] * queues
+
+        def take(home):
+            for a in range(queues):
+                x = (home + a) % queues
+                while True:
+                    t = f(nxt[x], x, group, queues)
+                    nxt[x] += 1
+                    if t < tiles:
+                        return t
+                    if nxt[x] > tiles + queues * group:                   # this queue is drained
+                        break
+            raise AssertionError("no tile left for a workgroup")
+
+        while len(handed) < tiles or any(running):
+            progressed = False
+            for x in range(queues):                                      # fill free slots in dispatch order
+                while len(running[x]) < resident and started[x] < quota[x]:
+                    t = take(x)
+                    handed.add(t)
+                    running[x].append(t)
+                    started[x] += 1
+                    progressed = True
+            # a tile can finish once every lower tile has been handed out (its look-back then completes)
+            low = 0
+            while low in handed:
+                low += 1
+            for x in range(queues):
+                done = [t for t in running[x] if t < low]
+                if done:
+                    running[x] = [t for t in running[x] if t >= low]
+                    progressed = True
+            assert progressed, f"stranded: lowest missing tile {low}, resident {running}"

@@ -86,6 +86,25 @@ def test_sort_stability_and_skew(ctx, kind, count):
     assert (gk == ok).all() and (gv == ov).all()
 
 
+def test_sort_single_ticket_queue_mode():
+    """contexts that are not the full 8-XCD device behind an unmasked stream take tiles in plain ticket order
+    (one queue).  LBVH_SORT_QUEUES=1 forces that mode on this box: same results, sizes beyond the point where the
+    8-queue form could have stranded tiles (> 9 M keys)."""
+    os.environ["LBVH_SORT_QUEUES"] = "1"
+    try:
+        c1 = H().Context(0)
+    finally:
+        del os.environ["LBVH_SORT_QUEUES"]
+    try:
+        for count, kind in ((100003, "random"), (1 << 21, "morton_pads"), (12_000_001, "random")):
+            keys, vals = sort_inputs(count, count % 97, kind)
+            k, v = gpu_sort(c1, keys, vals)
+            ok, ov = O.sort_pairs(keys, vals)
+            assert (k == ok).all() and (v == ov).all()
+    finally:
+        c1.close()
+
+
 def test_sort_count_zero_and_repeat(ctx):
     kb, vb = up(ctx, np.zeros(4, np.uint32)), up(ctx, np.zeros(4, np.uint32))
     N().check(ctx.handle, N().lib.lbvh_sort_pairs(ctx.handle, kb.device, vb.device, 0))
@@ -622,7 +641,105 @@ def test_cfg2_full_size(ctx):
     assert np.allclose(fast["t"], ref["t"], rtol=1e-5, atol=1e-5)
     frac = float((ref["t"] < L.MAX_FLOAT).mean())
     assert 0.2 < frac < 0.95
+    # BASELINE configs[2] at its own size: the 8 shards of this 1080p frame (what each of 8 GPUs traces with the BVH
+    # replicated), one after the other on this GPU, three frames each into a NaN-poisoned full-frame buffer — frames 2
+    # and 3 of a shard run its dispatch history and the cooperative heavy tiles (4 050 tiles per shard: trace_shared_kernel
+    # on the 1 M-triangle scene).  Stitched frame == unsharded fast frame == reference-mode frame == oracle samples.
+    from bench import shard_tiles
+    stitched = np.zeros_like(fast)
+    covered = np.zeros(fast.shape, dtype=np.int32)
+    for r in range(8):
+        owned = np.zeros(fast.shape, dtype=bool)
+        for x0, y0, x1, y1 in shard_tiles(r, 8, 1920, 1080):
+            owned[y0:y1, x0:x1] = True
+        covered += owned
+        for frame in range(3):
+            d._hits.fill_u32(0x7FC00000)
+            d.update_shard(cam, r, 8, mode=L.TRACE_FAST)
+            part = d.hits()
+            assert (part.view(np.uint32).reshape(1080, 1920, 4)[~owned] == 0x7FC00000).all()      # other shards' pixels untouched
+            assert (part["t"][owned] == ref["t"][owned]).all(), (r, frame)
+            same = (part["tri"] == ref["tri"]) & owned
+            assert same.sum() >= 0.9999 * owned.sum()                                              # exact ties in t only
+            assert (part["u"][same] == ref["u"][same]).all() and (part["v"][same] == ref["v"][same]).all()
+        stitched[owned] = part[owned]
+    assert (covered == 1).all()
+    assert (stitched["t"] == fast["t"]).all() and (stitched["t"] == ref["t"]).all()
+    assert (stitched[::16, ::16]["t"] == oh["t"]).all()
     d.on_destroy()
+
+
+def test_derived_scene_is_keyed_to_its_scene(ctx):
+    """VERDICT r1 item 7 / ADVICE: the derived traversal scene is a per-context cache; it must answer only for the scene
+    it was built from, and only until a library call rewrites that scene's buffers.  Two scenes of EQUAL triangle
+    count on one context, traced alternately; staged calls that move the triangles without lbvh_build_fast_scene; a
+    freed buffer.  A stale cache is LBVH_ERR_INVALID_ARG, never old hits with status OK."""
+    n_ = N()
+    a_tris = scenes.random_triangles(5000, seed=41, extent=60.0, edge=5.0)
+    b_tris = scenes.random_triangles(5000, seed=42, extent=60.0, edge=5.0)
+    cam = scenes.camera(120, 90, (0.0, 0.0, 200.0))
+    ccam = n_.Camera.from_dict(cam)
+    da = H().RaytracingMeshDrawer(ctx, a_tris).awake()
+    da.update(cam, mode=L.TRACE_REFERENCE)
+    ref_a = da.hits()
+    da.update(cam, mode=L.TRACE_FAST)
+    assert (da.hits()["t"] == ref_a["t"]).all()
+    db = H().RaytracingMeshDrawer(ctx, b_tris).awake()          # same n: the cache now belongs to scene B
+    db.update(cam, mode=L.TRACE_REFERENCE)
+    ref_b = db.hits()
+    assert not (ref_a["t"] == ref_b["t"]).all()
+    db.update(cam, mode=L.TRACE_FAST)
+    assert (db.hits()["t"] == ref_b["t"]).all()
+    # scene A again without rebuilding its derived scene: refused, not answered from B's geometry
+    sa = da.container.scene()
+    rc = n_.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, 120, 90, C.byref(sa), L.TRACE_FAST, da._hits.device, None)
+    assert rc == -1 and b"lbvh_build_fast_scene" in n_.lib.lbvh_last_error(ctx.handle)
+    for _ in range(2):                                          # alternate, rebuilding each time: always the right hits
+        da.build_fast_scene()
+        da.update(cam, mode=L.TRACE_FAST)
+        assert (da.hits()["t"] == ref_a["t"]).all()
+        db.build_fast_scene()
+        db.update(cam, mode=L.TRACE_FAST)
+        assert (db.hits()["t"] == ref_b["t"]).all()
+    # the staged chain re-run on moved triangles, without lbvh_build_fast_scene: the cache is stale
+    moved = b_tris.copy()
+    for f in ("a", "b", "c"):
+        moved[f] = moved[f] + np.float32(7.5)
+    db.container.triangle_data.local[:5000] = moved
+    db.container.triangle_data.sync()                           # lbvh_buffer_upload into the scene's triangles
+    sb = db.container.scene()
+    rc = n_.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, 120, 90, C.byref(sb), L.TRACE_FAST, db._hits.device, None)
+    assert rc == -1 and b"stale" in n_.lib.lbvh_last_error(ctx.handle)
+    db.rebuild(fast=False, staged=True)
+    rc = n_.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, 120, 90, C.byref(sb), L.TRACE_FAST, db._hits.device, None)
+    assert rc == -1
+    db.update(cam, mode=L.TRACE_REFERENCE)
+    ref_moved = db.hits()
+    db.build_fast_scene()
+    db.update(cam, mode=L.TRACE_FAST)
+    assert (db.hits()["t"] == ref_moved["t"]).all() and not (ref_moved["t"] == ref_b["t"]).all()
+    # lbvh_build_scene without LBVH_BUILD_FAST_SCENE re-sorts the indices: stale again; with the flag: valid (also replayed)
+    db.rebuild(fast=False)
+    assert n_.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, 120, 90, C.byref(sb), L.TRACE_FAST, db._hits.device, None) == -1
+    for _ in range(4):
+        db.rebuild(fast=True)
+        db.update(cam, mode=L.TRACE_FAST)
+        assert (db.hits()["t"] == ref_moved["t"]).all()
+    # graph replay keeps the host-side key in step: big, big, big (captured + replayed), small, big (replayed), trace big
+    for _ in range(3):
+        da.rebuild(fast=True)
+    db.rebuild(fast=True)
+    da.rebuild(fast=True)
+    da.update(cam, mode=L.TRACE_FAST)
+    assert (da.hits()["t"] == ref_a["t"]).all()
+    # a freed scene buffer cannot back the cache
+    da.on_destroy()
+    da2 = H().RaytracingMeshDrawer(ctx, a_tris)
+    da2.awake(fast=False)                                       # very likely the same addresses again
+    s2 = da2.container.scene()
+    assert n_.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, 120, 90, C.byref(s2), L.TRACE_FAST, db._hits.device, None) == -1
+    da2.on_destroy()
+    db.on_destroy()
 
 
 # ---- the compiled-language host layer (C++ classes over the C ABI) ---------------------------------------------

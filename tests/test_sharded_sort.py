@@ -123,6 +123,41 @@ def test_sharded_sort_host_logic_over_gloo(tmp_path, world):
         assert open(f"{out}.{r}").read() == "ok"
 
 
+def _cpu_worker_16m(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    from unitysimpleraytracing_amd.sharded_sort import ShardedSorter, block_of
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 16_000_000 + 512                      # cfg4's key count: 16 M Morton codes + the pads up to the capacity
+    keys, vals = _inputs("morton", n, 21)
+    lo, hi = block_of(rank, world, n)
+    ops = OracleKeyOps()
+    sorter = ShardedSorter(ops=ops)
+    k, v, counts = sorter.sort(torch.from_numpy(keys[lo:hi].view(np.int32).copy()), torch.from_numpy(vals[lo:hi].view(np.int32).copy()))
+    ok = k.numel() == counts[rank] and sum(counts) == n
+    # this rank's slice against the same slice of the one-process stable sort
+    order = np.argsort(keys, kind="stable")
+    start = sum(counts[:rank])
+    ok = ok and (k.numpy().view(np.uint32) == keys[order][start:start + counts[rank]]).all()
+    ok = ok and (v.numpy().view(np.uint32) == vals[order][start:start + counts[rank]]).all()
+    with open(f"{out_path}.{rank}", "w") as f:
+        f.write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_sort_sixteen_million_keys_eight_ranks(tmp_path):
+    """BASELINE configs[3]'s shape on CPU: 8 logical ranks (gloo), 16 M Morton-like keys + pads; every rank's slice
+    equals its part of the one-process stable sort."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result")
+    mp.spawn(_cpu_worker_16m, args=(8, _free_port(), out), nprocs=8, join=True)
+    for r in range(8):
+        assert open(f"{out}.{r}").read() == "ok"
+
+
 def test_block_of_partitions_the_capacity():
     from unitysimpleraytracing_amd.sharded_sort import block_of
     for cap in (0, 1, 7, 1024, 1_000_448, 16_000_000):
@@ -183,4 +218,52 @@ def test_sharded_sort_hip_kernels(tmp_path, world, backend):
     out = str(tmp_path / "result")
     mp.spawn(_gpu_worker, args=(world, _free_port(), out, backend), nprocs=world, join=True)
     for r in range(world):
+        assert open(f"{out}.{r}").read() == "ok"
+
+
+def _gpu_worker_cfg4(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    from unitysimpleraytracing_amd import _native as N
+    from unitysimpleraytracing_amd import scenes
+    from unitysimpleraytracing_amd.host import Context, DataBuffer, MeshBufferContainer
+    from unitysimpleraytracing_amd.sharded_sort import ShardedSorter, sort_container
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    sorter = ShardedSorter(ctx, always_exchange=True)
+    tris = scenes.tiled_torus(nu=400, nv=160)                    # cfg4's mesh: 16 M triangles, identical on every rank
+    c = MeshBufferContainer(ctx, tris)                           # Morton codes + pads, replicated
+    del tris
+    cap = c.capacity
+    # the one-GPU sort of the same keys (lbvh_sort_pairs over the whole capacity)
+    k1, v1 = DataBuffer(ctx, cap, np.uint32), DataBuffer(ctx, cap, np.uint32)
+    k1.local[:] = c.keys.get_data()
+    v1.local[:] = c.triangle_index.get_data()
+    k1.sync(); v1.sync()
+    N.check(ctx.handle, N.lib.lbvh_sort_pairs(ctx.handle, k1.device, v1.device, cap))
+    counts = sort_container(sorter, c)                           # sharded: RCCL-shaped exchange over gloo here
+    torch.cuda.synchronize()
+    ks, vs = c.keys.get_data(), c.triangle_index.get_data()
+    ok = sum(counts) == cap and (ks == k1.get_data()).all() and (vs == v1.get_data()).all()
+    ok = ok and (np.diff(ks.astype(np.int64)) >= 0).all() and (ks[16_000_000:] == 0xFFFFFFFF).all()
+    ok = ok and max(counts) - min(counts) <= 4096                # balanced up to the multiplicity of a splitter key
+    with open(f"{out_path}.{rank}", "w") as f:
+        f.write("ok" if ok else "mismatch")
+    c.dispose(); k1.dispose(); v1.dispose()
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_sharded_sort_cfg4_sixteen_million_triangles_two_ranks(tmp_path):
+    """BASELINE configs[3] at size: the Morton keys (+ pads) of the 16 M-triangle mesh, sorted by two ranks that share
+    cuda:0 (HIP kernels + the exchange over gloo) — bit-identical to lbvh_sort_pairs on one GPU."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result")
+    mp.spawn(_gpu_worker_cfg4, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in range(2):
         assert open(f"{out}.{r}").read() == "ok"

@@ -6,8 +6,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblbvh.so")
-ABI_VERSION = 4
+# LBVH_LIB: an alternative build of the same library (tools/build_variant.sh: A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("LBVH_LIB") or os.path.join(_HERE, "liblbvh.so")
+ABI_VERSION = 5
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -79,6 +80,7 @@ SIGNATURES = {
                                   _I32, _P, _P]),
     "lbvh_trace_primary_shard": (_I32, [_P, C.POINTER(Camera), _U32, _U32, C.POINTER(Scene), _I32, _P, _P]),
     "lbvh_build_scene": (_I32, [_P, _P, _U32, _U32, _F3, _F3, _P, _P, _P, _P, _P, _P, _U32]),
+    "lbvh_debug_sort_ticket_tile": (_U32, [_U32, _U32, _U32, _U32]),
     "lbvh_key_histogram": (_I32, [_P, _P, _U32, _P, _U32, _U32, _U32, _P]),
     "lbvh_lower_bound": (_I32, [_P, _P, _U32, _P, _U32, _P]),
     "lbvh_animate": (_I32, [_P, _P, _U32, _P, _P, C.c_float, C.c_float, _P]),

@@ -42,6 +42,53 @@ int lbvh_ensure_side(lbvh_context* ctx)
     return LBVH_OK;
 }
 
+static bool ranges_overlap(const void* a, size_t a_bytes, const void* b, size_t b_bytes)
+{
+    const uintptr_t a0 = (uintptr_t)a, b0 = (uintptr_t)b;
+    return a && b && a_bytes && b_bytes && a0 < b0 + b_bytes && b0 < a0 + a_bytes;
+}
+
+void lbvh_note_write(lbvh_context* ctx, const void* p, size_t bytes)
+{
+    if (!ctx->fast_valid) return;
+    const size_t n = ctx->fast_src.n;
+    if (ranges_overlap(p, bytes, ctx->fast_src.triangles, n * sizeof(lbvh_triangle)) ||
+        ranges_overlap(p, bytes, ctx->fast_src.sorted_indices, n * sizeof(uint32_t)) ||
+        ranges_overlap(p, bytes, ctx->fast_src.triangle_aabb, n * sizeof(lbvh_aabb)))
+        ctx->fast_valid = false;
+}
+
+void lbvh_note_fast_built(lbvh_context* ctx, const lbvh_scene& s)
+{
+    ctx->fast_src.triangles = s.triangles;
+    ctx->fast_src.sorted_indices = s.sorted_indices;
+    ctx->fast_src.triangle_aabb = s.triangle_aabb;
+    ctx->fast_src.n = s.n;
+    ctx->fast_valid = true;
+}
+
+int lbvh_require_fast(lbvh_context* ctx, const lbvh_scene& s, const char* who)
+{
+    if (!ctx->fast_nodes || ctx->fast_src.n != s.n || ctx->fast_src.triangles != s.triangles ||
+        ctx->fast_src.sorted_indices != s.sorted_indices || ctx->fast_src.triangle_aabb != s.triangle_aabb)
+        return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, who, "needs lbvh_build_fast_scene on this scene first");
+    if (!ctx->fast_valid)
+        return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, who,
+                              "the derived traversal scene is stale: the scene's triangles / sorted indices / triangle AABBs "
+                              "were written after lbvh_build_fast_scene — build it again");
+    return LBVH_OK;
+}
+
+int lbvh_check_fault(lbvh_context* ctx)
+{
+    if (!ctx->fault_host) return LBVH_OK;
+    const uint32_t code = __atomic_load_n(ctx->fault_host, __ATOMIC_RELAXED);
+    if (code == 0) return LBVH_OK;
+    char msg[96];
+    snprintf(msg, sizeof msg, "a bounded inter-workgroup wait gave up (fault %u): results of this context are invalid", code);
+    return lbvh_set_error(ctx, LBVH_ERR_HIP, "device-side protocol fault", msg);
+}
+
 hipEvent_t lbvh_prof_event(lbvh_context* ctx)
 {
     hipEvent_t e = nullptr;
@@ -97,6 +144,29 @@ static lbvh_status create_impl(int32_t device_id, void* stream, bool own, lbvh_c
         ctx->own_stream = false;
     }
     ctx->cur_stream = ctx->stream;
+    // 8 per-XCD ticket queues for the sort only on the layout they assume (in CPX/DPX/QPX partitions or
+    // behind a CU-masked stream the workgroups of a launch do not visit all eight XCDs in turn): the whole 256-CU
+    // device and a stream whose CU mask (if it can be read at all) enables every CU
+    {
+        bool full = prop.multiProcessorCount == 256;
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (full && hipExtStreamGetCUMask(ctx->stream, 8, mask) == hipSuccess) {
+            for (int i = 0; i < 8; i++) full = full && mask[i] == 0xFFFFFFFFu;
+        } else if (!own) {
+            full = false;           // a caller's stream whose mask cannot be read: assume nothing
+        }
+        (void)hipGetLastError();
+        ctx->sort_queues = full ? 8u : 1u;
+        if (getenv("LBVH_SORT_QUEUES")) ctx->sort_queues = atoi(getenv("LBVH_SORT_QUEUES")) == 8 ? 8u : 1u;   // tests: force a mode
+    }
+    if (hipHostMalloc((void**)&ctx->fault_host, 256, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&ctx->fault_dev, ctx->fault_host, 0) != hipSuccess) {
+        if (ctx->fault_host) (void)hipHostFree(ctx->fault_host);
+        if (own) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return lbvh_set_error(nullptr, LBVH_ERR_OUT_OF_MEMORY, "lbvh_create", "no mapped host memory for the fault word");
+    }
+    memset(ctx->fault_host, 0, 256);
     *out_ctx = ctx;
     return LBVH_OK;
 }
@@ -134,6 +204,7 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
     for (auto& s : ctx->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->fault_host) (void)hipHostFree(ctx->fault_host);
     delete ctx;
     return LBVH_OK;
 }
@@ -147,7 +218,7 @@ lbvh_status lbvh_sync(lbvh_context* ctx)
 {
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return LBVH_OK;
+    return lbvh_check_fault(ctx);
 }
 
 // ---- buffers -------------------------------------------------------------------------------
@@ -170,6 +241,12 @@ lbvh_status lbvh_buffer_free(lbvh_context* ctx, void* d_ptr)
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     if (!d_ptr) return LBVH_OK;
     LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // a freed scene buffer can no longer back the derived scene (its address may be handed out again)
+    if (ctx->fast_valid && (d_ptr == ctx->fast_src.triangles || d_ptr == ctx->fast_src.sorted_indices ||
+                            d_ptr == ctx->fast_src.triangle_aabb)) {
+        ctx->fast_valid = false;
+        ctx->fast_src.n = 0;
+    }
     LBVH_HIP_TRY(ctx, hipFree(d_ptr));
     return LBVH_OK;
 }
@@ -179,6 +256,7 @@ lbvh_status lbvh_buffer_fill_u32(lbvh_context* ctx, void* d_ptr, uint32_t value,
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     if (n_words == 0) return LBVH_OK;
     LBVH_REQUIRE(ctx, d_ptr != nullptr);
+    lbvh_note_write(ctx, d_ptr, n_words * 4);
     LBVH_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_ptr, (int)value, n_words, ctx->stream));
     return LBVH_OK;
 }
@@ -188,6 +266,7 @@ lbvh_status lbvh_buffer_upload(lbvh_context* ctx, void* d_dst, const void* h_src
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     if (bytes == 0) return LBVH_OK;
     LBVH_REQUIRE(ctx, d_dst != nullptr && h_src != nullptr);
+    lbvh_note_write(ctx, d_dst, bytes);
     LBVH_HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     // pageable host memory: the caller may reuse h_src as soon as we return
     LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -201,7 +280,7 @@ lbvh_status lbvh_buffer_download(lbvh_context* ctx, void* h_dst, const void* d_s
     LBVH_REQUIRE(ctx, h_dst != nullptr && d_src != nullptr);
     LBVH_HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return LBVH_OK;
+    return lbvh_check_fault(ctx);
 }
 
 // ---- events ----------------------------------------------------------------------------------

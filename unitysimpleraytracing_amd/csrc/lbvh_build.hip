@@ -251,9 +251,6 @@ __global__ __launch_bounds__(256) void tree_kernel(const uint32_t* __restrict__ 
     }
     if (split < 0 || (uint32_t)split + 1u >= n) return;   // only reachable with non-unique keys
 
-#ifdef LBVH_EXPERIMENT_TREE_NOSTORE
-    if (split != 0x12345678) { if (split == -7) internal[thread_id].index = (uint32_t)split; return; }
-#endif
     const bool left_leaf = split == first;                                                 // :114
     const bool right_leaf = split + 1 == last;                                             // :132
     uint32_t* node = reinterpret_cast<uint32_t*>(&internal[thread_id]);
@@ -395,11 +392,7 @@ __global__ __launch_bounds__(kRefitThreads) void refit_kernel(uint32_t n, const 
             if (t == 0 && lv.levels >= 2) store_box_plain(&lv.box[2][blockIdx.x], bmn, bmx);
         }
     }
-#ifdef LBVH_EXPERIMENT_REFIT_NOCLIMB
-    if (false) {
-#else
     if (j < n) {
-#endif
         bool stranded = false;      // FUSED: the carried box belongs to a finished node whose parent is not local
         for (int guard = 0; q != 0xFFFFFFFFu && guard < 64; guard++) {
             stranded = true;
@@ -442,11 +435,7 @@ __global__ __launch_bounds__(kRefitThreads) void refit_kernel(uint32_t n, const 
     // internal nodes of this index block that did not see both children arrive through LDS are the frontier
     // (one global atomic per workgroup: the list order is irrelevant)
     __syncthreads();
-#ifdef LBVH_EXPERIMENT_REFIT_NOCLIMB
-    const bool is_front = false;
-#else
     const bool is_front = j < n - 1 && s_flag[t] != 0x10001u;
-#endif
     uint32_t my = 0;
     if (is_front) my = atomicAdd(&s_front_n, 1u);
     // finished nodes (both children arrived): their children's boxes are the two parked entries of their slot.  Written
@@ -898,6 +887,9 @@ lbvh_status lbvh_morton_aabb(lbvh_context* ctx, const lbvh_triangle* d_triangles
     LBVH_REQUIRE(ctx, n == 0 || (d_triangles != nullptr && d_aabb != nullptr));
     LBVH_REQUIRE(ctx, ((uintptr_t)d_triangles & 15) == 0 && ((uintptr_t)d_aabb & 15) == 0);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    lbvh_note_write(ctx, d_keys, (size_t)capacity * 4);
+    lbvh_note_write(ctx, d_indices, (size_t)capacity * 4);
+    lbvh_note_write(ctx, d_aabb, (size_t)n * sizeof(lbvh_aabb));
     lbvh_launch_morton(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, nullptr, 0);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;

@@ -19,6 +19,12 @@ static_assert(sizeof(lbvh_hit) == 16, "hit record must be 16 bytes");
 
 #define LBVH_WAVE 64
 
+// device-side fault codes (ctx->fault_host): a bounded spin of an inter-workgroup protocol gave up
+#define LBVH_FAULT_SORT_LOOKBACK 1u
+// polls before a spin gives up: each poll is a round trip to the coherence point (>= 0.5 us), so this is seconds —
+// orders of magnitude beyond any legitimate wait (a predecessor tile's run time), and never a hung GPU
+#define LBVH_SPIN_LIMIT (1u << 22)
+
 // Derived traversal node for LBVH_TRACE_FAST: both child boxes + child references, 64 bytes,
 // one 64-B aligned fetch per traversal step.  Child reference: an index into the array of 64-byte lines that
 // holds the nodes and, from index fast_leaf_base on, the sorted triangles; bit 31 set = leaf.
@@ -81,7 +87,17 @@ struct lbvh_context {
     lbvh_fast_node* fast_nodes = nullptr;
     lbvh_fast_tri* fast_tris = nullptr;    // = fast_nodes + fast_capacity (same allocation)
     uint32_t fast_capacity = 0;            // = the line index of sorted triangle 0 (leaf base)
-    uint32_t fast_n = 0;
+    // what the derived scene was built FROM: LBVH_TRACE_FAST / lbvh_trace_rays accept a scene only if it names these
+    // buffers and no library call has written into them since (lbvh_note_write) — the reference's Dispatch binds its
+    // buffers statelessly (Sc/RaytracingMeshDrawer.cs:65-70), so a stale cache must never answer for a scene
+    struct { const void *triangles, *sorted_indices, *triangle_aabb; uint32_t n; } fast_src = {nullptr, nullptr, nullptr, 0};
+    bool fast_valid = false;
+    // sort: 8 per-XCD ticket queues only on the layout they were designed for (all 256 CUs of an SPX device behind an
+    // unmasked stream: workgroups dealt round-robin over the XCDs); anything else takes tiles in ticket order
+    uint32_t sort_queues = 1;
+    // device-side protocol faults (a bounded spin gave up): one mapped host word, checked by lbvh_sync / download
+    uint32_t* fault_host = nullptr;
+    uint32_t* fault_dev = nullptr;
     // packet traversal scheduling: step count of every tile in the last trace + the dispatch order made from it
     void* trace_queues = nullptr;
     size_t trace_queues_bytes = 0;
@@ -165,6 +181,16 @@ int lbvh_launch_gather_aligned_keys(lbvh_context* ctx, uint32_t n, const lbvh_aa
                                     const uint32_t* d_sorted_indices, const float box_min[3], const float box_max[3],
                                     lbvh_aabb* d_leaf_box_out, uint32_t* d_keys_out);
 
+// A library call is about to write [p, p + bytes): if that touches what the derived scene was built from, the
+// derived scene is stale from here on.
+void lbvh_note_write(lbvh_context* ctx, const void* p, size_t bytes);
+// the derived scene now describes `s` (called where lbvh_build_fast_scene's work is enqueued or replayed)
+void lbvh_note_fast_built(lbvh_context* ctx, const lbvh_scene& s);
+// LBVH_OK iff the derived scene was built from exactly these buffers and they have not been written since
+int lbvh_require_fast(lbvh_context* ctx, const lbvh_scene& s, const char* who);
+// non-zero fault word -> LBVH_ERR_HIP with the code in the message (after a stream sync)
+int lbvh_check_fault(lbvh_context* ctx);
+
 // Creates the side stream and its fork / join events on first use.
 int lbvh_ensure_side(lbvh_context* ctx);
 
@@ -177,13 +203,13 @@ __device__ __forceinline__ uint32_t lane_id()
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
-// number of set bits of `mask` in lanes below the calling lane (v_mbcnt_lo + v_mbcnt_hi)
 // which of the 8 XCDs (each with its own L2) this wave runs on: s_getreg_b32 HW_REG_XCC_ID (id 20), bits [3:0]
 __device__ __forceinline__ uint32_t xcc_id()
 {
     return (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u;
 }
 
+// number of set bits of `mask` in lanes below the calling lane (v_mbcnt_lo + v_mbcnt_hi)
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),

@@ -55,10 +55,7 @@ __global__ __launch_bounds__(256) void path_begin_kernel(lbvh_camera cam, lbvh_p
 // Secondary rays are incoherent, so the packet walk of lbvh_trace.hip does not apply: every lane walks on its
 // own (64-byte fused nodes, near child first, boxes beyond the best hit skipped) with its stack in LDS as
 // [entry][lane].  One wave per workgroup, no barriers.
-#ifndef LBVH_RAY_STACK
-#define LBVH_RAY_STACK 34
-#endif
-constexpr int kRayStack = LBVH_RAY_STACK;
+constexpr int kRayStack = 34;
 
 // Live rays only: alive_rays_kernel writes the miss record of every dead ray and compacts the indices of the live
 // ones (after the first bounce more than half of a frame's paths have left the scene).  (Sorting the live rays by direction octant + Morton code of the origin on top of this was
@@ -92,10 +89,7 @@ __global__ __launch_bounds__(256) void alive_rays_kernel(const lbvh_path_state* 
 // number of waves (every wave slot of the chip once) and the live rays are dealt out evenly: at least 64 per wave.
 // Measured per frame of 4 bounces: no refill 3.75 ms; fixed runs of 128 / 256 / 512 rays 1.83 / 2.62 / 4.44 ms
 // (long runs leave most of the chip empty).
-#ifndef LBVH_RAY_WAVES
-#define LBVH_RAY_WAVES 8192
-#endif
-constexpr uint32_t kRayWaves = LBVH_RAY_WAVES;
+constexpr uint32_t kRayWaves = 8192;
 
 __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* __restrict__ states, const uint32_t* __restrict__ n_alive,
                                                         const uint32_t* __restrict__ list, float t_min,
@@ -303,6 +297,7 @@ lbvh_status lbvh_animate(lbvh_context* ctx, const lbvh_triangle* d_rest, uint32_
     LBVH_REQUIRE(ctx, d_rest != d_out);
     LBVH_REQUIRE(ctx, ((uintptr_t)d_rest & 15) == 0 && ((uintptr_t)d_out & 15) == 0 && ((uintptr_t)d_centres & 15) == 0);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    lbvh_note_write(ctx, d_out, (size_t)n * sizeof(lbvh_triangle));
     LBVH_LAUNCH(ctx, animate_kernel, dim3((n + 255) / 256), dim3(256), d_rest, n, d_body, (const float4*)d_centres, cos_angle,
                 sin_angle, d_out);
     LBVH_HIP_TRY(ctx, hipGetLastError());
@@ -330,8 +325,10 @@ lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, 
     LBVH_REQUIRE(ctx, d_states != nullptr && h_scene != nullptr && d_hits != nullptr);
     LBVH_REQUIRE(ctx, ((uintptr_t)d_states & 15) == 0 && ((uintptr_t)d_hits & 15) == 0);
     LBVH_REQUIRE(ctx, count <= 0xFFFFFFFFull);
-    if (!ctx->fast_nodes || ctx->fast_n != h_scene->n)
-        return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_trace_rays", "needs lbvh_build_fast_scene on this scene first");
+    {
+        const int frc = lbvh_require_fast(ctx, *h_scene, "lbvh_trace_rays");
+        if (frc != LBVH_OK) return frc;
+    }
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     // scratch: [live-ray count (256 B) | indices of the live rays]
     int rc = lbvh_reserve(ctx, &ctx->ray_scratch, &ctx->ray_scratch_bytes, 256 + count * 4);
@@ -367,8 +364,10 @@ lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_
     if (count == 0) return LBVH_OK;
     LBVH_REQUIRE(ctx, h_scene != nullptr && h_scene->triangles != nullptr && d_hits != nullptr && d_states != nullptr);
     LBVH_REQUIRE(ctx, ((uintptr_t)d_states & 15) == 0 && ((uintptr_t)d_hits & 15) == 0 && count <= 0xFFFFFFFFull);
-    if (!ctx->fast_nodes || ctx->fast_n != h_scene->n)
-        return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_path_bounce", "needs lbvh_build_fast_scene on this scene first");
+    {
+        const int frc = lbvh_require_fast(ctx, *h_scene, "lbvh_path_bounce");
+        if (frc != LBVH_OK) return frc;
+    }
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = lbvh_reserve(ctx, &ctx->ray_scratch, &ctx->ray_scratch_bytes, 256 + count * 4);
     if (rc != LBVH_OK) return rc;

@@ -13,15 +13,22 @@
 //     (Scan.compute:15-96).  16 B/pair/pass + 4 B/pair once, against 20 B/pair/pass;
 //   * the reference's 8 one-bit split passes with 5 group barriers each (LocalRadixSort.compute:64-91,
 //     WavePrefixCountBits over 32 lanes) become one ranking step per key: the wave's 64 keys are
-//     matched on the whole 8-bit digit with 8 ballots, rank = v_mbcnt of the peer mask, per-wave digit
-//     counters in LDS;
+//     matched on the whole 8-bit digit through an LDS cell per (wave, digit) — every lane ORs its lane
+//     bit into the cell's 64-bit peer mask and reads it back; rank = v_mbcnt of the mask + the count
+//     the cell keeps of earlier items;
 //   * the tile is digit-sorted in LDS and written so consecutive lanes hit consecutive addresses of a
 //     digit run (the reference scatters 1024-key tiles: 16-B runs).
 // Inter-workgroup protocol (MI355X: 8 XCDs, private non-coherent L2s): a status word carries its own
 // flag (2 bits) and value (30 bits), is written with an agent-scope relaxed atomic store
 // (global_store_dword sc1, write-through) and polled with agent-scope relaxed atomic loads (sc1, L1
-// bypass) — no fences, no ordering between words needed, placement-independent.  Tiles take their
-// index from atomic tickets, so every tile a look-back waits for is already running.
+// bypass) — no fences, no ordering between words needed.  Tiles take their index from atomic tickets.
+// With ONE ticket queue (tile = ticket) every tile a look-back waits for has been handed out before the
+// waiting one: placement-independent by construction.  The 8-queue form below is only selected on the
+// layout it was designed for (lbvh_create: all 256 CUs, unmasked stream — there a slot that frees up on an
+// XCD is refilled by a workgroup whose home queue is that XCD's, so the lowest tile not yet handed out is
+// always the next one somebody takes); on anything else (CPX/DPX/QPX partitions, CU-masked streams) it
+// could strand the tiles of queues nobody calls home, so those contexts use one queue.  Every spin is
+// bounded (LBVH_SPIN_LIMIT): a protocol failure reports a fault through lbvh_sync, it never hangs the GPU.
 // XCD-aware tile order: a digit run written by tile T ends in the 128-B line where tile T+1's run of the
 // same digit begins.  If the two tiles run on different XCDs the line is half-written in two L2s and
 // reaches memory as two masked partial writes; on one XCD the halves merge in its L2.  So tickets are
@@ -39,10 +46,7 @@ constexpr uint32_t kFlagAgg = 1u << 30;    // value = this tile's (this group's)
 constexpr uint32_t kFlagIncl = 2u << 30;   // group words: value = digit count of groups 0..this
 constexpr uint32_t kValueMask = (1u << 30) - 1u;
 constexpr int kLook = 4;                   // group words inspected per look-back step
-#ifndef LBVH_LB_GROUP
-#define LBVH_LB_GROUP 8
-#endif
-constexpr int kLbGroup = LBVH_LB_GROUP;    // tiles per look-back group
+constexpr int kLbGroup = 8;                // tiles per look-back group
 
 // ---- all four digit histograms in one read of the keys ------------------------------------------
 __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t* __restrict__ keys,
@@ -115,17 +119,11 @@ __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t
     }
 }
 
-// Lanes of a wave that hold the same 8-bit digit: 8 ballots, one per digit bit.
-__device__ __forceinline__ uint64_t match_digit(uint32_t digit)
+// Ticket k of queue x -> tile.  queues == 8: queue x holds the tiles whose (tile / group) % 8 == x in increasing
+// order (`group` consecutive tiles per XCD in turn); queues == 1: tile = ticket.
+__host__ __device__ __forceinline__ uint32_t ticket_tile(uint32_t k, uint32_t x, uint32_t group, uint32_t queues)
 {
-    uint64_t peers = ~0ull;
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-        const bool bit = (digit >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        peers &= bit ? bal : ~bal;
-    }
-    return peers;
+    return (k / group) * (queues * group) + x * group + (k % group);
 }
 
 // ---- one pass: rank + look-back + scatter ----------------------------------------------------------
@@ -137,7 +135,9 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     uint32_t* status,                     // [tiles][256] tile words of this pass (zeroed per sort)
     uint32_t* gstatus,                    // [ceil(tiles / kLbGroup)][256] group words of this pass (zeroed per sort)
     uint32_t* tickets,                    // [8] per-XCD tile tickets of this pass (zeroed per sort)
-    uint32_t tiles, uint32_t group)       // group = consecutive tiles handed to one XCD
+    uint32_t tiles, uint32_t group,       // group = consecutive tiles handed to one XCD
+    uint32_t queues,                      // 8 = per-XCD ticket queues, 1 = tiles in ticket order
+    uint32_t* fault)                      // mapped host word: a bounded spin that gave up says so here
 {
     constexpr int TILE = THREADS * ITEMS;
     constexpr int WAVES = THREADS / LBVH_WAVE;
@@ -149,23 +149,19 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     __shared__ uint32_t s_gofs[kRadix];          // global base of digit d minus its local start
     __shared__ uint32_t s_wsum[DWAVES + 1];
     __shared__ uint32_t s_tile;
-#ifdef LBVH_EXPERIMENT_LDSPAD
-    __shared__ uint32_t s_pad[LBVH_EXPERIMENT_LDSPAD];   // occupancy experiment: fewer tiles per CU
-    if (count == 0xFFFFFFFFu) s_pad[threadIdx.x] = 1;
-#endif
 
     const uint32_t t = threadIdx.x;
     const uint32_t w = t >> 6;
     const uint32_t lane = lane_id();
     if (t == 0) {
-        // queue x holds the tiles whose (tile / group) % 8 == x, in increasing order; when the home queue is
-        // drained take from the others.  grid == tiles and every workgroup takes exactly one, so one is found.
-        const uint32_t home = xcc_id();
+        // when the home queue is drained take from the others.  grid == tiles and every workgroup takes exactly
+        // one, so one is found.
+        const uint32_t home = xcc_id() & (queues - 1u);
         uint32_t tile = 0;
-        for (uint32_t a = 0; a < 8u; a++) {
-            const uint32_t x = (home + a) & 7u;
+        for (uint32_t a = 0; a < queues; a++) {
+            const uint32_t x = (home + a) & (queues - 1u);
             const uint32_t k = __hip_atomic_fetch_add(tickets + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tile = (k / group) * (8u * group) + x * group + (k % group);
+            tile = ticket_tile(k, x, group, queues);
             if (tile < tiles) break;
         }
         s_tile = tile;
@@ -225,12 +221,8 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         for (int i = 0; i < ITEMS; i++) {
             const uint32_t d = (key[i] >> shift) & (kRadix - 1);
             u32x4* cell = cells + d;
-#ifdef LBVH_EXPERIMENT_NORANK
-            const u32x4 c = {(uint32_t)lane_bit, (uint32_t)(lane_bit >> 32), 0u, 0u};
-#else
             __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(cell), lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const u32x4 c = *reinterpret_cast<volatile u32x4*>(cell);
-#endif
             const uint64_t peers = ((uint64_t)c.y << 32) | c.x;
             const uint32_t r = mbcnt64(peers);              // same-digit lanes below me
             const uint32_t old = c.z;                       // same-digit keys of earlier items
@@ -266,7 +258,6 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         constexpr uint32_t G = (uint32_t)kLbGroup;
         const uint32_t g = tile / G, gi = tile % G;
         __hip_atomic_store(status + (size_t)tile * kRadix + t, kFlagAgg | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifndef LBVH_EXPERIMENT_NOLOOKBACK
         uint32_t in_group = 0;
         {
             const uint32_t* row0 = status + (size_t)(g * G) * kRadix + t;
@@ -277,13 +268,11 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
 #pragma unroll
             for (int j = 0; j < kLbGroup - 1; j++) {
                 if ((uint32_t)j >= gi) continue;
-                while ((v[j] & ~kValueMask) == 0) {
-#ifdef LBVH_EXPERIMENT_COUNT
-                    if (t == 0) __hip_atomic_fetch_add(tickets + 40, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-#ifdef LBVH_EXPERIMENT_SLEEP
-                    __builtin_amdgcn_s_sleep(LBVH_EXPERIMENT_SLEEP);
-#endif
+                for (uint32_t spins = 0; (v[j] & ~kValueMask) == 0; spins++) {
+                    if (spins > LBVH_SPIN_LIMIT) {
+                        __hip_atomic_store(fault, LBVH_FAULT_SORT_LOOKBACK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
                     v[j] = __hip_atomic_load(row0 + (size_t)j * kRadix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 in_group += v[j] & kValueMask;
@@ -306,7 +295,6 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         lb_leader = leader;
         lb_partial = in_group;
         lb_total = total;
-#endif
     }
     uint32_t gbase = 0;                                // first output index of digit t minus its local start
     {   // local layout: digits in order, waves in order inside a digit
@@ -352,10 +340,13 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     }
     if (t < (uint32_t)kRadix) {   // finish the look-back: decoupled walk over the group words, nearest first
         uint32_t before = 0;
-#ifndef LBVH_EXPERIMENT_NOLOOKBACK
         uint32_t p = lb_group;                       // next word to consume belongs to group p - 1
         bool done = p == 0;
-        while (!done) {
+        for (uint32_t spins = 0; !done; spins++) {
+            if (spins > LBVH_SPIN_LIMIT) {
+                __hip_atomic_store(fault, LBVH_FAULT_SORT_LOOKBACK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
 #pragma unroll
             for (int j = 0; j < kLook; j++) {
                 if (done) continue;
@@ -378,7 +369,6 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         if (lb_leader && lb_group > 0)
             __hip_atomic_store(gstatus + (size_t)lb_group * kRadix + t, kFlagIncl | ((before + lb_partial + lb_total) & kValueMask),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
         s_gofs[t] = gbase + before + lb_partial;
     }
     __syncthreads();
@@ -395,10 +385,7 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         const uint32_t k = s_xchg[pos];
         const uint32_t d = (k >> shift) & (kRadix - 1);
         if (j & 3) dig4[j / 4] |= d << (8 * (j & 3)); else dig4[j / 4] = d;
-        uint32_t dst = s_gofs[d] + pos;
-#ifdef LBVH_EXPERIMENT_NOSCATTER
-        dst = base + pos;
-#endif
+        const uint32_t dst = s_gofs[d] + pos;
         if (pos < nvalid) __builtin_amdgcn_raw_buffer_store_b32(k, keys_rsrc, dst * 4u, 0, 0);
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
@@ -409,10 +396,7 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {
         const uint32_t pos = (uint32_t)j * THREADS + t;
-        uint32_t dst = s_gofs[(dig4[j / 4] >> (8 * (j & 3))) & 255u] + pos;
-#ifdef LBVH_EXPERIMENT_NOSCATTER
-        dst = base + pos;
-#endif
+        const uint32_t dst = s_gofs[(dig4[j / 4] >> (8 * (j & 3))) & 255u] + pos;
         if (pos < nvalid) __builtin_amdgcn_raw_buffer_store_b32(s_xchg[pos], vals_rsrc, dst * 4u, 0, 0);
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
@@ -427,7 +411,7 @@ void launch_passes(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint
     for (uint32_t p = 0; p < (uint32_t)kPasses; p++) {   // ComputeBufferSorter.cs:102
         LBVH_LAUNCH(ctx, (sort_onesweep_kernel<THREADS, ITEMS>), dim3(tiles), dim3(THREADS), ks, vs, kd, vd, count,
                     8u * p, ghist + p * kRadix, status + (size_t)p * tiles * kRadix,
-                    gstatus + (size_t)p * groups * kRadix, tickets + 8u * p, tiles, group);
+                    gstatus + (size_t)p * groups * kRadix, tickets + 8u * p, tiles, group, ctx->sort_queues, ctx->fault_dev);
         uint32_t* tmp;
         tmp = ks; ks = kd; kd = tmp;
         tmp = vs; vs = vd; vd = tmp;
@@ -450,11 +434,7 @@ static int sort_prepare(lbvh_context* ctx, uint32_t count, sort_plan* pl)
     // tile = 512 threads x 16 keys (8192) for big inputs: long digit runs = fuller cache lines in the
     // scatter and short look-back chains (measured best of 256..1024 threads x 4..16 keys at 2^24..2^28);
     // 512 x 8 below 2 M keys so every CU still gets tiles
-#ifdef LBVH_EXPERIMENT_SMALL_ITEMS
-    const int threads = 512, items = count >= (1u << 21) ? 16 : LBVH_EXPERIMENT_SMALL_ITEMS;
-#else
     const int threads = 512, items = count >= (1u << 21) ? 16 : 8;
-#endif
     const uint32_t tile = (uint32_t)threads * (uint32_t)items;
     const uint32_t tiles = (uint32_t)(((uint64_t)count + tile - 1) / tile);
     const size_t pair_bytes = (((size_t)count * 4) + 255) & ~(size_t)255;
@@ -512,17 +492,9 @@ int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, ui
     if (hblocks > 256u * 8u) hblocks = 256u * 8u;
     LBVH_LAUNCH(ctx, sort_histogram_kernel, dim3(hblocks), dim3(kThreads), d_keys, count, ghist);
     // consecutive tiles per XCD: 16 when every XCD still gets several groups, fewer for small sorts
-#ifdef LBVH_EXPERIMENT_XCDGROUP
-    const uint32_t group = LBVH_EXPERIMENT_XCDGROUP;
-#else
     const uint32_t group = tiles >= 1024u ? 16u : tiles >= 128u ? 8u : 1u;
-#endif
     if (items == 16)
         launch_passes<512, 16>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
-#ifdef LBVH_EXPERIMENT_SMALL_ITEMS
-    else if (items == 4)
-        launch_passes<512, 4>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
-#endif
     else
         launch_passes<512, 8>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     LBVH_HIP_TRY(ctx, hipGetLastError());
@@ -537,9 +509,19 @@ extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint
     LBVH_REQUIRE(ctx, d_keys != nullptr && d_values != nullptr);
     LBVH_REQUIRE(ctx, count <= kValueMask);       // status words carry 30-bit counts
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    lbvh_note_write(ctx, d_keys, (size_t)count * 4);
+    lbvh_note_write(ctx, d_values, (size_t)count * 4);
     return (lbvh_status)lbvh_launch_sort(ctx, d_keys, d_values, count, false);
 }
 
+
+// Host-side view of the tile order (no GPU involved): the tile that ticket k of queue x stands for.  For the CPU
+// model test of the order invariant (tests/test_abi.py): every tile below a handed-out tile is handed out already
+// or is the next ticket of some queue.
+extern "C" uint32_t lbvh_debug_sort_ticket_tile(uint32_t k, uint32_t x, uint32_t group, uint32_t queues)
+{
+    return ticket_tile(k, x, group, queues);
+}
 
 // ---- cfg4: local kernels of the key-range sharded sort ---------------------------------------------
 

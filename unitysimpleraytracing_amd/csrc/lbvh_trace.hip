@@ -10,12 +10,13 @@
 //                         left, push right, pop right first; no pruning) — the parity mode and the
 //                         source of the reference-semantics visit counters.
 //   LBVH_TRACE_FAST       walks the derived 64-byte fused nodes (both child boxes + child refs in
-//                         one fetch, leaf triangles pre-gathered to 48 B in sorted order), visits
+//                         one fetch, leaf triangles pre-gathered to 64-byte lines in sorted order), visits
 //                         the nearer child first and skips boxes that start beyond the best hit.
 //                         Same candidate set minus boxes that cannot win => same min t.
 //
-// One wave (8x8 pixels) per workgroup; the traversal stack lives in LDS as [entry][lane]
-// (bank-conflict-free, no scratch memory); no barriers anywhere.
+// LBVH_TRACE_REFERENCE: one wave (8x8 pixels) per workgroup, per-lane stack in LDS as [entry][lane]
+// (bank-conflict-free, no scratch memory), no barriers.  LBVH_TRACE_FAST: one wave per 8x8-pixel packet with
+// a wave-shared stack in one VGPR (v_writelane / v_readlane), no LDS at all (see the packet section below).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -506,23 +507,11 @@ __device__ __forceinline__ void tile_rays(const trace_args& a, uint32_t tile, ui
 // atomic min on (ordered t, sorted triangle position): pruning is shared by all waves), and a wave with spare
 // stack entries hands its OLDEST one (the largest unvisited subtree) to an idle wave through a small LDS list.
 constexpr int kCoopWaves = 8;
-#ifndef LBVH_HEAVY_CLASS
-#define LBVH_HEAVY_CLASS 7
-#endif
-constexpr int kHeavyClass = LBVH_HEAVY_CLASS;   // cost classes >= this (>= 96 steps) are walked cooperatively
-#ifndef LBVH_COOP_GRAIN
-#define LBVH_COOP_GRAIN 32
-#endif
-constexpr uint32_t kCoopGrain = LBVH_COOP_GRAIN;   // steps of the last trace per cooperating wave
+constexpr int kHeavyClass = 7;             // cost classes >= this (>= 96 steps) are walked cooperatively
+constexpr uint32_t kCoopGrain = 32;        // steps of the last trace per cooperating wave
 constexpr uint32_t kCoopMaxWork = 12288;   // tiles per launch up to which every heavy class is walked cooperatively
-#ifndef LBVH_SHARED_MAX_WORK
-#define LBVH_SHARED_MAX_WORK 24576
-#endif
-constexpr uint32_t kSharedMaxWork = LBVH_SHARED_MAX_WORK; // ... and up to which the very heaviest are (beyond: one wave per tile only)
-#ifndef LBVH_HEAVY_CLASS_FULL
-#define LBVH_HEAVY_CLASS_FULL 9
-#endif
-constexpr uint32_t kHeavyClassFull = LBVH_HEAVY_CLASS_FULL;   // above that: only classes >= this (>= 192 steps; half frame: 152 us against 184 / 160 / 193 with 8 / 10 / 11)
+constexpr uint32_t kSharedMaxWork = 24576; // ... and up to which the very heaviest are (beyond: one wave per tile only)
+constexpr uint32_t kHeavyClassFull = 9;    // above that: only classes >= this (>= 192 steps; half frame: 152 us against 184 / 160 / 193 with 8 / 10 / 11)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 struct coop_params { uint32_t cap, first_class, grain; };
@@ -572,9 +561,6 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
 {
     const uint32_t tile = shard_tile(w, a.shard_index, a.shard_count);
     if (w >= n_work || tile >= a.tiles_x * a.tiles_y) return;        // cannot happen for a heavy item
-#ifdef LBVH_EXPERIMENT_SKIP_HEAVY
-    return;                                                           // timing floor of the rest of the launch (wrong hits)
-#endif
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     // as many waves as the tile's last step count is worth (about kCoopGrain steps each); the others leave now
     const uint32_t n_waves = min(max((cost[w] + heavy_cap.grain / 2u) / heavy_cap.grain, 2u), (uint32_t)kCoopWaves);
@@ -1014,7 +1000,7 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
         if (ctx->lane == 1 && ctx->ev_leaf_boxes) LBVH_HIP_TRY(ctx, hipEventRecord(ctx->ev_leaf_boxes, ctx->cur_stream));
         uint32_t* counter = nullptr;
         if ((rc = lbvh_refit_counter(ctx, s.n, &counter)) != LBVH_OK) return rc;
-        lbvh_launch_tree(ctx, s.n, t_keys, t_internal, t_leaf, counter);
+        if ((rc = lbvh_launch_tree(ctx, s.n, t_keys, t_internal, t_leaf, counter)) != LBVH_OK) return rc;
         // the refit writes the 64-byte traversal nodes (both child boxes + child references) directly
         rc = lbvh_launch_refit(ctx, s.n, t_internal, t_leaf, t_leaf_box, nullptr, t_bvh, ctx->fast_nodes, ctx->fast_capacity, true);
         if (rc != LBVH_OK) return rc;
@@ -1027,7 +1013,6 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
             LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((end - begin + 63) / 64), dim3(256), s, ctx->fast_tris, begin, end);
     }
     LBVH_HIP_TRY(ctx, hipGetLastError());
-    ctx->fast_n = s.n;
     return LBVH_OK;
 }
 
@@ -1036,7 +1021,10 @@ extern "C" {
 lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene, const float h_box_min[3],
                                   const float h_box_max[3])
 {
-    return build_fast_scene_parts(ctx, h_scene, h_box_min, h_box_max, 3);
+    if (ctx) ctx->fast_valid = false;        // the cache is being rewritten: valid again only if all of it is enqueued
+    const lbvh_status rc = build_fast_scene_parts(ctx, h_scene, h_box_min, h_box_max, 3);
+    if (rc == LBVH_OK) lbvh_note_fast_built(ctx, *h_scene);
+    return rc;
 }
 
 }  // extern "C"
@@ -1086,11 +1074,7 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
         ctx->lane = 1;
         ctx->cur_stream = ctx->side_stream;
         fast_scene = s;
-#ifdef LBVH_EXPERIMENT_SPLIT_TRIS
-        rc = build_fast_scene_parts(ctx, &s, h_box_min, h_box_max, 1 | 4);
-#else
         rc = build_fast_scene_parts(ctx, &s, h_box_min, h_box_max, 1);
-#endif
         hipError_t e = hipEventRecord(ctx->ev_join, ctx->side_stream);
         ctx->lane = 0;
         ctx->cur_stream = ctx->stream;
@@ -1102,7 +1086,7 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
     {
         uint32_t* counter = nullptr;
         if ((rc = (lbvh_status)lbvh_refit_counter(ctx, n, &counter)) != LBVH_OK) return rc;
-        lbvh_launch_tree(ctx, n, d_keys, d_internal, d_leaf, counter);
+        if ((rc = (lbvh_status)lbvh_launch_tree(ctx, n, d_keys, d_internal, d_leaf, counter)) != LBVH_OK) return rc;
         // the boxes in leaf order: lane 1 gathered them long ago (an exact copy of aabb[sortedTriangleIndices[i]],
         // BVH.compute:196-205) — a stream-ordered read instead of a second random gather
         const lbvh_aabb* leaf_boxes = d_aabb;
@@ -1118,11 +1102,7 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
     }
     if (fast) {
         // the sorted triangles do not depend on the traversal tree: they ride on the shorter lane
-#ifdef LBVH_EXPERIMENT_SPLIT_TRIS
-        if ((rc = build_fast_scene_parts(ctx, &fast_scene, h_box_min, h_box_max, 8)) != LBVH_OK) return rc;
-#else
         if ((rc = build_fast_scene_parts(ctx, &fast_scene, h_box_min, h_box_max, 2)) != LBVH_OK) return rc;
-#endif
         LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     return LBVH_OK;
@@ -1158,8 +1138,19 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
     if (key == 0) key = 1;
     static const bool env_no_graph = getenv("LBVH_NO_GRAPH") != nullptr;     // debugging / measurement switch
     const bool graphs = ctx->own_stream && !ctx->prof_enabled && !ctx->build_graph_off && !env_no_graph;
+    // Host-side state of the call, the same on every path below (plain launches, capture, replay): Morton and the sort
+    // rewrite keys / indices / triangle AABBs — whatever derived scene existed is stale — and with
+    // LBVH_BUILD_FAST_SCENE the derived scene describes THIS scene once the work is enqueued.
+    lbvh_scene built = {};
+    built.n = n; built.sorted_indices = d_indices; built.triangle_aabb = d_aabb; built.internal_nodes = d_internal;
+    built.leaf_nodes = d_leaf; built.bvh = d_bvh; built.triangles = d_triangles;
+    const bool fast_flag = (flags & LBVH_BUILD_FAST_SCENE) != 0;
+    lbvh_note_write(ctx, d_indices, (size_t)capacity * 4);
+    lbvh_note_write(ctx, d_aabb, (size_t)n * sizeof(lbvh_aabb));
+    if (fast_flag) ctx->fast_valid = false;
     if (graphs && ctx->build_graph && ctx->build_graph_key == key) {
         LBVH_HIP_TRY(ctx, hipGraphLaunch(ctx->build_graph, ctx->stream));
+        if (fast_flag) lbvh_note_fast_built(ctx, built);
         return LBVH_OK;
     }
     if (graphs && ctx->build_seen_key == key) {
@@ -1178,6 +1169,7 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
                 (void)hipGraphDestroy(graph);
                 ctx->build_graph_key = key;
                 LBVH_HIP_TRY(ctx, hipGraphLaunch(ctx->build_graph, ctx->stream));
+                if (fast_flag) lbvh_note_fast_built(ctx, built);
                 return LBVH_OK;
             }
             if (graph) (void)hipGraphDestroy(graph);
@@ -1195,6 +1187,7 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
     mix_scratch(mix);
     const uint64_t key2 = key ? key : 1;
     ctx->build_seen_key = rc == LBVH_OK ? key2 : 0;
+    if (rc == LBVH_OK && fast_flag) lbvh_note_fast_built(ctx, built);
     return rc;
 }
 
@@ -1237,9 +1230,10 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
             LBVH_LAUNCH(ctx, trace_reference_kernel<false>, dim3(n_tiles), dim3(64), a, s,
                                d_hits, d_stats);
     } else {
-        if (!ctx->fast_nodes || ctx->fast_n != s.n)
-            return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_trace_primary",
-                                  "LBVH_TRACE_FAST needs lbvh_build_fast_scene on this scene first");
+        {
+            const int frc = lbvh_require_fast(ctx, s, "lbvh_trace_primary (LBVH_TRACE_FAST)");
+            if (frc != LBVH_OK) return frc;
+        }
         // 1 ray per lane = 8 x 8-pixel packets: 0.27 ms; 1x2: 0.43, 2x1: 0.45, 3x1: 0.68, 4x1: 0.82, 2x2: 0.92 ms
         // (more rays per lane cut node fetches per ray but lengthen every step and the per-tile critical path;
         // while the tile queues still cost 0.7 ms per launch, 2x1 had looked best).  4-wide 128-byte nodes
