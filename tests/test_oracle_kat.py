@@ -1,7 +1,7 @@
-"""Pins the CPU oracle: hand-derived known-answer vectors (obtained by a
-thread-by-thread emulation of the reference kernels independent of oracle/lbvh_oracle.c), the
-literal emulation of the reference's five sort kernels, the reference's own runtime invariants,
-and its slab-test debug fixture.  CPU only."""
+"""Pins the CPU oracle: hand-derived known-answer vectors, the committed fixtures of the
+independent thread-per-id emulation of the reference kernels (oracle/literal_emulation.py -> tests/golden/*.npz),
+the literal emulation of the reference's five sort kernels, the reference's own runtime invariants, and its
+slab-test debug fixture.  CPU only."""
 import os
 
 import numpy as np
@@ -206,21 +206,85 @@ def test_ray_generation_reference_camera():
     assert d2[0] > 0 and d2[1] < 0
 
 
-# ---- committed golden fixtures are what the oracle produces today -----------------------------------
+# ---- the C oracle against the fixtures of the independent literal emulation ---------------------------------
 
-def test_golden_cfg1_matches_oracle():
-    g = np.load(os.path.join(GOLDEN, "cfg1_4096.npz"))
-    tris = scenes.random_triangles(4096, seed=1)
-    assert (np.stack([tris["a"], tris["b"], tris["c"]], axis=1) == g["positions"]).all()
-    b = O.Built(tris, capacity=scenes.capacity_for(4096))
+def _fixture(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    if "triangles" in g.files:
+        tris = np.ascontiguousarray(g["triangles"], dtype=L.TRIANGLE)
+    elif name == "cfg1_4096":
+        tris = scenes.random_triangles(4096, seed=1)
+        assert (np.stack([tris["a"], tris["b"], tris["c"]], axis=1) == g["positions"]).all()
+    else:
+        tris = scenes.grid_scene()
+    w, h = (int(x) for x in g["resolution"])
+    cam = {"screen_width": w, "screen_height": h, "camera_fov": float(g["camera_fov"]), "near_plane": float(g["camera_near"]),
+           "camera_to_world": g["camera_to_world"]}
+    return tris, cam, g
+
+
+@pytest.mark.parametrize("name", ["cfg1_4096", "grid_80x80", "example_object3", "viking_room"])
+def test_oracle_matches_the_emulation_fixtures(name):
+    """tests/golden/*.npz come from oracle/literal_emulation.py (thread-per-id Python emulation of the reference kernels,
+    written independently of lbvh_oracle.c; generator: tests/golden/make_golden.py).  The C oracle reproduces every
+    array bit for bit: Morton codes, sorted keys / indices, all node words, every box, every hit record field, the
+    visit counters, and the shaded image of the textured asset."""
+    tris, cam, g = _fixture(name)
+    n = len(tris)
+    b = O.Built(tris, capacity=scenes.capacity_for(n))
     assert (O.morton_aabb(tris)[0] == g["morton"]).all()
     assert (b.keys == g["sorted_keys"]).all() and (b.indices == g["sorted_indices"]).all()
-    assert (b.internal[:4095].view(np.uint32).reshape(-1, 6) == g["internal"]).all()
-    assert (b.leaf[:4096].view(np.uint32).reshape(-1, 2) == g["leaf"]).all()
-    assert (b.bvh["min"][:4095] == g["bvh_min"]).all() and (b.bvh["max"][:4095] == g["bvh_max"]).all()
-    hits, st = O.trace_primary(b, scenes.camera(64, 64, (0.0, 0.0, 300.0)))
-    assert (hits["t"] == g["hit_t"]).all() and (hits["tri"] == g["hit_tri"]).all()
+    assert (b.internal[: n - 1].view(np.uint32).reshape(-1, 6) == g["internal"]).all()
+    assert (b.leaf[:n].view(np.uint32).reshape(-1, 2) == g["leaf"]).all()
+    assert (b.triangle_aabb["min"][:n].view(np.uint32) == g["tri_min"].view(np.uint32)).all()
+    assert (b.triangle_aabb["max"][:n].view(np.uint32) == g["tri_max"].view(np.uint32)).all()
+    assert (b.bvh["min"][: n - 1].view(np.uint32) == g["bvh_min"].view(np.uint32)).all()
+    assert (b.bvh["max"][: n - 1].view(np.uint32) == g["bvh_max"].view(np.uint32)).all()
+    hits, st = O.trace_primary(b, cam)
+    assert (hits["t"].view(np.uint32) == g["hit_t"].view(np.uint32)).all() and (hits["tri"] == g["hit_tri"]).all()
+    assert (hits["u"].view(np.uint32) == g["hit_u"].view(np.uint32)).all() and (hits["v"].view(np.uint32) == g["hit_v"].view(np.uint32)).all()
     assert [int(st[f]) for f in st.dtype.names] == g["stats"].tolist()
+    if "shaded" in g.files:
+        assert (O.shade(hits, b.triangles, g["texture"]).view(np.uint16) == g["shaded"]).all()
+
+
+def test_reference_asset_is_the_procedural_grid():
+    """Assets/_Assets/ExampleObject3.obj (the mesh wired into the reference scene, Scene.unity:364), parsed in the build
+    container, is the 80x80 quad grid scenes.grid_scene() re-creates: same triangle count, same 1 156 distinct Morton
+    codes, same 784 hits and visit counters from the reference camera."""
+    a = np.load(os.path.join(GOLDEN, "example_object3.npz"))
+    b = np.load(os.path.join(GOLDEN, "grid_80x80.npz"))
+    assert len(a["triangles"]) == 12800 and len(np.unique(a["morton"])) == 1156
+    assert a["stats"].tolist() == b["stats"].tolist() and int(a["stats"][4]) == 784
+    assert (a["hit_t"] == b["hit_t"]).all()
+
+
+def test_literal_emulation_equals_oracle_on_a_fresh_scene():
+    """Not only on the frozen fixtures: a scene neither has seen, including duplicate Morton codes (a tiny mesh inside
+    the +-125 box) and the refit threads run in random orders (any schedule gives the same boxes)."""
+    from oracle import literal_emulation as E
+    rng = np.random.default_rng(123)
+    tris = scenes.random_triangles(300, seed=77, extent=0.4, edge=0.3)          # nearly all codes coincide
+    r = E.awake(tris["a"], tris["b"], tris["c"], capacity=1024)
+    b = O.Built(tris, capacity=1024)
+    n = 300
+    assert len(np.unique(r["morton"])) < 100                                                # 300 triangles, many ties
+    assert (b.keys == r["sorted_keys"]).all() and (b.indices == r["sorted_indices"]).all()
+    assert (b.internal.view(np.uint32).reshape(-1, 6) == r["internal"]).all()
+    assert (b.leaf.view(np.uint32).reshape(-1, 2) == r["leaf"]).all()
+    assert (b.bvh["min"][: n - 1] == r["bvh_min"]).all() and (b.bvh["max"][: n - 1] == r["bvh_max"]).all()
+    for _ in range(3):
+        mn, mx = E.bvh_constructor(n, r["internal"], r["leaf"], r["sorted_indices"], r["tri_min"], r["tri_max"],
+                                   thread_order=rng.permutation(n))
+        assert (mn == r["bvh_min"]).all() and (mx == r["bvh_max"]).all()
+    cam = scenes.camera(20, 12, (0.1, 0.0, 1.5))
+    t, tri, u, v, st = E.raytracing(r["scene"], cam)
+    hits, ost = O.trace_primary(b, cam)
+    assert (hits["t"] == t).all() and (hits["tri"] == tri).all() and (hits["u"] == u).all() and (hits["v"] == v).all()
+    assert [int(ost[f]) for f in ost.dtype.names] == st
+    # HLSL corner cases the emulation spells out
+    assert E.clz32(0) == 32 and E.clz32(1) == 31 and E.clz32(0x80000000) == 0            # firstbithigh(0) = -1
+    assert float(E.MAX_FLOAT) == 2139095040.0                                              # (float)0x7F7FFFFF
 
 
 def test_openmp_paths_equal_scalar():

@@ -50,3 +50,26 @@ def test_tiled_torus_is_deterministic_and_inside_the_morton_box():
     assert len(a) == 2 * 8 * 6 * 8 and (a == b).all()
     for f in ("a", "b", "c"):
         assert np.abs(a[f]).max() < 125.0
+
+
+def test_reference_assets_through_load_obj():
+    """the reference's own OBJ assets through the ingest.  /root/reference exists only in the build
+    container; the triangles it yields there are what tests/golden/{example_object3,viking_room}.npz hold (those files
+    carry the data to the GPU box, where the same triangles go through build -> trace -> shade)."""
+    import os
+    import numpy as np
+    from unitysimpleraytracing_amd import layouts as L
+    assets = "/root/reference/Assets/_Assets"
+    if not os.path.isdir(assets):
+        import pytest
+        pytest.skip("no /root/reference on this box")
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    for obj, fixture, faces in (("ExampleObject3.obj", "example_object3.npz", 12800), ("viking_room.obj", "viking_room.npz", 3828)):
+        t = scenes.load_obj(os.path.join(assets, obj))
+        assert t.dtype == L.TRIANGLE and len(t) == faces
+        g = np.load(os.path.join(golden, fixture))["triangles"]
+        assert t.tobytes() == np.ascontiguousarray(g, dtype=L.TRIANGLE).tobytes()
+    # the quad grid: 6 400 quads fanned into 12 800 triangles, all on z = 0 inside [-4, 4]^2, uv and normals carried
+    t = scenes.load_obj(os.path.join(assets, "ExampleObject3.obj"))
+    assert (t["a"][:, 2] == 0).all() and abs(t["a"][:, :2]).max() <= 4.0
+    assert (t["a_normal"][:, 2] != 0).all() and t["a_uv"].min() >= 0.0 and t["c_uv"].max() <= 1.0
