@@ -21,10 +21,21 @@ one launch per rank); no collective touches the data path.
 The JSON line carries both halves of the metric: `value` = primary Mrays/s = rays of the whole
 frame / the traversal part of a step (max over ranks), `build_Mtri_s` = triangles / the build
 part of a step; `ms_per_step` is the whole step (build + trace), wall clock, max over ranks.
+
+`roofline` describes the dominant kernel (the packet traversal) against what bounds it.  The kernel walks a
+cache-resident scene and is bound by vector-instruction issue, not by HBM, so:
+  bound "valu_issue": achieved = wave64 vector instructions per second (SQ_INSTS_VALU of a live rocprofv3 child pass of
+      this very run / the kernel's live HIP-event duration), peak = 1024 SIMDs x measured shader clock / 4 cycles;
+  roofline.hbm: the same kernel against HBM with its OWN algorithmic bytes (64 B per node line + 64 B per triangle
+      line fetched per packet + 16 B hit record per ray) — a small fraction of 8 TB/s, which is the point;
+  roofline.traffic: HBM-side bytes per launch from live FETCH_SIZE / WRITE_SIZE child passes (or null — never replayed
+      from a committed file).
+Without rocprofv3 (or with --no-live-counters) the object falls back to bound "hbm" with the own-bytes figures.
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -36,6 +47,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMDS = 1024                # 256 CUs x 4 SIMDs
+VALU_ISSUE_CYCLES = 4       # one wave64 vector instruction per 4 cycles per SIMD (guide: 'vector-instruction ISSUE cost')
 W, H = 1920, 1080
 CAMERA_POS = (0.0, 0.0, 250.0)
 N_TRIS = 1_000_000
@@ -48,6 +61,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sort-bench", action="store_true")
+    ap.add_argument("--no-live-counters", action="store_true", help="skip the rocprofv3 child passes (traffic = null)")
     ap.add_argument("--sort-keys-log2", type=int, default=26)
     ap.add_argument("--mode", choices=["fast", "reference"], default="fast")
     # cfg2 = BASELINE configs[1]/[2] (the metric's workload, default); cfg4 = configs[3]: 16 M triangles with the
@@ -75,6 +89,17 @@ def shard_tiles(shard_index, shard_count, width, height, tile_w=TILE_W, tile_h=T
         for t in range(g * group, min((g + 1) * group, n_tiles)):
             ty, tx = divmod(t, tiles_x)
             out.append((tx * tile_w, ty * tile_h, min((tx + 1) * tile_w, width), min((ty + 1) * tile_h, height)))
+    return out
+
+
+def yawed(cam, yaw_deg):
+    """the camera dict turned about the world Y axis (position kept): a moving-camera frame"""
+    cy, sy = math.cos(math.radians(yaw_deg)), math.sin(math.radians(yaw_deg))
+    yaw = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=np.float64)
+    m = np.array(cam["camera_to_world"], dtype=np.float32).reshape(4, 4).copy()
+    m[:3, :3] = (yaw @ m[:3, :3].astype(np.float64)).astype(np.float32)
+    out = dict(cam)
+    out["camera_to_world"] = m.reshape(-1).copy()
     return out
 
 
@@ -155,17 +180,17 @@ def main():
     from unitysimpleraytracing_amd import _native as N
     ccam = N.Camera.from_dict(cam)
 
-    def trace_frame():
+    def trace_share(camera=None, stats=None):
         # this rank's share of the frame (every world-th group of 8 adjacent 8x8-pixel tiles), one launch
         s = drawer.container.scene()
-        N.check(ctx.handle, N.lib.lbvh_trace_primary_shard(ctx.handle, C.byref(ccam), rank, world, C.byref(s), mode,
-                                                           hit_buf.device, None))
+        N.check(ctx.handle, N.lib.lbvh_trace_primary_shard(ctx.handle, C.byref(camera if camera is not None else ccam), rank, world,
+                                                           C.byref(s), mode, hit_buf.device, stats))
 
     def step(ev=None):
         rebuild()
         if ev:
             ctx.record(ev[0])       # rebuild | trace
-        trace_frame()
+        trace_share()
         if ev:
             ctx.record(ev[1])       # end of the step = start of the next one's rebuild
 
@@ -194,14 +219,39 @@ def main():
     build_ms_max = reduce_max(build_ms)
     trace_ms_max = reduce_max(trace_ms)
 
-    # ---- untimed extras (rank 0 prints them) ---------------------------------------------------
+    # ---- untimed extras ---------------------------------------------------------------------------
+    def timed_frames(frames, before=None, camera_of=None):
+        """mean device ms of this rank's share of `frames` frames (HIP events around the trace alone), max over ranks"""
+        e0, e1 = ctx.event(), ctx.event()
+        total = 0.0
+        for k in range(frames):
+            if before is not None:
+                before()
+            c = None if camera_of is None else N.Camera.from_dict(camera_of(k))
+            ctx.record(e0)
+            trace_share(c)
+            ctx.record(e1)
+            total += ctx.elapsed_ms(e0, e1)
+        ctx.destroy_event(e0); ctx.destroy_event(e1)
+        return reduce_max(total / frames)
+
+    reps = max(5, min(args.steps, 20))
+    extras = {}
+    if mode == L.TRACE_FAST:
+        # the timed steps trace a static camera: every frame's dispatch order comes from the previous frame's per-tile
+        # step counts.  What the same share costs (a) as a FIRST frame (history dropped before each), (b) with the
+        # camera turning 1 degree per frame (the history is one frame stale), (c) without the rebuild in between
+        trace_share(); ctx.sync()
+        extras["trace_static_scene_ms"] = round(timed_frames(reps), 4)
+        extras["trace_cold_ms"] = round(timed_frames(reps, before=ctx.trace_forget), 4)
+        extras["trace_moving_ms"] = round(timed_frames(reps, camera_of=lambda k: yawed(cam, 1.0 * (k + 1))), 4)
+        trace_share(); ctx.sync()                      # back to the timed camera's history
+
     out = None
     # every rank: hits found in its own share of the frame (one more launch of the timed trace, with counters);
     # summed over the ranks they must equal the whole frame's hit count in reference order (checked on rank 0)
     share_stats = DataBuffer(ctx, 1, L.TRACE_STATS)
-    s_all = drawer.container.scene()
-    N.check(ctx.handle, N.lib.lbvh_trace_primary_shard(ctx.handle, C.byref(ccam), rank, world, C.byref(s_all), mode,
-                                                       hit_buf.device, share_stats.device))
+    trace_share(stats=share_stats.device)
     share_hits = int(share_stats.get_data()[0]["hits"])
     if dist is not None:
         import torch
@@ -238,43 +288,57 @@ def main():
         k_sh, i_sh = c.keys.get_data().copy(), c.triangle_index.get_data().copy()
         drawer.rebuild(fast=False)
         sharded_sort_check = bool((c.keys.get_data() == k_sh).all() and (c.triangle_index.get_data() == i_sh).all())
+        drawer.rebuild(fast=(mode == L.TRACE_FAST))
     if rank == 0:
-        # algorithmic bytes of the traversal kernel from its own visit counters: one 64-B fused
-        # node per node fetch + 48 B per triangle fetch + 16 B hit record per ray
         stats_buf = DataBuffer(ctx, 1, L.TRACE_STATS)
         full = DataBuffer(ctx, W * H, L.HIT)
         s = drawer.container.scene()
-        N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s), mode,
-                                                     full.device, stats_buf.device))
-        st = stats_buf.get_data()[0]
+
+        def frame_stats(camera, m):
+            N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(camera), 0, 0, W, H, C.byref(s), m, full.device, stats_buf.device))
+            return stats_buf.get_data()[0].copy()
+
+        def own_bytes(st):          # the packet kernel's own algorithmic bytes per ray: node and triangle lines are per packet
+            return (64.0 * float(st["pops"]) + 64.0 * float(st["leaf_tests"])) / (W * H) + 16.0
+
+        def ref_bytes(rs):          # the reference algorithm's bytes per ray, 32 P + 24 B + 44 L + 48 T + 8
+            return (32.0 * float(rs["pops"]) + 24.0 * float(rs["box_hits"]) + 44.0 * float(rs["leaf_tests"])
+                    + 48.0 * float(rs["tri_tests"])) / (W * H) + 8.0
+
+        st = frame_stats(ccam, mode)
         hit_fraction = float(st["hits"]) / (W * H)
-        if mode == L.TRACE_FAST:   # packet kernel: node / triangle fetches are per 64-ray packet
-            own_bytes_per_ray = (64.0 * float(st["pops"]) + 48.0 * float(st["leaf_tests"])) / (W * H) + 16.0
-        else:
-            own_bytes_per_ray = None
-        # SURVEY.md section 8d per-ray figure in the REFERENCE's visit semantics:
-        # 32 P + 24 B + 44 L + 48 T + 8, P/B/L/T from the reference-order kernel's counters
-        # (tests pin them equal to the oracle's)
-        N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s),
-                                                     L.TRACE_REFERENCE, full.device, stats_buf.device))
-        rs = stats_buf.get_data()[0]
+        rs = frame_stats(ccam, L.TRACE_REFERENCE)
         # guard: the fast mode (after the timed steps: cost-ordered dispatch, history) found exactly the reference's hits
         if int(rs["hits"]) != int(st["hits"]) or int(rs["hits"]) != share_hits:
             raise SystemExit(f"hit counts differ: fast {int(st['hits'])}, all shards {share_hits}, reference {int(rs['hits'])}")
-        bytes_per_ray = (32.0 * float(rs["pops"]) + 24.0 * float(rs["box_hits"]) + 44.0 * float(rs["leaf_tests"])
-                         + 48.0 * float(rs["tri_tests"])) / (W * H) + 8.0
         ref_counts = {k: round(float(rs[k]) / (W * H), 3) for k in ("pops", "box_hits", "leaf_tests", "tri_tests")}
 
-        # the traversal kernel alone over the full frame, HIP events on its own stream
-        reps = max(5, min(args.steps, 20))
-        ctx.profile_begin()
-        for _ in range(reps):
-            N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s), mode,
-                                                         full.device, None))
-        prof = ctx.profile_end()
-        kname = [k for k in prof if "trace_" in k][0]
-        trace_kernel_ms = prof[kname][1] / prof[kname][0]
-        achieved = bytes_per_ray * W * H / (trace_kernel_ms * 1e-3) / 1e9
+        def kernel_ms_of(camera):
+            """the traversal kernel alone over the full frame: per-kernel HIP events on the library's own stream"""
+            for _ in range(2):
+                N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(camera), 0, 0, W, H, C.byref(s), mode, full.device, None))
+            ctx.profile_begin()
+            for _ in range(reps):
+                N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(camera), 0, 0, W, H, C.byref(s), mode, full.device, None))
+            prof = ctx.profile_end()
+            kname = [k for k in prof if "trace_" in k][0]
+            frame_ms = sum(v[1] for v in prof.values()) / reps          # traversal + tile filing
+            return kname, prof[kname][1] / prof[kname][0], frame_ms
+
+        kname, trace_kernel_ms, _ = kernel_ms_of(ccam)
+
+        # a second camera: closer to the mesh, most rays hit (misses are cheap, so Mrays/s goes with the hit fraction)
+        near_cam = N.Camera.from_dict(scenes.camera(W, H, (0.0, 0.0, 160.0)))
+        st2 = frame_stats(near_cam, mode)
+        rs2 = frame_stats(near_cam, L.TRACE_REFERENCE)
+        if int(rs2["hits"]) != int(st2["hits"]):
+            raise SystemExit(f"hit counts differ at camera z=160: fast {int(st2['hits'])}, reference {int(rs2['hits'])}")
+        _, near_kernel_ms, near_frame_ms = kernel_ms_of(near_cam)
+        near = {"workload": "same scene, camera (0,0,160): most rays hit", "hit_fraction": round(float(st2["hits"]) / (W * H), 4),
+                "trace_ms": round(near_frame_ms, 4), "Mrays_s": round(W * H / (near_frame_ms * 1e-3) / 1e6, 2),
+                "kernel_ms": round(near_kernel_ms, 4), "own_bytes_per_ray": round(own_bytes(st2), 1),
+                "steps_per_packet": round(float(st2["pops"]) / (W * H / 64.0), 1)}
+        kernel_ms_of(ccam)                              # history back to the timed camera
 
         # per-kernel breakdown of one build
         ctx.profile_begin()
@@ -294,39 +358,71 @@ def main():
         ref_build_ms = ctx.elapsed_ms(e0, e1) / 10.0
         drawer.rebuild(fast=(mode == L.TRACE_FAST))
 
-        # measured HBM copy rate of this box (float4 copy, 1 GiB)
+        # measured HBM copy rate of this box (float4 copy, 1 GiB) and the shader clock it holds under vector-ALU load
         nbytes = 1 << 30
         a = DataBuffer(ctx, nbytes // 4, np.uint32)
         b = DataBuffer(ctx, nbytes // 4, np.uint32)
         a.fill_u32(1)
         for _ in range(2):
             ctx.copy_probe(b.device, a.device, nbytes)
-        e0, e1 = ctx.event(), ctx.event()
         ctx.record(e0)
         for _ in range(10):
             ctx.copy_probe(b.device, a.device, nbytes)
         ctx.record(e1)
         copy_gbs = 2.0 * nbytes * 10 / (ctx.elapsed_ms(e0, e1) * 1e-3) / 1e9
         a.dispose(); b.dispose()
+        clock_mhz = ctx.clock_probe()
 
-        roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": None if cfg4 else measured_traffic("trace_packet_kernel<false"),
-                    "bytes_per_ray": round(bytes_per_ray, 1), "bytes_per_ray_basis": "reference visit order, "
-                    "32P+24B+44L+48T+8 (SURVEY 8d)", "reference_visits_per_ray": ref_counts,
-                    "own_bytes_per_ray": None if own_bytes_per_ray is None else round(own_bytes_per_ray, 1),
-                    "own_achieved": None if own_bytes_per_ray is None else
-                    round(own_bytes_per_ray * W * H / (trace_kernel_ms * 1e-3) / 1e9, 1),
-                    "kernel_ms": round(trace_kernel_ms, 4),
-                    "note": "achieved/frac price the kernel at the bytes of the reference's per-ray walk it replaces (SURVEY 8d); the "
-                            "packet kernel itself moves own_bytes_per_ray and is bound by vector / scalar instruction issue "
-                            "(instruction_issue; DESIGN.md section 7), not by HBM",
-                    "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
-                    "instruction_issue": None if cfg4 else issue_counters(trace_kernel_ms)}
+        # ---- the roofline object ----------------------------------------------------------------------
+        own_bpr = own_bytes(st) if mode == L.TRACE_FAST else None
+        bytes_per_ray = own_bpr if own_bpr is not None else ref_bytes(rs)
+        hbm_achieved = bytes_per_ray * W * H / (trace_kernel_ms * 1e-3) / 1e9
+        hbm = {"achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 4),
+               "bytes_per_ray": round(bytes_per_ray, 1),
+               "bytes_per_ray_basis": "the kernel's own algorithm: 64 B per node line + 64 B per triangle line per 64-ray packet "
+                                      "+ 16 B hit record per ray, from this run's visit counters" if own_bpr is not None else
+                                      "reference visit order, 32P+24B+44L+48T+8 (SURVEY 8d)",
+               "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(hbm_achieved / copy_gbs, 4)}
+        live = (world == 1 and not args.no_live_counters and not cfg4 and mode == L.TRACE_FAST)
+        traffic = issue = None
+        if live:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import live_counters as LC
+            child = [os.path.join(ROOT, "tools", "trace_only.py"), "--reps", "4", "--no-check"]
+            traffic = LC.hbm_traffic(child, "trace_packet_kernel")
+            issue = LC.issue_counters(child, "trace_packet_kernel")
+        roofline = {"kernel": kname, "kernel_ms": round(trace_kernel_ms, 4), "clock_MHz": round(clock_mhz, 1)}
+        if issue and issue.get("SQ_INSTS_VALU"):
+            valu = issue["SQ_INSTS_VALU"]
+            peak = SIMDS * clock_mhz * 1e6 / VALU_ISSUE_CYCLES / 1e9              # G wave-instructions per second
+            achieved = valu / (trace_kernel_ms * 1e-3) / 1e9
+            steps = float(st["pops"])
+            roofline.update({
+                "bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
+                "frac": round(achieved / peak, 4),
+                "basis": "SQ_INSTS_VALU of a live rocprofv3 --pmc child pass of this run (the same frame, cost-ordered dispatch) / the "
+                         "kernel's live HIP-event duration; peak = 1024 SIMDs x the measured shader clock / 4 cycles per wave64 "
+                         "vector instruction",
+                "valu_per_step": round(valu / steps, 1), "salu_per_step": round(issue.get("SQ_INSTS_SALU", 0.0) / steps, 1),
+                "steps": int(steps),
+                "lane_utilisation": round(issue.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(issue.get("SQ_ACTIVE_INST_VALU", 1.0), 1.0) / 64.0, 3),
+                "salu_issue_frac": round(issue.get("SQ_INSTS_SALU", 0.0) / (256 * clock_mhz * 1e6 * trace_kernel_ms * 1e-3), 4),
+                "waves_waiting_frac": round(issue.get("SQ_WAIT_ANY", 0.0) / max(issue.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3)})
+        else:
+            roofline.update({"bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"],
+                             "note": "no live instruction counters in this run: the kernel is priced against HBM with its own bytes; what "
+                                     "bounds it is vector-instruction issue (DESIGN.md section 7)"})
+        roofline["traffic"] = traffic
+        roofline["hbm"] = hbm
+        # what the kernel replaces: the reference algorithm's per-ray walk, priced at this kernel's duration (a speed-up
+        # figure, not a roofline fraction)
+        roofline["reference_equivalent_GBs"] = round(ref_bytes(rs) * W * H / (trace_kernel_ms * 1e-3) / 1e9, 1)
+        roofline["reference_bytes_per_ray"] = round(ref_bytes(rs), 1)
+        roofline["reference_visits_per_ray"] = ref_counts
 
         sort_roofline = None
         if not args.no_sort_bench:
-            sort_roofline = sort_microbench(ctx, args.sort_keys_log2, copy_gbs)
+            sort_roofline = sort_microbench(ctx, args.sort_keys_log2, copy_gbs, live and args.sort_keys_log2 == 26)
 
         cpu_baseline = None
         if world == 1 and not args.no_cpu_baseline and not cfg4:
@@ -363,6 +459,11 @@ def main():
             "roofline": roofline,
             "roofline_sort_scatter": sort_roofline,
             "cpu_baseline": cpu_baseline,
+            "trace_variants_ms": dict(extras, note="this rank's share of the frame, HIP events around the trace alone, max over ranks: "
+                                                   "static = frame after frame without the rebuild; cold = dispatch history dropped "
+                                                   "before every frame (what a first frame costs); moving = camera yawed 1 degree per frame")
+                                 if extras else None,
+            "second_camera": near,
             "build_kernels_ms": prof_build,
             "cfg5_dynamic": dynamic,
         }
@@ -382,43 +483,7 @@ def main():
         print(json.dumps(out))
 
 
-def measured_traffic(kernel_substr, largest_grid=True):
-    """HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (tools/prof.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950
-    note in MI355X_MICROARCH.md).  None if no profile has been committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*traffic.json")))
-    if not files:
-        return None
-    table = json.load(open(files[-1]))
-    rows = [(int(k.split("@")[1]), v) for k, v in table.items() if kernel_substr in k and v.get("fetch_bytes_x2") is not None
-            and v.get("write_bytes") is not None]
-    if not rows:
-        return None
-    rows.sort(key=lambda r: r[0])
-    v = rows[-1][1] if largest_grid else rows[0][1]
-    return {"bytes": round(v["fetch_bytes_x2"] + v["write_bytes"]), "fetch_bytes_x2": round(v["fetch_bytes_x2"]),
-            "write_bytes": round(v["write_bytes"]), "source": os.path.relpath(files[-1], ROOT)}
-
-
-def issue_counters(kernel_ms, clock_ghz=2.4):
-    """What actually bounds the packet kernel: the committed SQ instruction counters of the same frame
-    (tools/pmc_packet.sh) priced at the issue rates — one wave64 vector instruction per 4 cycles per SIMD
-    (1024 SIMDs), one scalar instruction per cycle per CU (256) — against this run's live kernel duration."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*packet_counters.json")))
-    if not files:
-        return None
-    c = json.load(open(files[-1]))
-    cycles = kernel_ms * 1e-3 * clock_ghz * 1e9
-    return {"valu_per_step": c["valu_per_step"], "salu_per_step": c["salu_per_step"], "steps": c["steps"],
-            "lane_utilisation": c["lane_utilisation"],
-            "valu_issue_frac": round(c["valu_issue_cycles_per_simd"] / cycles, 3),
-            "salu_issue_frac": round(c["salu_issue_cycles_per_cu"] / cycles, 3),
-            "clock_GHz": clock_ghz, "source": os.path.relpath(files[-1], ROOT)}
-
-
-def sort_microbench(ctx, log2n, copy_gbs):
+def sort_microbench(ctx, log2n, copy_gbs, live):
     """Radix-sort micro-bench on 2^log2n uniform random (key, value) pairs: large enough that the
     pairs stream from HBM, not from L2 / Infinity Cache.  Reports the scatter (downsweep) kernel:
     algorithmic 16 B per pair per launch (8 B read + 8 B written)."""
@@ -454,47 +519,58 @@ def sort_microbench(ctx, log2n, copy_gbs):
     down = [v for name, v in prof_sum.items() if "onesweep" in name][0]
     kernel_ms = down[1] / down[0]
     achieved = 16.0 * n / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    if live:
+        import live_counters as LC
+        traffic = LC.hbm_traffic([os.path.join(ROOT, "tools", "sort_bench.py"), str(log2n)], "sort_onesweep_kernel", pick="mean")
     return {"kernel": "sort scatter pass", "keys": n, "bound": "hbm", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": measured_traffic("sort_onesweep_kernel") if log2n == 26 else None,
-            "kernel_ms": round(kernel_ms, 4), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
+            "traffic": traffic, "algorithmic_bytes": 16 * n,
+            "kernel_ms": round(kernel_ms, 4), "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved / copy_gbs, 4),
             "sort_Gkeys_s": round(n / (sort_ms * 1e-3) / 1e9, 3), "sort_ms": round(sort_ms, 3),
             "kernels_ms": {name: round(v[1] / reps, 4) for name, v in prof_sum.items()}}
 
 
 def cpu_leg(tris, cam):
-    """CPU baseline (kind "port"): the oracle — a C restatement of the reference's C#/HLSL, the
-    only runnable form of it here (no dotnet/mono/dxc) — on this box's host cores with OpenMP.
-    Bounded sample: full 1 M-triangle builds for ~5 s, then the 1080p frame subsampled on a pixel
-    grid chosen from a pilot run so the traversal leg takes ~10 s."""
+    """CPU baseline (kind "port"): the oracle — a C restatement of the reference's C#/HLSL, the only runnable form of it
+    here (no dotnet/mono/dxc) — on this box's host cores.  Two figures, as north_star asks: scalar (1 thread) and OpenMP
+    (all cores: parallel-for over triangles / internal nodes / 8x8 ray tiles, parallel LSD radix sort, two-level
+    DistributeKeys scan, flag hand-off refit).  Bounded sample: warm full 1 M-triangle rebuilds, then the 1080p frame
+    subsampled on a pixel grid chosen from a pilot run so each traversal leg takes about 6 s."""
     import oracle as O
     threads = O.num_threads()
     cap = ((len(tris) + 1023) // 1024) * 1024
-    t0 = time.perf_counter()
-    builds = 0
-    while True:
-        b = O.Built(tris, capacity=cap, threads=threads)
-        builds += 1
-        if time.perf_counter() - t0 > 5.0 or builds >= 20:
-            break
-    build_s = (time.perf_counter() - t0) / builds
-    p0 = time.perf_counter()
-    pilot, _ = O.trace_primary(b, cam, step=(16, 16), threads=threads)
-    rate = pilot.size / max(time.perf_counter() - p0, 1e-6)              # rays/s estimate
-    step = 1
-    for s_ in (1, 2, 4, 8):
-        step = s_
-        if (W // s_) * (H // s_) / rate <= 10.0:
-            break
-    t1 = time.perf_counter()
-    hits, st = O.trace_primary(b, cam, step=(step, step), threads=threads)
-    t2 = time.perf_counter()
-    nrays = hits.size
-    return {"value": round(nrays / (t2 - t1) / 1e6, 4), "unit": "Mrays/s",
-            "build_Mtri_s": round(len(tris) / build_s / 1e6, 4), "cores": threads, "kind": "port",
-            "sample": f"{builds} full 1M-triangle builds ({build_s:.3f} s each) + the 1080p frame sampled every "
-                      f"{step} pixel(s) in x and y ({nrays} rays, {t2 - t1:.2f} s); reference visit order; OpenMP over "
-                      f"triangles / internal nodes / rays, serial LSD radix sort, DistributeKeys and refit"}
+    b = O.Built(tris, capacity=cap, threads=threads)           # allocates and touches every array once
+
+    def build_rate(th, budget_s):
+        t0, secs = time.perf_counter(), []
+        while len(secs) < 20 and (time.perf_counter() - t0 < budget_s or len(secs) < 2):
+            secs.append(b.rebuild(th))
+        return len(secs), min(secs)
+
+    def trace_rate(th, budget_s):
+        p0 = time.perf_counter()
+        pilot, _ = O.trace_primary(b, cam, step=(32, 32), threads=th)
+        rate = pilot.size / max(time.perf_counter() - p0, 1e-6)
+        step = 1
+        for s_ in (1, 2, 4, 8, 16, 32):
+            step = s_
+            if (W // s_) * (H // s_) / rate <= budget_s:
+                break
+        t1 = time.perf_counter()
+        hits, _ = O.trace_primary(b, cam, step=(step, step), threads=th)
+        dt = time.perf_counter() - t1
+        return hits.size / dt / 1e6, step, hits.size, dt
+
+    nb1, s1 = build_rate(1, 3.0)
+    nbt, st = build_rate(threads, 3.0)
+    r1, step1, n1, dt1 = trace_rate(1, 6.0)
+    rt, stept, nt, dtt = trace_rate(threads, 6.0)
+    return {"value": round(rt, 4), "unit": "Mrays/s", "build_Mtri_s": round(len(tris) / st / 1e6, 4), "cores": threads, "kind": "port",
+            "scalar": {"value": round(r1, 4), "unit": "Mrays/s", "build_Mtri_s": round(len(tris) / s1 / 1e6, 4), "cores": 1},
+            "sample": f"OpenMP x{threads}: best of {nbt} warm 1M-triangle rebuilds ({st:.4f} s) + the 1080p frame sampled every {stept} "
+                      f"pixel(s) in x and y ({nt} rays, {dtt:.2f} s); scalar: best of {nb1} rebuilds ({s1:.3f} s) + every {step1} "
+                      f"pixel(s) ({n1} rays, {dt1:.2f} s); reference visit order (no pruning), 8x8 ray tiles handed out dynamically"}
 
 
 if __name__ == "__main__":

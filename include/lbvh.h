@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LBVH_ABI_VERSION 5
+#define LBVH_ABI_VERSION 6
 
 /* ---- status codes ------------------------------------------------------------------------- */
 typedef int32_t lbvh_status;
@@ -413,6 +413,11 @@ lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_
 /* radiance (+ alpha) of the path states as RGBA16F, the reference's render-target format. */
 lbvh_status lbvh_path_resolve(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, uint16_t* d_rgba16f);
 
+/* LBVH_TRACE_FAST dispatches a frame's tiles in the order of their step counts in the PREVIOUS trace of the same frame
+ * layout (a scheduling hint kept by the context; any order gives the same hits).  This drops that history: the next
+ * trace runs as a first frame does (row-major).  For measuring cold frames. */
+lbvh_status lbvh_trace_forget(lbvh_context* ctx);
+
 /* Profiling aid: one LBVH_TRACE_FAST frame that also records, per 8x8-pixel tile (row-major,
  * ceil(W/8) x ceil(H/8) entries), the number of node fetches its packet needed. */
 lbvh_status lbvh_trace_tile_costs(lbvh_context* ctx, const lbvh_camera* h_camera, const lbvh_scene* h_scene,
@@ -439,6 +444,12 @@ typedef struct lbvh_profile_row {
 lbvh_status lbvh_profile_begin(lbvh_context* ctx);
 lbvh_status lbvh_profile_end(lbvh_context* ctx, lbvh_profile_row* h_rows, int32_t max_rows,
                              int32_t* out_rows);
+
+/* The shader clock the chip holds under a vector-ALU-bound load (MHz): every CU runs dependent fp32 work for a few
+ * hundred microseconds while each wave reads the shader-cycle counter (s_memtime) and the constant 100 MHz counter
+ * (s_memrealtime) before and after; the median ratio is returned.  Blocking.  Issue-rate figures (instructions per
+ * cycle x this clock) use it instead of assuming the 2.4 GHz maximum. */
+lbvh_status lbvh_clock_probe(lbvh_context* ctx, float* out_shader_mhz);
 
 /* Streaming device-to-device copy of `bytes` (float4 per lane) on the context's stream: the
  * box's own HBM copy rate is the measured roofline denominator quoted beside the 8 TB/s spec. */

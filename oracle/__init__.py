@@ -260,11 +260,19 @@ class Built:
         self.internal = np.empty(cap, dtype=L.INTERNAL_NODE)
         self.leaf = np.empty(cap, dtype=L.LEAF_NODE)
         self.bvh = np.zeros(cap, dtype=L.AABB)
-        rc = _lib.orc_build_all(_ptr(self.triangles), n, cap, _f3(L.SCENE_BOX_MIN), _f3(L.SCENE_BOX_MAX),
+        self.rebuild(threads)
+
+    def rebuild(self, threads=1):
+        """the whole Awake() chain again into the same arrays (CPU baseline: warm pages); returns the seconds it took"""
+        import time
+        t0 = time.perf_counter()
+        rc = _lib.orc_build_all(_ptr(self.triangles), self.n, self.capacity, _f3(L.SCENE_BOX_MIN), _f3(L.SCENE_BOX_MAX),
                                 _ptr(self.keys), _ptr(self.indices), _ptr(self.triangle_aabb),
                                 _ptr(self.internal), _ptr(self.leaf), _ptr(self.bvh), threads)
+        self.build_seconds = time.perf_counter() - t0
         if rc != 0:
             raise ValueError(f"orc_build_all rc={rc}")
+        return self.build_seconds
 
     def scene(self):
         s = _Scene()

@@ -134,6 +134,52 @@ void orc_sort_pairs(uint32_t* keys, uint32_t* values, uint32_t count)
     free(v2);
 }
 
+/* The same sort with OpenMP (CPU baseline only): every thread owns a contiguous chunk, counts its digits, and
+ * scatters its chunk in order behind (all smaller digits) + (the same digit in earlier chunks): stable, so the
+ * result is the one of orc_sort_pairs (tests/test_oracle_kat.py::test_openmp_paths_equal_scalar). */
+void orc_sort_pairs_mt(uint32_t* keys, uint32_t* values, uint32_t count, int threads)
+{
+#ifdef _OPENMP
+    if (threads > 1 && count >= 65536u) {
+        uint32_t* k2 = (uint32_t*)malloc((size_t)count * 4);
+        uint32_t* v2 = (uint32_t*)malloc((size_t)count * 4);
+        size_t* hist = (size_t*)malloc((size_t)threads * 256 * sizeof(size_t));
+        uint32_t *ks = keys, *vs = values, *kd = k2, *vd = v2;
+        const size_t chunk = ((size_t)count + (size_t)threads - 1) / (size_t)threads;
+        for (int bit_offset = 0; bit_offset < 32; bit_offset += 8) {
+#pragma omp parallel num_threads(threads)
+            {
+                const int t = omp_get_thread_num();
+                const size_t lo = (size_t)t * chunk < count ? (size_t)t * chunk : count;
+                const size_t hi = lo + chunk < count ? lo + chunk : count;
+                size_t* h = hist + (size_t)t * 256;
+                memset(h, 0, 256 * sizeof(size_t));
+                for (size_t i = lo; i < hi; i++) h[(ks[i] >> bit_offset) & 255u]++;
+#pragma omp barrier
+#pragma omp single
+                {
+                    size_t sum = 0;
+                    for (int d = 0; d < 256; d++)
+                        for (int u = 0; u < threads; u++) { size_t c = hist[(size_t)u * 256 + d]; hist[(size_t)u * 256 + d] = sum; sum += c; }
+                }
+                for (size_t i = lo; i < hi; i++) {
+                    const size_t dst = h[(ks[i] >> bit_offset) & 255u]++;
+                    kd[dst] = ks[i];
+                    vd[dst] = vs[i];
+                }
+            }
+            uint32_t* tmp;
+            tmp = ks; ks = kd; kd = tmp;
+            tmp = vs; vs = vd; vd = tmp;
+        }
+        free(k2); free(v2); free(hist);
+        return;
+    }
+#endif
+    (void)threads;
+    orc_sort_pairs(keys, values, count);
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* a-2..a-5  sort, LITERAL form: the reference's five kernels emulated thread by thread with    */
 /* WARP_SIZE 32 waves and THREADS_PER_BLOCK 1024 groups.  `tiles` generalises BLOCK_SIZE (512   */
@@ -293,6 +339,49 @@ void orc_distribute_keys(uint32_t* keys, uint32_t n)
     }
 }
 
+/* OpenMP form (CPU baseline only): new[i] = sum_{j=1..i} max(old[j] - old[j-1], 1), a two-level prefix sum. */
+void orc_distribute_keys_mt(uint32_t* keys, uint32_t n, int threads)
+{
+#ifdef _OPENMP
+    if (threads > 1 && n >= 65536u) {
+        uint32_t* part = (uint32_t*)calloc((size_t)threads + 1, 4);
+        uint32_t* first_old = (uint32_t*)calloc((size_t)threads + 1, 4);
+        const size_t chunk = ((size_t)n + (size_t)threads - 1) / (size_t)threads;
+        for (int t = 0; t < threads; t++) {           /* the old key just before each chunk, before anything is overwritten */
+            const size_t lo = (size_t)t * chunk;
+            first_old[t] = (lo > 0 && lo - 1 < n) ? keys[lo - 1] : 0u;
+        }
+#pragma omp parallel num_threads(threads)
+        {
+            const int t = omp_get_thread_num();
+            const size_t lo = (size_t)t * chunk < n ? (size_t)t * chunk : n;
+            const size_t hi = lo + chunk < n ? lo + chunk : n;
+            uint32_t sum = 0, prev = first_old[t];
+            for (size_t i = lo; i < hi; i++) {
+                if (i > 0) { const uint32_t diff = keys[i] - prev; sum += diff > 1u ? diff : 1u; }
+                prev = keys[i];
+            }
+            part[t + 1] = sum;
+#pragma omp barrier
+#pragma omp single
+            for (int u = 0; u < threads; u++) part[u + 1] += part[u];
+            uint32_t run = part[t];
+            prev = first_old[t];
+            for (size_t i = lo; i < hi; i++) {
+                const uint32_t old = keys[i];
+                if (i > 0) { const uint32_t diff = old - prev; run += diff > 1u ? diff : 1u; }
+                prev = old;
+                keys[i] = run;
+            }
+        }
+        free(part); free(first_old);
+        return;
+    }
+#endif
+    (void)threads;
+    orc_distribute_keys(keys, n);
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* a-7  TreeConstructor    Sh/BVH/BVH.compute:18-149                                            */
 /* ------------------------------------------------------------------------------------------- */
@@ -437,6 +526,38 @@ int orc_refit(uint32_t n, const lbvh_internal_node* internal, const lbvh_leaf_no
     }
     free(atomics);
     return rc;
+}
+
+/* OpenMP form (CPU baseline only): the reference's own scheme — one walker per leaf, the second arrival at a node
+ * merges — with the hand-off made explicit: an acq_rel exchange on the node's flag publishes the first arrival's box
+ * to the second (the reference has no such fence). */
+int orc_refit_mt(uint32_t n, const lbvh_internal_node* internal, const lbvh_leaf_node* leaf,
+                 const lbvh_aabb* triangle_aabb, const uint32_t* sorted_indices, lbvh_aabb* bvh, int threads)
+{
+#ifdef _OPENMP
+    if (threads > 1 && n >= 65536u) {
+        uint32_t* atomics = (uint32_t*)calloc(n, 4);
+        int rc = 0;
+#pragma omp parallel for num_threads(threads) schedule(static) reduction(| : rc)
+        for (int64_t tid = 0; tid < (int64_t)n; tid++) {
+            uint32_t parent = leaf[tid].parent;
+            uint32_t guard = 0;
+            while (parent != 0xFFFFFFFFu) {
+                if (parent >= n - 1 || ++guard > 64) { rc |= 2; break; }
+                if (__atomic_exchange_n(&atomics[parent], 1u, __ATOMIC_ACQ_REL) == 0) break;
+                const lbvh_internal_node nd = internal[parent];
+                const lbvh_aabb lb = nd.leftNodeType == LBVH_INTERNAL_NODE ? bvh[nd.leftNode] : triangle_aabb[sorted_indices[nd.leftNode]];
+                const lbvh_aabb rb = nd.rightNodeType == LBVH_INTERNAL_NODE ? bvh[nd.rightNode] : triangle_aabb[sorted_indices[nd.rightNode]];
+                bvh[parent] = merge_aabb(lb, rb);
+                parent = nd.parent;
+            }
+        }
+        free(atomics);
+        return rc ? -2 : 0;
+    }
+#endif
+    (void)threads;
+    return orc_refit(n, internal, leaf, triangle_aabb, sorted_indices, bvh);
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -589,19 +710,25 @@ int orc_trace_primary(const lbvh_camera* cam, int32_t x0, int32_t y0, int32_t x1
     const int64_t h = (y1 - y0 + y_step - 1) / y_step;
     uint64_t pops = 0, box_hits = 0, leaf_tests = 0, tri_tests = 0, nhits = 0;
     int overflow = 0;
+    /* 8x8-sample tiles handed out dynamically: neighbouring rays walk the same nodes (cache), and thousands of
+     * tiles keep every core busy to the end (whole rows left 256 threads with 270 chunks of very unequal cost) */
+    const int64_t tw = (w + 7) / 8, th = (h + 7) / 8;
 #ifdef _OPENMP
-#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 4) \
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 1) \
     reduction(+ : pops, box_hits, leaf_tests, tri_tests, nhits) reduction(| : overflow)
 #endif
-    for (int64_t j = 0; j < h; j++) {
-        for (int64_t i = 0; i < w; i++) {
-            ray_t ray;
-            orc_make_ray(cam, (uint32_t)(x0 + i * x_step), (uint32_t)(y0 + j * y_step), ray.origin,
-                         ray.dir, ray.inv_dir);
-            lbvh_trace_stats st = {0, 0, 0, 0, 0};
-            overflow |= trace_one(scene, &ray, &hits[j * w + i], &st);
-            pops += st.pops; box_hits += st.box_hits; leaf_tests += st.leaf_tests;
-            tri_tests += st.tri_tests; nhits += st.hits;
+    for (int64_t tile = 0; tile < tw * th; tile++) {
+        const int64_t j0 = (tile / tw) * 8, i0 = (tile % tw) * 8;
+        for (int64_t j = j0; j < j0 + 8 && j < h; j++) {
+            for (int64_t i = i0; i < i0 + 8 && i < w; i++) {
+                ray_t ray;
+                orc_make_ray(cam, (uint32_t)(x0 + i * x_step), (uint32_t)(y0 + j * y_step), ray.origin,
+                             ray.dir, ray.inv_dir);
+                lbvh_trace_stats st = {0, 0, 0, 0, 0};
+                overflow |= trace_one(scene, &ray, &hits[j * w + i], &st);
+                pops += st.pops; box_hits += st.box_hits; leaf_tests += st.leaf_tests;
+                tri_tests += st.tri_tests; nhits += st.hits;
+            }
         }
     }
     if (stats) {
@@ -879,11 +1006,11 @@ int orc_build_all(const lbvh_triangle* tris, uint32_t n, uint32_t capacity, cons
 {
     if (n < 2 || capacity < n) return -1;
     orc_morton_aabb(tris, n, capacity, box_min, box_max, keys, indices, tri_aabb, threads);
-    orc_sort_pairs(keys, indices, capacity);
-    orc_distribute_keys(keys, n);
+    orc_sort_pairs_mt(keys, indices, capacity, threads);
+    orc_distribute_keys_mt(keys, n, threads);
     memset(internal, 0xFF, (size_t)capacity * sizeof *internal);   /* NullLeaf fill :114-115 */
     memset(leaf, 0xFF, (size_t)capacity * sizeof *leaf);
     int rc = orc_build_tree(n, keys, internal, leaf, threads);
     if (rc) return rc;
-    return orc_refit(n, internal, leaf, tri_aabb, indices, bvh);
+    return orc_refit_mt(n, internal, leaf, tri_aabb, indices, bvh, threads);
 }

@@ -69,6 +69,12 @@ void orc_path_scatter(const lbvh_scene* s, const lbvh_hit* hits, size_t count, u
                       float albedo, lbvh_path_state* states);
 void orc_path_resolve(const lbvh_path_state* states, size_t count, uint16_t* rgba16f);
 
+/* OpenMP forms of the serial stages for the CPU baseline (bench.py cpu_baseline): identical results. */
+void orc_sort_pairs_mt(uint32_t* keys, uint32_t* values, uint32_t count, int threads);
+void orc_distribute_keys_mt(uint32_t* keys, uint32_t n, int threads);
+int orc_refit_mt(uint32_t n, const lbvh_internal_node* internal, const lbvh_leaf_node* leaf,
+                 const lbvh_aabb* triangle_aabb, const uint32_t* sorted_indices, lbvh_aabb* bvh, int threads);
+
 /* Awake() build chain on the host (Assets/_Scripts/RaytracingMeshDrawer.cs:30-51). */
 int orc_build_all(const lbvh_triangle* tris, uint32_t n, uint32_t capacity, const float box_min[3],
                   const float box_max[3], uint32_t* keys, uint32_t* indices, lbvh_aabb* tri_aabb,

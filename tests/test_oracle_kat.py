@@ -287,6 +287,18 @@ def test_literal_emulation_equals_oracle_on_a_fresh_scene():
     assert float(E.MAX_FLOAT) == 2139095040.0                                              # (float)0x7F7FFFFF
 
 
+def test_openmp_build_equals_scalar_at_size():
+    """the CPU baseline's OpenMP forms (parallel LSD sort, two-level DistributeKeys scan, flag hand-off refit) only switch
+    on above 65 536 elements: same arrays as the serial restatement, bit for bit"""
+    tris = scenes.tiled_torus(nu=40, nv=25, grid=4)            # 128 000 triangles, many equal Morton codes at this density
+    b1 = O.Built(tris, capacity=scenes.capacity_for(len(tris)), threads=1)
+    for threads in (3, 8):
+        bt = O.Built(tris, capacity=scenes.capacity_for(len(tris)), threads=threads)
+        assert (b1.keys == bt.keys).all() and (b1.indices == bt.indices).all()
+        assert (b1.internal == bt.internal).all() and (b1.leaf == bt.leaf).all()
+        assert (b1.bvh.view(np.uint32) == bt.bvh.view(np.uint32)).all()
+
+
 def test_openmp_paths_equal_scalar():
     tris = scenes.random_triangles(2048, seed=4)
     b1 = O.Built(tris, threads=1)

@@ -14,10 +14,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--mode", default="fast")
 ap.add_argument("--no-check", action="store_true")
+ap.add_argument("--cam-z", type=float, default=250.0)
 args = ap.parse_args()
 W, H = 1920, 1080
 tris = scenes.tiled_torus()
-cam = N.Camera.from_dict(scenes.camera(W, H, (0.0, 0.0, 250.0)))
+cam = N.Camera.from_dict(scenes.camera(W, H, (0.0, 0.0, args.cam_z)))
 ctx = Context(0)
 d = RaytracingMeshDrawer(ctx, tris).awake()
 hits = DataBuffer(ctx, W * H, L.HIT)

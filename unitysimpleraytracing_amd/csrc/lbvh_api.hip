@@ -1,5 +1,6 @@
 // lbvh_api.hip — context, buffers, events: the DataBuffer/ComputeBuffer half of the C ABI
 // (reference: Assets/_Scripts/DataBuffer.cs, Assets/_Scripts/ShaderContainer.cs).
+#include <algorithm>
 #include <cstdlib>
 #include "lbvh_common.h"
 
@@ -367,6 +368,54 @@ lbvh_status lbvh_profile_end(lbvh_context* ctx, lbvh_profile_row* h_rows, int32_
     }
     ctx->prof_spans.clear();
     *out_rows = n;
+    return LBVH_OK;
+}
+
+// ---- shader-clock probe ------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void clock_probe_kernel(uint2* __restrict__ out, uint32_t iterations, float seed)
+{
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    float a = seed + (float)threadIdx.x, b = seed * 0.5f, c = 1.0f, d = 0.25f;
+    for (uint32_t i = 0; i < iterations; i++) {          // four dependent chains: the vector ALUs stay busy
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            a = a * 0.999f + b;
+            b = b * 1.001f - c;
+            c = c * 0.998f + d;
+            d = d * 1.002f - a;
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (a + b + c + d == 12345.678f) out[0] = make_uint2(0u, 0u);          // keeps the loop alive
+    if ((threadIdx.x & 63u) == 0)
+        out[blockIdx.x * 4u + (threadIdx.x >> 6)] = make_uint2((uint32_t)(c1 - c0), (uint32_t)(r1 - r0));
+}
+
+lbvh_status lbvh_clock_probe(lbvh_context* ctx, float* out_shader_mhz)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, out_shader_mhz != nullptr);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t blocks = 2048, waves = blocks * 4;
+    uint2* d_out = nullptr;
+    LBVH_HIP_TRY(ctx, hipMalloc((void**)&d_out, waves * sizeof(uint2)));
+    std::vector<uint2> h(waves);
+    std::vector<double> ratio;
+    // the second launch is the measured one: the first brings the clock up
+    for (int rep = 0; rep < 2; rep++)
+        LBVH_LAUNCH(ctx, clock_probe_kernel, dim3(blocks), dim3(256), d_out, 6000u, 1.0f + (float)rep);
+    hipError_t e = hipMemcpyAsync(h.data(), d_out, waves * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_out);
+    LBVH_HIP_TRY(ctx, e);
+    for (const uint2& w : h)
+        if (w.y > 0) ratio.push_back((double)w.x / (double)w.y);
+    LBVH_REQUIRE(ctx, !ratio.empty());
+    std::nth_element(ratio.begin(), ratio.begin() + ratio.size() / 2, ratio.end());
+    *out_shader_mhz = (float)(ratio[ratio.size() / 2] * 100.0);          // s_memrealtime ticks at 100 MHz
     return LBVH_OK;
 }
 

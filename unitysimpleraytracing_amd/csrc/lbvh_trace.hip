@@ -1255,6 +1255,13 @@ lbvh_status lbvh_trace_primary(lbvh_context* ctx, const lbvh_camera* h_camera, i
     return trace_impl(ctx, h_camera, x0, y0, x1, y1, 0, 1, h_scene, mode, d_hits, d_stats);
 }
 
+lbvh_status lbvh_trace_forget(lbvh_context* ctx)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    ctx->trace_history = false;
+    return LBVH_OK;
+}
+
 lbvh_status lbvh_trace_tile_costs(lbvh_context* ctx, const lbvh_camera* h_camera, const lbvh_scene* h_scene,
                                   lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_steps)
 {

@@ -69,6 +69,16 @@ class Context:
         N.check(self.handle, N.lib.lbvh_profile_end(self.handle, rows, 64, C.byref(n)))
         return {rows[i].name.decode(): (int(rows[i].launches), float(rows[i].total_ms)) for i in range(n.value)}
 
+    def clock_probe(self):
+        """shader clock held under a vector-ALU-bound load, MHz (lbvh_clock_probe)"""
+        mhz = C.c_float()
+        N.check(self.handle, N.lib.lbvh_clock_probe(self.handle, C.byref(mhz)))
+        return mhz.value
+
+    def trace_forget(self):
+        """drop the traversal's dispatch history: the next LBVH_TRACE_FAST frame is a cold one"""
+        N.check(self.handle, N.lib.lbvh_trace_forget(self.handle))
+
     def copy_probe(self, dst, src, nbytes):
         N.check(self.handle, N.lib.lbvh_copy_bandwidth_probe(self.handle, dst, src, nbytes))
 
