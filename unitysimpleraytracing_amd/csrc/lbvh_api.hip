@@ -38,7 +38,7 @@ int lbvh_ensure_side(lbvh_context* ctx)
         LBVH_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
         LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_leaf_boxes, hipEventDisableTiming));
+        LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_hier, hipEventDisableTiming));
     }
     return LBVH_OK;
 }
@@ -196,11 +196,12 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
     if (ctx->build_graph) (void)hipGraphExecDestroy(ctx->build_graph);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->ev_leaf_boxes) (void)hipEventDestroy(ctx->ev_leaf_boxes);
+    if (ctx->ev_hier) (void)hipEventDestroy(ctx->ev_hier);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->fast_nodes) (void)hipFree(ctx->fast_nodes);
     if (ctx->trace_queues) (void)hipFree(ctx->trace_queues);
     if (ctx->fast_tree) (void)hipFree(ctx->fast_tree);
+    if (ctx->hier) (void)hipFree(ctx->hier);
     if (ctx->ray_scratch) (void)hipFree(ctx->ray_scratch);
     for (auto& s : ctx->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void morton_aabb_kernel(const lbvh_triangle* _
                                                           uint32_t* __restrict__ keys,
                                                           uint32_t* __restrict__ indices,
                                                           lbvh_aabb* __restrict__ aabb,
-                                                          uint32_t* __restrict__ zero, uint32_t zero_words)
+                                                          uint32_t* __restrict__ zero, uint32_t zero_words,
+                                                          lbvh_fast_tri* __restrict__ lines)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     // lbvh_build_scene: the sort that follows wants its counters and look-back words cleared; doing it here saves
@@ -65,6 +66,18 @@ __global__ __launch_bounds__(256) void morton_aabb_kernel(const lbvh_triangle* _
     float4* o = reinterpret_cast<float4*>(&aabb[i]);
     o[0] = make_float4(mn[0], mn[1], mn[2], 0.0f);
     o[1] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+    if (lines) {
+        // lbvh_build_scene: the derived scene's triangle line (lbvh_common.h lbvh_fast_tri: first vertex, the two edge
+        // vectors of Raytracing.compute:41-42, the triangle's index), in ORIGINAL order — the positions are in registers
+        // here, so no kernel has to gather the 128-byte records again after the sort
+        const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
+        const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+        float4* t = reinterpret_cast<float4*>(&lines[i]);
+        t[0] = make_float4(a.x, a.y, a.z, __uint_as_float(i));
+        t[1] = make_float4(a.x, a.y, a.z, e2x);
+        t[2] = make_float4(e1x, e1y, e1z, e2y);
+        t[3] = make_float4(e1x, e1y, e1z, e2z);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -190,49 +203,183 @@ __global__ __launch_bounds__(kDistThreads) void distribute_apply_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // a-7  TreeConstructor (Karras 2012)          BVH.compute:18-149
+// a-8  BVHConstructor, fused into it for lbvh_build_scene / lbvh_build_fast_scene (see "range hierarchy" below)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }   // :18-21
 
-__device__ __forceinline__ int delta(const uint32_t* __restrict__ codes, int x_code_idx, uint32_t x_code,
-                                     int y, int num_objects)                              // :23-33
+// The searches of a node probe keys at idx +- 1, 2, 4, ... and inside its range: for > 95 % of the nodes all of that
+// lies within a few hundred keys of idx.  The workgroup's keys plus a halo on each side are staged in LDS once,
+// coalesced, so the dependent chain of a search (~30 probes for the widest node of a wave; a wave runs as long as
+// its widest node) costs LDS latency per probe instead of an L2 round trip; probes past the halo read global memory.
+constexpr int kTreeThreads = 256;
+constexpr int kTreeHalo = 256;
+constexpr int kTreeWindow = kTreeThreads + 2 * kTreeHalo;
+
+struct key_window {
+    const uint32_t* __restrict__ codes;
+    const uint32_t* lds;
+    int w0, w1;                                     // keys [w0, w1) are lds[0 .. w1 - w0)
+    int num;
+    __device__ __forceinline__ uint32_t at(int y) const { return (y >= w0 && y < w1) ? lds[y - w0] : codes[y]; }
+    __device__ __forceinline__ int delta(uint32_t x_code, int y) const                    // :23-33 (x is always in range)
+    {
+        if (y >= 0 && y <= num - 1) return clz32(x_code ^ at(y));
+        return -1;
+    }
+};
+
+// ---- range hierarchy ------------------------------------------------------------------------------------------
+// The reference refits bottom-up: one thread per leaf climbs to the root, the second arrival at a node merges the
+// child boxes (BVH.compute:152-220).  The result is the union of the leaf AABBs in the node's leaf range, and min /
+// max are exact, so ANY evaluation order gives the same floats.  A node of a Karras tree covers a CONTIGUOUS range
+// [first, last] of the sorted leaves, and TreeConstructor has that range in its hands.  So inside lbvh_build_scene
+// the refit is no climb at all: gather_hier_kernel writes the leaf boxes in sorted order plus the union of every
+// aligned group of 2, 4, 8, ... leaves (a binary hierarchy, 2 x 32 B per leaf), and the tree kernel answers "box of
+// [a, b]" with <= 2 boxes per level (the classic bottom-up segment-tree walk): no arrival counters, no dependent
+// chain over tree levels, no second kernel, every node independent.  Both trees (the reference's and the derived
+// traversal tree) are over the same sorted leaves, so they share one hierarchy.
+// Layout: level k (blocks of 2^k leaves) starts at box index 2 N2 - (2 N2 >> k), N2 = the leaf count rounded up to a
+// power of two; only blocks that start below n are ever written or read.  Minima and maxima live in two arrays of
+// packed 12-byte corners: the queries are gathers, and what they cost is the number of distinct cache lines a wave's
+// load touches — 5 corners per 64-byte line instead of 2 boxes.
+typedef float f3 __attribute__((ext_vector_type(3)));
+struct corner3 { float x, y, z; };                  // 12 bytes, 4-byte aligned
+struct hier_t {
+    corner3* lo;            // [2 N2] minima
+    corner3* hi;            // [2 N2] maxima
+    uint32_t n2x2;          // 2 * N2
+    uint32_t levels;        // log2(N2): the top level has one block
+};
+
+__device__ __forceinline__ uint32_t hier_offset(uint32_t n2x2, uint32_t k) { return n2x2 - (n2x2 >> k); }
+
+__device__ __forceinline__ f3 load_corner(const corner3* p) { return *reinterpret_cast<const f3 __attribute__((aligned(4)))*>(p); }
+__device__ __forceinline__ void store_corner(corner3* p, float x, float y, float z)
 {
-    (void)x_code_idx;
-    if (y >= 0 && y <= num_objects - 1) return clz32(x_code ^ codes[y]);
-    return -1;
+    f3 v = {x, y, z};
+    *reinterpret_cast<f3 __attribute__((aligned(4)))*>(p) = v;
 }
 
-__global__ __launch_bounds__(256) void tree_kernel(const uint32_t* __restrict__ codes, uint32_t n,
-                                                   lbvh_internal_node* __restrict__ internal,
-                                                   lbvh_leaf_node* __restrict__ leaf, uint32_t* __restrict__ zero_word)
+// Unions of the leaf boxes a[q] .. b[q] (inclusive) for NQ ranges at once.  The walk over the levels needs no loaded
+// data (block indices come from a and b alone), so LV levels are resolved per round: all their block indices first,
+// then all loads back to back (a block that is not part of the range reads the NEUTRAL box kept at index 2 N2 - 1
+// instead of branching around the load), then the min / max — one memory latency per LV levels instead of one per
+// block (the straightforward loop measured 17 us per query at 1 M nodes, all of it waiting).
+template <int NQ, int LV>
+__device__ __forceinline__ void range_boxes(const hier_t& h, const uint32_t a[NQ], const uint32_t b[NQ], float mn[NQ][3],
+                                            float mx[NQ][3])
 {
-    const uint32_t thread_id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (thread_id == 0 && zero_word) *zero_word = 0u;      // the refit's frontier counter (lbvh_build_scene)
-    if (thread_id >= n - 1) return;                                                        // :101
-    const int num = (int)n;
-    const int idx = (int)thread_id;
-    const uint32_t self = codes[idx];
+    const uint32_t neutral = h.n2x2 - 1u;
+    uint32_t l[NQ], r[NQ];
+    bool more = false;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        l[q] = a[q];
+        r[q] = b[q] + 1u;
+        more = more || l[q] < r[q];
+#pragma unroll
+        for (int d = 0; d < 3; d++) { mn[q][d] = INFINITY; mx[q][d] = -INFINITY; }
+    }
+    for (uint32_t k = 0; more; k += LV) {
+        uint32_t idx[NQ][LV][2];
+        more = false;
+#pragma unroll
+        for (int v = 0; v < LV; v++) {
+            const uint32_t lev = min(k + (uint32_t)v, 31u);
+            const uint32_t off = hier_offset(h.n2x2, lev);
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const bool tl = l[q] < r[q] && (l[q] & 1u);
+                idx[q][v][0] = tl ? off + l[q] : neutral;
+                l[q] += tl ? 1u : 0u;
+                const bool tr = l[q] < r[q] && (r[q] & 1u);
+                r[q] -= tr ? 1u : 0u;
+                idx[q][v][1] = tr ? off + r[q] : neutral;
+                l[q] >>= 1;
+                r[q] >>= 1;
+            }
+        }
+        f3 lo[NQ][LV][2], hi[NQ][LV][2];
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+#pragma unroll
+            for (int v = 0; v < LV; v++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    lo[q][v][e] = load_corner(h.lo + idx[q][v][e]);
+                    hi[q][v][e] = load_corner(h.hi + idx[q][v][e]);
+                }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+#pragma unroll
+            for (int v = 0; v < LV; v++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    mn[q][0] = fminf(mn[q][0], lo[q][v][e].x); mn[q][1] = fminf(mn[q][1], lo[q][v][e].y);      // MergeAABB :152-170
+                    mn[q][2] = fminf(mn[q][2], lo[q][v][e].z);
+                    mx[q][0] = fmaxf(mx[q][0], hi[q][v][e].x); mx[q][1] = fmaxf(mx[q][1], hi[q][v][e].y);
+                    mx[q][2] = fmaxf(mx[q][2], hi[q][v][e].z);
+                }
+            more = more || l[q] < r[q];
+        }
+    }
+}
 
-    // DetermineRange :35-52 (idx is always in range, so delta only range-checks the other end)
-    const int dl = delta(codes, idx, self, idx - 1, num);
-    const int dr = delta(codes, idx, self, idx + 1, num);
+#ifndef LBVH_RQ_LV1
+#define LBVH_RQ_LV1 4
+#endif
+#ifndef LBVH_RQ_LV2
+#define LBVH_RQ_LV2 2
+#endif
+enum { TREE_TOPOLOGY = 0, TREE_REFERENCE = 1, TREE_FUSED = 2 };
+// TREE_TOPOLOGY   lbvh_build_tree: the reference's node arrays only
+// TREE_REFERENCE  + bvh[i] = box of the node's range (BVHData, BVH.compute:215)
+// TREE_FUSED      the derived traversal tree: nothing but the 64-byte traversal node (both child boxes + child references)
+template <int MODE>
+__global__ __launch_bounds__(kTreeThreads) void tree_kernel(const uint32_t* __restrict__ codes, uint32_t n,
+                                                            lbvh_internal_node* __restrict__ internal,
+                                                            lbvh_leaf_node* __restrict__ leaf, uint32_t* __restrict__ zero_word,
+                                                            hier_t hier, lbvh_aabb* __restrict__ bvh,
+                                                            lbvh_fast_node* __restrict__ fused, uint32_t leaf_base,
+                                                            const uint32_t* __restrict__ sorted_indices)
+{
+    __shared__ uint32_t s_keys[kTreeWindow];
+    const uint32_t thread_id = blockIdx.x * kTreeThreads + threadIdx.x;
+    if (thread_id == 0 && zero_word) *zero_word = 0u;      // lbvh_build_tree + lbvh_refit: the refit's frontier counter
+    key_window win;
+    win.codes = codes;
+    win.lds = s_keys;
+    win.num = (int)n;
+    win.w0 = max((int)(blockIdx.x * kTreeThreads) - kTreeHalo, 0);
+    win.w1 = min((int)(blockIdx.x * kTreeThreads) + kTreeThreads + kTreeHalo, (int)n);
+    for (int k = win.w0 + (int)threadIdx.x; k < win.w1; k += kTreeThreads) s_keys[k - win.w0] = codes[k];
+    __syncthreads();
+    // (no early return: the boxes leave through a workgroup-wide LDS transpose below)
+    const bool in_range = thread_id < n - 1;                                               // :101
+    const int idx = in_range ? (int)thread_id : 0;
+    const uint32_t self = win.at(idx);
+
+    // DetermineRange :35-52
+    const int dl = win.delta(self, idx - 1);
+    const int dr = win.delta(self, idx + 1);
     const int diff = dr - dl;
     const int d = (diff > 0) - (diff < 0);                                                 // sign(), :37
     const int dmin = d > 0 ? dl : (d < 0 ? dr : clz32(0u));                                // :38
     uint32_t lmax = 2;                                                                     // :39
-    while (delta(codes, idx, self, idx + (int)(lmax * (uint32_t)d), num) > dmin) lmax *= 2; // :40-41
+    while (in_range && win.delta(self, idx + (int)(lmax * (uint32_t)d)) > dmin) lmax *= 2; // :40-41
     int l = 0;
-    for (uint32_t t = lmax / 2; t >= 1; t /= 2) {                                          // :43
-        if (delta(codes, idx, self, idx + (int)(((uint32_t)l + t) * (uint32_t)d), num) > dmin)
+    for (uint32_t t = lmax / 2; t >= 1 && in_range; t /= 2) {                              // :43
+        if (win.delta(self, idx + (int)(((uint32_t)l + t) * (uint32_t)d)) > dmin)
             l += (int)t;                                                                   // :45-46
     }
     const int j = idx + l * d;                                                             // :49
     const int first = min(idx, j), last = max(idx, j);                                     // :50
 
     // FindSplit :54-92
-    int split;
-    {
-        const uint32_t first_code = codes[first];
-        const uint32_t last_code = codes[last];
+    int split = first;
+    if (in_range) {
+        const uint32_t first_code = win.at(first);
+        const uint32_t last_code = win.at(last);
         if (first_code == last_code) {
             split = (first + last) >> 1;                                                   // :61-62
         } else {
@@ -243,25 +390,64 @@ __global__ __launch_bounds__(256) void tree_kernel(const uint32_t* __restrict__ 
                 step = (step + 1) >> 1;                                                    // :78
                 const int new_split = split + step;
                 if (new_split < last) {
-                    const int split_prefix = clz32(first_code ^ codes[new_split]);
+                    const int split_prefix = clz32(first_code ^ win.at(new_split));
                     if (split_prefix > common_prefix) split = new_split;                   // :85-86
                 }
             } while (step > 1);
         }
     }
-    if (split < 0 || (uint32_t)split + 1u >= n) return;   // only reachable with non-unique keys
+    const bool valid = in_range && !(split < 0 || (uint32_t)split + 1u >= n);   // invalid: only reachable with non-unique keys
 
     const bool left_leaf = split == first;                                                 // :114
     const bool right_leaf = split + 1 == last;                                             // :132
-    uint32_t* node = reinterpret_cast<uint32_t*>(&internal[thread_id]);
-    // leftNode, leftNodeType, rightNode, rightNodeType as two 8-byte stores (node stride 24 B)
-    *reinterpret_cast<uint2*>(node + 0) = make_uint2((uint32_t)split, left_leaf ? LBVH_LEAF_NODE : LBVH_INTERNAL_NODE);
-    *reinterpret_cast<uint2*>(node + 2) = make_uint2((uint32_t)split + 1u, right_leaf ? LBVH_LEAF_NODE : LBVH_INTERNAL_NODE);
-    node[5] = thread_id;                                                                   // index :111
-    if (left_leaf) *reinterpret_cast<uint2*>(&leaf[split]) = make_uint2(thread_id, (uint32_t)split);  // :116-120
-    else internal[split].parent = thread_id;                                               // :126
-    if (right_leaf) *reinterpret_cast<uint2*>(&leaf[split + 1]) = make_uint2(thread_id, (uint32_t)split + 1u);
-    else internal[split + 1].parent = thread_id;                                           // :144
+    if (MODE != TREE_FUSED && valid) {
+        uint32_t* node = reinterpret_cast<uint32_t*>(&internal[thread_id]);
+        // leftNode, leftNodeType, rightNode, rightNodeType as two 8-byte stores (node stride 24 B)
+        *reinterpret_cast<uint2*>(node + 0) = make_uint2((uint32_t)split, left_leaf ? LBVH_LEAF_NODE : LBVH_INTERNAL_NODE);
+        *reinterpret_cast<uint2*>(node + 2) = make_uint2((uint32_t)split + 1u, right_leaf ? LBVH_LEAF_NODE : LBVH_INTERNAL_NODE);
+        node[5] = thread_id;                                                               // index :111
+        if (left_leaf) *reinterpret_cast<uint2*>(&leaf[split]) = make_uint2(thread_id, (uint32_t)split);  // :116-120
+        else internal[split].parent = thread_id;                                           // :126
+        if (right_leaf) *reinterpret_cast<uint2*>(&leaf[split + 1]) = make_uint2(thread_id, (uint32_t)split + 1u);
+        else internal[split + 1].parent = thread_id;                                       // :144
+    }
+    // The boxes: computed per node, written per LINE — every thread parks its record in LDS and the workgroup writes
+    // the block's records as consecutive float4 (a wave's store covers 1 KB of whole records, not 64 quarter lines).
+    constexpr int kQuads = MODE == TREE_FUSED ? 4 : 2;             // float4 per record: 64-byte traversal node / 32-byte AABB
+    __shared__ float4 s_out[MODE == TREE_TOPOLOGY ? 1 : kTreeThreads * kQuads];
+    if (MODE == TREE_REFERENCE) {
+        const uint32_t a[1] = {(uint32_t)first}, b[1] = {valid ? (uint32_t)last : (uint32_t)first};
+        float mn[1][3], mx[1][3];
+        range_boxes<1, LBVH_RQ_LV1>(hier, a, b, mn, mx);
+        s_out[threadIdx.x * 2 + 0] = make_float4(mn[0][0], mn[0][1], mn[0][2], 0.0f);      // :215
+        s_out[threadIdx.x * 2 + 1] = make_float4(mx[0][0], mx[0][1], mx[0][2], 0.0f);
+    }
+    if (MODE == TREE_FUSED) {
+        const uint32_t a[2] = {(uint32_t)first, (uint32_t)split + 1u};
+        const uint32_t b[2] = {(uint32_t)split, valid ? (uint32_t)last : (uint32_t)split};
+        float cmn[2][3], cmx[2][3];
+        range_boxes<2, LBVH_RQ_LV2>(hier, a, b, cmn, cmx);
+        // child reference: a line index — node index, or LEAF | leaf_base + the triangle's ORIGINAL index (the triangle
+        // lines stay in the caller's order: lbvh_common.h)
+        uint32_t lref = (uint32_t)split, rref = (uint32_t)split + 1u;
+        if (valid && left_leaf) lref = 0x80000000u | (leaf_base + sorted_indices[split]);
+        if (valid && right_leaf) rref = 0x80000000u | (leaf_base + sorted_indices[split + 1]);
+        s_out[threadIdx.x * 4 + 0] = make_float4(cmn[0][0], cmn[0][1], cmn[0][2], __uint_as_float(lref));
+        s_out[threadIdx.x * 4 + 1] = make_float4(cmx[0][0], cmx[0][1], cmx[0][2], __uint_as_float(rref));
+        s_out[threadIdx.x * 4 + 2] = make_float4(cmn[1][0], cmn[1][1], cmn[1][2], 0.0f);
+        s_out[threadIdx.x * 4 + 3] = make_float4(cmx[1][0], cmx[1][1], cmx[1][2], 0.0f);
+    }
+    if (MODE != TREE_TOPOLOGY) {
+        __syncthreads();
+        const uint32_t b0 = blockIdx.x * kTreeThreads;
+        float4* out = MODE == TREE_FUSED ? reinterpret_cast<float4*>(fused + b0) : reinterpret_cast<float4*>(bvh + b0);
+        const uint32_t live = n - 1 > b0 ? min(n - 1 - b0, (uint32_t)kTreeThreads) * kQuads : 0u;   // float4s of existing nodes
+#pragma unroll
+        for (int k = 0; k < kQuads; k++) {
+            const uint32_t q = (uint32_t)k * kTreeThreads + threadIdx.x;
+            if (q < live) out[q] = s_out[q];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -331,19 +517,15 @@ struct refit_levels_t {
     int levels;
 };
 
+// The stand-alone lbvh_refit (a caller's tree, no keys at hand): the climb described above.
 // sorted_indices == nullptr: tri_aabb is already in sorted (leaf) order.
-// FUSED (the derived traversal tree): every node finished here is written as the 64-byte traversal node holding
-// its two CHILDREN's boxes — both are in the merging thread's hands — instead of its own box; own boxes go to bvh[]
-// only where a frontier node will need them as a child box (fuse_frontier_kernel).
-template <bool FUSED>
 __global__ __launch_bounds__(kRefitThreads) void refit_kernel(uint32_t n, const lbvh_internal_node* __restrict__ internal,
                                                               const lbvh_leaf_node* __restrict__ leaf,
                                                               const lbvh_aabb* __restrict__ tri_aabb,
                                                               const uint32_t* __restrict__ sorted_indices,
                                                               lbvh_aabb* bvh, refit_levels_t lv,
                                                               uint32_t* __restrict__ frontier_count,
-                                                              uint32_t* __restrict__ frontier_list,
-                                                              lbvh_fast_node* __restrict__ fused, uint32_t leaf_base)
+                                                              uint32_t* __restrict__ frontier_list)
 {
     // parked child boxes, [side][slot] = {min xyz, range word | max xyz, -}: two 16-byte LDS accesses per box.
     // range word: first | last << 16 relative to the workgroup, bit 31 = the parked child is a leaf.   64 KB
@@ -393,16 +575,13 @@ __global__ __launch_bounds__(kRefitThreads) void refit_kernel(uint32_t n, const 
         }
     }
     if (j < n) {
-        bool stranded = false;      // FUSED: the carried box belongs to a finished node whose parent is not local
         for (int guard = 0; q != 0xFFFFFFFFu && guard < 64; guard++) {
-            stranded = true;
             if (q >= n - 1) break;
             // LOCAL arrival: q's index and the carried range lie inside the workgroup's 1024 indices.  Anything
             // else is a frontier node (refit_frontier computes it from the range levels).
             const bool local = q >= b0 && q - b0 < (uint32_t)kRefitThreads && first >= b0 &&
                                last - b0 < (uint32_t)kRefitThreads;
             if (!local) break;
-            stranded = false;
             const uint32_t slot = q - b0;
             const uint2 nd = s_node[slot];
             const uint32_t next = nd.y;
@@ -430,7 +609,6 @@ __global__ __launch_bounds__(kRefitThreads) void refit_kernel(uint32_t n, const 
             child_leaf = 0u;
             q = next;                                                                      // :217
         }
-        if (FUSED && stranded && child_leaf == 0u) store_box_plain(&bvh[child_id], mn, mx);
     }
     // internal nodes of this index block that did not see both children arrive through LDS are the frontier
     // (one global atomic per workgroup: the list order is irrelevant)
@@ -439,91 +617,22 @@ __global__ __launch_bounds__(kRefitThreads) void refit_kernel(uint32_t n, const 
     uint32_t my = 0;
     if (is_front) my = atomicAdd(&s_front_n, 1u);
     // finished nodes (both children arrived): their children's boxes are the two parked entries of their slot.  Written
-    // with 4 (traversal node) or 2 (box) threads per node — thread t takes float4 (t & 3) of node (t >> 2) + 256 k — so
-    // that a wave's store covers whole consecutive records instead of 64 quarter / half lines
-    if (FUSED) {
+    // with 2 threads per node — thread t takes float4 (t & 1) of node (t >> 1) + 512 k — so that a wave's store covers whole
+    // consecutive records instead of 64 half lines
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t slot = (t >> 2) + 256u * k, q = t & 3u, node = b0 + slot;
-            if (node >= n - 1 || s_flag[slot] != 0x10001u) continue;
-            float4 v = s_box[q >> 1][slot][q & 1u];
-            if (q < 2u) {
-                // .w of float4 0 / 1: the left / right child reference (line index; LEAF | leaf_base + sorted position)
-                const uint32_t leaf = __float_as_uint(s_box[q][slot][0].w) & 0x80000000u;
-                v.w = __uint_as_float(leaf | (s_node[slot].x + q + (leaf ? leaf_base : 0u)));
-            } else {
-                v.w = 0.0f;
-            }
-            reinterpret_cast<float4*>(&fused[node])[q] = v;
-        }
-    } else {
-#pragma unroll
-        for (uint32_t k = 0; k < 2; k++) {
-            const uint32_t slot = (t >> 1) + 512u * k, h = t & 1u, node = b0 + slot;
-            if (node >= n - 1 || s_flag[slot] != 0x10001u) continue;
-            const float4 l = s_box[0][slot][h], r = s_box[1][slot][h];
-            reinterpret_cast<float4*>(&bvh[node])[h] =                                     // :215
-                h == 0u ? make_float4(fminf(l.x, r.x), fminf(l.y, r.y), fminf(l.z, r.z), 0.0f)
-                        : make_float4(fmaxf(l.x, r.x), fmaxf(l.y, r.y), fmaxf(l.z, r.z), 0.0f);
-        }
-    }
-    if (FUSED && j < n - 1) {
-        const uint32_t f = s_flag[t];
-        if (f != 0x10001u && f != 0) {
-            // frontier node with one finished child parked here and nowhere else: fuse_frontier_kernel needs its box
-            const uint32_t side = (f & 1u) ? 0u : 1u;
-            const float4 pmn = s_box[side][t][0], pmx = s_box[side][t][1];
-            if (!(__float_as_uint(pmn.w) & 0x80000000u)) {
-                float4* o = reinterpret_cast<float4*>(&bvh[s_node[t].x + side]);
-                o[0] = make_float4(pmn.x, pmn.y, pmn.z, 0.0f);
-                o[1] = make_float4(pmx.x, pmx.y, pmx.z, 0.0f);
-            }
-        }
+    for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t slot = (t >> 1) + 512u * k, h = t & 1u, node = b0 + slot;
+        if (node >= n - 1 || s_flag[slot] != 0x10001u) continue;
+        const float4 l = s_box[0][slot][h], r = s_box[1][slot][h];
+        reinterpret_cast<float4*>(&bvh[node])[h] =                                     // :215
+            h == 0u ? make_float4(fminf(l.x, r.x), fminf(l.y, r.y), fminf(l.z, r.z), 0.0f)
+                    : make_float4(fmaxf(l.x, r.x), fmaxf(l.y, r.y), fmaxf(l.z, r.z), 0.0f);
     }
     __syncthreads();
     if (t == 0 && s_front_n)
         s_front_base = __hip_atomic_fetch_add(frontier_count, s_front_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (is_front) frontier_list[s_front_base + my] = j;
-}
-
-// FUSED: the traversal nodes of the frontier, after refit_frontier_kernel has written the frontier's own boxes.  A
-// child of a frontier node is a leaf, another frontier node, or a finished node whose box refit_kernel stored.
-__global__ __launch_bounds__(256) void fuse_frontier_kernel(uint32_t n, const lbvh_internal_node* __restrict__ internal,
-                                                            const uint32_t* __restrict__ count, const uint32_t* __restrict__ list,
-                                                            const lbvh_aabb* __restrict__ tri_aabb,
-                                                            const uint32_t* __restrict__ sorted_indices,
-                                                            const lbvh_aabb* __restrict__ bvh, lbvh_fast_node* __restrict__ fused,
-                                                            uint32_t leaf_base)
-{
-    const uint32_t total = *count;
-    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
-        const uint32_t node = list[e];
-        const uint32_t* nd = reinterpret_cast<const uint32_t*>(&internal[node]);
-        const uint2 lc = *reinterpret_cast<const uint2*>(nd + 0);
-        const uint2 rc = *reinterpret_cast<const uint2*>(nd + 2);
-        float4 b[4];
-        uint32_t ref[2];
-#pragma unroll
-        for (int side = 0; side < 2; side++) {
-            const uint2 c = side == 0 ? lc : rc;
-            const float4* src;
-            if (c.y == LBVH_INTERNAL_NODE) {
-                src = reinterpret_cast<const float4*>(&bvh[c.x]);
-                ref[side] = c.x;
-            } else {
-                src = reinterpret_cast<const float4*>(&tri_aabb[sorted_indices ? sorted_indices[c.x] : c.x]);
-                ref[side] = 0x80000000u | (leaf_base + c.x);   // leaf c sits at sorted position c (tree_kernel)
-            }
-            b[2 * side + 0] = src[0];
-            b[2 * side + 1] = src[1];
-        }
-        float4* o = reinterpret_cast<float4*>(&fused[node]);
-        o[0] = make_float4(b[0].x, b[0].y, b[0].z, __uint_as_float(ref[0]));
-        o[1] = make_float4(b[1].x, b[1].y, b[1].z, __uint_as_float(ref[1]));
-        o[2] = make_float4(b[2].x, b[2].y, b[2].z, 0.0f);
-        o[3] = make_float4(b[3].x, b[3].y, b[3].z, 0.0f);
-    }
 }
 
 // range level k >= 3 from level k - 1 (only built when level 2 alone would leave the top nodes with thousands of
@@ -647,45 +756,157 @@ __device__ __forceinline__ int32_t block_inclusive_max(int32_t v, int32_t* s_wav
     return max(incl, prefix);
 }
 
-// One pass over the sorted order does both jobs of the derived build's start: the triangle AABBs are gathered into
-// leaf order (the one random gather; everything after reads them in order) and the aligned-key terms code_i - i are
-// written where the keys will be, with the maximum of every 1024-term chunk.
+// One pass over the sorted order does the three jobs every later kernel of the build starts from: the triangle AABBs
+// are gathered into leaf order (the one random gather; level 0 of the range hierarchy), levels 1 .. 10 of the hierarchy
+// (unions of aligned groups of 2 .. 1024 leaves) are formed on the way — inside a wave by lane exchange, across the
+// workgroup's 16 waves-worth of leaves through LDS — and (TERMS) the aligned-key terms code_i - i are written where the
+// derived tree's keys will be, with the maximum of every 1024-term chunk.
 constexpr int kAkItems = 4;
-constexpr uint32_t kAkChunk = kAkThreads * kAkItems;
+constexpr uint32_t kAkChunk = kAkThreads * kAkItems;       // 1024 leaves per workgroup = hierarchy level 10
+constexpr uint32_t kHierLocalLevels = 10;
 
-__global__ __launch_bounds__(kAkThreads) void gather_terms_kernel(const lbvh_aabb* __restrict__ tri_aabb,
-                                                                  const uint32_t* __restrict__ sorted_indices, uint32_t n,
-                                                                  box3 scene, lbvh_aabb* __restrict__ leaf_box,
-                                                                  int32_t* __restrict__ terms, int32_t* __restrict__ chunk_max)
+__device__ __forceinline__ void store_hier(const hier_t& h, uint32_t k, uint32_t block, const float mn[3], const float mx[3])
+{
+    const size_t e = (size_t)hier_offset(h.n2x2, k) + block;
+    store_corner(h.lo + e, mn[0], mn[1], mn[2]);
+    store_corner(h.hi + e, mx[0], mx[1], mx[2]);
+}
+
+template <bool TERMS>
+__global__ __launch_bounds__(kAkThreads) void gather_hier_kernel(const lbvh_aabb* __restrict__ tri_aabb,
+                                                                 const uint32_t* __restrict__ sorted_indices, uint32_t n,
+                                                                 box3 scene, hier_t hier, int32_t* __restrict__ terms,
+                                                                 int32_t* __restrict__ chunk_max)
 {
     __shared__ int32_t s_wave[kAkThreads / LBVH_WAVE];
+    __shared__ float s_six[6][kAkItems * (kAkThreads / LBVH_WAVE)];     // the 16 level-6 boxes of this workgroup, in leaf order
+    const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
     int32_t mine = INT32_MIN;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // the NEUTRAL box of range_boxes: the unused slot behind the top level
+        store_corner(hier.lo + (hier.n2x2 - 1u), INFINITY, INFINITY, INFINITY);
+        store_corner(hier.hi + (hier.n2x2 - 1u), -INFINITY, -INFINITY, -INFINITY);
+    }
 #pragma unroll
     for (int k = 0; k < kAkItems; k++) {
         const uint32_t i = blockIdx.x * kAkChunk + (uint32_t)k * kAkThreads + threadIdx.x;
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
         if (i < n) {
             const float4* src = reinterpret_cast<const float4*>(&tri_aabb[sorted_indices[i]]);
-            const float4 mn = src[0], mx = src[1];
-            float4* dst = reinterpret_cast<float4*>(&leaf_box[i]);
-            dst[0] = mn;
-            dst[1] = mx;
-            const float bmn[3] = {mn.x, mn.y, mn.z}, bmx[3] = {mx.x, mx.y, mx.z};
-            uint32_t q[3];
+            const float4 a = src[0], b = src[1];
+            mn[0] = a.x; mn[1] = a.y; mn[2] = a.z;
+            mx[0] = b.x; mx[1] = b.y; mx[2] = b.z;
+            store_hier(hier, 0, i, mn, mx);                               // level 0: the exact floats BVH.compute:196-205 reads
+            if (TERMS) {
+                uint32_t q[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    float cen = (mn[d] + mx[d]) * 0.5f;
+                    cen = cen - scene.mn[d];
+                    cen = cen / (scene.mx[d] - scene.mn[d]);
+                    q[d] = quantize(cen);
+                }
+                const int32_t term = (int32_t)(expand_bits(q[0]) * 4u + expand_bits(q[1]) * 2u + expand_bits(q[2])) - (int32_t)i;
+                terms[i] = term;
+                mine = max(mine, term);
+            }
+        }
+        // levels 1 .. 6 inside the wave: after step s the lanes whose low s bits are zero hold the union of their 2^s leaves
+#pragma unroll
+        for (uint32_t lev = 1; lev <= 6; lev++) {
 #pragma unroll
             for (int d = 0; d < 3; d++) {
-                float cen = (bmn[d] + bmx[d]) * 0.5f;
-                cen = cen - scene.mn[d];
-                cen = cen / (scene.mx[d] - scene.mn[d]);
-                q[d] = quantize(cen);
+                mn[d] = fminf(mn[d], __shfl_xor(mn[d], 1 << (lev - 1)));
+                mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], 1 << (lev - 1)));
             }
-            const int32_t term = (int32_t)(expand_bits(q[0]) * 4u + expand_bits(q[1]) * 2u + expand_bits(q[2])) - (int32_t)i;
-            terms[i] = term;
-            mine = max(mine, term);
+            if ((lane & ((1u << lev) - 1u)) == 0 && i < n && lev <= hier.levels) store_hier(hier, lev, i >> lev, mn, mx);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) { s_six[d][k * 4 + w] = mn[d]; s_six[3 + d][k * 4 + w] = mx[d]; }
         }
     }
-    int32_t all;
-    (void)block_inclusive_max(mine, s_wave, &all);
-    if (threadIdx.x == 0) chunk_max[blockIdx.x] = all;
+    if (TERMS) {
+        int32_t all;
+        (void)block_inclusive_max(mine, s_wave, &all);                    // (barrier inside)
+        if (threadIdx.x == 0) chunk_max[blockIdx.x] = all;
+    } else {
+        __syncthreads();
+    }
+    // levels 7 .. 10 from the 16 level-6 boxes (entry e covers leaves [block * 1024 + 64 e, + 64))
+    if (threadIdx.x < 16u) {
+        const uint32_t e = threadIdx.x, start = blockIdx.x * kAkChunk + e * 64u;
+        float mn[3], mx[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) { mn[d] = s_six[d][e]; mx[d] = s_six[3 + d][e]; }
+#pragma unroll
+        for (uint32_t lev = 7; lev <= kHierLocalLevels; lev++) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                mn[d] = fminf(mn[d], __shfl_xor(mn[d], 1 << (lev - 7), 16));
+                mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], 1 << (lev - 7), 16));
+            }
+            if ((e & ((1u << (lev - 6)) - 1u)) == 0 && start < n && lev <= hier.levels) store_hier(hier, lev, start >> lev, mn, mx);
+        }
+    }
+}
+
+// hierarchy levels above 10 (blocks of 2048 leaves and more): a few hundred boxes at 1 M leaves, one workgroup.
+// Level 10 is read once into LDS (when it fits: up to 4 M leaves) and every higher level is formed there — one barrier
+// per level instead of a store -> barrier -> load round trip through memory.
+constexpr uint32_t kTopLds = 4096;
+__global__ __launch_bounds__(1024) void hier_top_kernel(hier_t hier, uint32_t n)
+{
+    __shared__ float s_box[6][kTopLds];
+    uint32_t count = (n + (1u << kHierLocalLevels) - 1u) >> kHierLocalLevels;          // blocks of level 10
+    uint32_t lev = kHierLocalLevels;
+    // levels too wide for the LDS image go through memory
+    while (count > kTopLds) {
+        const uint32_t next = (count + 1u) >> 1;
+        for (uint32_t e = threadIdx.x; e < next; e += 1024u) {
+            const size_t c0 = (size_t)hier_offset(hier.n2x2, lev) + 2 * e;
+            f3 a = load_corner(hier.lo + c0), b = load_corner(hier.hi + c0);
+            if (2 * e + 1 < count) {
+                const f3 a2 = load_corner(hier.lo + c0 + 1), b2 = load_corner(hier.hi + c0 + 1);
+                a.x = fminf(a.x, a2.x); a.y = fminf(a.y, a2.y); a.z = fminf(a.z, a2.z);
+                b.x = fmaxf(b.x, b2.x); b.y = fmaxf(b.y, b2.y); b.z = fmaxf(b.z, b2.z);
+            }
+            const float mn[3] = {a.x, a.y, a.z}, mx[3] = {b.x, b.y, b.z};
+            store_hier(hier, lev + 1, e, mn, mx);
+        }
+        __syncthreads();          // the next level reads what this one wrote (same workgroup: visible after the barrier)
+        count = next;
+        lev++;
+    }
+    for (uint32_t e = threadIdx.x; e < count; e += 1024u) {
+        const size_t c = (size_t)hier_offset(hier.n2x2, lev) + e;
+        const f3 a = load_corner(hier.lo + c), b = load_corner(hier.hi + c);
+        s_box[0][e] = a.x; s_box[1][e] = a.y; s_box[2][e] = a.z;
+        s_box[3][e] = b.x; s_box[4][e] = b.y; s_box[5][e] = b.z;
+    }
+    __syncthreads();
+    while (lev < hier.levels) {
+        const uint32_t next = (count + 1u) >> 1;
+        float mn[4][3], mx[4][3];                  // next <= 2048: at most 2 entries per thread ... 4 keeps it simple
+        uint32_t mine = 0;
+        for (uint32_t e = threadIdx.x; e < next; e += 1024u, mine++) {
+            const bool two = 2 * e + 1 < count;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                mn[mine][d] = two ? fminf(s_box[d][2 * e], s_box[d][2 * e + 1]) : s_box[d][2 * e];
+                mx[mine][d] = two ? fmaxf(s_box[3 + d][2 * e], s_box[3 + d][2 * e + 1]) : s_box[3 + d][2 * e];
+            }
+        }
+        __syncthreads();
+        mine = 0;
+        for (uint32_t e = threadIdx.x; e < next; e += 1024u, mine++) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) { s_box[d][e] = mn[mine][d]; s_box[3 + d][e] = mx[mine][d]; }
+            store_hier(hier, lev + 1, e, mn[mine], mx[mine]);
+        }
+        __syncthreads();
+        count = next;
+        lev++;
+    }
 }
 
 __global__ __launch_bounds__(kAkThreads) void aligned_keys_scan_kernel(int32_t* __restrict__ chunk_max, uint32_t chunks)
@@ -740,20 +961,95 @@ __global__ __launch_bounds__(kAkThreads) void aligned_keys_apply_kernel(uint32_t
 int lbvh_launch_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, lbvh_internal_node* d_internal,
                      lbvh_leaf_node* d_leaf, uint32_t* d_zero_word)
 {
-    const uint32_t blocks = (n - 1 + 255) / 256;
-    LBVH_LAUNCH(ctx, tree_kernel, dim3(blocks), dim3(256), d_keys, n, d_internal, d_leaf, d_zero_word);
+    const uint32_t blocks = (n - 1 + kTreeThreads - 1) / kTreeThreads;
+    LBVH_LAUNCH(ctx, tree_kernel<TREE_TOPOLOGY>, dim3(blocks), dim3(kTreeThreads), d_keys, n, d_internal, d_leaf, d_zero_word,
+                hier_t{nullptr, nullptr, 0u, 0u}, (lbvh_aabb*)nullptr, (lbvh_fast_node*)nullptr, 0u, (const uint32_t*)nullptr);
+    return LBVH_OK;
+}
+
+// the context's range hierarchy for n leaves (grown lazily; one per context: both lanes of a build read the same one)
+static int hier_plan(lbvh_context* ctx, uint32_t n, hier_t* h)
+{
+    uint32_t n2 = 2, levels = 1;
+    while (n2 < n) { n2 <<= 1; levels++; }
+    const size_t half = ((size_t)2 * n2 * sizeof(corner3) + 255) & ~(size_t)255;
+    const int rc = lbvh_reserve(ctx, &ctx->hier, &ctx->hier_bytes, 2 * half);
+    if (rc != LBVH_OK) return rc;
+    h->lo = (corner3*)ctx->hier;
+    h->hi = (corner3*)((char*)ctx->hier + half);
+    h->n2x2 = 2u * n2;
+    h->levels = levels;
+    return LBVH_OK;
+}
+
+int lbvh_hier_reserve(lbvh_context* ctx, uint32_t n)
+{
+    hier_t h;
+    return hier_plan(ctx, n, &h);
+}
+
+int lbvh_launch_gather_hier(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices,
+                            const float box_min[3], const float box_max[3], uint32_t* d_aligned_keys_out)
+{
+    hier_t h;
+    int rc = hier_plan(ctx, n, &h);
+    if (rc != LBVH_OK) return rc;
+    box3 scene;
+    for (int k = 0; k < 3; k++) { scene.mn[k] = box_min ? box_min[k] : 0.0f; scene.mx[k] = box_max ? box_max[k] : 1.0f; }
+    const uint32_t chunks = (n + kAkChunk - 1) / kAkChunk;
+    if (d_aligned_keys_out) {
+        rc = lbvh_reserve(ctx, &ctx->scan_scratch[ctx->lane], &ctx->scan_scratch_bytes[ctx->lane], (size_t)chunks * 8);
+        if (rc != LBVH_OK) return rc;
+        int32_t* chunk_max = (int32_t*)ctx->scan_scratch[ctx->lane];
+        LBVH_LAUNCH(ctx, gather_hier_kernel<true>, dim3(chunks), dim3(kAkThreads), d_triangle_aabb, d_sorted_indices, n, scene, h,
+                    (int32_t*)d_aligned_keys_out, chunk_max);
+        if (chunks <= kSelfScanChunks) {
+            LBVH_LAUNCH(ctx, aligned_keys_apply_kernel<true>, dim3(chunks), dim3(kAkThreads), n, chunk_max, d_aligned_keys_out);
+        } else {
+            LBVH_LAUNCH(ctx, aligned_keys_scan_kernel, dim3(1), dim3(kAkThreads), chunk_max, chunks);
+            LBVH_LAUNCH(ctx, aligned_keys_apply_kernel<false>, dim3(chunks), dim3(kAkThreads), n, chunk_max, d_aligned_keys_out);
+        }
+    } else {
+        LBVH_LAUNCH(ctx, gather_hier_kernel<false>, dim3(chunks), dim3(kAkThreads), d_triangle_aabb, d_sorted_indices, n, scene, h,
+                    (int32_t*)nullptr, (int32_t*)nullptr);
+    }
+    if (h.levels > kHierLocalLevels) LBVH_LAUNCH(ctx, hier_top_kernel, dim3(1), dim3(1024), h, n);
+    return LBVH_OK;
+}
+
+int lbvh_launch_tree_boxes(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, lbvh_internal_node* d_internal,
+                           lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh)
+{
+    hier_t h;
+    const int rc = hier_plan(ctx, n, &h);
+    if (rc != LBVH_OK) return rc;
+    const uint32_t blocks = (n - 1 + kTreeThreads - 1) / kTreeThreads;
+    LBVH_LAUNCH(ctx, tree_kernel<TREE_REFERENCE>, dim3(blocks), dim3(kTreeThreads), d_keys, n, d_internal, d_leaf, (uint32_t*)nullptr, h,
+                d_bvh, (lbvh_fast_node*)nullptr, 0u, (const uint32_t*)nullptr);
+    return LBVH_OK;
+}
+
+int lbvh_launch_tree_fused(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, const uint32_t* d_sorted_indices,
+                           lbvh_fast_node* d_fused, uint32_t leaf_base)
+{
+    hier_t h;
+    const int rc = hier_plan(ctx, n, &h);
+    if (rc != LBVH_OK) return rc;
+    const uint32_t blocks = (n - 1 + kTreeThreads - 1) / kTreeThreads;
+    LBVH_LAUNCH(ctx, tree_kernel<TREE_FUSED>, dim3(blocks), dim3(kTreeThreads), d_keys, n, (lbvh_internal_node*)nullptr,
+                (lbvh_leaf_node*)nullptr, (uint32_t*)nullptr, h, (lbvh_aabb*)nullptr, d_fused, leaf_base, d_sorted_indices);
     return LBVH_OK;
 }
 
 int lbvh_launch_morton(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
                        const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
-                       lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words)
+                       lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines)
 {
     box3 scene;
     for (int k = 0; k < 3; k++) { scene.mn[k] = h_box_min[k]; scene.mx[k] = h_box_max[k]; }
     const uint32_t blocks = (capacity + 255) / 256;
     LBVH_LAUNCH(ctx, morton_aabb_kernel, dim3(blocks), dim3(256), d_triangles, n, capacity, scene, d_keys, d_indices, d_aabb,
-                d_zero, zero_words);
+                d_zero, zero_words, d_lines);
     return LBVH_OK;
 }
 
@@ -819,8 +1115,7 @@ int lbvh_refit_counter(lbvh_context* ctx, uint32_t n, uint32_t** d_counter)
 }
 
 int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d_internal, const lbvh_leaf_node* d_leaf,
-                      const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh,
-                      lbvh_fast_node* d_fused, uint32_t fused_leaf_base, bool counter_cleared)
+                      const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh, bool counter_cleared)
 {
     refit_plan plan;
     {
@@ -832,12 +1127,8 @@ int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d
     uint32_t* list = plan.list;
     if (!counter_cleared) LBVH_HIP_TRY(ctx, hipMemsetAsync(count, 0, 256, ctx->cur_stream));
     const uint32_t blocks = (n + kRefitThreads - 1) / kRefitThreads;
-    if (d_fused)
-        LBVH_LAUNCH(ctx, refit_kernel<true>, dim3(blocks), dim3(kRefitThreads), n, d_internal, d_leaf, d_triangle_aabb,
-                    d_sorted_indices, d_bvh, lv, count, list, d_fused, fused_leaf_base);
-    else
-        LBVH_LAUNCH(ctx, refit_kernel<false>, dim3(blocks), dim3(kRefitThreads), n, d_internal, d_leaf, d_triangle_aabb,
-                    d_sorted_indices, d_bvh, lv, count, list, d_fused, 0u);
+    LBVH_LAUNCH(ctx, refit_kernel, dim3(blocks), dim3(kRefitThreads), n, d_internal, d_leaf, d_triangle_aabb, d_sorted_indices, d_bvh,
+                lv, count, list);
     if (blocks > 1) {       // a single workgroup finishes the whole tree in LDS
         for (int k = 3; k <= lv.levels; k++)
             LBVH_LAUNCH(ctx, refit_level_kernel, dim3((lv.count[k] + 255) / 256), dim3(256), lv, k);
@@ -845,30 +1136,6 @@ int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d
         if (fblocks > 2048u) fblocks = 2048u;
         LBVH_LAUNCH(ctx, refit_frontier_kernel, dim3(fblocks), dim3(256), n, d_internal, count, list, d_triangle_aabb,
                     d_sorted_indices, d_bvh, lv);
-        if (d_fused)
-            LBVH_LAUNCH(ctx, fuse_frontier_kernel, dim3(blocks < 64u ? blocks : 64u), dim3(256), n, d_internal, count, list,
-                        d_triangle_aabb, d_sorted_indices, d_bvh, d_fused, fused_leaf_base);
-    }
-    return LBVH_OK;
-}
-
-int lbvh_launch_gather_aligned_keys(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_triangle_aabb,
-                                    const uint32_t* d_sorted_indices, const float box_min[3], const float box_max[3],
-                                    lbvh_aabb* d_leaf_box_out, uint32_t* d_keys_out)
-{
-    box3 scene;
-    for (int k = 0; k < 3; k++) { scene.mn[k] = box_min[k]; scene.mx[k] = box_max[k]; }
-    const uint32_t chunks = (n + kAkChunk - 1) / kAkChunk;
-    int rc = lbvh_reserve(ctx, &ctx->scan_scratch[ctx->lane], &ctx->scan_scratch_bytes[ctx->lane], (size_t)chunks * 8);
-    if (rc != LBVH_OK) return rc;
-    int32_t* chunk_max = (int32_t*)ctx->scan_scratch[ctx->lane];
-    LBVH_LAUNCH(ctx, gather_terms_kernel, dim3(chunks), dim3(kAkThreads), d_triangle_aabb, d_sorted_indices, n, scene,
-                d_leaf_box_out, (int32_t*)d_keys_out, chunk_max);
-    if (chunks <= kSelfScanChunks) {
-        LBVH_LAUNCH(ctx, aligned_keys_apply_kernel<true>, dim3(chunks), dim3(kAkThreads), n, chunk_max, d_keys_out);
-    } else {
-        LBVH_LAUNCH(ctx, aligned_keys_scan_kernel, dim3(1), dim3(kAkThreads), chunk_max, chunks);
-        LBVH_LAUNCH(ctx, aligned_keys_apply_kernel<false>, dim3(chunks), dim3(kAkThreads), n, chunk_max, d_keys_out);
     }
     return LBVH_OK;
 }
@@ -890,7 +1157,7 @@ lbvh_status lbvh_morton_aabb(lbvh_context* ctx, const lbvh_triangle* d_triangles
     lbvh_note_write(ctx, d_keys, (size_t)capacity * 4);
     lbvh_note_write(ctx, d_indices, (size_t)capacity * 4);
     lbvh_note_write(ctx, d_aabb, (size_t)n * sizeof(lbvh_aabb));
-    lbvh_launch_morton(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, nullptr, 0);
+    lbvh_launch_morton(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, nullptr, 0, nullptr);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }
@@ -943,7 +1210,7 @@ lbvh_status lbvh_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* 
     LBVH_REQUIRE(ctx, ((uintptr_t)d_internal & 7) == 0 && ((uintptr_t)d_triangle_aabb & 15) == 0 &&
                           ((uintptr_t)d_bvh & 15) == 0);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = lbvh_launch_refit(ctx, n, d_internal, d_leaf, d_triangle_aabb, d_sorted_indices, d_bvh, nullptr, 0u, false);
+    int rc = lbvh_launch_refit(ctx, n, d_internal, d_leaf, d_triangle_aabb, d_sorted_indices, d_bvh, false);
     if (rc != LBVH_OK) return rc;
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;

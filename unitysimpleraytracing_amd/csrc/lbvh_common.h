@@ -36,11 +36,14 @@ struct alignas(64) lbvh_fast_node {
 };
 static_assert(sizeof(lbvh_fast_node) == 64, "fast node must be 64 bytes");
 
-// Triangle in SORTED order for LBVH_TRACE_FAST: first vertex and the two edge vectors e1 = b - a, e2 = c - a (the
-// fp32 differences the intersection test starts with, Raytracing.compute:41-42, taken once at build time) and the
-// original triangle index (no extra gather for the hit record).  A 64-byte line in the SAME allocation as the
-// traversal nodes, right behind them: a child reference (node index, or LEAF | leaf_base + sorted position) is one
-// index into one array of 64-byte lines, and a line fetch is base + (index << 6) whatever it points at.
+// Triangle line for LBVH_TRACE_FAST, one per triangle in the caller's ORIGINAL order (measured: sorted or original
+// order of these lines makes no difference to the traversal, 0.226 ms either way, and original order lets the Morton
+// kernel write them from the positions it has in registers — no gather of the 128-byte records after the sort):
+// first vertex and the two edge vectors e1 = b - a, e2 = c - a (the fp32 differences the intersection test starts
+// with, Raytracing.compute:41-42, taken once at build time) and the triangle's index (the hit record's
+// triangleIndex).  A 64-byte line in the SAME allocation as the traversal nodes, right behind them: a child reference
+// (node index, or LEAF | leaf_base + triangle index) is one index into one array of 64-byte lines, and a line fetch
+// is base + (index << 6) whatever it points at.
 // Layout: the packet walk fetches node lines with dwords k and k + 4 (k = 0, 1, 2 and 8, 9, 10) swapped for the axes
 // its rays travel down (lbvh_trace.hip), and fetches a child's line before it knows — per lane — what the child
 // is; so the triangle line reads the same under any such swap: a and e1 are stored twice, e2 and the index sit in
@@ -69,8 +72,10 @@ struct lbvh_context {
     hipStream_t cur_stream = nullptr;
     int lane = 0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_leaf_boxes = nullptr;    // lane 1 has gathered the triangle AABBs into leaf order (fast_leaf_boxes)
-    lbvh_aabb* fast_leaf_boxes = nullptr;  // inside fast_tree; valid for the build in flight
+    hipEvent_t ev_hier = nullptr;          // lane 1 has finished the range hierarchy of the build in flight
+    // range hierarchy of the sorted leaf boxes (lbvh_build.hip): level 0 = the leaf AABBs in sorted order
+    void* hier = nullptr;
+    size_t hier_bytes = 0;
     // lbvh_build_scene replays a captured hipGraph when it is called again with the same arguments (per-frame
     // rebuilds): ~20 short dependent kernels on two streams, launch gaps included, become one graph launch
     hipGraphExec_t build_graph = nullptr;
@@ -160,26 +165,33 @@ int lbvh_set_error(lbvh_context* ctx, int code, const char* what, const char* de
 // d_zero_word (may be nullptr): a word the tree kernel clears on the way — the counter of the refit that follows
 int lbvh_launch_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, lbvh_internal_node* d_internal,
                      lbvh_leaf_node* d_leaf, uint32_t* d_zero_word);
-// Morton / AABB kernel that also clears d_zero[0 .. zero_words) (the scratch of the sort that follows)
+// Morton / AABB kernel that also clears d_zero[0 .. zero_words) (the scratch of the sort that follows) and, with
+// d_lines, writes the derived scene's 64-byte triangle lines (original order)
 int lbvh_launch_morton(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
                        const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
-                       lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words);
+                       lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines);
 // the sort with its scratch described / already cleared by the caller
 int lbvh_sort_scratch(lbvh_context* ctx, uint32_t count, uint32_t** d_zero, uint32_t* zero_words);
 int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t count, bool scratch_cleared);
 // the frontier counter lbvh_launch_refit(n) will use on the current lane (sizes the scratch)
 int lbvh_refit_counter(lbvh_context* ctx, uint32_t n, uint32_t** d_counter);
+// the stand-alone refit (lbvh_refit): d_sorted_indices may be nullptr (boxes already in leaf order)
 int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d_internal, const lbvh_leaf_node* d_leaf,
-                      const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh,
-                      lbvh_fast_node* d_fused, uint32_t fused_leaf_base, bool counter_cleared);
-// d_sorted_indices may be nullptr in lbvh_launch_refit: boxes already in leaf order.  d_fused != nullptr (a tree made
-// by lbvh_launch_tree only): write the 64-byte traversal nodes instead of d_bvh, which then only holds the few
-// boxes the frontier needs; leaf references are LEAF | fused_leaf_base + sorted position.
-// The start of the derived build: leaf_box[i] = aabb[sorted[i]] and the aligned traversal keys
-// k'_i = i + max_{j<=i}(morton(centre of leaf_box[j]) - j), strictly increasing.
-int lbvh_launch_gather_aligned_keys(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_triangle_aabb,
-                                    const uint32_t* d_sorted_indices, const float box_min[3], const float box_max[3],
-                                    lbvh_aabb* d_leaf_box_out, uint32_t* d_keys_out);
+                      const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices, lbvh_aabb* d_bvh, bool counter_cleared);
+// The refit of lbvh_build_scene / lbvh_build_fast_scene is a range query inside the tree kernel (lbvh_build.hip, "range
+// hierarchy"): lbvh_launch_gather_hier writes the leaf boxes in sorted order + the union of every aligned group of
+// 2^k leaves into the context's hierarchy (and, with d_aligned_keys_out, the derived tree's aligned keys
+// k'_i = i + max_{j<=i}(morton(centre of leaf box j) - j)); the two tree launchers below read it.
+int lbvh_hier_reserve(lbvh_context* ctx, uint32_t n);      // sizes the hierarchy (no launch): before a graph capture
+int lbvh_launch_gather_hier(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices,
+                            const float box_min[3], const float box_max[3], uint32_t* d_aligned_keys_out);
+// TreeConstructor + BVHData in one kernel (the reference's arrays)
+int lbvh_launch_tree_boxes(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, lbvh_internal_node* d_internal,
+                           lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh);
+// the derived traversal tree: 64-byte traversal nodes straight from the keys (leaf references
+// LEAF | leaf_base + ORIGINAL triangle index, looked up in d_sorted_indices)
+int lbvh_launch_tree_fused(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, const uint32_t* d_sorted_indices,
+                           lbvh_fast_node* d_fused, uint32_t leaf_base);
 
 // A library call is about to write [p, p + bytes): if that touches what the derived scene was built from, the
 // derived scene is stale from here on.

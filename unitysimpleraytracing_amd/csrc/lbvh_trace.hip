@@ -168,18 +168,18 @@ __global__ __launch_bounds__(64) void trace_reference_kernel(trace_args a, lbvh_
 // ---------------------------------------------------------------------------------------------
 // derived fast-traversal scene
 // ---------------------------------------------------------------------------------------------
-// Four lanes per triangle: lane q of a quad reads float4 q of the 128-byte reference triangle (a, b, c: the 48
-// contiguous bytes of its positions) and writes float4 q of the 64-byte line, so a wave's one store covers 16
-// whole lines (1 KB contiguous) instead of 64 quarter lines; a / b / c travel inside the quad by DPP quad_perm.
-__global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh_fast_tri* __restrict__ tris, uint32_t begin,
-                                                              uint32_t end)
+// lbvh_build_fast_scene's triangle lines (lbvh_build_scene gets them from the Morton kernel instead): one line per
+// triangle in the caller's order.  Four lanes per triangle: lane q of a quad reads float4 q of the 128-byte reference
+// triangle (a, b, c: the 48 contiguous bytes of its positions) and writes float4 q of the 64-byte line, so a wave's
+// one store covers 16 whole lines (1 KB contiguous); a / b / c travel inside the quad by DPP quad_perm.
+__global__ __launch_bounds__(256) void build_fast_tris_kernel(const lbvh_triangle* __restrict__ triangles,
+                                                              lbvh_fast_tri* __restrict__ tris, uint32_t n)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t pos = begin + (t >> 2), q = t & 3u;
-    const bool live = pos < end;
-    const uint32_t tri = live ? s.sorted_indices[pos] : 0u;
+    const uint32_t tri = t >> 2, q = t & 3u;
+    const bool live = tri < n;
     float4 mine = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (live && q < 3u) mine = reinterpret_cast<const float4*>(&s.triangles[tri])[q];
+    if (live && q < 3u) mine = reinterpret_cast<const float4*>(&triangles[tri])[q];
     // quad_perm:[k,k,k,k] = 0x00 / 0x55 / 0xAA: every lane of the quad reads lane k's value (all lanes active here)
 #define LBVH_QUAD(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true))
 #define LBVH_QUAD3(name, ctrl) \
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void build_fast_tris_kernel(lbvh_scene s, lbvh
                      : q == 1u ? make_float4(ax, ay, az, e2x)
                      : q == 2u ? make_float4(e1x, e1y, e1z, e2y)
                                : make_float4(e1x, e1y, e1z, e2z);
-    if (live) reinterpret_cast<float4*>(&tris[pos])[q] = out;
+    if (live) reinterpret_cast<float4*>(&tris[tri])[q] = out;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -954,7 +954,23 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
 
 }  // namespace
 
-// parts: 1 = traversal tree + fused nodes, 2 = sorted triangles (independent of the tree), 3 = both
+// one array of 64-byte lines for the derived scene: [capacity traversal nodes | capacity triangle lines]
+static lbvh_status ensure_fast_lines(lbvh_context* ctx, uint32_t n)
+{
+    if (ctx->fast_capacity >= n) return LBVH_OK;
+    LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->side_stream) LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->side_stream));
+    if (ctx->fast_nodes) { LBVH_HIP_TRY(ctx, hipFree(ctx->fast_nodes)); ctx->fast_nodes = nullptr; }
+    ctx->fast_tris = nullptr;
+    ctx->fast_capacity = 0;
+    ctx->fast_valid = false;
+    LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->fast_nodes, (size_t)n * (sizeof(lbvh_fast_node) + sizeof(lbvh_fast_tri))));
+    ctx->fast_tris = reinterpret_cast<lbvh_fast_tri*>(ctx->fast_nodes + n);
+    ctx->fast_capacity = n;
+    return LBVH_OK;
+}
+
+// parts: 1 = traversal tree + fused nodes, 2 = triangle lines (independent of the tree), 3 = both
 static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h_scene, const float h_box_min[3],
                                           const float h_box_max[3], int parts)
 {
@@ -965,53 +981,29 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
     LBVH_REQUIRE(ctx, s.sorted_indices && s.triangle_aabb && s.internal_nodes && s.leaf_nodes && s.bvh &&
                           s.triangles);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->fast_capacity < s.n) {
-        LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->side_stream) LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->side_stream));
-        if (ctx->fast_nodes) { LBVH_HIP_TRY(ctx, hipFree(ctx->fast_nodes)); ctx->fast_nodes = nullptr; }
-        ctx->fast_tris = nullptr;
-        ctx->fast_capacity = 0;
-        // one array of 64-byte lines: [capacity traversal nodes | capacity sorted triangles]
-        LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->fast_nodes, (size_t)s.n * (sizeof(lbvh_fast_node) + sizeof(lbvh_fast_tri))));
-        ctx->fast_tris = reinterpret_cast<lbvh_fast_tri*>(ctx->fast_nodes + s.n);
-        ctx->fast_capacity = s.n;
+    {
+        const lbvh_status arc = ensure_fast_lines(ctx, s.n);
+        if (arc != LBVH_OK) return arc;
     }
     // The traversal tree: same sorted triangle order as the scene, its own topology over aligned keys
     // (lbvh_build.hip) and its own boxes.  The scene's internalNodes / leafNodes / bvhData — the
     // reference's bit-exact arrays — are not read here: any tree over the same leaves gives the same
     // hits (every leaf keeps its own AABB test), a tighter one just gives them sooner.
-    const size_t n = s.n;
-    const size_t keys_bytes = (n * 4 + 255) & ~(size_t)255, int_bytes = (n * sizeof(lbvh_internal_node) + 255) & ~(size_t)255,
-                 leaf_bytes = (n * sizeof(lbvh_leaf_node) + 255) & ~(size_t)255, box_bytes = n * sizeof(lbvh_aabb);
-    int rc = lbvh_reserve(ctx, &ctx->fast_tree, &ctx->fast_tree_bytes, keys_bytes + int_bytes + leaf_bytes + 2 * box_bytes);
+    int rc = lbvh_reserve(ctx, &ctx->fast_tree, &ctx->fast_tree_bytes, (size_t)s.n * 4);
     if (rc != LBVH_OK) return rc;
-    char* p = (char*)ctx->fast_tree;
-    uint32_t* t_keys = (uint32_t*)p;
-    lbvh_internal_node* t_internal = (lbvh_internal_node*)(p + keys_bytes);
-    lbvh_leaf_node* t_leaf = (lbvh_leaf_node*)(p + keys_bytes + int_bytes);
-    lbvh_aabb* t_bvh = (lbvh_aabb*)(p + keys_bytes + int_bytes + leaf_bytes);
-    lbvh_aabb* t_leaf_box = (lbvh_aabb*)(p + keys_bytes + int_bytes + leaf_bytes + box_bytes);
-    // the one random gather: triangle AABBs into sorted (leaf) order; everything after reads them in order
+    uint32_t* t_keys = (uint32_t*)ctx->fast_tree;
     if (parts & 1) {
-        rc = lbvh_launch_gather_aligned_keys(ctx, s.n, s.triangle_aabb, s.sorted_indices, h_box_min, h_box_max, t_leaf_box, t_keys);
+        // the one random gather: triangle AABBs into sorted (leaf) order + the range hierarchy over them + aligned keys
+        rc = lbvh_launch_gather_hier(ctx, s.n, s.triangle_aabb, s.sorted_indices, h_box_min, h_box_max, t_keys);
         if (rc != LBVH_OK) return rc;
-        // lbvh_build_scene: the reference lane's refit reads these leaf-ordered boxes instead of gathering them again
-        ctx->fast_leaf_boxes = t_leaf_box;
-        if (ctx->lane == 1 && ctx->ev_leaf_boxes) LBVH_HIP_TRY(ctx, hipEventRecord(ctx->ev_leaf_boxes, ctx->cur_stream));
-        uint32_t* counter = nullptr;
-        if ((rc = lbvh_refit_counter(ctx, s.n, &counter)) != LBVH_OK) return rc;
-        if ((rc = lbvh_launch_tree(ctx, s.n, t_keys, t_internal, t_leaf, counter)) != LBVH_OK) return rc;
-        // the refit writes the 64-byte traversal nodes (both child boxes + child references) directly
-        rc = lbvh_launch_refit(ctx, s.n, t_internal, t_leaf, t_leaf_box, nullptr, t_bvh, ctx->fast_nodes, ctx->fast_capacity, true);
-        if (rc != LBVH_OK) return rc;
+        // lbvh_build_scene: the reference lane's tree kernel takes its boxes from the same hierarchy
+        if (ctx->lane == 1 && ctx->ev_hier) LBVH_HIP_TRY(ctx, hipEventRecord(ctx->ev_hier, ctx->cur_stream));
+        // topology + both child boxes of every node in one kernel: the 64-byte traversal nodes
+        if ((rc = lbvh_launch_tree_fused(ctx, s.n, t_keys, s.sorted_indices, ctx->fast_nodes, ctx->fast_capacity)) != LBVH_OK) return rc;
     }
-    // parts 2 / 4 / 8: all / the first half / the second half of the sorted triangles
-    if (parts & 14) {
-        const uint32_t half = (s.n / 2u) & ~15u;
-        const uint32_t begin = (parts & 8) ? half : 0u, end = (parts & 4) ? half : s.n;
-        if (end > begin)
-            LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((end - begin + 63) / 64), dim3(256), s, ctx->fast_tris, begin, end);
-    }
+    // part 2: the triangle lines (independent of the tree and of the sort)
+    if (parts & 2)
+        LBVH_LAUNCH(ctx, build_fast_tris_kernel, dim3((s.n + 63) / 64), dim3(256), s.triangles, ctx->fast_tris, s.n);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }
@@ -1054,13 +1046,18 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
         uint32_t* zero = nullptr;
         uint32_t zero_words = 0;
         if ((rc = (lbvh_status)lbvh_sort_scratch(ctx, capacity, &zero, &zero_words)) != LBVH_OK) return rc;
-        lbvh_launch_morton(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, zero, zero_words);
+        lbvh_fast_tri* lines = nullptr;
+        if (flags & LBVH_BUILD_FAST_SCENE) {        // the derived scene's triangle lines ride on the Morton kernel
+            if ((rc = ensure_fast_lines(ctx, n)) != LBVH_OK) return rc;
+            lines = ctx->fast_tris;
+        }
+        lbvh_launch_morton(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, zero, zero_words, lines);
         if ((rc = (lbvh_status)lbvh_launch_sort(ctx, d_keys, d_indices, capacity, zero != nullptr)) != LBVH_OK) return rc;
     }
     const bool fast = (flags & LBVH_BUILD_FAST_SCENE) != 0;
-    lbvh_scene fast_scene = {};
     if (fast) {
-        // lane 1: the derived traversal scene needs only the sorted indices and the triangle AABBs
+        // lane 1: the derived traversal scene needs only the sorted indices and the triangle AABBs; its first kernels also
+        // build the range hierarchy both tree kernels take their boxes from
         LBVH_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
         lbvh_scene s;
@@ -1073,7 +1070,6 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
         s.triangles = d_triangles;
         ctx->lane = 1;
         ctx->cur_stream = ctx->side_stream;
-        fast_scene = s;
         rc = build_fast_scene_parts(ctx, &s, h_box_min, h_box_max, 1);
         hipError_t e = hipEventRecord(ctx->ev_join, ctx->side_stream);
         ctx->lane = 0;
@@ -1081,30 +1077,17 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
         if (rc != LBVH_OK) return rc;
         LBVH_HIP_TRY(ctx, e);
     }
-    // lane 0: the reference's arrays
+    // lane 0: the reference's arrays.  DistributeKeys runs beside lane 1's gather; then TreeConstructor + BVHData in one
+    // kernel, as soon as lane 1's hierarchy is there.
     if ((rc = lbvh_distribute_keys(ctx, d_keys, n)) != LBVH_OK) return rc;
-    {
-        uint32_t* counter = nullptr;
-        if ((rc = (lbvh_status)lbvh_refit_counter(ctx, n, &counter)) != LBVH_OK) return rc;
-        if ((rc = (lbvh_status)lbvh_launch_tree(ctx, n, d_keys, d_internal, d_leaf, counter)) != LBVH_OK) return rc;
-        // the boxes in leaf order: lane 1 gathered them long ago (an exact copy of aabb[sortedTriangleIndices[i]],
-        // BVH.compute:196-205) — a stream-ordered read instead of a second random gather
-        const lbvh_aabb* leaf_boxes = d_aabb;
-        const uint32_t* leaf_order = d_indices;
-        if (fast && ctx->fast_leaf_boxes) {
-            LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_leaf_boxes, 0));
-            leaf_boxes = ctx->fast_leaf_boxes;
-            leaf_order = nullptr;
-        }
-        if ((rc = (lbvh_status)lbvh_launch_refit(ctx, n, d_internal, d_leaf, leaf_boxes, leaf_order, d_bvh, nullptr, 0u, true)) != LBVH_OK)
-            return rc;
-        LBVH_HIP_TRY(ctx, hipGetLastError());
-    }
     if (fast) {
-        // the sorted triangles do not depend on the traversal tree: they ride on the shorter lane
-        if ((rc = build_fast_scene_parts(ctx, &fast_scene, h_box_min, h_box_max, 2)) != LBVH_OK) return rc;
-        LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_hier, 0));
+    } else {
+        if ((rc = (lbvh_status)lbvh_launch_gather_hier(ctx, n, d_aabb, d_indices, nullptr, nullptr, nullptr)) != LBVH_OK) return rc;
     }
+    if ((rc = (lbvh_status)lbvh_launch_tree_boxes(ctx, n, d_keys, d_internal, d_leaf, d_bvh)) != LBVH_OK) return rc;
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    if (fast) LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return LBVH_OK;
 }
 
@@ -1130,6 +1113,7 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
     for (int k = 0; k < 3; k++) { uint32_t b; memcpy(&b, &h_box_min[k], 4); mix(b); memcpy(&b, &h_box_max[k], 4); mix(b); }
     auto mix_scratch = [&](decltype(mix)& m) {      // every context-owned buffer the captured kernels point into
         m((uint64_t)(uintptr_t)ctx->fast_nodes); m((uint64_t)(uintptr_t)ctx->fast_tris); m((uint64_t)(uintptr_t)ctx->fast_tree);
+        m((uint64_t)(uintptr_t)ctx->hier);
         m((uint64_t)(uintptr_t)ctx->sort_scratch);
         for (int l = 0; l < 2; l++) { m((uint64_t)(uintptr_t)ctx->scan_scratch[l]); m((uint64_t)(uintptr_t)ctx->refit_scratch[l]); }
     };
