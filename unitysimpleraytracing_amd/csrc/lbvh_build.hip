@@ -36,47 +36,65 @@ __global__ __launch_bounds__(256) void morton_aabb_kernel(const lbvh_triangle* _
                                                           uint32_t* __restrict__ zero, uint32_t zero_words,
                                                           lbvh_fast_tri* __restrict__ lines)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b0 = blockIdx.x * 256u, i = b0 + threadIdx.x;
     // lbvh_build_scene: the sort that follows wants its counters and look-back words cleared; doing it here saves
     // a fill kernel in the chain
-    for (uint32_t w = i; w < zero_words; w += gridDim.x * blockDim.x) zero[w] = 0u;
-    if (i >= capacity) return;
-    if (i >= n) {   // DataBuffer<uint>(.., uint.MaxValue)  MeshBufferContainer.cs:108-109
+    for (uint32_t w = i; w < zero_words; w += gridDim.x * 256u) zero[w] = 0u;
+    // records leave through LDS: a thread produces one triangle's 32-byte AABB and 64-byte line, the workgroup stores
+    // them as consecutive float4 (a wave's store = 1 KB of whole records instead of 64 half / quarter lines)
+    __shared__ float4 s_box[256 * 2];
+    __shared__ float4 s_line[256 * 4];
+    if (i < capacity && i >= n) {   // DataBuffer<uint>(.., uint.MaxValue)  MeshBufferContainer.cs:108-109
         keys[i] = 0xFFFFFFFFu;
         indices[i] = 0xFFFFFFFFu;
-        return;
     }
-    // only the three padded positions (48 of the 128 bytes) are read
-    const float4* p = reinterpret_cast<const float4*>(&tris[i]);
-    const float4 a = p[0], b = p[1], c = p[2];
-    const float ax[3] = {a.x, a.y, a.z}, bx[3] = {b.x, b.y, b.z}, cx[3] = {c.x, c.y, c.z};
-    float mn[3], mx[3];
-    uint32_t q[3];
+    if (i < n) {
+        // only the three padded positions (48 of the 128 bytes) are read
+        const float4* p = reinterpret_cast<const float4*>(&tris[i]);
+        const float4 a = p[0], b = p[1], c = p[2];
+        const float ax[3] = {a.x, a.y, a.z}, bx[3] = {b.x, b.y, b.z}, cx[3] = {c.x, c.y, c.z};
+        float mn[3], mx[3];
+        uint32_t q[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        mn[k] = fminf(fminf(ax[k], bx[k]), cx[k]) - 0.001f;      // GetCentroidAndAABB :54-63
-        mx[k] = fmaxf(fmaxf(ax[k], bx[k]), cx[k]) + 0.001f;
-        float cen = (mn[k] + mx[k]) * 0.5f;                      // :65
-        cen = cen - scene.mn[k];                                 // NormalizeCentroid :76-81
-        cen = cen / (scene.mx[k] - scene.mn[k]);
-        q[k] = quantize(cen);
+        for (int k = 0; k < 3; k++) {
+            mn[k] = fminf(fminf(ax[k], bx[k]), cx[k]) - 0.001f;      // GetCentroidAndAABB :54-63
+            mx[k] = fmaxf(fmaxf(ax[k], bx[k]), cx[k]) + 0.001f;
+            float cen = (mn[k] + mx[k]) * 0.5f;                      // :65
+            cen = cen - scene.mn[k];                                 // NormalizeCentroid :76-81
+            cen = cen / (scene.mx[k] - scene.mn[k]);
+            q[k] = quantize(cen);
+        }
+        keys[i] = expand_bits(q[0]) * 4u + expand_bits(q[1]) * 2u + expand_bits(q[2]);   // :46-49
+        indices[i] = i;
+        s_box[threadIdx.x * 2 + 0] = make_float4(mn[0], mn[1], mn[2], 0.0f);
+        s_box[threadIdx.x * 2 + 1] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+        if (lines) {
+            // lbvh_build_scene: the derived scene's triangle line (lbvh_common.h lbvh_fast_tri: first vertex, the two edge
+            // vectors of Raytracing.compute:41-42, the triangle's index), in ORIGINAL order — the positions are in
+            // registers here, so no kernel has to gather the 128-byte records again after the sort
+            const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
+            const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+            s_line[threadIdx.x * 4 + 0] = make_float4(a.x, a.y, a.z, __uint_as_float(i));
+            s_line[threadIdx.x * 4 + 1] = make_float4(a.x, a.y, a.z, e2x);
+            s_line[threadIdx.x * 4 + 2] = make_float4(e1x, e1y, e1z, e2y);
+            s_line[threadIdx.x * 4 + 3] = make_float4(e1x, e1y, e1z, e2z);
+        }
     }
-    keys[i] = expand_bits(q[0]) * 4u + expand_bits(q[1]) * 2u + expand_bits(q[2]);   // :46-49
-    indices[i] = i;
-    float4* o = reinterpret_cast<float4*>(&aabb[i]);
-    o[0] = make_float4(mn[0], mn[1], mn[2], 0.0f);
-    o[1] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+    __syncthreads();
+    const uint32_t live = n > b0 ? min(n - b0, 256u) : 0u;          // triangles of this block
+    float4* ob = reinterpret_cast<float4*>(aabb + b0);
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t f = k * 256u + threadIdx.x;
+        if (f < live * 2u) ob[f] = s_box[f];
+    }
     if (lines) {
-        // lbvh_build_scene: the derived scene's triangle line (lbvh_common.h lbvh_fast_tri: first vertex, the two edge
-        // vectors of Raytracing.compute:41-42, the triangle's index), in ORIGINAL order — the positions are in registers
-        // here, so no kernel has to gather the 128-byte records again after the sort
-        const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
-        const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
-        float4* t = reinterpret_cast<float4*>(&lines[i]);
-        t[0] = make_float4(a.x, a.y, a.z, __uint_as_float(i));
-        t[1] = make_float4(a.x, a.y, a.z, e2x);
-        t[2] = make_float4(e1x, e1y, e1z, e2y);
-        t[3] = make_float4(e1x, e1y, e1z, e2z);
+        float4* ol = reinterpret_cast<float4*>(lines + b0);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t f = k * 256u + threadIdx.x;
+            if (f < live * 4u) ol[f] = s_line[f];
+        }
     }
 }
 
@@ -988,8 +1006,17 @@ int lbvh_hier_reserve(lbvh_context* ctx, uint32_t n)
     return hier_plan(ctx, n, &h);
 }
 
+int lbvh_launch_hier_top(lbvh_context* ctx, uint32_t n)
+{
+    hier_t h;
+    const int rc = hier_plan(ctx, n, &h);
+    if (rc != LBVH_OK) return rc;
+    if (h.levels > kHierLocalLevels) LBVH_LAUNCH(ctx, hier_top_kernel, dim3(1), dim3(1024), h, n);
+    return LBVH_OK;
+}
+
 int lbvh_launch_gather_hier(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices,
-                            const float box_min[3], const float box_max[3], uint32_t* d_aligned_keys_out)
+                            const float box_min[3], const float box_max[3], uint32_t* d_aligned_keys_out, bool with_top)
 {
     hier_t h;
     int rc = hier_plan(ctx, n, &h);
@@ -1013,7 +1040,7 @@ int lbvh_launch_gather_hier(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_tr
         LBVH_LAUNCH(ctx, gather_hier_kernel<false>, dim3(chunks), dim3(kAkThreads), d_triangle_aabb, d_sorted_indices, n, scene, h,
                     (int32_t*)nullptr, (int32_t*)nullptr);
     }
-    if (h.levels > kHierLocalLevels) LBVH_LAUNCH(ctx, hier_top_kernel, dim3(1), dim3(1024), h, n);
+    if (with_top && h.levels > kHierLocalLevels) LBVH_LAUNCH(ctx, hier_top_kernel, dim3(1), dim3(1024), h, n);
     return LBVH_OK;
 }
 

@@ -72,7 +72,7 @@ struct lbvh_context {
     hipStream_t cur_stream = nullptr;
     int lane = 0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_hier = nullptr;          // lane 1 has finished the range hierarchy of the build in flight
+    hipEvent_t ev_hier = nullptr;          // the range hierarchy of the build in flight is complete
     // range hierarchy of the sorted leaf boxes (lbvh_build.hip): level 0 = the leaf AABBs in sorted order
     void* hier = nullptr;
     size_t hier_bytes = 0;
@@ -183,8 +183,10 @@ int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d
 // 2^k leaves into the context's hierarchy (and, with d_aligned_keys_out, the derived tree's aligned keys
 // k'_i = i + max_{j<=i}(morton(centre of leaf box j) - j)); the two tree launchers below read it.
 int lbvh_hier_reserve(lbvh_context* ctx, uint32_t n);      // sizes the hierarchy (no launch): before a graph capture
+// with_top = false leaves the levels above 1024 leaves to a later lbvh_launch_hier_top
 int lbvh_launch_gather_hier(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_triangle_aabb, const uint32_t* d_sorted_indices,
-                            const float box_min[3], const float box_max[3], uint32_t* d_aligned_keys_out);
+                            const float box_min[3], const float box_max[3], uint32_t* d_aligned_keys_out, bool with_top);
+int lbvh_launch_hier_top(lbvh_context* ctx, uint32_t n);
 // TreeConstructor + BVHData in one kernel (the reference's arrays)
 int lbvh_launch_tree_boxes(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, lbvh_internal_node* d_internal,
                            lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh);

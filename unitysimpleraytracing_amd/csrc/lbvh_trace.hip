@@ -994,9 +994,11 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
     uint32_t* t_keys = (uint32_t*)ctx->fast_tree;
     if (parts & 1) {
         // the one random gather: triangle AABBs into sorted (leaf) order + the range hierarchy over them + aligned keys
-        rc = lbvh_launch_gather_hier(ctx, s.n, s.triangle_aabb, s.sorted_indices, h_box_min, h_box_max, t_keys);
+        rc = lbvh_launch_gather_hier(ctx, s.n, s.triangle_aabb, s.sorted_indices, h_box_min, h_box_max, t_keys, true);
         if (rc != LBVH_OK) return rc;
         // lbvh_build_scene: the reference lane's tree kernel takes its boxes from the same hierarchy
+        // (the single-workgroup top-levels kernel on lane 0 instead, beside the aligned-keys scan, measured slower: the
+        // two extra cross-stream dependencies cost more than the 7 us they take off this lane — 0.293 vs 0.287 ms)
         if (ctx->lane == 1 && ctx->ev_hier) LBVH_HIP_TRY(ctx, hipEventRecord(ctx->ev_hier, ctx->cur_stream));
         // topology + both child boxes of every node in one kernel: the 64-byte traversal nodes
         if ((rc = lbvh_launch_tree_fused(ctx, s.n, t_keys, s.sorted_indices, ctx->fast_nodes, ctx->fast_capacity)) != LBVH_OK) return rc;
@@ -1077,13 +1079,13 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
         if (rc != LBVH_OK) return rc;
         LBVH_HIP_TRY(ctx, e);
     }
-    // lane 0: the reference's arrays.  DistributeKeys runs beside lane 1's gather; then TreeConstructor + BVHData in one
-    // kernel, as soon as lane 1's hierarchy is there.
+    // lane 0: the reference's arrays: DistributeKeys beside lane 1's gather, then TreeConstructor + BVHData in one kernel
+    // as soon as the hierarchy is there
     if ((rc = lbvh_distribute_keys(ctx, d_keys, n)) != LBVH_OK) return rc;
     if (fast) {
         LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_hier, 0));
     } else {
-        if ((rc = (lbvh_status)lbvh_launch_gather_hier(ctx, n, d_aabb, d_indices, nullptr, nullptr, nullptr)) != LBVH_OK) return rc;
+        if ((rc = (lbvh_status)lbvh_launch_gather_hier(ctx, n, d_aabb, d_indices, nullptr, nullptr, nullptr, true)) != LBVH_OK) return rc;
     }
     if ((rc = (lbvh_status)lbvh_launch_tree_boxes(ctx, n, d_keys, d_internal, d_leaf, d_bvh)) != LBVH_OK) return rc;
     LBVH_HIP_TRY(ctx, hipGetLastError());
