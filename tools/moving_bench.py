@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Traversal time of the cfg2 frame with a static camera, with the dispatch history dropped before every frame (cold)
+and with the camera yawing / dollying between frames: what the previous frame's per-tile costs are worth as a
+dispatch hint when the picture changes.  Prints mean ms per frame (HIP events around the trace)."""
+import ctypes as C, math, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unitysimpleraytracing_amd import _native as N, layouts as L, scenes
+from unitysimpleraytracing_amd.host import Context, DataBuffer, RaytracingMeshDrawer
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)) + "/..")
+from bench import yawed
+W, H = 1920, 1080
+with Context(0) as ctx:
+    d = RaytracingMeshDrawer(ctx, scenes.tiled_torus()).awake()
+    hits = DataBuffer(ctx, W * H, L.HIT)
+    s = d.container.scene()
+    base = scenes.camera(W, H, (0.0, 0.0, 250.0))
+
+    def run(label, cams, forget=False, frames=24):
+        e0, e1 = ctx.event(), ctx.event()
+        tot = 0.0
+        for k in range(frames + 4):
+            if forget:
+                ctx.trace_forget()
+            cam = N.Camera.from_dict(cams(k))
+            ctx.record(e0)
+            N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(cam), 0, 0, W, H, C.byref(s), L.TRACE_FAST, hits.device, None))
+            ctx.record(e1)
+            ms = ctx.elapsed_ms(e0, e1)
+            if k >= 4:
+                tot += ms
+        print(f"{label:28s} {tot / frames:.4f} ms")
+    run("static", lambda k: base)
+    run("cold", lambda k: base, forget=True)
+    for deg in (0.25, 1.0, 3.0):
+        run(f"yaw {deg} deg/frame", lambda k: yawed(base, deg * (k + 1)))
+    run("dolly 1 unit/frame", lambda k: scenes.camera(W, H, (0.0, 0.0, 250.0 - k)))
+    d.on_destroy()

@@ -110,6 +110,7 @@ struct lbvh_context {
     uint32_t trace_layout_work = 0;
     bool trace_history = false;
     uint32_t trace_counts_turn = 0;  // which of the two class-counter sets the next filing counts into
+    lbvh_camera trace_camera = {};   // camera of the trace the history was recorded under
     // the traversal tree of the derived scene (aligned keys, own topology and boxes)
     void* fast_tree = nullptr;
     size_t fast_tree_bytes = 0;
