@@ -538,9 +538,20 @@ def cpu_leg(tris, cam):
     DistributeKeys scan, flag hand-off refit).  Bounded sample: warm full 1 M-triangle rebuilds, then the 1080p frame
     subsampled on a pixel grid chosen from a pilot run so each traversal leg takes about 6 s."""
     import oracle as O
-    threads = O.num_threads()
     cap = ((len(tris) + 1023) // 1024) * 1024
-    b = O.Built(tris, capacity=cap, threads=threads)           # allocates and touches every array once
+    b = O.Built(tris, capacity=cap, threads=min(O.num_threads(), 16))          # allocates and touches every array once
+    # threads actually worth using: the box may show more hardware threads than this process is allowed to run on
+    # (cgroup quota, affinity), and barrier-heavy OpenMP phases collapse when oversubscribed — pick the count that
+    # builds fastest
+    allowed = min(O.num_threads(), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else O.num_threads())
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            allowed = max(1, min(allowed, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    candidates = sorted({c for c in (4, 8, 16, 32, 64, 128, 256, allowed) if c <= allowed} | {allowed})
+    threads = min(candidates, key=lambda c: min(b.rebuild(c) for _ in range(2)))
 
     def build_rate(th, budget_s):
         t0, secs = time.perf_counter(), []
