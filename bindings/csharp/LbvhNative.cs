@@ -68,6 +68,11 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern int lbvh_build_scene(IntPtr ctx, IntPtr dTriangles, uint n, uint capacity, float[] boxMin,
         float[] boxMax, IntPtr dKeys, IntPtr dIndices, IntPtr dAabb, IntPtr dInternal, IntPtr dLeaf, IntPtr dBvh, uint flags);
 
+    // LBVH_TRACE_FAST keeps a dispatch hint from the previous frame; this drops it (the next frame runs as a first frame)
+    [DllImport(Lib)] public static extern int lbvh_trace_forget(IntPtr ctx);
+    // measurement helper: shader clock held under a vector-ALU-bound load, MHz
+    [DllImport(Lib)] public static extern int lbvh_clock_probe(IntPtr ctx, out float shaderMhz);
+
     // dynamic scene + secondary rays (BASELINE configs[4]; extension, no reference counterpart)
     [DllImport(Lib)] public static extern int lbvh_animate(IntPtr ctx, IntPtr dRestTriangles, uint n, IntPtr dBodyIds, IntPtr dBodyCentres,
         float cosAngle, float sinAngle, IntPtr dTrianglesOut);
