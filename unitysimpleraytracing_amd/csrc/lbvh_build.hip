@@ -871,16 +871,16 @@ __global__ __launch_bounds__(kAkThreads) void gather_hier_kernel(const lbvh_aabb
 // hierarchy levels above 10 (blocks of 2048 leaves and more): a few hundred boxes at 1 M leaves, one workgroup.
 // Level 10 is read once into LDS (when it fits: up to 4 M leaves) and every higher level is formed there — one barrier
 // per level instead of a store -> barrier -> load round trip through memory.
-constexpr uint32_t kTopLds = 4096;
-__global__ __launch_bounds__(1024) void hier_top_kernel(hier_t hier, uint32_t n)
+template <uint32_t THREADS, uint32_t LDS_BOXES>
+__device__ __forceinline__ void hier_top_levels(const hier_t& hier, uint32_t n, float (&s_box)[6][LDS_BOXES])
 {
-    __shared__ float s_box[6][kTopLds];
+    constexpr uint32_t kPer = (LDS_BOXES / 2 + THREADS - 1) / THREADS;                   // entries of a level per thread
     uint32_t count = (n + (1u << kHierLocalLevels) - 1u) >> kHierLocalLevels;          // blocks of level 10
     uint32_t lev = kHierLocalLevels;
     // levels too wide for the LDS image go through memory
-    while (count > kTopLds) {
+    while (count > LDS_BOXES) {
         const uint32_t next = (count + 1u) >> 1;
-        for (uint32_t e = threadIdx.x; e < next; e += 1024u) {
+        for (uint32_t e = threadIdx.x; e < next; e += THREADS) {
             const size_t c0 = (size_t)hier_offset(hier.n2x2, lev) + 2 * e;
             f3 a = load_corner(hier.lo + c0), b = load_corner(hier.hi + c0);
             if (2 * e + 1 < count) {
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(1024) void hier_top_kernel(hier_t hier, uint32_t n)
         count = next;
         lev++;
     }
-    for (uint32_t e = threadIdx.x; e < count; e += 1024u) {
+    for (uint32_t e = threadIdx.x; e < count; e += THREADS) {
         const size_t c = (size_t)hier_offset(hier.n2x2, lev) + e;
         const f3 a = load_corner(hier.lo + c), b = load_corner(hier.hi + c);
         s_box[0][e] = a.x; s_box[1][e] = a.y; s_box[2][e] = a.z;
@@ -904,27 +904,40 @@ __global__ __launch_bounds__(1024) void hier_top_kernel(hier_t hier, uint32_t n)
     __syncthreads();
     while (lev < hier.levels) {
         const uint32_t next = (count + 1u) >> 1;
-        float mn[4][3], mx[4][3];                  // next <= 2048: at most 2 entries per thread ... 4 keeps it simple
-        uint32_t mine = 0;
-        for (uint32_t e = threadIdx.x; e < next; e += 1024u, mine++) {
-            const bool two = 2 * e + 1 < count;
+        float mn[kPer][3], mx[kPer][3];
 #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                mn[mine][d] = two ? fminf(s_box[d][2 * e], s_box[d][2 * e + 1]) : s_box[d][2 * e];
-                mx[mine][d] = two ? fmaxf(s_box[3 + d][2 * e], s_box[3 + d][2 * e + 1]) : s_box[3 + d][2 * e];
+        for (uint32_t k = 0; k < kPer; k++) {
+            const uint32_t e = threadIdx.x + k * THREADS;
+            if (e < next) {
+                const bool two = 2 * e + 1 < count;
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    mn[k][d] = two ? fminf(s_box[d][2 * e], s_box[d][2 * e + 1]) : s_box[d][2 * e];
+                    mx[k][d] = two ? fmaxf(s_box[3 + d][2 * e], s_box[3 + d][2 * e + 1]) : s_box[3 + d][2 * e];
+                }
             }
         }
         __syncthreads();
-        mine = 0;
-        for (uint32_t e = threadIdx.x; e < next; e += 1024u, mine++) {
 #pragma unroll
-            for (int d = 0; d < 3; d++) { s_box[d][e] = mn[mine][d]; s_box[3 + d][e] = mx[mine][d]; }
-            store_hier(hier, lev + 1, e, mn[mine], mx[mine]);
+        for (uint32_t k = 0; k < kPer; k++) {
+            const uint32_t e = threadIdx.x + k * THREADS;
+            if (e < next) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) { s_box[d][e] = mn[k][d]; s_box[3 + d][e] = mx[k][d]; }
+                store_hier(hier, lev + 1, e, mn[k], mx[k]);
+            }
         }
         __syncthreads();
         count = next;
         lev++;
     }
+}
+
+constexpr uint32_t kTopLds = 4096;
+__global__ __launch_bounds__(1024) void hier_top_kernel(hier_t hier, uint32_t n)
+{
+    __shared__ float s_box[6][kTopLds];
+    hier_top_levels<1024, kTopLds>(hier, n, s_box);
 }
 
 __global__ __launch_bounds__(kAkThreads) void aligned_keys_scan_kernel(int32_t* __restrict__ chunk_max, uint32_t chunks)
@@ -948,12 +961,20 @@ __global__ __launch_bounds__(kAkThreads) void aligned_keys_scan_kernel(int32_t* 
 
 // keys[i] = i + max_{j <= i} term_j, in place over the terms
 // SELF: chunk_excl still holds the raw per-chunk maxima (see distribute_apply_kernel)
+// One workgroup past the chunks (hier.levels != 0) forms the hierarchy's top levels meanwhile: they depend on the gather
+// alone, like this scan — one launch less on the derived lane's critical path (8.5 us + a gap).
+constexpr uint32_t kTopLdsSmall = 1024;
 template <bool SELF>
 __global__ __launch_bounds__(kAkThreads) void aligned_keys_apply_kernel(uint32_t n, const int32_t* __restrict__ chunk_excl,
-                                                                        uint32_t* keys)
+                                                                        uint32_t* keys, hier_t hier)
 {
     __shared__ int32_t s_wave[kAkThreads / LBVH_WAVE];
     __shared__ int32_t s_before[kAkThreads / LBVH_WAVE];
+    if (blockIdx.x * kAkChunk >= n) {          // the extra workgroup
+        __shared__ float s_box[6][kTopLdsSmall];
+        hier_top_levels<kAkThreads, kTopLdsSmall>(hier, n, s_box);
+        return;
+    }
     int32_t carry;
     if (SELF) {
         int32_t part = INT32_MIN;
@@ -1030,12 +1051,17 @@ int lbvh_launch_gather_hier(lbvh_context* ctx, uint32_t n, const lbvh_aabb* d_tr
         int32_t* chunk_max = (int32_t*)ctx->scan_scratch[ctx->lane];
         LBVH_LAUNCH(ctx, gather_hier_kernel<true>, dim3(chunks), dim3(kAkThreads), d_triangle_aabb, d_sorted_indices, n, scene, h,
                     (int32_t*)d_aligned_keys_out, chunk_max);
+        // (with_top: the top levels ride on the apply kernel as one more workgroup)
+        const bool ride = with_top && h.levels > kHierLocalLevels;
         if (chunks <= kSelfScanChunks) {
-            LBVH_LAUNCH(ctx, aligned_keys_apply_kernel<true>, dim3(chunks), dim3(kAkThreads), n, chunk_max, d_aligned_keys_out);
+            LBVH_LAUNCH(ctx, aligned_keys_apply_kernel<true>, dim3(chunks + (ride ? 1u : 0u)), dim3(kAkThreads), n, chunk_max,
+                        d_aligned_keys_out, h);
         } else {
             LBVH_LAUNCH(ctx, aligned_keys_scan_kernel, dim3(1), dim3(kAkThreads), chunk_max, chunks);
-            LBVH_LAUNCH(ctx, aligned_keys_apply_kernel<false>, dim3(chunks), dim3(kAkThreads), n, chunk_max, d_aligned_keys_out);
+            LBVH_LAUNCH(ctx, aligned_keys_apply_kernel<false>, dim3(chunks + (ride ? 1u : 0u)), dim3(kAkThreads), n, chunk_max,
+                        d_aligned_keys_out, h);
         }
+        return LBVH_OK;
     } else {
         LBVH_LAUNCH(ctx, gather_hier_kernel<false>, dim3(chunks), dim3(kAkThreads), d_triangle_aabb, d_sorted_indices, n, scene, h,
                     (int32_t*)nullptr, (int32_t*)nullptr);
