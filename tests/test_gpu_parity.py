@@ -618,6 +618,50 @@ def test_odd_frame_sizes_repeated(ctx):
     d.on_destroy()
 
 
+def test_equal_t_hits_pick_the_lowest_triangle_index_on_every_path(ctx):
+    """coincident triangles are hit at exactly the same t.  The reference keeps whichever its visit order meets
+    first; LBVH_TRACE_FAST keeps the lowest triangle index — on the one-wave packet path, on the cooperative heavy-tile
+    path and for every shard count alike, frame after frame (the dispatch history decides which path a tile takes)."""
+    base = scenes.tiled_torus(nu=40, nv=24, grid=3)                 # 51 840 triangles
+    rng = np.random.default_rng(5)
+    dup = base[rng.choice(len(base), size=len(base) // 2, replace=False)]      # every second triangle exists twice
+    tris = np.concatenate([base, dup])
+    tris = tris[rng.permutation(len(tris))]
+    d, c, b = build_both(ctx, tris)
+    cam = scenes.camera(320, 200, (2.0, -1.0, 95.0))
+    oh, _ = O.trace_primary(b, cam, threads=8)
+    # the expected index of a hit pixel: the lowest index among the triangles that give exactly the oracle's t there
+    d.update(cam, mode=L.TRACE_REFERENCE)
+    ref = d.hits()
+    assert (ref["t"] == oh["t"]).all() and (ref["tri"] == oh["tri"]).all()
+    frames = []
+    for frame in range(3):                                       # full frame: packet path, then cost-ordered
+        d.update(cam, mode=L.TRACE_FAST)
+        frames.append(d.hits())
+    for shards in (2, 8):                                        # shares: cooperative heavy tiles from the second frame on
+        for frame in range(3):
+            d._hits.fill_u32(0x7FC00000)
+            for r in range(shards):
+                d.update_shard(cam, r, shards, mode=L.TRACE_FAST)
+            frames.append(d.hits())
+    first = frames[0]
+    assert (first["t"] == oh["t"]).all()
+    for f in frames[1:]:
+        assert (f == first).all()                                # every field, every frame, every path
+    hit = first["t"] < L.MAX_FLOAT
+    # where the reference's choice has a duplicate with a lower index, the fast mode reports that lower index
+    key = np.stack([tris["a"], tris["b"], tris["c"]], axis=1).reshape(len(tris), -1)
+    _, inverse = np.unique(key, axis=0, return_inverse=True)
+    lowest = np.full(inverse.max() + 1, len(tris), dtype=np.int64)
+    np.minimum.at(lowest, inverse, np.arange(len(tris)))
+    twin = lowest[inverse]                                       # lowest index of each triangle's coincident group
+    same_group = inverse[first["tri"][hit]] == inverse[oh["tri"][hit]]
+    assert same_group.mean() > 0.999                              # (other exact ties: shared edges)
+    assert (first["tri"][hit][same_group] == twin[oh["tri"][hit]][same_group]).all()
+    assert (first["tri"][hit] != oh["tri"][hit]).any()            # the case is really exercised
+    d.on_destroy()
+
+
 def test_camera_inside_the_scene_and_negative_t(ctx):
     """The reference accepts t < 0 hits (no t > 0 test, Raytracing.compute:70) when the leaf box
     straddles the origin; both traversal modes must keep that."""

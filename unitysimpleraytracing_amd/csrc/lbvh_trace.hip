@@ -310,6 +310,16 @@ struct packet_rays {
 
 struct walk_counters { uint32_t pops, box, leaf, tri; };
 
+// The accept rule of LBVH_TRACE_FAST: the reference's strict `t < best` (Raytracing.compute:95) and, among triangles hit
+// at EXACTLY the same t, the lowest triangle index.  The reference keeps whichever of them its own visit order meets
+// first; a walk that visits in another order (near child first here, several waves at once on heavy tiles) needs a rule
+// that does not depend on the order, or tri / u / v of such a pixel would change with the dispatch history and the
+// shard count.  A miss carries t = MAX_FLOAT and index 0, so it never wins a tie.
+__device__ __forceinline__ bool closer(float dist, uint32_t tri, float best_t, uint32_t best_tri)
+{
+    return dist < best_t || (dist == best_t && tri < best_tri);
+}
+
 // Walk the tree for one packet; returns the number of steps (node fetches).
 // stack[slot] := value, both wave-uniform: one v_writelane_b32 (the lane select goes through M0: a vector instruction
 // takes one SGPR operand; both operands come from the scalar unit, so there is no lane-select hazard)
@@ -422,7 +432,7 @@ __device__ __forceinline__ uint32_t walk_packet(const line_source& src, packet_r
                     if (STATS) C.tri++;
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_fast_triangle(P.ray[r], v0, v1, v2, u, v);
-                    if (dist < P.best_t[r]) { P.best_t[r] = dist; P.best_tri[r] = __float_as_uint(v0.w); P.best_u[r] = u; P.best_v[r] = v; }
+                    if (closer(dist, __float_as_uint(v0.w), P.best_t[r], P.best_tri[r])) { P.best_t[r] = dist; P.best_tri[r] = __float_as_uint(v0.w); P.best_u[r] = u; P.best_v[r] = v; }
                 }
                 hit_r[r] = hit_r[r] && !(tr[r] > P.best_t[r]);
                 any_r |= hit_r[r];
@@ -439,7 +449,7 @@ __device__ __forceinline__ uint32_t walk_packet(const line_source& src, packet_r
                     if (STATS) C.tri++;
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_fast_triangle(P.ray[r], v0, v1, v2, u, v);
-                    if (dist < P.best_t[r]) { P.best_t[r] = dist; P.best_tri[r] = __float_as_uint(v0.w); P.best_u[r] = u; P.best_v[r] = v; }
+                    if (closer(dist, __float_as_uint(v0.w), P.best_t[r], P.best_tri[r])) { P.best_t[r] = dist; P.best_tri[r] = __float_as_uint(v0.w); P.best_u[r] = u; P.best_v[r] = v; }
                 }
                 hit_l[r] = hit_l[r] && !(tl[r] > P.best_t[r]);
                 any_l |= hit_l[r];
@@ -644,7 +654,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                     if (STATS) C.tri++;
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_fast_triangle(P.ray[0], v0, v1, v2, u, v);
-                    if (dist < best_t) {
+                    if (dist <= best_t && dist != LBVH_MAX_FLOAT) {    // ties go to the atomic: (t, line index) orders them (see closer())
                         best_t = dist;
                         atomicMin(&S.best[lane], ((unsigned long long)ordered_key(dist) << 32) | (lref & 0x7FFFFFFFu));
                     }
@@ -659,7 +669,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                     if (STATS) C.tri++;
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_fast_triangle(P.ray[0], v0, v1, v2, u, v);
-                    if (dist < best_t) {
+                    if (dist <= best_t && dist != LBVH_MAX_FLOAT) {    // ties go to the atomic: (t, line index) orders them (see closer())
                         best_t = dist;
                         atomicMin(&S.best[lane], ((unsigned long long)ordered_key(dist) << 32) | (rref & 0x7FFFFFFFu));
                     }
