@@ -10,6 +10,7 @@ from unitysimpleraytracing_amd.host import Context, DataBuffer, RaytracingMeshDr
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)) + "/..")
 from bench import yawed
 W, H = 1920, 1080
+SHARDS = int(sys.argv[1]) if len(sys.argv) > 1 else 1          # trace shard 0 of SHARDS (one GPU's share of the frame)
 with Context(0) as ctx:
     d = RaytracingMeshDrawer(ctx, scenes.tiled_torus()).awake()
     hits = DataBuffer(ctx, W * H, L.HIT)
@@ -24,7 +25,7 @@ with Context(0) as ctx:
                 ctx.trace_forget()
             cam = N.Camera.from_dict(cams(k))
             ctx.record(e0)
-            N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(cam), 0, 0, W, H, C.byref(s), L.TRACE_FAST, hits.device, None))
+            N.check(ctx.handle, N.lib.lbvh_trace_primary_shard(ctx.handle, C.byref(cam), 0, SHARDS, C.byref(s), L.TRACE_FAST, hits.device, None))
             ctx.record(e1)
             ms = ctx.elapsed_ms(e0, e1)
             if k >= 4:

@@ -524,6 +524,7 @@ constexpr uint32_t kCoopMaxWork = 12288;   // tiles per launch up to which every
 constexpr uint32_t kSharedMaxWork = 24576; // ... and up to which the very heaviest are (beyond: one wave per tile only)
 constexpr uint32_t kHeavyClassFull = 9;    // above that: only classes >= this (>= 192 steps; half frame: 152 us against 184 / 160 / 193 with 8 / 10 / 11)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kMovedCoopMaxWork = 6144;  // ... when the camera has moved since the costs were recorded (launch_packets)
 constexpr uint32_t kMaxSpread = 4;         // tiles a cost is spread over at most when the camera has moved (file_tiles_kernel)
 
 struct coop_params { uint32_t cap, first_class, grain; };
@@ -975,6 +976,11 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
         spread = (uint32_t)fminf(fmaxf(floorf(tiles + 0.5f), 1.0f), (float)kMaxSpread);
     }
     ctx->trace_camera = a.cam;
+    // (re-measured after the walk's instruction diet: 1/8 frame 90 us with class 7 against 94 / 109 with 8 / 9;
+    // 1/4 frame 139 us with 7 against 117 / 121 with 8 / 9)
+    const uint32_t first_class = n_work <= kCoopMaxWork / 2u ? (uint32_t)kHeavyClass
+                                 : n_work <= kCoopMaxWork   ? (uint32_t)kHeavyClass + 1u
+                                                            : kHeavyClassFull;
     if (have_history) {
         const tile_grid grid = {a.tiles_x, a.tiles_y, a.shard_index, a.shard_count, spread};
         LBVH_LAUNCH(ctx, file_tiles_kernel, dim3((n_work + 1023) / 1024), dim3(1024), cost, n_work, counts, lists, next_counts, grid);
@@ -986,12 +992,14 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     // 6 144 tiles, of 128 or more up to 12 288, only those of 192 steps or more up to 24 576, none beyond — a whole
     // 1080p frame runs the plain kernel: 225 us against 234 / 225 with the heaviest classes cooperative (1080p
     // whole / half / quarter / eighth of the frame at the time: 287 -> 275, 234 -> 190, 226 -> 170, 212 -> 103 us).
-    if (have_history && n_work <= kSharedMaxWork) {
-        // (re-measured after the walk's instruction diet: 1/8 frame 90 us with class 7 against 94 / 109 with 8 / 9;
-        // 1/4 frame 139 us with 7 against 117 / 121 with 8 / 9)
-        const uint32_t first_class = n_work <= kCoopMaxWork / 2u ? (uint32_t)kHeavyClass
-                                     : n_work <= kCoopMaxWork   ? (uint32_t)kHeavyClass + 1u
-                                                                : kHeavyClassFull;
+    // With a camera that has moved the costs are spread over the neighbouring tiles, which is right for the ORDER but
+    // makes every neighbour of a heavy tile a cooperative one (+50 % steps each): half a 1080p frame with a 1 degree
+    // yaw per frame took 0.34 ms that way against 0.156 static and 0.245 with no history at all.  Such a launch keeps
+    // the spread order and walks one wave per tile (0.209 ms); only below 6 144 tiles do cooperative tiles still win
+    // (1/2, 1/3, 1/4, 1/8 of the frame, yaw 1 degree: 0.209 / 0.197 / 0.187 / 0.174 ms with this rule, 0.361 / 0.275 /
+    // 0.232 / 0.174 with cooperative tiles throughout, 0.245 / 0.196 / 0.233 / 0.190 cold).
+    const bool stale_coop = spread != 0 && n_work > kMovedCoopMaxWork;
+    if (have_history && n_work <= kSharedMaxWork && !stale_coop) {
         coop_params hp = {n_work / 4u, first_class, kCoopGrain};
         const uint32_t blocks = hp.cap + (n_work + kCoopWaves - 1) / kCoopWaves;
         if (d_stats)
