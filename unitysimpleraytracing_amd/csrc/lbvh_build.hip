@@ -233,18 +233,82 @@ constexpr int kTreeThreads = 256;
 constexpr int kTreeHalo = 256;
 constexpr int kTreeWindow = kTreeThreads + 2 * kTreeHalo;
 
+typedef __attribute__((address_space(3))) const uint32_t lds_u32;
 struct key_window {
-    const uint32_t* __restrict__ codes;
-    const uint32_t* lds;
+    lds_u32* lds;                                   // an LDS pointer by TYPE (a generic one makes every probe a flat_load)
     int w0, w1;                                     // keys [w0, w1) are lds[0 .. w1 - w0)
     int num;
-    __device__ __forceinline__ uint32_t at(int y) const { return (y >= w0 && y < w1) ? lds[y - w0] : codes[y]; }
-    __device__ __forceinline__ int delta(uint32_t x_code, int y) const                    // :23-33 (x is always in range)
+    __device__ __forceinline__ bool inside(int y) const { return (uint32_t)(y - w0) < (uint32_t)(w1 - w0); }
+    __device__ __forceinline__ uint32_t at(int y) const { return lds[y - w0]; }            // y inside the window
+    // delta(x, y) of BVH.compute:23-33 for a y inside the window (x is always in range); `left` is set when y is a
+    // valid key OUTSIDE the window: the node is a WIDE one and goes to wide_node_search below
+    __device__ __forceinline__ int delta(uint32_t x_code, int y, bool& left) const
     {
-        if (y >= 0 && y <= num - 1) return clz32(x_code ^ at(y));
-        return -1;
+        if (y < 0 || y > num - 1) return -1;
+        if (!inside(y)) { left = true; return -1; }
+        return clz32(x_code ^ at(y));
     }
 };
+
+// ---- wide nodes -------------------------------------------------------------------------------------------------------
+// A node whose searches leave the LDS window (range beyond ~256 leaves: one node in ~128) would run the outside probes
+// as dependent global loads, one after the other while the rest of its wave waits: a handful for most, ~60 for the
+// root.  Such a node is handed to its WAVE instead: all 64 lanes probe at once.  Both searches of the reference are
+// "last position where a monotone predicate still holds" (delta(idx, idx + l d) is non-increasing in l for strictly
+// increasing keys; so is the prefix shared with the first key): any search strategy returns the same position, so a
+// 64-ary search (log64 instead of log2 dependent round trips) is bit-identical.
+// last l in [lo, hi) with pred(l), given pred(lo) and !pred(hi) (hi may be "one past"): all lanes call, result uniform
+template <typename Pred>
+__device__ __forceinline__ uint32_t last_true_64ary(uint32_t lo, uint32_t hi, Pred pred)
+{
+    const uint32_t lane = lane_id();
+    while (hi - lo > 1u) {
+        const uint32_t span = hi - lo;                               // candidates lo+1 .. hi-1
+        const uint32_t step = (span + 63u) / 64u;                    // >= 1; 63 probes lo + step, lo + 2 step, ...
+        const uint32_t l = lo + (lane + 1u) * step;
+        const bool p = lane < 63u && l < hi && pred(l);
+        const uint64_t m = __ballot(p);
+        const uint32_t cnt = (uint32_t)__builtin_ctzll(~m);          // consecutive true from lane 0 (lane 63 never is)
+        lo += cnt * step;
+        hi = min(hi, lo + step);
+    }
+    return lo;
+}
+
+// DetermineRange + FindSplit of node idx by the whole wave (uniform arguments and results)
+__device__ __forceinline__ void wide_node_search(const uint32_t* __restrict__ codes, int num, int idx, int& first, int& last,
+                                                 int& split)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t self = codes[idx];
+    auto dlt = [&](int y) -> int { return (y >= 0 && y <= num - 1) ? clz32(self ^ codes[y]) : -1; };      // :23-33
+    const int dl = dlt(idx - 1), dr = dlt(idx + 1);
+    const int diff = dr - dl;
+    const int d = (diff > 0) - (diff < 0);                                                 // :37
+    const int dmin = d > 0 ? dl : (d < 0 ? dr : clz32(0u));                                // :38
+    // :39-41  lmax = 2; while (delta(idx + lmax d) > dmin) lmax *= 2: lane k tries 2 << k, the first failure ends it
+    uint32_t lmax;
+    {
+        const uint32_t cand = 2u << (lane & 31u);
+        const bool p = lane < 31u && dlt(idx + (int)(cand * (uint32_t)d)) > dmin;
+        const uint64_t m = __ballot(p);
+        lmax = 2u << (uint32_t)__builtin_ctzll(~m);
+    }
+    // :42-47  the largest l < lmax with delta(idx + l d) > dmin (l = 0 always qualifies: delta(idx, idx) = 32)
+    const uint32_t l = last_true_64ary(0u, lmax, [&](uint32_t q) { return dlt(idx + (int)(q * (uint32_t)d)) > dmin; });
+    const int j = idx + (int)l * d;                                                        // :49
+    first = min(idx, j);                                                                   // :50
+    last = max(idx, j);
+    // FindSplit :54-92: the last position in [first, last) that shares more than the range's common prefix with `first`
+    const uint32_t first_code = codes[first], last_code = codes[last];
+    if (first_code == last_code) {
+        split = (first + last) >> 1;                                                       // :61-62
+    } else {
+        const int common_prefix = clz32(first_code ^ last_code);                           // :67
+        split = (int)last_true_64ary((uint32_t)first, (uint32_t)last,
+                                     [&](uint32_t q) { return clz32(first_code ^ codes[q]) > common_prefix; });
+    }
+}
 
 // ---- range hierarchy ------------------------------------------------------------------------------------------
 // The reference refits bottom-up: one thread per leaf climbs to the root, the second arrival at a node merges the
@@ -365,8 +429,7 @@ __global__ __launch_bounds__(kTreeThreads) void tree_kernel(const uint32_t* __re
     const uint32_t thread_id = blockIdx.x * kTreeThreads + threadIdx.x;
     if (thread_id == 0 && zero_word) *zero_word = 0u;      // lbvh_build_tree + lbvh_refit: the refit's frontier counter
     key_window win;
-    win.codes = codes;
-    win.lds = s_keys;
+    win.lds = (lds_u32*)s_keys;
     win.num = (int)n;
     win.w0 = max((int)(blockIdx.x * kTreeThreads) - kTreeHalo, 0);
     win.w1 = min((int)(blockIdx.x * kTreeThreads) + kTreeThreads + kTreeHalo, (int)n);
@@ -376,43 +439,56 @@ __global__ __launch_bounds__(kTreeThreads) void tree_kernel(const uint32_t* __re
     const bool in_range = thread_id < n - 1;                                               // :101
     const int idx = in_range ? (int)thread_id : 0;
     const uint32_t self = win.at(idx);
+    bool wide = false;             // a probe left the window: the node is searched by the whole wave further down
 
     // DetermineRange :35-52
-    const int dl = win.delta(self, idx - 1);
-    const int dr = win.delta(self, idx + 1);
+    const int dl = win.delta(self, idx - 1, wide);
+    const int dr = win.delta(self, idx + 1, wide);
     const int diff = dr - dl;
     const int d = (diff > 0) - (diff < 0);                                                 // sign(), :37
     const int dmin = d > 0 ? dl : (d < 0 ? dr : clz32(0u));                                // :38
     uint32_t lmax = 2;                                                                     // :39
-    while (in_range && win.delta(self, idx + (int)(lmax * (uint32_t)d)) > dmin) lmax *= 2; // :40-41
+    while (in_range && win.delta(self, idx + (int)(lmax * (uint32_t)d), wide) > dmin) lmax *= 2;       // :40-41
     int l = 0;
-    for (uint32_t t = lmax / 2; t >= 1 && in_range; t /= 2) {                              // :43
-        if (win.delta(self, idx + (int)(((uint32_t)l + t) * (uint32_t)d)) > dmin)
+    for (uint32_t t = lmax / 2; t >= 1 && in_range && !wide; t /= 2) {                     // :43
+        if (win.delta(self, idx + (int)(((uint32_t)l + t) * (uint32_t)d), wide) > dmin)
             l += (int)t;                                                                   // :45-46
     }
     const int j = idx + l * d;                                                             // :49
-    const int first = min(idx, j), last = max(idx, j);                                     // :50
+    int first = min(idx, j), last = max(idx, j);                                           // :50
 
     // FindSplit :54-92
     int split = first;
-    if (in_range) {
-        const uint32_t first_code = win.at(first);
-        const uint32_t last_code = win.at(last);
-        if (first_code == last_code) {
-            split = (first + last) >> 1;                                                   // :61-62
+    if (in_range && !wide) {
+        if (!win.inside(first) || !win.inside(last)) {
+            wide = true;
         } else {
-            const int common_prefix = clz32(first_code ^ last_code);                       // :67
-            split = first;
-            int step = last - first;
-            do {
-                step = (step + 1) >> 1;                                                    // :78
-                const int new_split = split + step;
-                if (new_split < last) {
-                    const int split_prefix = clz32(first_code ^ win.at(new_split));
-                    if (split_prefix > common_prefix) split = new_split;                   // :85-86
-                }
-            } while (step > 1);
+            const uint32_t first_code = win.at(first);
+            const uint32_t last_code = win.at(last);
+            if (first_code == last_code) {
+                split = (first + last) >> 1;                                               // :61-62
+            } else {
+                const int common_prefix = clz32(first_code ^ last_code);                   // :67
+                split = first;
+                int step = last - first;
+                do {                                   // (probes stay inside [first, last], hence inside the window)
+                    step = (step + 1) >> 1;                                                // :78
+                    const int new_split = split + step;
+                    if (new_split < last) {
+                        const int split_prefix = clz32(first_code ^ win.at(new_split));
+                        if (split_prefix > common_prefix) split = new_split;               // :85-86
+                    }
+                } while (step > 1);
+            }
         }
+    }
+    // the wave's wide nodes, one after the other, every lane probing
+    for (uint64_t todo = __ballot(in_range && wide); todo != 0; todo &= todo - 1) {
+        const int src = __builtin_ctzll(todo);
+        const int widx = __builtin_amdgcn_readlane(idx, src);
+        int f, la, sp;
+        wide_node_search(codes, (int)n, widx, f, la, sp);
+        if ((int)lane_id() == src) { first = f; last = la; split = sp; }
     }
     const bool valid = in_range && !(split < 0 || (uint32_t)split + 1u >= n);   // invalid: only reachable with non-unique keys
 
