@@ -196,6 +196,40 @@ def test_build_tree_bit_exact(ctx, n):
         b.dispose()
 
 
+def _wide_node_keys(shape, n):
+    i = np.arange(n, dtype=np.uint64)
+    if shape == "dense":                       # every range a power of two: searches end exactly on window borders
+        k = i
+    elif shape == "two_islands":               # the root splits 257 leaves from the left end
+        k = np.where(i < 257, i, (1 << 31) + i)
+    elif shape == "doubling_clusters":         # clusters of 1, 2, 4, ... keys, each under its own high bit pattern
+        c = np.floor(np.log2(i + 1)).astype(np.uint64)
+        k = (c << np.uint64(24)) + (i + 1 - (np.uint64(1) << c))
+    elif shape == "sparse_top":                # long runs that differ in the low bits only, then one far key
+        k = (i >> np.uint64(13) << np.uint64(20)) + (i & np.uint64(8191))
+    else:                                      # "right_heavy": ranges that grow towards the END of the array (d = -1 searches)
+        k = (np.uint64(1) << np.uint64(32)) - np.uint64(1) - _wide_node_keys("doubling_clusters", n)[::-1].astype(np.uint64)
+    k = k.astype(np.uint32)
+    assert (np.diff(k.astype(np.int64)) > 0).all()
+    return k
+
+
+@pytest.mark.parametrize("shape", ["dense", "two_islands", "doubling_clusters", "sparse_top", "right_heavy"])
+@pytest.mark.parametrize("n", [257, 65536, 200001])
+def test_build_tree_wide_nodes_bit_exact(ctx, shape, n):
+    """Nodes whose searches leave the workgroup's LDS key window are searched by the whole wave with a 64-ary search
+    (wide_node_search, lbvh_build.hip): same ranges and splits as BVH.compute:35-92 on key sets built to put range
+    ends and splits on, just before and just after the window borders, in both search directions."""
+    keys = _wide_node_keys(shape, n)
+    cap = n + 3
+    kb, ib, lb = gpu_tree(ctx, keys, n, cap)
+    oi, ol = O.build_tree(keys, n, capacity=cap, threads=8)
+    assert (words(ib.get_data()) == words(oi)).all()
+    assert (words(lb.get_data()) == words(ol)).all()
+    for b in (kb, ib, lb):
+        b.dispose()
+
+
 def test_build_tree_known_answer(ctx):
     keys = np.array([0, 1, 3, 4, 18, 23, 24, 29], dtype=np.uint32)
     kb, ib, lb = gpu_tree(ctx, keys, 8, 8)
