@@ -70,6 +70,7 @@ public static class LbvhNative
 
     // LBVH_TRACE_FAST keeps a dispatch hint from the previous frame; this drops it (the next frame runs as a first frame)
     [DllImport(Lib)] public static extern int lbvh_trace_forget(IntPtr ctx);
+    [DllImport(Lib)] public static extern int lbvh_debug_ray_stack_split(IntPtr ctx, uint ldsEntries);
     // measurement helper: shader clock held under a vector-ALU-bound load, MHz
     [DllImport(Lib)] public static extern int lbvh_clock_probe(IntPtr ctx, out float shaderMhz);
 

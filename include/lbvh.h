@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LBVH_ABI_VERSION 6
+#define LBVH_ABI_VERSION 7
 
 /* ---- status codes ------------------------------------------------------------------------- */
 typedef int32_t lbvh_status;
@@ -384,11 +384,17 @@ typedef struct lbvh_path_state {
 
 /* Closest hit for `count` arbitrary rays taken from the path states (origin, dir; dead paths are skipped and
  * get a miss record): one ray per lane over the derived traversal scene (lbvh_build_fast_scene), near-first,
- * t-pruned, per-lane LDS stack.  Accept rule = the reference's (own-AABB slab test, Moeller-Trumbore, strict
+ * t-pruned, per-lane stack of 64 entries like the reference's (Raytracing.compute:113; the first 16 in LDS, deeper
+ * ones in device memory).  Accept rule = the reference's (own-AABB slab test, Moeller-Trumbore, strict
  * t < best) plus t > t_min, which secondary rays need to leave their surface and the reference lacks
  * (Raytracing.compute:70). */
 lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, float t_min,
                             const lbvh_scene* h_scene, lbvh_hit* d_hits);
+
+/* Test hook: how many of a ray's stack entries live in LDS (1..16, default 16) before the walker of lbvh_trace_rays /
+ * lbvh_path_bounce spills to its device-memory slab.  Results do not depend on it; tests lower it so the deep part
+ * of the stack is exercised by ordinary scenes. */
+lbvh_status lbvh_debug_ray_stack_split(lbvh_context* ctx, uint32_t lds_entries);
 
 /* Camera rays into path states (origin/dir as Raytracing.compute:108-126, throughput 1, radiance 0, alive). */
 lbvh_status lbvh_path_begin(lbvh_context* ctx, const lbvh_camera* h_camera, lbvh_path_state* d_states);

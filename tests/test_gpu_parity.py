@@ -1005,6 +1005,43 @@ def test_secondary_rays_and_path_trace_bit_exact(ctx):
     pt.drawer.on_destroy()
 
 
+@pytest.mark.parametrize("lds_entries", [1, 2, 5])
+def test_secondary_rays_deep_stack_in_device_memory(ctx, lds_entries):
+    """trace_rays_kernel keeps the first 16 stack entries of a lane in LDS and deeper ones in a device-memory slab.
+    With the split lowered to 1 / 2 / 5 entries (lbvh_debug_ray_stack_split) ordinary rays use the slab all the time:
+    hit records identical to the default split's, record for record, and `t` identical to the oracle's."""
+    tris, body, centres = scenes.tiled_torus(nu=40, nv=24, grid=3, with_bodies=True)
+    pt = H().DynamicPathTracer(ctx, tris, body, centres, t_min=1e-3, albedo=0.7, seed=11)
+    b = O.Built(tris, capacity=pt.drawer.container.capacity, threads=8)
+    cam = scenes.camera(200, 120, (0.0, 0.0, 150.0))
+    st = O.path_begin(cam)
+    ph, _ = O.trace_primary(b, cam, threads=8)
+    O.path_scatter(b, ph.reshape(-1), st, 0, 11, 0.7)
+    assert st["alive"].sum() > 2000
+    sb = H().DataBuffer(ctx, len(st), L.PATH_STATE)
+    sb.local[:] = st
+    sb.sync()
+    hb = H().DataBuffer(ctx, len(st), L.HIT)
+    s = pt.drawer.container.scene()
+    n_ = N()
+    assert n_.lib.lbvh_debug_ray_stack_split(ctx.handle, 0) == -1 and n_.lib.lbvh_debug_ray_stack_split(ctx.handle, 17) == -1
+    try:
+        frames = []
+        for split in (16, lds_entries):
+            n_.check(ctx.handle, n_.lib.lbvh_debug_ray_stack_split(ctx.handle, split))
+            hb.local[:] = np.zeros(1, L.HIT)
+            hb.local["t"] = np.nan
+            hb.sync()
+            n_.check(ctx.handle, n_.lib.lbvh_trace_rays(ctx.handle, sb.device, len(st), 1e-3, C.byref(s), hb.device))
+            frames.append(hb.get_data().copy())
+    finally:
+        n_.check(ctx.handle, n_.lib.lbvh_debug_ray_stack_split(ctx.handle, 16))
+    assert (words(frames[0]) == words(frames[1])).all()
+    oh = O.trace_rays(b, st, 1e-3, threads=8)
+    assert (frames[1]["t"] == oh["t"]).all()
+    pt.drawer.on_destroy()
+
+
 @pytest.mark.parametrize("res", [(1, 1), (5, 3), (63, 1), (65, 9)])
 def test_path_trace_tiny_frames(ctx, res):
     """Ray counts below / around one wave: live-ray compaction, lane refill and lbvh_path_bounce at the edges."""

@@ -117,6 +117,7 @@ struct lbvh_context {
 
     // lbvh_trace_rays: live-ray list
     void* ray_scratch = nullptr;
+    uint32_t ray_stack_lds = 16;              // lbvh_debug_ray_stack_split
     size_t ray_scratch_bytes = 0;
 
     // per-kernel event profiling (lbvh_profile_begin / lbvh_profile_end)

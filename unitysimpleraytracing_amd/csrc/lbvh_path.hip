@@ -55,7 +55,12 @@ __global__ __launch_bounds__(256) void path_begin_kernel(lbvh_camera cam, lbvh_p
 // Secondary rays are incoherent, so the packet walk of lbvh_trace.hip does not apply: every lane walks on its
 // own (64-byte fused nodes, near child first, boxes beyond the best hit skipped) with its stack in LDS as
 // [entry][lane].  One wave per workgroup, no barriers.
-constexpr int kRayStack = 34;
+// The first kRayStackLds entries of a lane's stack are in LDS (4 KB per wave: all 32 wave slots of a CU fit; with 34
+// entries in LDS only 18 did and the four bounces took 1.70 ms instead of 1.46), deeper ones — rare: the fused tree
+// is walked near child first — in a per-wave slab of global memory, up to 64 entries in all like the reference's
+// stack (Raytracing.compute:113).
+constexpr int kRayStackLds = 16;
+constexpr int kRayStackDeep = 48;
 
 // Live rays only: alive_rays_kernel writes the miss record of every dead ray and compacts the indices of the live
 // ones (after the first bounce more than half of a frame's paths have left the scene).  (Sorting the live rays by direction octant + Morton code of the origin on top of this was
@@ -90,13 +95,20 @@ __global__ __launch_bounds__(256) void alive_rays_kernel(const lbvh_path_state* 
 // Measured per frame of 4 bounces: no refill 3.75 ms; fixed runs of 128 / 256 / 512 rays 1.83 / 2.62 / 4.44 ms
 // (long runs leave most of the chip empty).
 constexpr uint32_t kRayWaves = 8192;
+// ray scratch: [live-ray count (256 B) | indices of the live rays | deep stack slabs of kRayWaves waves]
+constexpr size_t kDeepBytes = (size_t)kRayWaves * kRayStackDeep * LBVH_WAVE * 4;
+static inline size_t list_bytes(size_t count) { return (count * 4 + 255) & ~(size_t)255; }
+static inline uint32_t* deep_stacks(lbvh_context* ctx, size_t count) { return (uint32_t*)((char*)ctx->ray_scratch + 256 + list_bytes(count)); }
 
 __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* __restrict__ states, const uint32_t* __restrict__ n_alive,
                                                         const uint32_t* __restrict__ list, float t_min,
                                                         const lbvh_fast_node* __restrict__ nodes,
-                                                        const lbvh_fast_tri* __restrict__ tris, lbvh_hit* __restrict__ hits)
+                                                        const lbvh_fast_tri* __restrict__ tris, lbvh_hit* __restrict__ hits,
+                                                        uint32_t* __restrict__ deep,     // [gridDim.x][kRayStackDeep][64]
+                                                        uint32_t lds_depth)              // <= kRayStackLds
 {
-    __shared__ uint32_t s_stack[kRayStack][LBVH_WAVE];
+    __shared__ uint32_t s_stack[kRayStackLds][LBVH_WAVE];
+    uint32_t* my_deep = deep + (size_t)blockIdx.x * (kRayStackDeep * LBVH_WAVE) + threadIdx.x;
     const uint32_t lane = threadIdx.x;
     const uint32_t total = *n_alive;
     const uint32_t run = max((total + gridDim.x - 1) / gridDim.x, (uint32_t)LBVH_WAVE);
@@ -154,14 +166,16 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* _
             if (go_l && go_r) {
                 const bool l_near = tl <= tr;
                 node = l_near ? lref : rref;
-                if (sp < (uint32_t)kRayStack) { s_stack[sp][lane] = l_near ? rref : lref; sp++; }
+                const uint32_t far = l_near ? rref : lref;
+                if (sp < lds_depth) { s_stack[sp][lane] = far; sp++; }
+                else if (sp < lds_depth + (uint32_t)kRayStackDeep) { my_deep[(sp - lds_depth) * LBVH_WAVE] = far; sp++; }
             } else if (go_l) {
                 node = lref;
             } else if (go_r) {
                 node = rref;
             } else if (sp != 0) {
                 sp--;
-                node = s_stack[sp][lane];
+                node = sp < lds_depth ? s_stack[sp][lane] : my_deep[(sp - lds_depth) * LBVH_WAVE];
             } else {
                 float4 out;
                 out.x = best_t;
@@ -331,7 +345,7 @@ lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, 
     }
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     // scratch: [live-ray count (256 B) | indices of the live rays]
-    int rc = lbvh_reserve(ctx, &ctx->ray_scratch, &ctx->ray_scratch_bytes, 256 + count * 4);
+    int rc = lbvh_reserve(ctx, &ctx->ray_scratch, &ctx->ray_scratch_bytes, 256 + list_bytes(count) + kDeepBytes);
     if (rc != LBVH_OK) return rc;
     uint32_t* n_alive = (uint32_t*)ctx->ray_scratch;
     uint32_t* list = (uint32_t*)((char*)ctx->ray_scratch + 256);
@@ -339,8 +353,16 @@ lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, 
     LBVH_LAUNCH(ctx, alive_rays_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), d_states, count, n_alive, list, d_hits);
     const uint32_t ray_waves = (uint32_t)std::min<size_t>(kRayWaves, (count + LBVH_WAVE - 1) / LBVH_WAVE);
     LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive,
-                list, t_min, ctx->fast_nodes, ctx->fast_tris, d_hits);
+                list, t_min, ctx->fast_nodes, ctx->fast_tris, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds);
     LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_debug_ray_stack_split(lbvh_context* ctx, uint32_t lds_entries)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, lds_entries >= 1 && lds_entries <= (uint32_t)kRayStackLds);
+    ctx->ray_stack_lds = lds_entries;
     return LBVH_OK;
 }
 
@@ -369,7 +391,7 @@ lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_
         if (frc != LBVH_OK) return frc;
     }
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = lbvh_reserve(ctx, &ctx->ray_scratch, &ctx->ray_scratch_bytes, 256 + count * 4);
+    int rc = lbvh_reserve(ctx, &ctx->ray_scratch, &ctx->ray_scratch_bytes, 256 + list_bytes(count) + kDeepBytes);
     if (rc != LBVH_OK) return rc;
     uint32_t* n_alive = (uint32_t*)ctx->ray_scratch;
     uint32_t* list = (uint32_t*)((char*)ctx->ray_scratch + 256);
@@ -378,7 +400,7 @@ lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_
                 bounce, seed, albedo, d_states, n_alive, list);
     const uint32_t ray_waves = (uint32_t)std::min<size_t>(kRayWaves, (count + LBVH_WAVE - 1) / LBVH_WAVE);
     LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, ctx->fast_nodes,
-                ctx->fast_tris, d_hits);
+                ctx->fast_tris, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }
