@@ -45,7 +45,7 @@ constexpr int kPasses = 4;
 constexpr uint32_t kFlagAgg = 1u << 30;    // value = this tile's (this group's) digit count
 constexpr uint32_t kFlagIncl = 2u << 30;   // group words: value = digit count of groups 0..this
 constexpr uint32_t kValueMask = (1u << 30) - 1u;
-constexpr int kLook = 4;                   // group words inspected per look-back step
+constexpr int kLook = 2;                   // group words inspected per look-back step
 constexpr int kLbGroup = 8;                // tiles per look-back group
 
 // ---- all four digit histograms in one read of the keys ------------------------------------------
