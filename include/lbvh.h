@@ -411,8 +411,9 @@ lbvh_status lbvh_path_scatter(lbvh_context* ctx, const lbvh_scene* h_scene, cons
 /* lbvh_path_scatter for bounce `bounce` followed by lbvh_trace_rays for the next segment of the paths that go on,
  * as one call: the scatter kernel itself lists those paths, so no pass over all path states is needed before the
  * trace.  d_hits holds the hit records of the segment just traced on entry and those of the next segment on
- * return; records of finished paths are left as they are (a path ends on a miss, so they already read "miss").
- * Same results as the two calls. */
+ * return.  The record of a path that ends in this call (it ends on a miss) becomes {t = MAX_FLOAT, triangle =
+ * 0xFFFFFFFF, 0, 0} — still a miss to every reader; a later lbvh_path_bounce on the same buffers recognises it and
+ * skips the finished path without reading its 64-byte state.  States, radiance and image: the same as the two calls. */
 lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_path_state* d_states, lbvh_hit* d_hits,
                              size_t count, uint32_t bounce, uint32_t seed, float albedo, float t_min);
 

@@ -204,14 +204,18 @@ __device__ __forceinline__ float path_rnd(uint32_t seed, uint32_t index, uint32_
 }
 
 // one path's bounce; returns true when the path goes on
-__device__ __forceinline__ bool scatter_path(const lbvh_triangle* __restrict__ triangles, const lbvh_hit* __restrict__ hits, size_t i,
+// MARK (lbvh_path_bounce, which owns the hit records between its calls): a path that ends leaves a DEAD record in
+// hits[i] (t = MAX_FLOAT, triangle 0xFFFFFFFF), and a later bounce that finds it skips the path without touching its
+// 64-byte state — after the first bounce most of a frame's paths are dead.
+template <bool MARK>
+__device__ __forceinline__ bool scatter_path(const lbvh_triangle* __restrict__ triangles, const lbvh_hit* hits, size_t i,
                                              uint32_t bounce, uint32_t seed, float albedo, lbvh_path_state* __restrict__ states);
 
 // LIST: also append the indices of the paths that go on (one global atomic per workgroup), so that the next
 // segment is traced without a separate pass over all path states
 template <bool LIST>
 __global__ __launch_bounds__(256) void path_scatter_kernel(const lbvh_triangle* __restrict__ triangles,
-                                                           const lbvh_hit* __restrict__ hits, size_t count, uint32_t bounce,
+                                                           const lbvh_hit* hits, size_t count, uint32_t bounce,
                                                            uint32_t seed, float albedo, lbvh_path_state* __restrict__ states,
                                                            uint32_t* __restrict__ n_alive, uint32_t* __restrict__ list)
 {
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void path_scatter_kernel(const lbvh_triangle* 
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
     }
-    const bool on = i < count && scatter_path(triangles, hits, i, bounce, seed, albedo, states);
+    const bool on = i < count && scatter_path<LIST>(triangles, hits, i, bounce, seed, albedo, states);
     if (LIST) {
         const uint64_t m = __ballot(on);
         uint32_t wave_ofs = 0;
@@ -234,14 +238,18 @@ __global__ __launch_bounds__(256) void path_scatter_kernel(const lbvh_triangle* 
     }
 }
 
-__device__ __forceinline__ bool scatter_path(const lbvh_triangle* __restrict__ triangles, const lbvh_hit* __restrict__ hits, size_t i,
+template <bool MARK>
+__device__ __forceinline__ bool scatter_path(const lbvh_triangle* __restrict__ triangles, const lbvh_hit* hits, size_t i,
                                              uint32_t bounce, uint32_t seed, float albedo, lbvh_path_state* __restrict__ states)
 {
-    float4* st = reinterpret_cast<float4*>(&states[i]);
-    float4 o = st[0], d = st[1], thr = st[2], rad = st[3];
-    if (__float_as_uint(o.w) == 0u) return false;
     const float4 h = reinterpret_cast<const float4*>(hits)[i];
-    if (!(h.x < LBVH_MAX_FLOAT)) {
+    const bool missed = !(h.x < LBVH_MAX_FLOAT);
+    if (MARK && missed && __float_as_uint(h.y) == 0xFFFFFFFFu) return false;      // ended in an earlier bounce
+    float4* st = reinterpret_cast<float4*>(&states[i]);
+    float4 o = st[0];
+    if (__float_as_uint(o.w) == 0u) return false;
+    float4 d = st[1], thr = st[2], rad = st[3];
+    if (missed) {
         const float sk = 0.5f * (d.y + 1.0f);
         rad.x = rad.x + thr.x * ((1.0f - sk) * 1.0f + sk * 0.5f);
         rad.y = rad.y + thr.y * ((1.0f - sk) * 1.0f + sk * 0.7f);
@@ -249,6 +257,7 @@ __device__ __forceinline__ bool scatter_path(const lbvh_triangle* __restrict__ t
         o.w = __uint_as_float(0u);
         st[0] = o;
         st[3] = rad;
+        if (MARK) reinterpret_cast<float4*>(const_cast<lbvh_hit*>(hits))[i] = make_float4(LBVH_MAX_FLOAT, __uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f);
         return false;
     }
     if (bounce == 0) rad.w = 1.0f;
