@@ -421,8 +421,10 @@ lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_
 lbvh_status lbvh_path_resolve(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, uint16_t* d_rgba16f);
 
 /* LBVH_TRACE_FAST dispatches a frame's tiles in the order of their step counts in the PREVIOUS trace of the same frame
- * layout (a scheduling hint kept by the context; any order gives the same hits).  This drops that history: the next
- * trace runs as a first frame does (row-major).  For measuring cold frames. */
+ * layout (a scheduling hint kept by the context; any order gives the same hits).  When the camera differs from that
+ * trace's, a tile takes the count of the place it came from: the ray through its centre, at the distance of the scene
+ * box's centre, projected with the previous camera (exact for a turn of the camera), widened by one tile.  This call
+ * drops the history: the next trace runs as a first frame does (row-major).  For measuring cold frames. */
 lbvh_status lbvh_trace_forget(lbvh_context* ctx);
 
 /* Profiling aid: one LBVH_TRACE_FAST frame that also records, per 8x8-pixel tile (row-major,

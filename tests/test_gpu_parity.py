@@ -565,6 +565,56 @@ def test_trace_fast_from_inside_the_scene(ctx, pos, yaw, pitch):
     d.on_destroy()
 
 
+def test_trace_fast_camera_changes_between_frames(ctx):
+    """The dispatch order of a frame comes from the previous frame's tile costs, looked up where the picture came from
+    (file_tiles_kernel: the two cameras' rotation, the change of position at the scene centre's depth).  A hint only:
+    whatever the camera does between two frames — turn, roll, move, look away from the scene and back, a sheared or
+    singular or non-finite previous matrix, another lens — every frame's hits are the oracle's."""
+    tris = scenes.tiled_torus(nu=24, nv=16, grid=3)
+    d, c, b = build_both(ctx, tris)
+    base = scenes.camera(200, 120, (0.0, 0.0, 150.0))
+
+    def with_matrix(cam, fn):
+        m = np.array(cam["camera_to_world"], dtype=np.float32).reshape(4, 4).copy()
+        fn(m)
+        out = dict(cam)
+        out["camera_to_world"] = m.reshape(-1).copy()
+        return out
+
+    def roll(m):
+        a = np.float32(0.3)
+        r = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=np.float32)
+        m[:3, :3] = m[:3, :3] @ r
+
+    def shear(m):
+        m[0, 1] += np.float32(0.25)
+        m[:3, :3] *= np.float32(1.5)
+
+    def singular(m):
+        m[:3, 2] = m[:3, 0]
+
+    wide = dict(base)
+    wide["camera_fov"] = np.float32(0.9)
+    sequence = [base, _rotated(base, 1.0, 0.0), _rotated(base, 3.0, -2.0), with_matrix(base, roll),
+                scenes.camera(200, 120, (4.0, -3.0, 146.0)), _rotated(base, 170.0, 0.0), base,
+                with_matrix(base, shear), base, wide, base, _rotated(scenes.camera(200, 120, (30.0, 10.0, 90.0)), -25.0, 8.0)]
+    for k, cam in enumerate(sequence):
+        if d._hits is not None:
+            d._hits.fill_u32(0xFFFFFFFF)
+        d.update(cam, mode=L.TRACE_FAST)
+        fh = d.hits()
+        oh, _ = O.trace_primary(b, cam, threads=8)
+        assert (fh["t"] == oh["t"]).all(), k
+    # a previous camera whose matrix cannot be inverted, or holds no numbers at all: the next frame files in place
+    ref, _ = O.trace_primary(b, base, threads=8)
+    for fn in (singular, lambda m: m.fill(np.nan), lambda m: m.fill(0.0)):
+        d.update(with_matrix(base, fn), mode=L.TRACE_FAST)          # (its own hits are whatever such a camera sees)
+        d._hits.fill_u32(0xFFFFFFFF)
+        d.update(base, mode=L.TRACE_FAST)
+        assert (d.hits()["t"] == ref["t"]).all()
+    d.on_destroy()
+
+
 @pytest.mark.parametrize("shards", [2, 3, 8])
 def test_shards_union_equals_the_full_frame(ctx, shards):
     """lbvh_trace_primary_shard: one launch per GPU; the shards partition the frame exactly as bench.shard_tiles

@@ -36,4 +36,9 @@ with Context(0) as ctx:
     for deg in (0.25, 1.0, 3.0):
         run(f"yaw {deg} deg/frame", lambda k: yawed(base, deg * (k + 1)))
     run("dolly 1 unit/frame", lambda k: scenes.camera(W, H, (0.0, 0.0, 250.0 - k)))
+    # back and forth, so that the scene stays in view (the one-way turns above end up looking past it)
+    tri = lambda k: abs((k % 16) - 8) - 4            # -4 .. 4 in steps of 1
+    for deg in (1.0, 2.0):
+        run(f"yaw {deg} deg/frame, +-{4 * deg:.0f} deg", lambda k: yawed(base, deg * tri(k)))
+    run("strafe 2 units/frame, +-8", lambda k: scenes.camera(W, H, (2.0 * tri(k), 0.0, 250.0)))
     d.on_destroy()

@@ -109,6 +109,7 @@ struct lbvh_context {
     uint64_t trace_layout = 0;      // frame layout (tiles, shard, origin) the history belongs to
     uint32_t trace_layout_work = 0;
     bool trace_history = false;
+    float fast_centre[3] = {0.0f, 0.0f, 0.0f};   // centre of the scene box the derived scene was built with
     uint32_t trace_counts_turn = 0;  // which of the two class-counter sets the next filing counts into
     lbvh_camera trace_camera = {};   // camera of the trace the history was recorded under
     // the traversal tree of the derived scene (aligned keys, own topology and boxes)

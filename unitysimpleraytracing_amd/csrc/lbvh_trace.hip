@@ -525,7 +525,6 @@ constexpr uint32_t kSharedMaxWork = 24576; // ... and up to which the very heavi
 constexpr uint32_t kHeavyClassFull = 9;    // above that: only classes >= this (>= 192 steps; half frame: 152 us against 184 / 160 / 193 with 8 / 10 / 11)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kMovedCoopMaxWork = 6144;  // ... when the camera has moved since the costs were recorded (launch_packets)
-constexpr uint32_t kMaxSpread = 4;         // tiles a cost is spread over at most when the camera has moved (file_tiles_kernel)
 
 struct coop_params { uint32_t cap, first_class, grain; };
 
@@ -865,12 +864,25 @@ __device__ __forceinline__ uint32_t order_class(uint32_t steps)
     return c > 15u ? 15u : c;
 }
 
-// `spread` > 0 (the camera has moved since the costs were recorded): a tile is filed under the largest cost found within
-// `spread` tiles of it — what was heavy one frame ago is heavy a few tiles further on now, and a heavy tile that starts
-// late is the whole frame's tail (yaw of 1 degree per 1080p frame = 2.3 tiles: 0.320 ms with the stale order, against
-// 0.215 static and 0.309 with no history at all).  Sharded launches only see their own tiles: neighbours owned by
-// other shards are skipped.
-struct tile_grid { uint32_t tiles_x, tiles_y, shard_index, shard_count, spread; };
+// The camera has moved since the costs were recorded (`spread` > 0): the costs are looked up where the picture WAS.
+// The point on the ray through a tile's centre is taken back into the old camera's frame (q = old world-to-camera x
+// new camera-to-world, rotation part; shift = the new position seen from the old camera) and projected with the old
+// projection: exact for a turn of the camera, at the image's edge as well as in its centre (1 degree of yaw at 1080p
+// is 2.3 tiles in the middle and 4.8 at the left and right edge).  What a change of POSITION does depends on depth,
+// which nobody knows here: it is applied at the distance of the scene box's centre, and a tile is filed under the
+// largest cost within `spread` tiles of the place it came from (a heavy tile that starts late is the whole frame's
+// tail).  Parts of the picture that were outside the old frame take the
+// cost of the nearest old tile.  Sharded launches only see their own tiles: places owned by other shards are skipped.
+struct tile_grid {
+    uint32_t tiles_x, tiles_y, shard_index, shard_count, spread;
+    uint32_t reproject;          // 0: look the cost up in place
+    float q[9];                  // new camera space -> old camera space (row-major)
+    float shift[3];              // new camera position in old camera space
+    float depth;                 // distance at which the change of position is applied (the scene box's centre)
+    float cam_w, cam_h, near;    // camera-space extent of the image plane (make_ray)
+    float px_w, px_h;            // screen_width, screen_height
+    int32_t x0, y0;              // the traced rectangle's origin
+};
 
 __device__ __forceinline__ uint32_t item_of_tile(const tile_grid& g, uint32_t tile)      // inverse of shard_tile; ~0u: not owned
 {
@@ -896,7 +908,30 @@ __global__ __launch_bounds__(1024) void file_tiles_kernel(const uint32_t* __rest
         uint32_t c = cost[i];
         const uint32_t tile = shard_tile(i, grid.shard_index, grid.shard_count);
         if (grid.spread != 0 && tile < grid.tiles_x * grid.tiles_y) {
-            const int ty = (int)(tile / grid.tiles_x), tx = (int)(tile - (uint32_t)ty * grid.tiles_x), r = (int)grid.spread;
+            int ty = (int)(tile / grid.tiles_x), tx = (int)(tile - (uint32_t)ty * grid.tiles_x);
+            const int r = (int)grid.spread;
+            if (grid.reproject) {
+                // the ray through the tile's centre (make_ray's camera-space direction), seen from the old camera
+                const float px = (float)grid.x0 + (float)tx * 8.0f + 4.0f, py = (float)grid.y0 + (float)ty * 8.0f + 4.0f;
+                const float d0 = -0.5f * grid.cam_w + grid.cam_w / grid.px_w * px;
+                const float d1 = -0.5f * grid.cam_h + grid.cam_h / grid.px_h * py;
+                const float d2 = -grid.near;
+                // ... as far out as the middle of the scene: that is where the change of position is charged
+                const float s = grid.depth / sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+                const float ox = (grid.q[0] * d0 + grid.q[1] * d1 + grid.q[2] * d2) * s + grid.shift[0];
+                const float oy = (grid.q[3] * d0 + grid.q[4] * d1 + grid.q[5] * d2) * s + grid.shift[1];
+                const float oz = (grid.q[6] * d0 + grid.q[7] * d1 + grid.q[8] * d2) * s + grid.shift[2];
+                if (oz < -1e-6f * grid.near) {                       // in front of the old camera
+                    const float k = grid.near / -oz;
+                    const float opx = (ox * k + 0.5f * grid.cam_w) * (grid.px_w / grid.cam_w);
+                    const float opy = (oy * k + 0.5f * grid.cam_h) * (grid.px_h / grid.cam_h);
+                    const float ftx = floorf((opx - (float)grid.x0) * 0.125f), fty = floorf((opy - (float)grid.y0) * 0.125f);
+                    tx = (int)fminf(fmaxf(ftx, 0.0f), (float)(grid.tiles_x - 1));
+                    ty = (int)fminf(fmaxf(fty, 0.0f), (float)(grid.tiles_y - 1));
+                    const uint32_t k0 = item_of_tile(grid, (uint32_t)ty * grid.tiles_x + (uint32_t)tx);
+                    if (k0 < n_work) c = cost[k0];
+                }
+            }
             for (int dy = -r; dy <= r; dy++)
                 for (int dx = -r; dx <= r; dx++) {
                     const int x = tx + dx, y = ty + dy;
@@ -955,25 +990,58 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     const uint64_t layout = ((uint64_t)a.tiles_x << 48) ^ ((uint64_t)a.tiles_y << 32) ^ ((uint64_t)a.shard_index << 16) ^
                             (uint64_t)a.shard_count ^ ((uint64_t)(uint32_t)a.x0 << 8) ^ ((uint64_t)(uint32_t)a.y0 << 24);
     const bool have_history = ctx->trace_layout == layout && ctx->trace_layout_work == n_work && ctx->trace_history;
-    // How far did the picture move since the costs were recorded?  A turn of the camera shifts it by angle x (pixels per
-    // radian at the image centre); a change of position or of the projection counts as one tile (measured at 1080p:
-    // yaw 0.25 / 1 degree per frame = 0.5 / 2 tiles: spread 1 / 2 give 0.221 / 0.253 ms against 0.246 / 0.315 with
-    // the stale order as it is; spreading further than the motion blurs the order: 0.25 degrees with spread 3: 0.254)
+    // Has the picture moved since the costs were recorded?  Then they are looked up where each tile came from (the
+    // rotation between the two cameras, exact) and spread over one tile around that place (rounding to whole tiles,
+    // and what a change of position does to near geometry).  Measured at 1080p, yaw 1 degree per frame: 0.315 ms with
+    // the stale order as it is, 0.255 with the costs spread over 2 tiles in place (round 2's first form), see DESIGN 7.
     uint32_t spread = 0;
+    tile_grid grid = {};
     if (memcmp(&ctx->trace_camera, &a.cam, sizeof(lbvh_camera)) != 0) {
-        const float* m0 = ctx->trace_camera.camera_to_world;
-        const float* m1 = a.cam.camera_to_world;
-        float worst = 1.0f;                                            // smallest cosine between matching axes
-        for (int c = 0; c < 3; c++) {
-            float dot = 0.0f, l0 = 0.0f, l1 = 0.0f;
-            for (int r = 0; r < 3; r++) { dot += m0[4 * r + c] * m1[4 * r + c]; l0 += m0[4 * r + c] * m0[4 * r + c]; l1 += m1[4 * r + c] * m1[4 * r + c]; }
-            const float cs = (l0 > 0.0f && l1 > 0.0f) ? dot / sqrtf(l0 * l1) : 0.0f;
-            worst = fminf(worst, cs);
+        spread = 1;
+        const lbvh_camera& c0 = ctx->trace_camera;
+        const lbvh_camera& c1 = a.cam;
+        const bool same_lens = c0.screen_width == c1.screen_width && c0.screen_height == c1.screen_height &&
+                               c0.camera_fov == c1.camera_fov && c0.near_plane == c1.near_plane;
+        // q = inverse(R0) x R1 over the rotation parts (general 3x3 inverse: Unity's matrix carries a z flip)
+        const float* m = c0.camera_to_world;
+        const double r0[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
+        const double det = r0[0] * (r0[4] * r0[8] - r0[5] * r0[7]) - r0[1] * (r0[3] * r0[8] - r0[5] * r0[6]) +
+                           r0[2] * (r0[3] * r0[7] - r0[4] * r0[6]);
+        if (same_lens && fabs(det) > 1e-12 && c1.camera_fov > 0.0f && c1.near_plane > 0.0f) {
+            const double inv[9] = {(r0[4] * r0[8] - r0[5] * r0[7]) / det, (r0[2] * r0[7] - r0[1] * r0[8]) / det, (r0[1] * r0[5] - r0[2] * r0[4]) / det,
+                                   (r0[5] * r0[6] - r0[3] * r0[8]) / det, (r0[0] * r0[8] - r0[2] * r0[6]) / det, (r0[2] * r0[3] - r0[0] * r0[5]) / det,
+                                   (r0[3] * r0[7] - r0[4] * r0[6]) / det, (r0[1] * r0[6] - r0[0] * r0[7]) / det, (r0[0] * r0[4] - r0[1] * r0[3]) / det};
+            const float* n = c1.camera_to_world;
+            const double r1[9] = {n[0], n[1], n[2], n[4], n[5], n[6], n[8], n[9], n[10]};
+            bool finite = true;
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) {
+                    const double v = inv[3 * r + 0] * r1[0 + c] + inv[3 * r + 1] * r1[3 + c] + inv[3 * r + 2] * r1[6 + c];
+                    grid.q[3 * r + c] = (float)v;
+                    finite = finite && std::isfinite(grid.q[3 * r + c]);
+                }
+            // the new camera's position seen from the old one, and how far out the scene is
+            const double dp[3] = {(double)n[3] - m[3], (double)n[7] - m[7], (double)n[11] - m[11]};
+            for (int r = 0; r < 3; r++) {
+                grid.shift[r] = (float)(inv[3 * r + 0] * dp[0] + inv[3 * r + 1] * dp[1] + inv[3 * r + 2] * dp[2]);
+                finite = finite && std::isfinite(grid.shift[r]);
+            }
+            {
+                const double cx = (double)ctx->fast_centre[0] - n[3], cy = (double)ctx->fast_centre[1] - n[7], cz = (double)ctx->fast_centre[2] - n[11];
+                grid.depth = (float)sqrt(cx * cx + cy * cy + cz * cz);
+                finite = finite && std::isfinite(grid.depth) && grid.depth > 0.0f;
+            }
+            if (finite) {
+                grid.reproject = 1;
+                grid.near = c1.near_plane;
+                grid.cam_h = 2.0f * c1.near_plane * c1.camera_fov;
+                grid.cam_w = (float)c1.screen_width * grid.cam_h / (float)c1.screen_height;
+                grid.px_w = (float)c1.screen_width;
+                grid.px_h = (float)c1.screen_height;
+                grid.x0 = a.x0;
+                grid.y0 = a.y0;
+            }
         }
-        const float angle = acosf(fminf(fmaxf(worst, -1.0f), 1.0f));
-        const float px_per_rad = (float)a.cam.screen_height / (2.0f * fmaxf(a.cam.camera_fov, 1e-6f));
-        const float tiles = angle * px_per_rad / 8.0f;
-        spread = (uint32_t)fminf(fmaxf(floorf(tiles + 0.5f), 1.0f), (float)kMaxSpread);
     }
     ctx->trace_camera = a.cam;
     // (re-measured after the walk's instruction diet: 1/8 frame 90 us with class 7 against 94 / 109 with 8 / 9;
@@ -982,7 +1050,8 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
                                  : n_work <= kCoopMaxWork   ? (uint32_t)kHeavyClass + 1u
                                                             : kHeavyClassFull;
     if (have_history) {
-        const tile_grid grid = {a.tiles_x, a.tiles_y, a.shard_index, a.shard_count, spread};
+        grid.tiles_x = a.tiles_x; grid.tiles_y = a.tiles_y; grid.shard_index = a.shard_index; grid.shard_count = a.shard_count;
+        grid.spread = spread;
         LBVH_LAUNCH(ctx, file_tiles_kernel, dim3((n_work + 1023) / 1024), dim3(1024), cost, n_work, counts, lists, next_counts, grid);
         ctx->trace_counts_turn ^= 1u;
     }
@@ -1060,6 +1129,7 @@ static lbvh_status build_fast_scene_parts(lbvh_context* ctx, const lbvh_scene* h
     // (lbvh_build.hip) and its own boxes.  The scene's internalNodes / leafNodes / bvhData — the
     // reference's bit-exact arrays — are not read here: any tree over the same leaves gives the same
     // hits (every leaf keeps its own AABB test), a tighter one just gives them sooner.
+    for (int k = 0; k < 3; k++) ctx->fast_centre[k] = 0.5f * (h_box_min[k] + h_box_max[k]);      // (launch_packets: depth proxy)
     int rc = lbvh_reserve(ctx, &ctx->fast_tree, &ctx->fast_tree_bytes, (size_t)s.n * 4);
     if (rc != LBVH_OK) return rc;
     uint32_t* t_keys = (uint32_t*)ctx->fast_tree;
