@@ -1110,3 +1110,15 @@ def test_path_trace_tiny_frames(ctx, res):
         assert same.mean() > 0.98 or same.size < 64
         assert (img.view(np.uint16).reshape(-1, 4)[same] == oimg.view(np.uint16).reshape(-1, 4)[same]).all()
     pt.drawer.on_destroy()
+
+
+def test_randomised_parity_soak_short():
+    """tools/fuzz_parity.py for 15 seconds with a fixed seed: random sorts, random scenes (soup, tori, duplicated and
+    degenerate triangles, one Morton cell, outside the scene box) built staged and through lbvh_build_scene, random
+    cameras / resolutions / shard counts over several frames, all against the oracle.  (Longer runs: the tool itself.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "15", "20261003"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all equal" in r.stdout

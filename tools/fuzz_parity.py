@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Randomised parity soak (GPU box): for a time budget, draw scenes of random size and shape (uniform soup, clustered
+soup with duplicated triangles, degenerate slivers, tiled tori, all triangles in one Morton cell, triangles outside the
+scene box), build them through lbvh_build_scene AND through the staged calls, and compare every array with the CPU
+oracle; trace a random camera (inside / outside the scene, random resolution incl. ragged tiles, random shard count,
+two or three frames so cost-ordered / cooperative / reprojected dispatch all run) in fast and reference mode against the
+oracle's frame.  Also sorts random (key, value) arrays of random size and digit structure.  Prints one line per case and a
+summary; exits non-zero on the first mismatch.   usage: python tools/fuzz_parity.py [seconds] [seed]"""
+import ctypes as C, math, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle as O
+from unitysimpleraytracing_amd import _native as N, layouts as L, scenes
+from unitysimpleraytracing_amd.host import Context, DataBuffer, RaytracingMeshDrawer
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) & 0xFFFFFF
+rng = np.random.default_rng(seed0)
+print("seed", seed0, "budget", budget, "s", flush=True)
+
+
+def words(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def make_scene(kind, n):
+    if kind == "soup":
+        return scenes.random_triangles(n, seed=int(rng.integers(1 << 30)))
+    if kind == "torus":
+        nu = int(rng.integers(6, 40)); nv = int(rng.integers(4, 24)); g = int(rng.integers(1, 4))
+        return scenes.tiled_torus(nu=nu, nv=nv, grid=g, seed=int(rng.integers(1 << 30)))
+    t = scenes.random_triangles(n, seed=int(rng.integers(1 << 30)))
+    if kind == "dups":               # every triangle several times over + a cluster in one cell
+        k = max(n // 4, 1)
+        t[k:2 * k] = t[:k][: len(t[k:2 * k])]
+        t[2 * k:3 * k] = t[:k][: len(t[2 * k:3 * k])]
+        for f in ("a", "b", "c"):
+            t[f][3 * k:] = t[f][3 * k:] * np.float32(1e-3)
+    elif kind == "one_cell":
+        for f in ("a", "b", "c"):
+            t[f] = t[f] * np.float32(1e-4) + np.float32(17.0)
+    elif kind == "slivers":
+        t["b"] = t["a"] + (t["b"] - t["a"]) * np.float32(1e-6)
+    elif kind == "outside":
+        for f in ("a", "b", "c"):
+            t[f] = t[f] * np.float32(3.0)
+    return t
+
+
+def random_camera(w, h):
+    pos = tuple(float(x) for x in rng.uniform(-140, 140, 3)) if rng.random() < 0.5 else (0.0, 0.0, float(rng.uniform(150, 400)))
+    cam = scenes.camera(w, h, pos)
+    if rng.random() < 0.7:
+        yaw, pitch = math.radians(rng.uniform(-180, 180)), math.radians(rng.uniform(-60, 60))
+        cy, sy, cp, sp = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch)
+        R = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+        m = np.array(cam["camera_to_world"], dtype=np.float32).reshape(4, 4).copy()
+        m[:3, :3] = (R @ m[:3, :3].astype(np.float64)).astype(np.float32)
+        cam = dict(cam); cam["camera_to_world"] = m.reshape(-1).copy()
+    return cam
+
+
+cases = 0
+t_end = time.time() + budget
+with Context(0) as ctx:
+    while time.time() < t_end:
+        cases += 1
+        # ---- a sort ------------------------------------------------------------------------------------------------
+        count = int(rng.choice([rng.integers(1, 5000), rng.integers(5000, 400000), rng.integers(400000, 3000000)]))
+        shift = int(rng.integers(0, 25))
+        keys = (rng.integers(0, 1 << 32, size=count, dtype=np.uint64) >> np.uint64(shift) << np.uint64(rng.integers(0, shift + 1))).astype(np.uint32)
+        if rng.random() < 0.3:
+            keys[count - count // 5:] = 0xFFFFFFFF
+        vals = rng.permutation(count).astype(np.uint32)
+        kb = DataBuffer(ctx, count, np.uint32); vb = DataBuffer(ctx, count, np.uint32)
+        kb.local[:] = keys; vb.local[:] = vals; kb.sync(); vb.sync()
+        N.check(ctx.handle, N.lib.lbvh_sort_pairs(ctx.handle, kb.device, vb.device, count))
+        ok, ov = O.sort_pairs(keys, vals)
+        assert (kb.get_data() == ok).all() and (vb.get_data() == ov).all(), ("sort", count, shift)
+        kb.dispose(); vb.dispose()
+        # ---- a scene -----------------------------------------------------------------------------------------------
+        kind = str(rng.choice(["soup", "torus", "dups", "one_cell", "slivers", "outside"]))
+        n = int(rng.choice([rng.integers(2, 70), rng.integers(70, 3000), rng.integers(3000, 120000)]))
+        tris = make_scene(kind, n)
+        n = len(tris)
+        d = RaytracingMeshDrawer(ctx, tris).awake(fast=True)
+        c = d.container
+        b = O.Built(tris, capacity=c.capacity, threads=8)
+        for how in ("awake", "rebuild", "rebuild"):                      # staged chain, then lbvh_build_scene (plain, then graph)
+            if how == "rebuild":
+                c.bvh_internal_node.fill_u32(0, mirror=False); c.bvh_data.fill_u32(0x7FC00000, mirror=False)
+                d.rebuild(fast=True)
+            bad_leaf, bad_inner = c.get_all_gpu_data()
+            assert len(bad_leaf) == 0 and len(bad_inner) == 0, (kind, n, how)
+            assert (c.keys.local == b.keys).all() and (c.triangle_index.local == b.indices).all(), (kind, n, how, "keys")
+            assert (words(c.bvh_internal_node.local)[: 6 * (n - 1)] == words(b.internal)[: 6 * (n - 1)]).all(), (kind, n, how, "internal")
+            assert (words(c.bvh_leaf_node.local)[: 2 * n] == words(b.leaf)[: 2 * n]).all(), (kind, n, how, "leaf")
+            assert (c.bvh_data.local["min"][: n - 1] == b.bvh["min"][: n - 1]).all() and (c.bvh_data.local["max"][: n - 1] == b.bvh["max"][: n - 1]).all(), (kind, n, how, "boxes")
+        w, h = int(rng.integers(1, 260)), int(rng.integers(1, 140))
+        cam = random_camera(w, h)
+        oh, _ = O.trace_primary(b, cam, threads=8)
+        shards = int(rng.choice([1, 1, 2, 3, 8]))
+        for frame in range(3):
+            cam_f = cam
+            d._hits = None if frame == 0 else d._hits
+            if shards == 1:
+                d.update(cam_f, mode=L.TRACE_FAST)
+                fh = d.hits()
+            else:
+                for r in range(shards):
+                    d.update_shard(cam_f, r, shards, mode=L.TRACE_FAST)
+                fh = d.hits()
+            assert (fh["t"] == oh["t"]).all(), (kind, n, w, h, shards, frame, "fast t")
+        d.update(cam, mode=L.TRACE_REFERENCE)
+        rh = d.hits()
+        assert (words(rh) == words(oh)).all(), (kind, n, w, h, "reference hits")
+        # a second camera: the history of the first one is reprojected
+        cam2 = random_camera(w, h)
+        oh2, _ = O.trace_primary(b, cam2, threads=8)
+        d.update(cam2, mode=L.TRACE_FAST)
+        assert (d.hits()["t"] == oh2["t"]).all(), (kind, n, w, h, "second camera")
+        d.on_destroy()
+        print(f"case {cases}: sort {count} >> {shift}; {kind} n={n} {w}x{h} shards {shards}: ok", flush=True)
+print("cases", cases, "all equal")
