@@ -114,9 +114,19 @@ with Context(0) as ctx:
         d.update(cam, mode=L.TRACE_REFERENCE)
         rh = d.hits()
         assert (words(rh) == words(oh)).all(), (kind, n, w, h, "reference hits")
+        # a sub-rectangle of the frame, two frames (its own history), then the same rectangle from a turned camera
+        if w >= 3 and h >= 3:
+            x0, y0 = int(rng.integers(0, w - 1)), int(rng.integers(0, h - 1))
+            x1, y1 = int(rng.integers(x0 + 1, w + 1)), int(rng.integers(y0 + 1, h + 1))
+            for frame in range(2):
+                d.update(cam, rect=(x0, y0, x1, y1), mode=L.TRACE_FAST)
+                assert (d.hits()["t"] == oh["t"][y0:y1, x0:x1]).all(), (kind, n, w, h, (x0, y0, x1, y1), frame, "rectangle")
         # a second camera: the history of the first one is reprojected
         cam2 = random_camera(w, h)
         oh2, _ = O.trace_primary(b, cam2, threads=8)
+        if w >= 3 and h >= 3:
+            d.update(cam2, rect=(x0, y0, x1, y1), mode=L.TRACE_FAST)
+            assert (d.hits()["t"] == oh2["t"][y0:y1, x0:x1]).all(), (kind, n, w, h, "rectangle, second camera")
         d.update(cam2, mode=L.TRACE_FAST)
         assert (d.hits()["t"] == oh2["t"]).all(), (kind, n, w, h, "second camera")
         d.on_destroy()
