@@ -10,7 +10,7 @@
 //                         left, push right, pop right first; no pruning) — the parity mode and the
 //                         source of the reference-semantics visit counters.
 //   LBVH_TRACE_FAST       walks the derived 64-byte fused nodes (both child boxes + child refs in
-//                         one fetch, leaf triangles pre-gathered to 64-byte lines in sorted order), visits
+//                         one fetch, the triangles as 64-byte lines in the caller's order behind them), visits
 //                         the nearer child first and skips boxes that start beyond the best hit.
 //                         Same candidate set minus boxes that cannot win => same min t.
 //
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void build_fast_tris_kernel(const lbvh_triangl
 //     by v_readlane with a scalar stack pointer — no LDS, no scratch;
 //   * all control flow is scalar (conditions come from ballots).
 // The kernel is bound by instruction issue (68 vector + 49 scalar instructions per step, vector
-// issue 84 % busy over the frame), so the step is written for instruction count: see walk_packet's SIGNS form.
+// issue 88-91 % busy over the frame), so the step is written for instruction count: see walk_packet's SIGNS form.
 // Each lane still sees every node it would visit alone (it votes for it), the leaf's own AABB slab
 // test gates the triangle test per lane, and the accept rule is the reference's strict t < best —
 // so per-ray results equal the reference order's min t.
@@ -247,7 +247,7 @@ struct uniform_node {        // one fused node, wave-uniform (lives in SGPRs)
 // the scalar cache's miss path, which several CUs share — measured again at the end of round 1: 0.315 vs 0.285 ms):
 // lane k loads dword k & 15, i.e. one coalesced 64-byte line per 16-lane row through the CU's vector L1.
 #define LBVH_RL(v, k) __int_as_float(__builtin_amdgcn_readlane((v), (k)))
-// a 64-byte line (node or sorted triangle) by reference: the address is base + (index << 6), computed on the scalar
+// a 64-byte line (node or triangle) by reference: the address is base + (index << 6), computed on the scalar
 // unit; the load takes it as an SGPR base + the lane's constant byte offset (no vector address arithmetic in the walk)
 __device__ __forceinline__ int fetch_line_dword(const lbvh_fast_node* __restrict__ lines, uint32_t ref, uint32_t lane_bytes)
 {
@@ -290,7 +290,7 @@ __device__ __forceinline__ uniform_node broadcast_node(int w)
     return nd;
 }
 
-// same for a sorted-triangle line (lbvh_fast_tri: v0 and index in dwords 0-3, e1 in 8-10, e2 in 7, 11, 15)
+// same for a triangle line (lbvh_fast_tri: v0 and index in dwords 0-3, e1 in 8-10, e2 in 7, 11, 15)
 __device__ __forceinline__ void broadcast_tri(int w, float4& v0, float4& v1, float4& v2)
 {
     v0 = make_float4(LBVH_RL(w, 0), LBVH_RL(w, 1), LBVH_RL(w, 2), LBVH_RL(w, 3));
@@ -515,7 +515,7 @@ __device__ __forceinline__ void tile_rays(const trace_args& a, uint32_t tile, ui
 // 287 us for all of it) is the critical path of its heaviest tile — hundreds of dependent fetch -> test -> vote
 // steps.  Tiles the previous trace filed under the heavy cost classes are therefore walked by kCoopWaves waves
 // together: every wave walks its own chain with a private stack, the packet's 64 best hits live in LDS (64-bit
-// atomic min on (ordered t, sorted triangle position): pruning is shared by all waves), and a wave with spare
+// atomic min on (ordered t, line index of the triangle): pruning is shared by all waves), and a wave with spare
 // stack entries hands its OLDEST one (the largest unvisited subtree) to an idle wave through a small LDS list.
 constexpr int kCoopWaves = 8;
 constexpr int kHeavyClass = 7;             // cost classes >= this (>= 96 steps) are walked cooperatively
@@ -548,7 +548,7 @@ __device__ __forceinline__ float key_value(uint32_t k)
 }
 
 struct coop_shared {
-    unsigned long long best[64];     // per ray: ordered t << 32 | sorted triangle position
+    unsigned long long best[64];     // per ray: ordered t << 32 | line index of the triangle
     uint32_t give[32];               // subtrees on offer
     uint32_t give_n, lock, idle, steps;
 };
