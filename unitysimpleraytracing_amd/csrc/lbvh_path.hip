@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void path_begin_kernel(lbvh_camera cam, lbvh_p
 
 // ---- arbitrary rays: one ray per lane over the derived traversal scene -----------------------------------
 // Secondary rays are incoherent, so the packet walk of lbvh_trace.hip does not apply: every lane walks on its
-// own (64-byte fused nodes, near child first, boxes beyond the best hit skipped) with its stack in LDS as
+// own (64-byte fused nodes, near child first, boxes beyond the best hit skipped) with a stack of its own, laid out
 // [entry][lane].  One wave per workgroup, no barriers.
 // The first kRayStackLds entries of a lane's stack are in LDS (4 KB per wave: all 32 wave slots of a CU fit; with 34
 // entries in LDS only 18 did and the four bounces took 1.70 ms instead of 1.46), deeper ones — rare: the fused tree
