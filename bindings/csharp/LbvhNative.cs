@@ -25,6 +25,14 @@ public static class LbvhNative
         public fixed float cameraToWorld[16];      // row-major m00..m33 (Matrix4x4 m00,m01,...)
     }
 
+    [StructLayout(LayoutKind.Sequential, CharSet = CharSet.Ansi)]
+    public struct ProfileRow
+    {
+        [MarshalAs(UnmanagedType.ByValTStr, SizeConst = 48)] public string name;     // char name[48]
+        public uint launches;
+        public float totalMs;
+    }
+
     [StructLayout(LayoutKind.Sequential)]
     public struct Scene
     {
@@ -73,6 +81,21 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern int lbvh_debug_ray_stack_split(IntPtr ctx, uint ldsEntries);
     // measurement helper: shader clock held under a vector-ALU-bound load, MHz
     [DllImport(Lib)] public static extern int lbvh_clock_probe(IntPtr ctx, out float shaderMhz);
+    // a context whose work is ordered by a stream the caller owns (hipStream_t), e.g. an interop stream
+    [DllImport(Lib)] public static extern int lbvh_create_on_stream(int deviceId, IntPtr hipStream, out IntPtr ctx);
+    // one LBVH_TRACE_FAST frame that also records the node fetches of every 8x8-pixel tile
+    [DllImport(Lib)] public static extern int lbvh_trace_tile_costs(IntPtr ctx, ref Camera camera, ref Scene scene, IntPtr dHits,
+        IntPtr dStats, IntPtr dTileSteps);
+    // HIP events on the context's stream, per-kernel timing rows, the float4 copy the sort's roofline is quoted against
+    [DllImport(Lib)] public static extern int lbvh_event_create(IntPtr ctx, out IntPtr ev);
+    [DllImport(Lib)] public static extern int lbvh_event_destroy(IntPtr ctx, IntPtr ev);
+    [DllImport(Lib)] public static extern int lbvh_event_record(IntPtr ctx, IntPtr ev);
+    [DllImport(Lib)] public static extern int lbvh_event_elapsed_ms(IntPtr ctx, IntPtr start, IntPtr stop, out float ms);
+    [DllImport(Lib)] public static extern int lbvh_profile_begin(IntPtr ctx);
+    [DllImport(Lib)] public static extern int lbvh_profile_end(IntPtr ctx, [Out] ProfileRow[] rows, int maxRows, out int nRows);
+    [DllImport(Lib)] public static extern int lbvh_copy_bandwidth_probe(IntPtr ctx, IntPtr dDst, IntPtr dSrc, UIntPtr bytes);
+    // host-side model of the sort's tile hand-out order (no GPU involved)
+    [DllImport(Lib)] public static extern uint lbvh_debug_sort_ticket_tile(uint k, uint x, uint group, uint queues);
 
     // dynamic scene + secondary rays (BASELINE configs[4]; extension, no reference counterpart)
     [DllImport(Lib)] public static extern int lbvh_animate(IntPtr ctx, IntPtr dRestTriangles, uint n, IntPtr dBodyIds, IntPtr dBodyCentres,

@@ -135,3 +135,21 @@ def test_sort_ticket_order_model(queues, group, tiles):
                     running[x] = [t for t in running[x] if t >= low]
                     progressed = True
             assert progressed, f"stranded: lowest missing tile {low}, resident {running}"
+
+
+def test_csharp_binding_declares_every_entry_point_with_the_headers_arity():
+    """bindings/csharp/LbvhNative.cs cannot be compiled here (no C# toolchain): at least every function of include/lbvh.h
+    has a [DllImport] of the same name and parameter count, nothing else is imported, and each name is exported."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "lbvh.h")).read(), flags=re.S)
+    protos = re.findall(r"\b(?:lbvh_status|int32_t|uint32_t|const char\*)\s+(lbvh_\w+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S)
+    c = {name: (0 if args.strip() in ("", "void") else len(args.split(","))) for name, args in protos}
+    cs = re.sub(r"//.*", "", open(os.path.join(root, "bindings", "csharp", "LbvhNative.cs")).read())
+    imports = re.findall(r"\[DllImport\(Lib\)\]\s*public static extern \w+\s+(lbvh_\w+)\s*\(([^;]*?)\)\s*;", cs, flags=re.S)
+    d = {name: (0 if not args.strip() else len(args.split(","))) for name, args in imports}
+    assert len(c) >= 40 and set(c) == set(d), (sorted(set(c) - set(d)), sorted(set(d) - set(c)))
+    assert not [(k, c[k], d[k]) for k in c if c[k] != d[k]]
+    from unitysimpleraytracing_amd import _native as N
+    for name in d:
+        assert hasattr(N.lib, name), name
