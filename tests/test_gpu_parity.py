@@ -944,6 +944,7 @@ def test_cpp_host_driver_matches_oracle():
     hit = oh["t"] < L.MAX_FLOAT
     assert res["hits"] == int(hit.sum())
     assert abs(res["t_sum"] - float(oh["t"][hit].astype(np.float64).sum())) < 1e-3
+    assert res["shards_equal"] is True and res["update_device_ms"] > 0.0       # UpdateShard x 3 == Update; lbvh::Event
 
 
 def test_cpp_dynamic_path_tracer_matches_oracle():

@@ -76,9 +76,22 @@ int main(int argc, char** argv)
         cam.near_plane = 0.3f;
         const float m[16] = {-1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 300, 0, 0, 0, 1};
         std::memcpy(cam.camera_to_world, m, sizeof m);
+        lbvh::Event e0(ctx), e1(ctx);
+        e0.record();
         drawer.Update(cam, LBVH_TRACE_FAST);
+        e1.record();
         ctx.sync();
         auto t2 = std::chrono::steady_clock::now();
+        const float update_device_ms = lbvh::Event::elapsed_ms(e0, e1);
+        // the same frame as three shards traced one after the other into the one buffer: must reproduce it exactly
+        drawer.Hits().GetData();
+        const std::vector<lbvh_hit> whole = drawer.Hits().LocalBuffer();
+        drawer.Hits().Fill(0xFFFFFFFFu);
+        for (uint32_t r = 0; r < 3; r++) drawer.UpdateShard(cam, r, 3, LBVH_TRACE_FAST);
+        drawer.Hits().GetData();
+        const bool shards_equal = std::memcmp(whole.data(), drawer.Hits().LocalBuffer().data(), whole.size() * sizeof(lbvh_hit)) == 0;
+        ctx.trace_forget();
+        drawer.Update(cam, LBVH_TRACE_FAST);
         drawer.Container().GetAllGpuData();          // throws on a corrupted node (MeshBufferContainer.cs:181-195)
         drawer.Hits().GetData();
         uint64_t key_sum = 0, node_sum = 0;
@@ -91,11 +104,11 @@ int main(int argc, char** argv)
         double tsum = 0;
         for (size_t i = 0; i < (size_t)w * h; i++)
             if (drawer.Hits().LocalBuffer()[i].t < LBVH_MAX_FLOAT) { hits++; tsum += drawer.Hits().LocalBuffer()[i].t; }
-        std::printf("{\"triangles\": %u, \"rays\": %d, \"awake_ms\": %.3f, \"update_ms\": %.3f, \"key_sum\": %llu, "
-                    "\"node_sum\": %llu, \"hits\": %zu, \"t_sum\": %.6f}\n",
+        std::printf("{\"triangles\": %u, \"rays\": %d, \"awake_ms\": %.3f, \"update_ms\": %.3f, \"update_device_ms\": %.4f, "
+                    "\"key_sum\": %llu, \"node_sum\": %llu, \"hits\": %zu, \"t_sum\": %.6f, \"shards_equal\": %s}\n",
                     n, w * h, std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                    std::chrono::duration<double, std::milli>(t2 - t1).count(), (unsigned long long)key_sum,
-                    (unsigned long long)node_sum, hits, tsum);
+                    std::chrono::duration<double, std::milli>(t2 - t1).count(), update_device_ms, (unsigned long long)key_sum,
+                    (unsigned long long)node_sum, hits, tsum, shards_equal ? "true" : "false");
     } catch (const lbvh::Error& e) {
         std::fprintf(stderr, "%s\n", e.what());
         return 1;

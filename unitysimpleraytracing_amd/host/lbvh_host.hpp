@@ -32,14 +32,51 @@ inline void check(lbvh_context* ctx, lbvh_status s)
 // The implicit Unity graphics device + IShaderContainer (Assets/_Scripts/ShaderContainer.cs:6-40).
 class Context {
 public:
-    explicit Context(int device_id = 0) { check(nullptr, lbvh_create(device_id, &ctx_)); }
+    explicit Context(int device_id = 0)
+    {
+        check_abi();
+        check(nullptr, lbvh_create(device_id, &ctx_));
+    }
+    // a context whose work is ordered by a stream the caller owns (hipStream_t)
+    Context(int device_id, void* hip_stream)
+    {
+        check_abi();
+        check(nullptr, lbvh_create_on_stream(device_id, hip_stream, &ctx_));
+    }
     ~Context() { if (ctx_) lbvh_destroy(ctx_); }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
     lbvh_context* get() const { return ctx_; }
     void sync() { check(ctx_, lbvh_sync(ctx_)); }
+    // LBVH_TRACE_FAST keeps the previous frame's per-tile costs as a dispatch hint: drop it (the next frame is a first frame)
+    void trace_forget() { check(ctx_, lbvh_trace_forget(ctx_)); }
+    static int device_count() { return lbvh_device_count(); }
 private:
+    static void check_abi()
+    {
+        if (lbvh_abi_version() != LBVH_ABI_VERSION)
+            throw Error(LBVH_ERR_INVALID_ARG, "liblbvh.so was built from another include/lbvh.h (ABI version)");
+    }
     lbvh_context* ctx_ = nullptr;
+};
+
+// A HIP event on the context's stream (measurement: elapsed_ms waits for `stop`).
+class Event {
+public:
+    explicit Event(Context& ctx) : ctx_(ctx) { check(ctx_.get(), lbvh_event_create(ctx_.get(), &ev_)); }
+    ~Event() { if (ev_) lbvh_event_destroy(ctx_.get(), ev_); }
+    Event(const Event&) = delete;
+    Event& operator=(const Event&) = delete;
+    void record() { check(ctx_.get(), lbvh_event_record(ctx_.get(), ev_)); }
+    static float elapsed_ms(Event& start, Event& stop)
+    {
+        float ms = 0.0f;
+        check(start.ctx_.get(), lbvh_event_elapsed_ms(start.ctx_.get(), start.ev_, stop.ev_, &ms));
+        return ms;
+    }
+private:
+    Context& ctx_;
+    void* ev_ = nullptr;
 };
 
 // Assets/_Scripts/DataBuffer.cs
@@ -240,6 +277,16 @@ public:
         const lbvh_scene s = container_->Scene();
         check(ctx_.get(), lbvh_trace_primary(ctx_.get(), &cam, 0, 0, cam.screen_width, cam.screen_height, &s, mode,
                                              (lbvh_hit*)hits_->DeviceBuffer(), nullptr));
+    }
+    // one GPU's share of the frame (every shard_count-th group of 8 adjacent 8x8-pixel tiles), one launch; the hit buffer
+    // has the full frame's layout and only the shard's pixels are written (BASELINE configs[2]: BVH replicated, rays sharded)
+    void UpdateShard(const lbvh_camera& cam, uint32_t shard_index, uint32_t shard_count, int mode = LBVH_TRACE_FAST)
+    {
+        const size_t rays = (size_t)cam.screen_width * cam.screen_height;
+        if (!hits_ || hits_->Size() < rays) hits_.reset(new DataBuffer<lbvh_hit>(ctx_, rays));
+        const lbvh_scene s = container_->Scene();
+        check(ctx_.get(), lbvh_trace_primary_shard(ctx_.get(), &cam, shard_index, shard_count, &s, mode,
+                                                   (lbvh_hit*)hits_->DeviceBuffer(), nullptr));
     }
     // _objectDrawer.SetTexture("_meshTexture", ...) :61 — RGBA8, row 0 at v = 0
     void SetTexture(const std::vector<uint8_t>& rgba8, int width, int height)
