@@ -95,13 +95,20 @@ __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t
             }
         }
     };
-    for (uint32_t i0 = blockIdx.x * kThreads + t; i0 < nvec; i0 += stride * 2) {
-        const bool ok1 = i0 + stride < nvec;
-        const u32x4 a = vkeys[i0];
-        u32x4 b2 = {0u, 0u, 0u, 0u};
-        if (ok1) b2 = vkeys[i0 + stride];
-        add_key(a.x); add_key(a.y); add_key(a.z); add_key(a.w);
-        if (ok1) { add_key(b2.x); add_key(b2.y); add_key(b2.z); add_key(b2.w); }
+    for (uint32_t i0 = blockIdx.x * kThreads + t; i0 < nvec; i0 += stride * 4) {
+        // four 16-byte loads in flight per thread, read as streaming data (the passes read the keys again from memory
+        // anyway once they are beyond the L2): 0.092 -> 0.084 ms at 2^26 keys, 10.7 -> 9.7 us at 2^20
+        u32x4 v[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ok[k] = i0 + (uint32_t)k * stride < nvec;
+            v[k] = u32x4{0u, 0u, 0u, 0u};
+            if (ok[k]) v[k] = __builtin_nontemporal_load(&vkeys[i0 + (uint32_t)k * stride]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (ok[k]) { add_key(v[k].x); add_key(v[k].y); add_key(v[k].z); add_key(v[k].w); }
     }
     if (blockIdx.x == 0 && t < 8u) {                   // at most 3 head + 3 tail keys
         const uint32_t idx = t < 4u ? t : tail0 + (t - 4u);
@@ -140,6 +147,10 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     uint32_t* fault)                      // mapped host word: a bounded spin that gave up says so here
 {
     constexpr int TILE = THREADS * ITEMS;
+    // Big sorts (16 keys per thread: from 2 M keys) read every key and value exactly once per pass: loaded as streaming
+    // data (sc1 nt: not kept in L2) they leave the L2 to the scatter's partial lines, which wait there for the tile that
+    // completes them — 1.24 -> 1.19 ms per 2^26 pairs, 0.367 -> 0.346 at 2^24; cache-resident sorts keep the default.
+    constexpr int kLoadPolicy = ITEMS >= 16 ? 6 : 0;
     constexpr int WAVES = THREADS / LBVH_WAVE;
     constexpr int DWAVES = kRadix / LBVH_WAVE;   // waves that own the 256 digits
     // tile exchange buffer: keys first, then values; during ranking it holds the per-wave rank cells
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const uint32_t idx = wave_base + (uint32_t)i * LBVH_WAVE + lane;
-        const uint32_t k = __builtin_amdgcn_raw_buffer_load_b32(keys_in_rsrc, idx * 4u, 0, 0);
+        const uint32_t k = __builtin_amdgcn_raw_buffer_load_b32(keys_in_rsrc, idx * 4u, 0, kLoadPolicy);
         key[i] = idx < count ? k : 0xFFFFFFFFu;
     }
 
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(vals_in), 0, (int)(count * 4u), 0x00020000);
 #pragma unroll
         for (int i = 0; i < ITEMS; i++)
-            val[i] = __builtin_amdgcn_raw_buffer_load_b32(vals_in_rsrc, (wave_base + (uint32_t)i * LBVH_WAVE + lane) * 4u, 0, 0);
+            val[i] = __builtin_amdgcn_raw_buffer_load_b32(vals_in_rsrc, (wave_base + (uint32_t)i * LBVH_WAVE + lane) * 4u, 0, kLoadPolicy);
     }
     if (t < (uint32_t)kRadix) {   // finish the look-back: decoupled walk over the group words, nearest first
         uint32_t before = 0;
