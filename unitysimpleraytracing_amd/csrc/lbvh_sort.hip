@@ -134,7 +134,7 @@ __host__ __device__ __forceinline__ uint32_t ticket_tile(uint32_t k, uint32_t x,
 }
 
 // ---- one pass: rank + look-back + scatter ----------------------------------------------------------
-template <int THREADS, int ITEMS>
+template <int THREADS, int ITEMS, bool STREAM>
 __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t count, uint32_t shift,
@@ -147,10 +147,11 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     uint32_t* fault)                      // mapped host word: a bounded spin that gave up says so here
 {
     constexpr int TILE = THREADS * ITEMS;
-    // Big sorts (16 keys per thread: from 2 M keys) read every key and value exactly once per pass: loaded as streaming
-    // data (sc1 nt: not kept in L2) they leave the L2 to the scatter's partial lines, which wait there for the tile that
-    // completes them — 1.24 -> 1.19 ms per 2^26 pairs, 0.367 -> 0.346 at 2^24; cache-resident sorts keep the default.
-    constexpr int kLoadPolicy = ITEMS >= 16 ? 6 : 0;
+    // STREAM (sorts from 8 M pairs: beyond what the L2s hold): every key and value is read exactly once per pass, and
+    // loaded as streaming data (sc1 nt: not kept in L2) they leave the L2 to the scatter's partial lines, which wait
+    // there for the tile that completes them — 1.24 -> 1.19 ms per 2^26 pairs, 0.367 -> 0.346 at 2^24; at 2^22 (32 MB of
+    // pairs) the default policy is the faster one (0.129 against 0.134 ms).
+    constexpr int kLoadPolicy = STREAM ? 6 : 0;
     constexpr int WAVES = THREADS / LBVH_WAVE;
     constexpr int DWAVES = kRadix / LBVH_WAVE;   // waves that own the 256 digits
     // tile exchange buffer: keys first, then values; during ranking it holds the per-wave rank cells
@@ -413,14 +414,14 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     }
 }
 
-template <int THREADS, int ITEMS>
+template <int THREADS, int ITEMS, bool STREAM>
 void launch_passes(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t* alt_keys, uint32_t* alt_vals,
                    uint32_t count, uint32_t tiles, uint32_t* ghist, uint32_t* status, uint32_t* gstatus, uint32_t groups,
                    uint32_t* tickets, uint32_t group)
 {
     uint32_t *ks = d_keys, *vs = d_values, *kd = alt_keys, *vd = alt_vals;
     for (uint32_t p = 0; p < (uint32_t)kPasses; p++) {   // ComputeBufferSorter.cs:102
-        LBVH_LAUNCH(ctx, (sort_onesweep_kernel<THREADS, ITEMS>), dim3(tiles), dim3(THREADS), ks, vs, kd, vd, count,
+        LBVH_LAUNCH(ctx, (sort_onesweep_kernel<THREADS, ITEMS, STREAM>), dim3(tiles), dim3(THREADS), ks, vs, kd, vd, count,
                     8u * p, ghist + p * kRadix, status + (size_t)p * tiles * kRadix,
                     gstatus + (size_t)p * groups * kRadix, tickets + 8u * p, tiles, group, ctx->sort_queues, ctx->fault_dev);
         uint32_t* tmp;
@@ -504,10 +505,12 @@ int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, ui
     LBVH_LAUNCH(ctx, sort_histogram_kernel, dim3(hblocks), dim3(kThreads), d_keys, count, ghist);
     // consecutive tiles per XCD: 16 when every XCD still gets several groups, fewer for small sorts
     const uint32_t group = tiles >= 1024u ? 16u : tiles >= 128u ? 8u : 1u;
-    if (items == 16)
-        launch_passes<512, 16>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
+    if (items == 16 && count >= (1u << 23))
+        launch_passes<512, 16, true>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
+    else if (items == 16)
+        launch_passes<512, 16, false>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     else
-        launch_passes<512, 8>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
+        launch_passes<512, 8, false>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;   // 4 passes: the result is back in d_keys / d_values
 }
