@@ -496,14 +496,28 @@ __global__ __launch_bounds__(kTreeThreads) void tree_kernel(const uint32_t* __re
     const bool right_leaf = split + 1 == last;                                             // :132
     if (MODE != TREE_FUSED && valid) {
         uint32_t* node = reinterpret_cast<uint32_t*>(&internal[thread_id]);
+        // Inside lbvh_build_scene (TREE_REFERENCE) the reference's arrays are written as streaming data, here and below:
+        // the frame that follows a rebuild walks the DERIVED scene, and 64 MB of node words and boxes written last would
+        // push its lines out of the caches — trace part of a cfg2 step 0.245 -> 0.230 ms, the rebuild itself unchanged.
+        // (lbvh_build_tree alone, TREE_TOPOLOGY, is followed by lbvh_refit, which reads the nodes: ordinary stores.)
+        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+        auto st2 = [](void* p, uint32_t x, uint32_t y) {
+            const u2v v = {x, y};
+            if (MODE == TREE_REFERENCE) __builtin_nontemporal_store(v, reinterpret_cast<u2v*>(p));
+            else *reinterpret_cast<u2v*>(p) = v;
+        };
+        auto st1 = [](uint32_t* p, uint32_t x) {
+            if (MODE == TREE_REFERENCE) __builtin_nontemporal_store(x, p);
+            else *p = x;
+        };
         // leftNode, leftNodeType, rightNode, rightNodeType as two 8-byte stores (node stride 24 B)
-        *reinterpret_cast<uint2*>(node + 0) = make_uint2((uint32_t)split, left_leaf ? LBVH_LEAF_NODE : LBVH_INTERNAL_NODE);
-        *reinterpret_cast<uint2*>(node + 2) = make_uint2((uint32_t)split + 1u, right_leaf ? LBVH_LEAF_NODE : LBVH_INTERNAL_NODE);
-        node[5] = thread_id;                                                               // index :111
-        if (left_leaf) *reinterpret_cast<uint2*>(&leaf[split]) = make_uint2(thread_id, (uint32_t)split);  // :116-120
-        else internal[split].parent = thread_id;                                           // :126
-        if (right_leaf) *reinterpret_cast<uint2*>(&leaf[split + 1]) = make_uint2(thread_id, (uint32_t)split + 1u);
-        else internal[split + 1].parent = thread_id;                                       // :144
+        st2(node + 0, (uint32_t)split, left_leaf ? LBVH_LEAF_NODE : LBVH_INTERNAL_NODE);
+        st2(node + 2, (uint32_t)split + 1u, right_leaf ? LBVH_LEAF_NODE : LBVH_INTERNAL_NODE);
+        st1(&node[5], thread_id);                                                          // index :111
+        if (left_leaf) st2(&leaf[split], thread_id, (uint32_t)split);                      // :116-120
+        else st1(&internal[split].parent, thread_id);                                      // :126
+        if (right_leaf) st2(&leaf[split + 1], thread_id, (uint32_t)split + 1u);
+        else st1(&internal[split + 1].parent, thread_id);                                  // :144
     }
     // The boxes: computed per node, written per LINE — every thread parks its record in LDS and the workgroup writes
     // the block's records as consecutive float4 (a wave's store covers 1 KB of whole records, not 64 quarter lines).
@@ -539,7 +553,10 @@ __global__ __launch_bounds__(kTreeThreads) void tree_kernel(const uint32_t* __re
 #pragma unroll
         for (int k = 0; k < kQuads; k++) {
             const uint32_t q = (uint32_t)k * kTreeThreads + threadIdx.x;
-            if (q < live) out[q] = s_out[q];
+            if (q < live) {
+                if (MODE == TREE_REFERENCE) lbvh_nt_store(&out[q], s_out[q]);
+                else out[q] = s_out[q];
+            }
         }
     }
 }

@@ -262,3 +262,17 @@ __device__ __forceinline__ uint32_t wave_total_from_inclusive(uint32_t inclusive
     return (uint32_t)__builtin_amdgcn_readlane((int)inclusive, 63);
 }
 
+#if defined(__HIPCC__)
+// streaming (non-temporal) 16-byte accesses: data read or written once by a kernel, not to be kept in the caches
+typedef float lbvh_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 lbvh_nt_load(const float4* p)
+{
+    const lbvh_f4v v = __builtin_nontemporal_load(reinterpret_cast<const lbvh_f4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lbvh_nt_store(float4* p, const float4 v)
+{
+    const lbvh_f4v w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<lbvh_f4v*>(p));
+}
+#endif
