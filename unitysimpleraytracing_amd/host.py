@@ -421,10 +421,11 @@ class DynamicPathTracer:
             self.image_buf = DataBuffer(self.ctx, count, np.uint64)
         h = self.ctx.handle
         s = self.drawer.container.scene()
-        N.check(h, N.lib.lbvh_path_begin(h, C.byref(cam), self.states.device))
-        # primary rays: the coherent packet kernel
+        # primary rays: the coherent packet kernel — BEFORE the path states are initialised: 132 MB of state stores right
+        # in front of it push the scene out of the caches (the frame's primary trace 0.274 -> 0.253 ms)
         N.check(h, N.lib.lbvh_trace_primary(h, C.byref(cam), 0, 0, cam.screen_width, cam.screen_height, C.byref(s),
                                             L.TRACE_FAST, self.hits.device, None))
+        N.check(h, N.lib.lbvh_path_begin(h, C.byref(cam), self.states.device))
         # bounce b = scatter at the hits of segment b + trace of segment b + 1 (one call); the last bounce only scatters
         for b in range(bounces):
             N.check(h, N.lib.lbvh_path_bounce(h, C.byref(s), self.states.device, self.hits.device, count, b, self.seed,
