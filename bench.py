@@ -103,14 +103,51 @@ def yawed(cam, yaw_deg):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` from a plain launch: start the N ranks as CHILD processes (one per GPU, the environment
+    torch.distributed.run would give them) and exit with their worst return code.  Nothing in this parent has touched HIP
+    or torch at this point (no exec of a GPU-initialised process anywhere); rank 0's JSON line goes straight to stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p_ in list(pending):
+                rc = p_.poll()
+                if rc is None:
+                    continue
+                pending.remove(p_)
+                if rc != 0:
+                    worst = worst or rc
+                    for q in pending:                  # one rank failed: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+    raise SystemExit(worst)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     dist = None
     device_id = local_rank if args.device is None else args.device
     if world > 1:

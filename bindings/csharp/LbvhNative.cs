@@ -1,8 +1,10 @@
 // LbvhNative.cs — P/Invoke binding of liblbvh.so (include/lbvh.h) for the reference's C# host.
 //
-// SOURCE ONLY: this image has no C# toolchain (no dotnet/mono/csc), so this file is not compiled or
-// tested here; it is the shim a maintainer of drzhn/UnitySimpleRaytracing would add under
-// Assets/_Scripts/ to replace ComputeShader.Dispatch with the native library (see INTEGRATION.md).
+// SOURCE ONLY: this image has no C# toolchain (no dotnet/mono/csc), so this file is not compiled here;
+// tests/test_abi.py checks every declaration's name and arity against include/lbvh.h.  It is the shim a
+// maintainer of drzhn/UnitySimpleRaytracing adds under Assets/_Scripts/ together with the re-hosted classes
+// next to it (DataBuffer / MeshBufferContainer / ComputeBufferSorter / BVHConstructor / RaytracingMeshDrawer
+// `.Native.cs`, which replace the reference files of the same class names; see INTEGRATION.md).
 // Struct layouts are the reference's own Sequential/Pack=16 structs (SceneDataTypes.cs), which are
 // already byte-identical to lbvh_triangle / lbvh_aabb / lbvh_internal_node / lbvh_leaf_node.
 using System;
@@ -12,17 +14,21 @@ public static class LbvhNative
 {
     const string Lib = "lbvh";   // liblbvh.so on Linux
 
+    public const int ABI_VERSION = 7;             // LBVH_ABI_VERSION of the include/lbvh.h this file was written against
     public const int TRACE_REFERENCE = 0, TRACE_FAST = 1;
+    public const uint BUILD_FAST_SCENE = 1, BUILD_RESET_NODES = 2;      // lbvh_build_scene flags
 
     [StructLayout(LayoutKind.Sequential)]
     public struct Hit { public float t; public uint tri; public float u, v; }
 
+    // lbvh_camera (include/lbvh.h): the 16 matrix floats are plain fields, row-major m00..m33 as Unity's Matrix4x4 names
+    // them, so the struct needs no `unsafe` / "allow unsafe code" project setting and marshals by value as it is.
     [StructLayout(LayoutKind.Sequential)]
-    public unsafe struct Camera
+    public struct Camera
     {
         public int screenWidth, screenHeight;
         public float cameraFov, nearPlane;
-        public fixed float cameraToWorld[16];      // row-major m00..m33 (Matrix4x4 m00,m01,...)
+        public float m00, m01, m02, m03, m10, m11, m12, m13, m20, m21, m22, m23, m30, m31, m32, m33;
     }
 
     [StructLayout(LayoutKind.Sequential, CharSet = CharSet.Ansi)]
@@ -118,46 +124,5 @@ public static class LbvhNative
     {
         if (status != 0)
             throw new InvalidOperationException($"lbvh status {status}: {Marshal.PtrToStringAnsi(lbvh_last_error(ctx))}");
-    }
-}
-
-// DataBuffer<T> with the ComputeBuffer replaced by a device pointer (Assets/_Scripts/DataBuffer.cs).
-public class NativeDataBuffer<T> : IDisposable where T : struct
-{
-    public IntPtr DeviceBuffer { get; private set; }
-    public T[] LocalBuffer { get; }
-    readonly IntPtr _ctx;
-    readonly int _stride = Marshal.SizeOf(typeof(T));
-
-    public NativeDataBuffer(IntPtr ctx, int size)
-    {
-        _ctx = ctx;
-        LocalBuffer = new T[size];
-        LbvhNative.Check(ctx, LbvhNative.lbvh_buffer_alloc(ctx, (UIntPtr)size, (UIntPtr)_stride, out var p));
-        DeviceBuffer = p;
-    }
-
-    public NativeDataBuffer(IntPtr ctx, int size, uint initialWord) : this(ctx, size)   // DataBuffer(size, initialValue)
-    {
-        LbvhNative.Check(ctx, LbvhNative.lbvh_buffer_fill_u32(ctx, DeviceBuffer, initialWord, (UIntPtr)((long)size * _stride / 4)));
-    }
-
-    public void GetData()                                                               // DataBuffer.GetData
-    {
-        var h = GCHandle.Alloc(LocalBuffer, GCHandleType.Pinned);
-        try { LbvhNative.Check(_ctx, LbvhNative.lbvh_buffer_download(_ctx, h.AddrOfPinnedObject(), DeviceBuffer, (UIntPtr)((long)LocalBuffer.Length * _stride))); }
-        finally { h.Free(); }
-    }
-
-    public void Sync()                                                                  // DataBuffer.Sync
-    {
-        var h = GCHandle.Alloc(LocalBuffer, GCHandleType.Pinned);
-        try { LbvhNative.Check(_ctx, LbvhNative.lbvh_buffer_upload(_ctx, DeviceBuffer, h.AddrOfPinnedObject(), (UIntPtr)((long)LocalBuffer.Length * _stride))); }
-        finally { h.Free(); }
-    }
-
-    public void Dispose()
-    {
-        if (DeviceBuffer != IntPtr.Zero) { LbvhNative.lbvh_buffer_free(_ctx, DeviceBuffer); DeviceBuffer = IntPtr.Zero; }
     }
 }

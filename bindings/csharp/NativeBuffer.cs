@@ -1,0 +1,66 @@
+// NativeBuffer.cs — what UnityEngine.ComputeBuffer is to the reference, for HIP device memory.
+//
+// Only the members the reference touches exist: the (count, stride) constructor (Assets/_Scripts/DataBuffer.cs:27),
+// SetData / GetData with a managed array (DataBuffer.cs:20,52,58; ComputeBufferSorter.cs:93,109,139), Release
+// (DataBuffer.cs:74), plus `count` / `stride`.  `Pointer` is the device address the P/Invoke calls take.
+// SOURCE ONLY (no C# toolchain in the build image).
+using System;
+using System.Runtime.InteropServices;
+
+public sealed class NativeBuffer : IDisposable
+{
+    public IntPtr Pointer { get; private set; }
+    public int count { get; }
+    public int stride { get; }
+
+    public NativeBuffer(int count, int stride)
+    {
+        if (count <= 0 || stride <= 0) throw new ArgumentException("NativeBuffer: count and stride must be positive");
+        this.count = count;
+        this.stride = stride;
+        IntPtr ctx = LbvhContext.Handle;
+        LbvhNative.Check(ctx, LbvhNative.lbvh_buffer_alloc(ctx, (UIntPtr)(ulong)count, (UIntPtr)(ulong)stride, out IntPtr p));
+        Pointer = p;
+    }
+
+    long Bytes(Array data)
+    {
+        long bytes = (long)data.Length * stride;
+        if (bytes > (long)count * stride) throw new ArgumentException("NativeBuffer: array larger than the buffer");
+        return bytes;
+    }
+
+    /// Host array -> device (ComputeBuffer.SetData); blocking like Unity's.
+    public void SetData(Array data)
+    {
+        IntPtr ctx = LbvhContext.Handle;
+        GCHandle h = GCHandle.Alloc(data, GCHandleType.Pinned);
+        try { LbvhNative.Check(ctx, LbvhNative.lbvh_buffer_upload(ctx, Pointer, h.AddrOfPinnedObject(), (UIntPtr)(ulong)Bytes(data))); }
+        finally { h.Free(); }
+    }
+
+    /// Device -> host array (ComputeBuffer.GetData): waits for the work enqueued so far, the reference's only sync point.
+    public void GetData(Array data)
+    {
+        IntPtr ctx = LbvhContext.Handle;
+        GCHandle h = GCHandle.Alloc(data, GCHandleType.Pinned);
+        try { LbvhNative.Check(ctx, LbvhNative.lbvh_buffer_download(ctx, h.AddrOfPinnedObject(), Pointer, (UIntPtr)(ulong)Bytes(data))); }
+        finally { h.Free(); }
+    }
+
+    /// Every 32-bit word of the buffer = value (the fill constructors' uint.MaxValue / NullLeaf patterns), on the device.
+    public void Fill(uint value)
+    {
+        IntPtr ctx = LbvhContext.Handle;
+        LbvhNative.Check(ctx, LbvhNative.lbvh_buffer_fill_u32(ctx, Pointer, value, (UIntPtr)(ulong)((long)count * stride / 4)));
+    }
+
+    public void Release()
+    {
+        if (Pointer == IntPtr.Zero) return;
+        LbvhNative.lbvh_buffer_free(LbvhContext.Handle, Pointer);
+        Pointer = IntPtr.Zero;
+    }
+
+    public void Dispose() => Release();
+}

@@ -39,8 +39,9 @@ typedef int32_t lbvh_status;
 #define LBVH_OK                 0
 #define LBVH_ERR_INVALID_ARG   -1   /* null pointer, n < 2, n > capacity, bad tile rectangle ...   */
 #define LBVH_ERR_OUT_OF_MEMORY -2
-#define LBVH_ERR_HIP           -3   /* a HIP runtime call failed, or a device-side wait gave up (lbvh_sync /
-                                       lbvh_buffer_download report it); see lbvh_last_error           */
+#define LBVH_ERR_HIP           -3   /* a HIP runtime call failed, or a device-side wait gave up (the next lbvh_sync /
+                                       lbvh_buffer_download reports it ONCE: what was enqueued before that call is
+                                       invalid, later work is judged on its own); see lbvh_last_error  */
 #define LBVH_ERR_NO_DEVICE     -4   /* no usable gfx950 device                                     */
 
 /* ---- scene structs: the reference's buffer element layouts --------------------------------- */
@@ -412,8 +413,10 @@ lbvh_status lbvh_path_scatter(lbvh_context* ctx, const lbvh_scene* h_scene, cons
  * as one call: the scatter kernel itself lists those paths, so no pass over all path states is needed before the
  * trace.  d_hits holds the hit records of the segment just traced on entry and those of the next segment on
  * return.  The record of a path that ends in this call (it ends on a miss) becomes {t = MAX_FLOAT, triangle =
- * 0xFFFFFFFF, 0, 0} — still a miss to every reader; a later lbvh_path_bounce on the same buffers recognises it and
- * skips the finished path without reading its 64-byte state.  States, radiance and image: the same as the two calls. */
+ * 0xFFFFFFFF, 0, 0} — still a miss to every reader; a later lbvh_path_bounce (bounce > 0) on the same buffers recognises
+ * it and skips the finished path without reading its 64-byte state.  At bounce 0 every record is the caller's: one that
+ * was pre-filled with 0xFFFFFFFF words and never traced is an ordinary miss (sky term, path ends), as in
+ * lbvh_path_scatter.  States, radiance and image: the same as the two calls. */
 lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_path_state* d_states, lbvh_hit* d_hits,
                              size_t count, uint32_t bounce, uint32_t seed, float albedo, float t_min);
 

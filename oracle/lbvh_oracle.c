@@ -149,12 +149,16 @@ void orc_sort_pairs_mt(uint32_t* keys, uint32_t* values, uint32_t count, int thr
         for (int bit_offset = 0; bit_offset < 32; bit_offset += 8) {
 #pragma omp parallel num_threads(threads)
             {
-                const int t = omp_get_thread_num();
-                const size_t lo = (size_t)t * chunk < count ? (size_t)t * chunk : count;
-                const size_t hi = lo + chunk < count ? lo + chunk : count;
-                size_t* h = hist + (size_t)t * 256;
-                memset(h, 0, 256 * sizeof(size_t));
-                for (size_t i = lo; i < hi; i++) h[(ks[i] >> bit_offset) & 255u]++;
+                /* chunks are dealt to the threads the runtime actually granted (it may be fewer than asked for:
+                 * OMP_THREAD_LIMIT, OMP_DYNAMIC, nesting): thread t takes chunks t, t + nth, ... in both phases */
+                const int nth = omp_get_num_threads();
+                for (int c = omp_get_thread_num(); c < threads; c += nth) {
+                    const size_t lo = (size_t)c * chunk < count ? (size_t)c * chunk : count;
+                    const size_t hi = lo + chunk < count ? lo + chunk : count;
+                    size_t* h = hist + (size_t)c * 256;
+                    memset(h, 0, 256 * sizeof(size_t));
+                    for (size_t i = lo; i < hi; i++) h[(ks[i] >> bit_offset) & 255u]++;
+                }
 #pragma omp barrier
 #pragma omp single
                 {
@@ -162,10 +166,15 @@ void orc_sort_pairs_mt(uint32_t* keys, uint32_t* values, uint32_t count, int thr
                     for (int d = 0; d < 256; d++)
                         for (int u = 0; u < threads; u++) { size_t c = hist[(size_t)u * 256 + d]; hist[(size_t)u * 256 + d] = sum; sum += c; }
                 }
-                for (size_t i = lo; i < hi; i++) {
-                    const size_t dst = h[(ks[i] >> bit_offset) & 255u]++;
-                    kd[dst] = ks[i];
-                    vd[dst] = vs[i];
+                for (int c = omp_get_thread_num(); c < threads; c += nth) {
+                    const size_t lo = (size_t)c * chunk < count ? (size_t)c * chunk : count;
+                    const size_t hi = lo + chunk < count ? lo + chunk : count;
+                    size_t* h = hist + (size_t)c * 256;
+                    for (size_t i = lo; i < hi; i++) {
+                        const size_t dst = h[(ks[i] >> bit_offset) & 255u]++;
+                        kd[dst] = ks[i];
+                        vd[dst] = vs[i];
+                    }
                 }
             }
             uint32_t* tmp;
@@ -353,25 +362,31 @@ void orc_distribute_keys_mt(uint32_t* keys, uint32_t n, int threads)
         }
 #pragma omp parallel num_threads(threads)
         {
-            const int t = omp_get_thread_num();
-            const size_t lo = (size_t)t * chunk < n ? (size_t)t * chunk : n;
-            const size_t hi = lo + chunk < n ? lo + chunk : n;
-            uint32_t sum = 0, prev = first_old[t];
-            for (size_t i = lo; i < hi; i++) {
-                if (i > 0) { const uint32_t diff = keys[i] - prev; sum += diff > 1u ? diff : 1u; }
-                prev = keys[i];
+            /* chunks dealt to the threads actually granted, as in orc_sort_pairs_mt */
+            const int nth = omp_get_num_threads();
+            for (int c = omp_get_thread_num(); c < threads; c += nth) {
+                const size_t lo = (size_t)c * chunk < n ? (size_t)c * chunk : n;
+                const size_t hi = lo + chunk < n ? lo + chunk : n;
+                uint32_t sum = 0, prev = first_old[c];
+                for (size_t i = lo; i < hi; i++) {
+                    if (i > 0) { const uint32_t diff = keys[i] - prev; sum += diff > 1u ? diff : 1u; }
+                    prev = keys[i];
+                }
+                part[c + 1] = sum;
             }
-            part[t + 1] = sum;
 #pragma omp barrier
 #pragma omp single
             for (int u = 0; u < threads; u++) part[u + 1] += part[u];
-            uint32_t run = part[t];
-            prev = first_old[t];
-            for (size_t i = lo; i < hi; i++) {
-                const uint32_t old = keys[i];
-                if (i > 0) { const uint32_t diff = old - prev; run += diff > 1u ? diff : 1u; }
-                prev = old;
-                keys[i] = run;
+            for (int c = omp_get_thread_num(); c < threads; c += nth) {
+                const size_t lo = (size_t)c * chunk < n ? (size_t)c * chunk : n;
+                const size_t hi = lo + chunk < n ? lo + chunk : n;
+                uint32_t run = part[c], prev = first_old[c];
+                for (size_t i = lo; i < hi; i++) {
+                    const uint32_t old = keys[i];
+                    if (i > 0) { const uint32_t diff = old - prev; run += diff > 1u ? diff : 1u; }
+                    prev = old;
+                    keys[i] = run;
+                }
             }
         }
         free(part); free(first_old);

@@ -947,6 +947,44 @@ def test_cpp_host_driver_matches_oracle():
     assert res["shards_equal"] is True and res["update_device_ms"] > 0.0       # UpdateShard x 3 == Update; lbvh::Event
 
 
+def test_cpp_host_driver_ingests_an_obj_file(tmp_path):
+    """VERDICT r2 item 6 / SURVEY 8(f) rank 4: the compiled host takes an OBJ asset without Python — lbvh::LoadObj ->
+    MeshBufferContainer -> Sort -> DistributeKeys -> ConstructTree -> ConstructBVH -> Update — and lands on the oracle's
+    keys, node words and hit distances for the same file (here the reference's ExampleObject3 grid, re-emitted as an OBJ
+    with quads from the committed fixture's triangles)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "unitysimpleraytracing_amd", "host", "lbvh_driver")
+    g = np.load(os.path.join(root, "tests", "golden", "example_object3.npz"))["triangles"]
+    tris = np.ascontiguousarray(g, dtype=L.TRIANGLE)[:6000]
+    lines = []
+    for k, t in enumerate(tris):
+        for f in ("a", "b", "c"):
+            lines.append("v %r %r %r" % tuple(float(x) for x in t[f]))
+            lines.append("vt %r %r" % tuple(float(x) for x in t[f + "_uv"]))
+            lines.append("vn %r %r %r" % tuple(float(x) for x in t[f + "_normal"]))
+        lines.append("f %d/%d/%d %d/%d/%d %d/%d/%d" % tuple(3 * k + 1 + c for c in (0, 0, 0, 1, 1, 1, 2, 2, 2)))
+    obj = tmp_path / "grid.obj"
+    obj.write_text("\n".join(lines) + "\n")
+    assert scenes.load_obj(str(obj)).tobytes() == tris.tobytes()                 # the file carries the fixture's floats exactly
+    res = json.loads(subprocess.run([exe, "obj", str(obj), "160", "120", "15.7"], check=True, capture_output=True, text=True).stdout)
+    n = len(tris)
+    assert res["triangles"] == n
+    b = O.Built(tris, capacity=scenes.capacity_for(n), threads=8)
+    assert res["key_sum"] == int(b.keys[:n].astype(np.uint64).sum())
+    nd = b.internal[: n - 1]
+    node_sum = int((nd["leftNode"].astype(np.uint64) * np.uint64(3) + nd["rightNode"].astype(np.uint64) * np.uint64(5)
+                    + nd["parent"].astype(np.uint64) * np.uint64(7) + nd["leftNodeType"].astype(np.uint64)
+                    + nd["rightNodeType"].astype(np.uint64)).sum(dtype=np.uint64))
+    assert res["node_sum"] == node_sum
+    oh, _ = O.trace_primary(b, scenes.camera(160, 120, (0.0, 0.0, 15.7)), threads=8)
+    hit = oh["t"] < L.MAX_FLOAT
+    assert res["hits"] == int(hit.sum()) > 100
+    assert abs(res["t_sum"] - float(oh["t"][hit].astype(np.float64).sum())) < 1e-3
+    assert res["shards_equal"] is True
+
+
 def test_cpp_dynamic_path_tracer_matches_oracle():
     """BASELINE configs[4] in miniature through host/lbvh_host.hpp DynamicPathTracer (animate, rebuild, 2 bounces)."""
     import json
@@ -1110,6 +1148,40 @@ def test_path_trace_tiny_frames(ctx, res):
         same = (gst["origin"] == ost["origin"]).all(axis=1) & (gst["dir"] == ost["dir"]).all(axis=1)
         assert same.mean() > 0.98 or same.size < 64
         assert (img.view(np.uint16).reshape(-1, 4)[same] == oimg.view(np.uint16).reshape(-1, 4)[same]).all()
+    pt.drawer.on_destroy()
+
+
+def test_path_bounce_zero_treats_prefilled_hit_records_as_misses(ctx):
+    """a hit buffer pre-filled with 0xFFFFFFFF words (what lbvh_driver.cpp does) and only partly traced holds
+    {t >= MAX_FLOAT, triangle = 0xFFFFFFFF} records that are the CALLER's, not marks of paths that ended earlier: at
+    bounce 0 lbvh_path_bounce must treat them as lbvh_path_scatter does (sky term, path ends) — states and next-segment
+    hits identical to the two separate calls."""
+    tris, body, centres = scenes.tiled_torus(nu=20, nv=12, grid=2, with_bodies=True)
+    pt = H().DynamicPathTracer(ctx, tris, body, centres, t_min=1e-3, albedo=0.7, seed=3)
+    cam = scenes.camera(96, 64, (0.0, 0.0, 90.0))
+    ccam = N().Camera.from_dict(cam)
+    count = 96 * 64
+    s = pt.drawer.container.scene()
+    h, lib = ctx.handle, N().lib
+    out = []
+    for fused in (True, False):
+        states = H().DataBuffer(ctx, count, L.PATH_STATE)
+        hits = H().DataBuffer(ctx, count, L.HIT)
+        hits.fill_u32(0xFFFFFFFF, mirror=False)                                   # t = NaN-pattern >= MAX_FLOAT test: !(t < MAX)
+        N().check(h, lib.lbvh_trace_primary(h, C.byref(ccam), 0, 0, 96, 32, C.byref(s), L.TRACE_FAST, hits.device, None))   # top half only
+        N().check(h, lib.lbvh_path_begin(h, C.byref(ccam), states.device))
+        if fused:
+            N().check(h, lib.lbvh_path_bounce(h, C.byref(s), states.device, hits.device, count, 0, 3, 0.7, 1e-3))
+        else:
+            N().check(h, lib.lbvh_path_scatter(h, C.byref(s), hits.device, count, 0, 3, 0.7, states.device))
+            N().check(h, lib.lbvh_trace_rays(h, states.device, count, 1e-3, C.byref(s), hits.device))
+        out.append((states.get_data().copy(), hits.get_data().copy()))
+        states.dispose(); hits.dispose()
+    (st_f, hit_f), (st_s, hit_s) = out
+    assert (words(st_f) == words(st_s)).all()
+    untraced = np.arange(count) >= 96 * 32
+    assert (st_f["alive"][untraced] == 0).all() and (st_f["radiance"][untraced] > 0).all()      # they got their sky term
+    assert (hit_f["t"] == hit_s["t"]).all()
     pt.drawer.on_destroy()
 
 

@@ -310,6 +310,36 @@ def test_openmp_paths_equal_scalar():
     assert (h1 == h4).all() and s1 == s4
 
 
+def test_openmp_forms_when_the_runtime_grants_fewer_threads_than_asked():
+    """orc_sort_pairs_mt / orc_distribute_keys_mt computed their chunks from the REQUESTED thread count and
+    indexed them by omp_get_thread_num(): with OMP_THREAD_LIMIT below the request whole chunks were never processed.
+    Runs in a child process (the limit is read when libgomp loads) at a size that engages the parallel forms."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+import oracle as O
+rng = np.random.default_rng(11)
+n = 200_000
+keys = rng.integers(0, 1 << 30, n, dtype=np.uint64).astype(np.uint32)
+keys[::7] = keys[3]                                  # duplicates: stability matters
+vals = np.arange(n, dtype=np.uint32)
+k1, v1 = O.sort_pairs(keys, vals)
+k8, v8 = keys.copy(), vals.copy()
+O._lib.orc_sort_pairs_mt(O._ptr(k8), O._ptr(v8), n, 8)
+assert (k1 == k8).all() and (v1 == v8).all(), "parallel sort differs"
+d1 = O.distribute_keys(k1, n)
+d8 = k1.copy()
+O._lib.orc_distribute_keys_mt(O._ptr(d8), n, 8)
+assert (d1 == d8).all(), "parallel DistributeKeys differs"
+print("ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    env = dict(os.environ, OMP_THREAD_LIMIT="2", OMP_DYNAMIC="true")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 # ---- a-9 tail: shading (Raytracing.compute:178-184) -------------------------------------------------------
 
 def _shade_inputs(n_hits=300, seed=0):

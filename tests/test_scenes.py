@@ -73,3 +73,62 @@ def test_reference_assets_through_load_obj():
     t = scenes.load_obj(os.path.join(assets, "ExampleObject3.obj"))
     assert (t["a"][:, 2] == 0).all() and abs(t["a"][:, :2]).max() <= 4.0
     assert (t["a_normal"][:, 2] != 0).all() and t["a_uv"].min() >= 0.0 and t["c_uv"].max() <= 1.0
+
+
+# ---- the compiled host's ingest (host/lbvh_mesh.hpp) against the Python twin -------------------------------------------
+
+def _cpp_triangles(obj_text, tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "unitysimpleraytracing_amd", "host", "obj_to_triangles")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    src, out = tmp_path / "mesh.obj", tmp_path / "mesh.bin"
+    src.write_text(obj_text)
+    r = subprocess.run([exe, str(src), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return np.fromfile(out, dtype=L.TRIANGLE)
+
+
+def test_cpp_obj_ingest_equals_the_python_ingest(tmp_path):
+    """VERDICT r2 item 6: lbvh::LoadObj + lbvh::MeshTriangles (what `new MeshBufferContainer(mesh)` gathers,
+    MeshBufferContainer.cs:117-146) produce the 128-byte records scenes.load_obj does, byte for byte: polygons fanned,
+    mixed corner formats, negative indices, comments, missing uv / normals (face normals in fp32), odd number formats."""
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-50, 50, (40, 3))
+    soup = "".join(f"v {x:.9g} {y:.7e} {float(z)!r}\n" for x, y, z in pts)
+    soup += "".join(f"f {a} {b} {c} {d}  # quad\n" for a, b, c, d in rng.integers(1, 41, (30, 4)))
+    soup += "f -1 -2 -3\nf 1 1 1\n"                                    # relative indices; a zero-area face (normal 0)
+    cases = [OBJ, "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n", soup,
+             "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\nf 2//1 4//1 3//1\n",          # normals, no uv
+             "v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0.25 0.5\nvt 1 0\nvt 0 1\nf 1/1 2/2 3/3\n"]                       # uv, no normals
+    for text in cases:
+        want = scenes.load_obj(text, is_text=True)
+        got = _cpp_triangles(text, tmp_path)
+        assert len(got) == len(want) and got.tobytes() == want.tobytes()
+
+
+def test_cpp_obj_ingest_rejects_malformed_files(tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "unitysimpleraytracing_amd", "host", "obj_to_triangles")
+    for text in ("v 0 0\n", "v 0 0 0\nf 1 2 3\n", "v 0 0 x\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 0\n"):
+        src = tmp_path / "bad.obj"
+        src.write_text(text)
+        r = subprocess.run([exe, str(src), str(tmp_path / "bad.bin")], capture_output=True, text=True)
+        assert r.returncode == 1 and "OBJ line" in r.stderr, (text, r.stderr)
+    assert subprocess.run([exe, str(tmp_path / "missing.obj"), str(tmp_path / "x.bin")], capture_output=True).returncode == 1
+
+
+def test_cpp_obj_ingest_on_the_reference_assets(tmp_path):
+    import glob
+    import os
+    objs = sorted(glob.glob("/root/reference/Assets/_Assets/*.obj"))
+    if not objs:
+        import pytest
+        pytest.skip("no /root/reference on this box")
+    for obj in objs:
+        want = scenes.load_obj(obj)
+        got = _cpp_triangles(open(obj).read(), tmp_path)
+        assert len(want) > 0 and got.tobytes() == want.tobytes(), obj

@@ -83,10 +83,13 @@ int lbvh_require_fast(lbvh_context* ctx, const lbvh_scene& s, const char* who)
 int lbvh_check_fault(lbvh_context* ctx)
 {
     if (!ctx->fault_host) return LBVH_OK;
-    const uint32_t code = __atomic_load_n(ctx->fault_host, __ATOMIC_RELAXED);
+    // reported ONCE: the word is taken (exchanged with 0), so the sync / download that follows the failed work returns
+    // LBVH_ERR_HIP and later work on the context (a repeated sort, the next rebuild) is judged on its own (the
+    // word used to stay set for the life of the context).  Callers run after a stream sync: no kernel is writing it.
+    const uint32_t code = __atomic_exchange_n(ctx->fault_host, 0u, __ATOMIC_RELAXED);
     if (code == 0) return LBVH_OK;
-    char msg[96];
-    snprintf(msg, sizeof msg, "a bounded inter-workgroup wait gave up (fault %u): results of this context are invalid", code);
+    char msg[128];
+    snprintf(msg, sizeof msg, "a bounded inter-workgroup wait gave up (fault %u): results enqueued before this call are invalid", code);
     return lbvh_set_error(ctx, LBVH_ERR_HIP, "device-side protocol fault", msg);
 }
 
@@ -408,7 +411,8 @@ lbvh_status lbvh_clock_probe(lbvh_context* ctx, float* out_shader_mhz)
     // the second launch is the measured one: the first brings the clock up
     for (int rep = 0; rep < 2; rep++)
         LBVH_LAUNCH(ctx, clock_probe_kernel, dim3(blocks), dim3(256), d_out, 6000u, 1.0f + (float)rep);
-    hipError_t e = hipMemcpyAsync(h.data(), d_out, waves * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipGetLastError();                     // a failed launch must not be read back as a clock
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_out, waves * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_out);
     LBVH_HIP_TRY(ctx, e);

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(kTreeThreads) void tree_kernel(const uint32_t* __re
     __syncthreads();
     // (no early return: the boxes leave through a workgroup-wide LDS transpose below)
     const bool in_range = thread_id < n - 1;                                               // :101
-    const int idx = in_range ? (int)thread_id : 0;
+    const int idx = in_range ? (int)thread_id : win.w0;    // threads past the last node: a key INSIDE the window (results unused)
     const uint32_t self = win.at(idx);
     bool wide = false;             // a probe left the window: the node is searched by the whole wave further down
 

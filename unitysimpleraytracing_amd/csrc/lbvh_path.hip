@@ -95,8 +95,10 @@ __global__ __launch_bounds__(256) void alive_rays_kernel(const lbvh_path_state* 
 // Measured per frame of 4 bounces: no refill 3.75 ms; fixed runs of 128 / 256 / 512 rays 1.83 / 2.62 / 4.44 ms
 // (long runs leave most of the chip empty).
 constexpr uint32_t kRayWaves = 8192;
-// ray scratch: [live-ray count (256 B) | indices of the live rays | deep stack slabs of kRayWaves waves]
-constexpr size_t kDeepBytes = (size_t)kRayWaves * kRayStackDeep * LBVH_WAVE * 4;
+// ray scratch: [live-ray count (256 B) | indices of the live rays | deep stack slabs of the launch's waves]
+static inline uint32_t ray_waves_of(size_t count) { return (uint32_t)std::min<size_t>(kRayWaves, (count + LBVH_WAVE - 1) / LBVH_WAVE); }
+// the slab is indexed by blockIdx.x: one launch needs ray_waves_of(count) of them (a 64-ray call: 12 KB, not 96 MB)
+static inline size_t deep_bytes(size_t count) { return (size_t)ray_waves_of(count) * kRayStackDeep * LBVH_WAVE * 4; }
 static inline size_t list_bytes(size_t count) { return (count * 4 + 255) & ~(size_t)255; }
 static inline uint32_t* deep_stacks(lbvh_context* ctx, size_t count) { return (uint32_t*)((char*)ctx->ray_scratch + 256 + list_bytes(count)); }
 
@@ -244,7 +246,9 @@ __device__ __forceinline__ bool scatter_path(const lbvh_triangle* __restrict__ t
 {
     const float4 h = reinterpret_cast<const float4*>(hits)[i];
     const bool missed = !(h.x < LBVH_MAX_FLOAT);
-    if (MARK && missed && __float_as_uint(h.y) == 0xFFFFFFFFu) return false;      // ended in an earlier bounce
+    // ended in an earlier bounce: only lbvh_path_bounce writes DEAD records, so at bounce 0 a {MAX_FLOAT, 0xFFFFFFFF} record is
+    // the caller's own fill value (an untraced pixel) and is an ordinary miss, as in lbvh_path_scatter
+    if (MARK && bounce > 0u && missed && __float_as_uint(h.y) == 0xFFFFFFFFu) return false;
     float4* st = reinterpret_cast<float4*>(&states[i]);
     float4 o = st[0];
     if (__float_as_uint(o.w) == 0u) return false;
@@ -354,13 +358,13 @@ lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, 
     }
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     // scratch: [live-ray count (256 B) | indices of the live rays]
-    int rc = lbvh_reserve(ctx, &ctx->ray_scratch, &ctx->ray_scratch_bytes, 256 + list_bytes(count) + kDeepBytes);
+    int rc = lbvh_reserve(ctx, &ctx->ray_scratch, &ctx->ray_scratch_bytes, 256 + list_bytes(count) + deep_bytes(count));
     if (rc != LBVH_OK) return rc;
     uint32_t* n_alive = (uint32_t*)ctx->ray_scratch;
     uint32_t* list = (uint32_t*)((char*)ctx->ray_scratch + 256);
     LBVH_HIP_TRY(ctx, hipMemsetAsync(n_alive, 0, 4, ctx->cur_stream));
     LBVH_LAUNCH(ctx, alive_rays_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), d_states, count, n_alive, list, d_hits);
-    const uint32_t ray_waves = (uint32_t)std::min<size_t>(kRayWaves, (count + LBVH_WAVE - 1) / LBVH_WAVE);
+    const uint32_t ray_waves = ray_waves_of(count);
     LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive,
                 list, t_min, ctx->fast_nodes, ctx->fast_tris, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds);
     LBVH_HIP_TRY(ctx, hipGetLastError());
@@ -400,14 +404,14 @@ lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_
         if (frc != LBVH_OK) return frc;
     }
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = lbvh_reserve(ctx, &ctx->ray_scratch, &ctx->ray_scratch_bytes, 256 + list_bytes(count) + kDeepBytes);
+    int rc = lbvh_reserve(ctx, &ctx->ray_scratch, &ctx->ray_scratch_bytes, 256 + list_bytes(count) + deep_bytes(count));
     if (rc != LBVH_OK) return rc;
     uint32_t* n_alive = (uint32_t*)ctx->ray_scratch;
     uint32_t* list = (uint32_t*)((char*)ctx->ray_scratch + 256);
     LBVH_HIP_TRY(ctx, hipMemsetAsync(n_alive, 0, 4, ctx->cur_stream));
     LBVH_LAUNCH(ctx, path_scatter_kernel<true>, dim3((unsigned)((count + 255) / 256)), dim3(256), h_scene->triangles, d_hits, count,
                 bounce, seed, albedo, d_states, n_alive, list);
-    const uint32_t ray_waves = (uint32_t)std::min<size_t>(kRayWaves, (count + LBVH_WAVE - 1) / LBVH_WAVE);
+    const uint32_t ray_waves = ray_waves_of(count);
     LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, ctx->fast_nodes,
                 ctx->fast_tris, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds);
     LBVH_HIP_TRY(ctx, hipGetLastError());

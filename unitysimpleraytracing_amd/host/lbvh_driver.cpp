@@ -1,12 +1,15 @@
 // lbvh_driver.cpp — BASELINE config 1 ("plumbing") through the C++ host classes: 4 096 random
 // triangles, 256x256 primary rays, the reference's Awake() + Update() call order.  Prints stage
 // timings and checksums the parity tests compare with the oracle.  Links only liblbvh.so.
+//     lbvh_driver [n] [w] [h] [dynamic]          seeded random triangles (cfg1)
+//     lbvh_driver obj <file.obj> [w] [h] [z]     mesh ingest (lbvh_mesh.hpp) -> Awake -> Update, camera at (0, 0, z)
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
 #include "lbvh_host.hpp"
+#include "lbvh_mesh.hpp"
 
 static uint64_t splitmix64(uint64_t& s)
 {
@@ -19,11 +22,26 @@ static float uniform(uint64_t& s, float lo, float hi) { return lo + (hi - lo) * 
 
 int main(int argc, char** argv)
 {
-    const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 4096;
-    const int w = argc > 2 ? atoi(argv[2]) : 256, h = argc > 3 ? atoi(argv[3]) : 256;
-    std::vector<lbvh_triangle> mesh(n);
+    const bool from_obj = argc > 2 && std::strcmp(argv[1], "obj") == 0;
+    uint32_t n = !from_obj && argc > 1 ? (uint32_t)atoi(argv[1]) : 4096;
+    const int w = from_obj ? (argc > 3 ? atoi(argv[3]) : 256) : (argc > 2 ? atoi(argv[2]) : 256);
+    const int h = from_obj ? (argc > 4 ? atoi(argv[4]) : 256) : (argc > 3 ? atoi(argv[3]) : 256);
+    const float cam_z = from_obj && argc > 5 ? (float)atof(argv[5]) : 300.0f;
+    std::vector<lbvh_triangle> mesh;
+    if (from_obj) {
+        try {
+            mesh = lbvh::MeshTriangles(lbvh::LoadObj(argv[2]));       // MeshBufferContainer.cs:117-146 for an OBJ asset
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "%s\n", e.what());
+            return 1;
+        }
+        n = (uint32_t)mesh.size();
+    } else {
+        mesh.resize(n);
+    }
     uint64_t seed = 1;
     for (auto& t : mesh) {
+        if (from_obj) break;
         std::memset(&t, 0, sizeof t);
         for (int k = 0; k < 3; k++) {
             const float c = uniform(seed, -100.0f, 100.0f);
@@ -33,7 +51,7 @@ int main(int argc, char** argv)
         }
         t.b_uv[0] = 1.0f; t.c_uv[1] = 1.0f;
     }
-    const bool dynamic = argc > 4 && std::strcmp(argv[4], "dynamic") == 0;
+    const bool dynamic = !from_obj && argc > 4 && std::strcmp(argv[4], "dynamic") == 0;
     try {
         lbvh::Context ctx(0);
         if (dynamic) {
@@ -74,7 +92,7 @@ int main(int argc, char** argv)
         cam.screen_width = w; cam.screen_height = h;
         cam.camera_fov = (float)std::tan(60.0 * 3.14159265358979323846 / 180.0 / 2.0);   // Mathf.Tan(fov * Deg2Rad / 2)
         cam.near_plane = 0.3f;
-        const float m[16] = {-1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 300, 0, 0, 0, 1};
+        const float m[16] = {-1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, cam_z, 0, 0, 0, 1};
         std::memcpy(cam.camera_to_world, m, sizeof m);
         lbvh::Event e0(ctx), e1(ctx);
         e0.record();
