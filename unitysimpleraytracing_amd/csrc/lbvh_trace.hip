@@ -495,6 +495,171 @@ __device__ __forceinline__ uint32_t walk_packet(const line_source& src, packet_r
     }
 }
 
+// ---- the lean step: primary rays (one origin), ordered signs ---------------------------------------------------------
+// Measured instruction costs on gfx950 with >= 4 waves per SIMD (tools/ubench/instcost.hip, profiles/r3): v_mul / v_add /
+// v_sub / v_mov / v_fma on VGPRs issue in 2.3 cycles per wave; anything with a DPP or SGPR operand, every v_cmp,
+// v_min / v_max / min3 / max3, v_readlane and v_cndmask (SGPR mask) in 4.3; v_cndmask with VCC in 23; one scalar
+// instruction per cycle per CU (4 SIMDs share it).  A step of the generic walker above is ~69 vector + ~50 scalar
+// instructions: the four SIMDs of a CU need the scalar unit for as long as they need their own vector pipes.  This form
+// is written against that table:
+//   * all rays of a primary packet leave ONE origin, so `plane - origin` is formed once for the whole line (lane k holds
+//     plane k: one full-rate v_sub) and each ray's 12 products take the difference as a DPP operand — 12 v_mul_dpp
+//     instead of 12 v_sub_dpp + 12 v_mul, the same two roundings per product ((plane - o) * inv), bit-identical;
+//   * `tmax > tmin && tmax > 0` is `tmax > max(tmin, 0)` (no NaNs with finite non-zero inverse directions); lanes
+//     without a ray carry best = -inf, which no box entry can precede: the `active` mask is gone from the step;
+//   * lane masks stay in SGPRs from the compare to the branch (no bool -> v_cndmask -> v_cmp round trips), the best-hit
+//     update is four moves under the accept mask, the uniform select of the next node line names its SGPR mask.
+// Same nodes visited, same triangles tested in the same order with the same arithmetic as walk_packet<.., SIGNS = true>.
+__device__ __forceinline__ int select_line(int if_set, int if_clear, bool uniform_cond)
+{
+    // v_cndmask_b32 with an SGPR-pair mask (4.3 cycles); the VCC form the compiler picks for a uniform select costs 23
+    const uint64_t m = __builtin_amdgcn_ballot_w64(uniform_cond);
+    int out;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(out) : "v"(if_clear), "v"(if_set), "s"(m));
+    return out;
+}
+
+// population count of a lane mask as ONE scalar instruction with a 32-bit result (the builtin's 64-bit result type makes
+// the compiler count the halves separately: mask_count above)
+__device__ __forceinline__ int lanes_in(uint64_t m)
+{
+    int out;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(out) : "s"(m) : "scc");
+    return out;
+}
+
+// max(x, 0) as ONE v_max_f32 (fmaxf's NaN canonicalisation costs a second one; x is never a NaN here)
+__device__ __forceinline__ float max_zero(float x)
+{
+    float out;
+    asm("v_max_f32 %0, 0, %1" : "=v"(out) : "v"(x));
+    return out;
+}
+
+struct lean_tri { float tvx, tvy, tvz, e1x, e1y, e1z, e2x, e2y, e2z; uint32_t index; };
+
+// the triangle line `w` (this lane's dword under the sign-ordered fetch pattern) -> its values in every lane's VECTOR
+// registers by DPP row broadcasts (v_mov_b32_dpp, 4.3 cycles each — what a v_readlane costs — but every product that
+// uses them afterwards is a VGPR x VGPR instruction at the full rate instead of a half-rate one with an SGPR operand;
+// each value is used three times).  All lanes must be active here (a DPP read of a switched-off lane yields 0): the
+// caller runs the whole test on every lane and masks the result.  tvec = origin - first vertex comes out of ONE
+// subtraction over the line (Raytracing.compute:52: tvec = ray.origin - v0)
+__device__ __forceinline__ lean_tri uniform_tri(int w, float o_lane)
+{
+    const int tv = __float_as_int(o_lane - __int_as_float(w));
+    lean_tri t;
+    t.tvx = row_dword<0>(tv); t.tvy = row_dword<1>(tv); t.tvz = row_dword<2>(tv);
+    t.index = (uint32_t)__builtin_amdgcn_readlane(w, 3);
+    t.e1x = row_dword<8>(w); t.e1y = row_dword<9>(w); t.e1z = row_dword<10>(w);
+    t.e2x = row_dword<7>(w); t.e2y = row_dword<11>(w); t.e2z = row_dword<15>(w);
+    return t;
+}
+
+// RayTriangleIntersection (Raytracing.compute:37-73) with tvec given; the operation order of ray_triangle_edges.
+// Returns "a hit" and its t / u / v; nothing is selected or written on a miss.
+__device__ __forceinline__ bool lean_triangle(const ray_t& r, const lean_tri& T, float& t_out, float& u_out, float& v_out)
+{
+    const float px = r.dy * T.e2z - r.dz * T.e2y;
+    const float py = r.dz * T.e2x - r.dx * T.e2z;
+    const float pz = r.dx * T.e2y - r.dy * T.e2x;
+    const float det = dot3(T.e1x, T.e1y, T.e1z, px, py, pz);
+    const float inv_det = 1.0f / det;
+    const float u = dot3(T.tvx, T.tvy, T.tvz, px, py, pz) * inv_det;
+    const float qx = T.tvy * T.e1z - T.tvz * T.e1y;
+    const float qy = T.tvz * T.e1x - T.tvx * T.e1z;
+    const float qz = T.tvx * T.e1y - T.tvy * T.e1x;
+    const float v = dot3(r.dx, r.dy, r.dz, qx, qy, qz) * inv_det;
+    t_out = dot3(T.e2x, T.e2y, T.e2z, qx, qy, qz) * inv_det;
+    u_out = u;
+    v_out = v;
+    // :49 |det| < 1e-8, :55 u outside [0, 1], :62 v < 0 or u + v > 1 (comparisons false for NaN as in the reference's order)
+    return !(det < 1e-8f && det > -1e-8f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f);
+}
+
+template <bool BUF>
+__device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, packet_rays<1>& P, uint32_t neg)
+{
+    const uint32_t lane = lane_id();
+    const ray_t r = P.ray[0];
+    int stack = 0;            // wave-shared stack: slot k lives in lane k of this VGPR
+    uint32_t sp = 0, steps = 0;
+    const uint32_t node_bytes = node_line_bytes(lane, true, neg);
+    const uint32_t axis = lane & 3u;          // dword k of a line is a plane (or a vertex coordinate) of axis k & 3; 3: no plane
+    const float o_lane = axis == 0u ? r.ox : (axis == 1u ? r.oy : (axis == 2u ? r.oz : 0.0f));
+    float best_t = P.act[0] ? P.best_t[0] : -INFINITY;
+    uint32_t best_tri = P.best_tri[0];
+    float best_u = P.best_u[0], best_v = P.best_v[0];
+    int w_node = fetch_line<BUF>(src, 0u, node_bytes);
+    for (;;) {
+        const uint32_t lref = (uint32_t)__builtin_amdgcn_readlane(w_node, 3), rref = (uint32_t)__builtin_amdgcn_readlane(w_node, 7);
+        const bool leaf_l = (int)lref < 0, leaf_r = (int)rref < 0;
+        const int w_l = fetch_line<BUF>(src, lref, node_bytes);        // both children in flight before the tests
+        const int w_r = fetch_line<BUF>(src, rref, node_bytes);
+        steps++;
+        const int d = __float_as_int(__int_as_float(w_node) - o_lane);     // every plane minus the origin, once
+        const float tl = fmaxf(row_dword<0>(d) * r.ix, fmaxf(row_dword<1>(d) * r.iy, row_dword<2>(d) * r.iz));
+        const float fl = fminf(row_dword<4>(d) * r.ix, fminf(row_dword<5>(d) * r.iy, row_dword<6>(d) * r.iz));
+        const float tr = fmaxf(row_dword<8>(d) * r.ix, fmaxf(row_dword<9>(d) * r.iy, row_dword<10>(d) * r.iz));
+        const float fr = fminf(row_dword<12>(d) * r.ix, fminf(row_dword<13>(d) * r.iy, row_dword<14>(d) * r.iz));
+        // (a mask is the AND of the ballots of single compares: the ballot of an AND goes through v_cndmask + v_cmp)
+        const bool box_l = fl > max_zero(tl), box_r = fr > max_zero(tr);
+        const bool near_l = !(tl > best_t), near_r = !(tr > best_t);
+        bool hit_l = box_l && near_l, hit_r = box_r && near_r;
+        uint64_t ml = __builtin_amdgcn_ballot_w64(box_l) & __builtin_amdgcn_ballot_w64(near_l);
+        uint64_t mr = __builtin_amdgcn_ballot_w64(box_r) & __builtin_amdgcn_ballot_w64(near_r);
+        // leaves first: their hits tighten best_t before anything is entered
+        if (leaf_l) {
+            if (ml != 0) {
+                const lean_tri T = uniform_tri(w_l, o_lane);
+                float t, u, v;            // every lane computes; the lanes that hit the leaf's box may keep the result
+                if (lean_triangle(r, T, t, u, v) && hit_l && closer(t, T.index, best_t, best_tri)) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
+                const bool still_r = !(tr > best_t);
+                hit_r = hit_r && still_r;
+                mr &= __builtin_amdgcn_ballot_w64(still_r);
+            }
+            ml = 0;
+        }
+        if (leaf_r) {
+            if (mr != 0) {
+                const lean_tri T = uniform_tri(w_r, o_lane);
+                float t, u, v;
+                if (lean_triangle(r, T, t, u, v) && hit_r && closer(t, T.index, best_t, best_tri)) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
+                ml &= __builtin_amdgcn_ballot_w64(!(tl > best_t));
+            }
+            mr = 0;
+        }
+        if (ml != 0 && mr != 0) {
+            const uint64_t both = ml & mr, le = __builtin_amdgcn_ballot_w64(tl <= tr);
+            const int by_votes = lanes_in(both & le) - lanes_in(both & ~le), by_lanes = lanes_in(ml) - lanes_in(mr);
+            const bool l_near = (by_votes != 0 ? by_votes : by_lanes) >= 0;
+            push_slot(stack, l_near ? rref : lref, sp & 63u);
+            sp++;
+            w_node = select_line(w_l, w_r, l_near);
+        } else if (ml != 0) {
+            w_node = w_l;
+        } else if (mr != 0) {
+            w_node = w_r;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            w_node = fetch_line<BUF>(src, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), node_bytes);
+        }
+    }
+    P.best_t[0] = best_t; P.best_tri[0] = best_tri; P.best_u[0] = best_u; P.best_v[0] = best_v;
+    return steps;
+}
+
+// do all active rays of the packet leave the same point (primary rays of a pinhole camera do)?
+__device__ __forceinline__ bool packet_one_origin(const packet_rays<1>& P)
+{
+    const ray_t& r = P.ray[0];
+    const uint64_t act = __ballot(P.act[0]);
+    if (act == 0) return false;
+    const int first = __builtin_ctzll(act);
+    const float ox = LBVH_RL(__float_as_int(r.ox), first), oy = LBVH_RL(__float_as_int(r.oy), first), oz = LBVH_RL(__float_as_int(r.oz), first);
+    return __ballot(P.act[0] && r.ox == ox && r.oy == oy && r.oz == oz) == act;
+}
+
 template <int RX, int RY>
 __device__ __forceinline__ void tile_rays(const trace_args& a, uint32_t tile, uint32_t lane, packet_rays<RX * RY>& P,
                                           uint32_t& px0, uint32_t& py0)
@@ -771,7 +936,9 @@ __device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_
     src.lines = nodes;
     src.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<lbvh_fast_node*>(nodes), 0, (int)a.line_bytes, 0x00020000);
     uint32_t steps;
-    if (a.line_bytes != 0)
+    if (!STATS && ordered && packet_one_origin(P))
+        steps = a.line_bytes != 0 ? walk_packet_lean<true>(src, P, neg) : walk_packet_lean<false>(src, P, neg);
+    else if (a.line_bytes != 0)
         steps = ordered ? walk_packet<STATS, 1, true, true>(src, P, C, neg) : walk_packet<STATS, 1, false, true>(src, P, C, 0u);
     else
         steps = ordered ? walk_packet<STATS, 1, true, false>(src, P, C, neg) : walk_packet<STATS, 1, false, false>(src, P, C, 0u);
