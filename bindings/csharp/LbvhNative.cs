@@ -14,7 +14,7 @@ public static class LbvhNative
 {
     const string Lib = "lbvh";   // liblbvh.so on Linux
 
-    public const int ABI_VERSION = 7;             // LBVH_ABI_VERSION of the include/lbvh.h this file was written against
+    public const int ABI_VERSION = 8;             // LBVH_ABI_VERSION of the include/lbvh.h this file was written against
     public const int TRACE_REFERENCE = 0, TRACE_FAST = 1;
     public const uint BUILD_FAST_SCENE = 1, BUILD_RESET_NODES = 2;      // lbvh_build_scene flags
 
@@ -118,6 +118,12 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern int lbvh_key_histogram(IntPtr ctx, IntPtr dKeys, uint count, uint[] prefixes, uint nPrefixes,
         uint prefixShift, uint shift, IntPtr dHist);
     [DllImport(Lib)] public static extern int lbvh_lower_bound(IntPtr ctx, IntPtr dSortedKeys, uint count, uint[] probes, uint nProbes,
+        IntPtr dPositions);
+
+    // the same two with prefixes / probes in device memory (the sharded sort's splitter search stays on the GPU)
+    [DllImport(Lib)] public static extern int lbvh_key_histogram_device(IntPtr ctx, IntPtr dKeys, uint count, IntPtr dPrefixes, uint nPrefixes,
+        uint prefixShift, uint shift, IntPtr dHist);
+    [DllImport(Lib)] public static extern int lbvh_lower_bound_device(IntPtr ctx, IntPtr dSortedKeys, uint count, IntPtr dProbes, uint nProbes,
         IntPtr dPositions);
 
     public static void Check(IntPtr ctx, int status)

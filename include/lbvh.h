@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LBVH_ABI_VERSION 7
+#define LBVH_ABI_VERSION 8
 
 /* ---- status codes ------------------------------------------------------------------------- */
 typedef int32_t lbvh_status;
@@ -229,6 +229,15 @@ lbvh_status lbvh_key_histogram(lbvh_context* ctx, const uint32_t* d_keys, uint32
  * n_probes <= 64. */
 lbvh_status lbvh_lower_bound(lbvh_context* ctx, const uint32_t* d_sorted_keys, uint32_t count,
                              const uint32_t* h_probes, uint32_t n_probes, uint32_t* d_positions);
+
+/* The same two with the prefixes / probes read from DEVICE memory (u32 arrays of n entries): the sharded sort keeps
+ * its splitter search on the device between the RCCL all-reduces — digit histogram, all-reduce, digit selection
+ * (a few torch operations on the [W-1][256] table), next histogram — with no host round trip per round. */
+lbvh_status lbvh_key_histogram_device(lbvh_context* ctx, const uint32_t* d_keys, uint32_t count,
+                                      const uint32_t* d_prefixes, uint32_t n_prefixes, uint32_t prefix_shift,
+                                      uint32_t shift, uint32_t* d_hist);
+lbvh_status lbvh_lower_bound_device(lbvh_context* ctx, const uint32_t* d_sorted_keys, uint32_t count,
+                                    const uint32_t* d_probes, uint32_t n_probes, uint32_t* d_positions);
 
 /* ---- stage a-6: DistributeKeys ---------------------------------------------------------------- */
 

@@ -235,6 +235,12 @@ def ray_box(bmin, bmax, origin, inv_dir):
     return bool(_lib.orc_ray_box(_f3(bmin), _f3(bmax), _f3(origin), _f3(inv_dir)))
 
 
+def ray_triangle(origin, direction, triangle):
+    """RayTriangleIntersection (Raytracing.compute:37-73) of one ray with one TRIANGLE record: its t, or MAX_FLOAT"""
+    _lib.orc_ray_triangle.restype = C.c_float
+    return np.float32(_lib.orc_ray_triangle(_f3(origin), _f3(direction), _f3(triangle["a"]), _f3(triangle["b"]), _f3(triangle["c"])))
+
+
 def make_ray(camera, px, py):
     cam = _camera(camera)
     o = np.zeros(3, dtype=np.float32)

@@ -657,6 +657,13 @@ void orc_make_ray(const lbvh_camera* cam, uint32_t px, uint32_t py, float origin
 }
 
 /* CheckTriangle  :89-103 */
+/* the triangle test on its own (tests: which triangles does a ray hit at exactly which t) */
+float orc_ray_triangle(const float orig[3], const float dir[3], const float a[3], const float b[3], const float c[3])
+{
+    float u, v;
+    return ray_triangle(orig, dir, a, b, c, &u, &v);
+}
+
 static void check_triangle(uint32_t triangle_index, const ray_t* ray, const lbvh_scene* s,
                            lbvh_hit* result, lbvh_trace_stats* st)
 {

@@ -43,6 +43,7 @@ int orc_refit(uint32_t n, const lbvh_internal_node* internal, const lbvh_leaf_no
 /* a-9 pieces  Assets/_Shaders/Raytracing/Raytracing.compute:75-87 and :108-126 */
 int orc_ray_box(const float bmin[3], const float bmax[3], const float origin[3],
                 const float inv_dir[3]);
+float orc_ray_triangle(const float orig[3], const float dir[3], const float a[3], const float b[3], const float c[3]);
 void orc_make_ray(const lbvh_camera* cam, uint32_t px, uint32_t py, float origin[3], float dir[3],
                   float inv_dir[3]);
 

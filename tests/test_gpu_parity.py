@@ -114,6 +114,32 @@ def test_sort_count_zero_and_repeat(ctx):
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
 
 
+def _rocprim():
+    import ctypes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "oracle", "librocprim_sort.so")
+    assert os.path.exists(path), "build it with __graft_entry__.build() (oracle/Makefile)"
+    lib = ctypes.CDLL(path)
+    lib.rocprim_sort_pairs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    lib.rocprim_sort_pairs.restype = ctypes.c_int
+    return lib
+
+
+@pytest.mark.parametrize("kind,count", [("random", 1 << 20), ("random", 3 * 8192 * 16 + 777), ("morton_pads", 1000000 + 37),
+                                        ("few_digits", 300001), ("all_equal", 70000), ("reversed", 131072), ("random", 1 << 24)])
+def test_sort_equals_rocprim_radix_sort(ctx, kind, count):
+    """a THIRD implementation of "stable sort of (key, value) pairs", written by someone else and
+    running on the same GPU — rocPRIM's DeviceRadixSort::SortPairs through hipCUB (oracle/rocprim_sort.hip, tests only).
+    Keys AND values of lbvh_sort_pairs equal it on random, duplicate-heavy, padded, all-equal and reversed inputs, up
+    to 16 M pairs (the oracle is not in this comparison at all)."""
+    keys, vals = sort_inputs(count, count % 1013, kind)
+    gk, gv = gpu_sort(ctx, keys, vals)
+    rk, rv = keys.copy(), vals.copy()
+    rc = _rocprim().rocprim_sort_pairs(rk.ctypes.data, rv.ctypes.data, count)
+    assert rc == 0, f"hip error {rc} inside the rocPRIM checker"
+    assert (gk == rk).all() and (gv == rv).all()
+
+
 def test_sort_16m_properties(ctx):
     """cfg4 size (16 M keys): sortedness, stability and permutation without the oracle in the loop."""
     count = 16_000_000
@@ -762,6 +788,55 @@ def test_camera_inside_the_scene_and_negative_t(ctx):
 
 
 # ---- BASELINE size: 1 M triangles, 1080p -------------------------------------------------------------------
+
+def test_fast_mode_image_differs_from_reference_mode_only_where_t_ties(ctx, capsys):
+    """LBVH_TRACE_FAST resolves hits at EXACTLY equal t to the lowest triangle index, the reference
+    to its own visit order (Raytracing.compute:95, strict `<`): a shaded FAST frame may differ from the reference's on those
+    pixels.  Bound it at the metric's own size — the 1 M-triangle / 1080p frame of cfg2, a second camera inside the
+    scene, and a scene with every second triangle duplicated: t is identical everywhere, the hit record differs ONLY on
+    pixels where two triangles are hit at the same t (verified by testing the other triangle with the oracle), the
+    RGBA16F images are identical everywhere else, and the pixel counts are printed."""
+    rng = np.random.default_rng(5)
+    tex = rng.integers(0, 256, (64, 64, 4), dtype=np.uint8)
+    cases = [("cfg2 1M tris, camera z=250", scenes.tiled_torus(), (0.0, 0.0, 250.0), 1920, 1080, 64),
+             ("cfg2 1M tris, camera inside", scenes.tiled_torus(), (3.0, 2.0, 20.0), 1920, 1080, 64)]
+    dup = scenes.tiled_torus(nu=40, nv=24, grid=3)
+    dup = np.concatenate([dup, dup[::2]])                                  # coincident triangles: ties on every hit of theirs
+    cases.append(("every second triangle duplicated", dup, (0.0, 0.0, 140.0), 640, 360, 1 << 30))
+    for name, tris, pos, w, h, max_diff in cases:
+        d = H().RaytracingMeshDrawer(ctx, tris).awake()
+        d.set_texture(tex)
+        cam = scenes.camera(w, h, pos)
+        frames = {}
+        for mode in (L.TRACE_REFERENCE, L.TRACE_FAST):
+            d.update(cam, mode=mode)
+            hits = d.hits().copy()
+            d.shade()
+            frames[mode] = (hits, d.image().copy())
+        (rh, rimg), (fh, fimg) = frames[L.TRACE_REFERENCE], frames[L.TRACE_FAST]
+        assert (rh["t"] == fh["t"]).all()                                  # what north_star pins: identical, not within 1e-5
+        differs = (words(rh) != words(fh)).reshape(h, w, 4).any(axis=2)
+        assert (differs == (rh["tri"] != fh["tri"]).reshape(h, w)).all()   # a record differs iff another triangle won
+        # on those pixels BOTH triangles are hit at that very t: test the other mode's triangle with the oracle's arithmetic
+        ys, xs = np.nonzero(differs)
+        assert len(ys) <= max_diff, (name, len(ys))
+        if len(ys):
+            st = O.path_begin(cam).reshape(h, w)
+            for y, x in list(zip(ys, xs))[:200]:
+                for other in (rh, fh):
+                    t = O.ray_triangle(st[y, x]["origin"], st[y, x]["dir"], tris[int(other.reshape(h, w)[y, x]["tri"])])
+                    assert t == rh.reshape(h, w)[y, x]["t"], (name, y, x)
+        same = ~differs
+        assert (fimg.view(np.uint16).reshape(h, w, 4)[same] == rimg.view(np.uint16).reshape(h, w, 4)[same]).all()
+        img_diff = (fimg.view(np.uint16).reshape(h, w, 4) != rimg.view(np.uint16).reshape(h, w, 4)).any(axis=2)
+        assert (img_diff <= differs).all()
+        with capsys.disabled():
+            print(f"\n  [{name}] {w}x{h}: {int(differs.sum())} pixel(s) of {w * h} resolve a t tie differently; "
+                  f"{int(img_diff.sum())} of them shade differently; fast picks the lower index on "
+                  f"{int((fh['tri'].reshape(h, w)[differs] < rh['tri'].reshape(h, w)[differs]).sum())}")
+        assert (fh["tri"].reshape(h, w)[differs] < rh["tri"].reshape(h, w)[differs]).all()      # the documented rule
+        d.on_destroy()
+
 
 def test_cfg2_full_size(ctx):
     tris = scenes.tiled_torus()                                    # 1 000 000 triangles

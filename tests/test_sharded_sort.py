@@ -49,14 +49,14 @@ class OracleKeyOps:
         d = (k >> np.uint32(shift)) & np.uint32(255)
         if prefixes is None:
             rows = [np.bincount(d, minlength=256)]
-        else:
+        else:                                   # an int64 tensor of u32 values, as HipKeyOps takes it
             top = k.astype(np.uint64) >> np.uint64(prefix_shift)
-            rows = [np.bincount(d[top == p], minlength=256) for p in prefixes]
+            rows = [np.bincount(d[top == np.uint64(int(p) & 0xFFFFFFFF)], minlength=256) for p in prefixes.tolist()]
         return torch.from_numpy(np.stack(rows).astype(np.uint32).view(np.int32))
 
     def lower_bound(self, sorted_keys, probes):
         import torch
-        pos = np.searchsorted(sorted_keys.numpy().view(np.uint32), np.asarray(probes, dtype=np.uint32), side="left")
+        pos = np.searchsorted(sorted_keys.numpy().view(np.uint32), (probes.numpy() & 0xFFFFFFFF).astype(np.uint32), side="left")
         return torch.from_numpy(pos.astype(np.int32))
 
     def empty(self, n):

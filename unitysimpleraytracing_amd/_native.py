@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LBVH_LIB: an alternative build of the same library (tools/build_variant.sh: A/B measurements of kernel variants)
 LIB_PATH = os.environ.get("LBVH_LIB") or os.path.join(_HERE, "liblbvh.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -83,6 +83,8 @@ SIGNATURES = {
     "lbvh_debug_sort_ticket_tile": (_U32, [_U32, _U32, _U32, _U32]),
     "lbvh_key_histogram": (_I32, [_P, _P, _U32, _P, _U32, _U32, _U32, _P]),
     "lbvh_lower_bound": (_I32, [_P, _P, _U32, _P, _U32, _P]),
+    "lbvh_key_histogram_device": (_I32, [_P, _P, _U32, _P, _U32, _U32, _U32, _P]),
+    "lbvh_lower_bound_device": (_I32, [_P, _P, _U32, _P, _U32, _P]),
     "lbvh_animate": (_I32, [_P, _P, _U32, _P, _P, C.c_float, C.c_float, _P]),
     "lbvh_trace_rays": (_I32, [_P, _P, _SZ, C.c_float, C.POINTER(Scene), _P]),
     "lbvh_path_begin": (_I32, [_P, C.POINTER(Camera), _P]),

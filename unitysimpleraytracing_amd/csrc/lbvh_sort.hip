@@ -543,14 +543,18 @@ struct probe_args { uint32_t v[64]; };
 struct prefix_args { uint32_t v[16]; };
 
 // one 8-bit digit histogram per selected key prefix, privatised in LDS
+// (prefixes: by value from the host, or — d_prefixes != nullptr — read from device memory: the sharded sort keeps its
+// splitter search on the device between the all-reduces)
 __global__ __launch_bounds__(256) void key_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t count,
-                                                            prefix_args prefixes, uint32_t n_prefixes,
-                                                            uint32_t prefix_shift, uint32_t shift,
+                                                            prefix_args prefixes, const uint32_t* __restrict__ d_prefixes,
+                                                            uint32_t n_prefixes, uint32_t prefix_shift, uint32_t shift,
                                                             uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t s_hist[16 * 256];
     const uint32_t bins = n_prefixes * 256u;
     for (uint32_t i = threadIdx.x; i < bins; i += 256) s_hist[i] = 0;
+    if (d_prefixes)
+        for (uint32_t p = 0; p < n_prefixes; ++p) prefixes.v[p] = d_prefixes[p];
     __syncthreads();
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
         const uint32_t k = keys[i];
@@ -571,11 +575,11 @@ __global__ __launch_bounds__(256) void key_histogram_kernel(const uint32_t* __re
 }
 
 __global__ void lower_bound_kernel(const uint32_t* __restrict__ keys, uint32_t count, probe_args probes,
-                                   uint32_t n_probes, uint32_t* __restrict__ out)
+                                   const uint32_t* __restrict__ d_probes, uint32_t n_probes, uint32_t* __restrict__ out)
 {
     const uint32_t j = threadIdx.x;
     if (j >= n_probes) return;
-    const uint32_t probe = probes.v[j];
+    const uint32_t probe = d_probes ? d_probes[j] : probes.v[j];
     uint32_t lo = 0, hi = count;
     while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -584,22 +588,52 @@ __global__ void lower_bound_kernel(const uint32_t* __restrict__ keys, uint32_t c
     out[j] = lo;
 }
 
-extern "C" lbvh_status lbvh_key_histogram(lbvh_context* ctx, const uint32_t* d_keys, uint32_t count,
-                                          const uint32_t* h_prefixes, uint32_t n_prefixes, uint32_t prefix_shift,
-                                          uint32_t shift, uint32_t* d_hist)
+static lbvh_status key_histogram_impl(lbvh_context* ctx, const uint32_t* d_keys, uint32_t count, const uint32_t* h_prefixes,
+                                      const uint32_t* d_prefixes, uint32_t n_prefixes, uint32_t prefix_shift, uint32_t shift,
+                                      uint32_t* d_hist)
 {
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     LBVH_REQUIRE(ctx, d_hist != nullptr && n_prefixes >= 1 && n_prefixes <= 16 && shift <= 24 && prefix_shift <= 32);
-    LBVH_REQUIRE(ctx, (prefix_shift == 32 && n_prefixes == 1) || (prefix_shift < 32 && h_prefixes != nullptr));
+    LBVH_REQUIRE(ctx, (prefix_shift == 32 && n_prefixes == 1) || (prefix_shift < 32 && (h_prefixes != nullptr || d_prefixes != nullptr)));
     LBVH_REQUIRE(ctx, count == 0 || d_keys != nullptr);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     LBVH_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, (size_t)n_prefixes * 256 * 4, ctx->cur_stream));
     if (count == 0) return LBVH_OK;
     prefix_args pa = {};
-    if (prefix_shift < 32) for (uint32_t p = 0; p < n_prefixes; ++p) pa.v[p] = h_prefixes[p];
+    if (prefix_shift < 32 && h_prefixes) for (uint32_t p = 0; p < n_prefixes; ++p) pa.v[p] = h_prefixes[p];
     uint32_t blocks = (count + 4095u) / 4096u;
     if (blocks > 2048u) blocks = 2048u;
-    LBVH_LAUNCH(ctx, key_histogram_kernel, dim3(blocks), dim3(256), d_keys, count, pa, n_prefixes, prefix_shift, shift, d_hist);
+    LBVH_LAUNCH(ctx, key_histogram_kernel, dim3(blocks), dim3(256), d_keys, count, pa, prefix_shift < 32 ? d_prefixes : nullptr, n_prefixes,
+                prefix_shift, shift, d_hist);
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
+}
+
+extern "C" lbvh_status lbvh_key_histogram(lbvh_context* ctx, const uint32_t* d_keys, uint32_t count,
+                                          const uint32_t* h_prefixes, uint32_t n_prefixes, uint32_t prefix_shift,
+                                          uint32_t shift, uint32_t* d_hist)
+{
+    return key_histogram_impl(ctx, d_keys, count, h_prefixes, nullptr, n_prefixes, prefix_shift, shift, d_hist);
+}
+
+extern "C" lbvh_status lbvh_key_histogram_device(lbvh_context* ctx, const uint32_t* d_keys, uint32_t count,
+                                                 const uint32_t* d_prefixes, uint32_t n_prefixes, uint32_t prefix_shift,
+                                                 uint32_t shift, uint32_t* d_hist)
+{
+    return key_histogram_impl(ctx, d_keys, count, nullptr, d_prefixes, n_prefixes, prefix_shift, shift, d_hist);
+}
+
+static lbvh_status lower_bound_impl(lbvh_context* ctx, const uint32_t* d_sorted_keys, uint32_t count, const uint32_t* h_probes,
+                                    const uint32_t* d_probes, uint32_t n_probes, uint32_t* d_positions)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    if (n_probes == 0) return LBVH_OK;
+    LBVH_REQUIRE(ctx, (h_probes != nullptr || d_probes != nullptr) && d_positions != nullptr && n_probes <= 64);
+    LBVH_REQUIRE(ctx, count == 0 || d_sorted_keys != nullptr);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    probe_args pa = {};
+    if (h_probes) for (uint32_t j = 0; j < n_probes; ++j) pa.v[j] = h_probes[j];
+    LBVH_LAUNCH(ctx, lower_bound_kernel, dim3(1), dim3(64), d_sorted_keys, count, pa, d_probes, n_probes, d_positions);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }
@@ -607,14 +641,11 @@ extern "C" lbvh_status lbvh_key_histogram(lbvh_context* ctx, const uint32_t* d_k
 extern "C" lbvh_status lbvh_lower_bound(lbvh_context* ctx, const uint32_t* d_sorted_keys, uint32_t count,
                                         const uint32_t* h_probes, uint32_t n_probes, uint32_t* d_positions)
 {
-    if (!ctx) return LBVH_ERR_INVALID_ARG;
-    if (n_probes == 0) return LBVH_OK;
-    LBVH_REQUIRE(ctx, h_probes != nullptr && d_positions != nullptr && n_probes <= 64);
-    LBVH_REQUIRE(ctx, count == 0 || d_sorted_keys != nullptr);
-    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    probe_args pa = {};
-    for (uint32_t j = 0; j < n_probes; ++j) pa.v[j] = h_probes[j];
-    LBVH_LAUNCH(ctx, lower_bound_kernel, dim3(1), dim3(64), d_sorted_keys, count, pa, n_probes, d_positions);
-    LBVH_HIP_TRY(ctx, hipGetLastError());
-    return LBVH_OK;
+    return lower_bound_impl(ctx, d_sorted_keys, count, h_probes, nullptr, n_probes, d_positions);
+}
+
+extern "C" lbvh_status lbvh_lower_bound_device(lbvh_context* ctx, const uint32_t* d_sorted_keys, uint32_t count,
+                                               const uint32_t* d_probes, uint32_t n_probes, uint32_t* d_positions)
+{
+    return lower_bound_impl(ctx, d_sorted_keys, count, nullptr, d_probes, n_probes, d_positions);
 }

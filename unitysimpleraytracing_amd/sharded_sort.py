@@ -6,13 +6,15 @@ the data crosses it ONCE (one all-to-all of key ranges, all 7 links busy) instea
 pass; the only RCCL all-reduces are the [W-1][256] MSD digit histograms that pick the splitters.
 
     1. every rank sorts its own block                       lbvh_sort_pairs      (local, HBM-bound)
-    2. ranks agree on the W-1 splitter keys = the order     lbvh_key_histogram   (local)
+    2. ranks agree on the W-1 splitter keys = the order     lbvh_key_histogram_device (local)
        statistics at q*N/W: four MSD rounds, each one        all_reduce(SUM)      (RCCL, <= 28 KB)
        all-reduce of the 8-bit digit histograms of the keys
-       that share the prefix found so far
-    3. send offsets of the splitters in the sorted block    lbvh_lower_bound     (local)
-    4. one exchange: rank q receives every key in            all_to_all_single    (RCCL over xGMI)
+       that share the prefix found so far; the digit is
+       picked on the device (torch ops on the small table)
+    3. send offsets of the splitters in the sorted block    lbvh_lower_bound_device (local)
+    4. one exchange: rank q receives every (key, value) in  all_to_all_single    (RCCL over xGMI, 64-bit words)
        [splitter_q, splitter_q+1) from every rank, in rank order
+   One host synchronisation per sort (the [W][W] send-count table that all_to_all_single takes as host integers).
     5. every rank sorts what it received                    lbvh_sort_pairs      (local)
 
 The concatenation of the ranks' results is bit-identical to lbvh_sort_pairs over the whole array:
@@ -50,18 +52,25 @@ class HipKeyOps:
                                                        C.c_void_p(vals.data_ptr()), keys.numel()))
 
     def key_histogram(self, keys, prefixes, prefix_shift, shift):
-        n_p = 1 if prefixes is None else len(prefixes)
+        """prefixes: None (every key) or an int64 DEVICE tensor of u32 values — they never visit the host"""
+        n_p = 1 if prefixes is None else prefixes.numel()
         hist = torch.empty(n_p * 256, dtype=torch.int32, device=self.device)
-        arr = None if prefixes is None else (C.c_uint32 * n_p)(*[int(p) for p in prefixes])
-        N.check(self.ctx.handle, N.lib.lbvh_key_histogram(self.ctx.handle, C.c_void_p(keys.data_ptr()), keys.numel(),
-                                                          arr, n_p, prefix_shift, shift, C.c_void_p(hist.data_ptr())))
+        if prefixes is None:
+            N.check(self.ctx.handle, N.lib.lbvh_key_histogram(self.ctx.handle, C.c_void_p(keys.data_ptr()), keys.numel(),
+                                                              None, 1, prefix_shift, shift, C.c_void_p(hist.data_ptr())))
+        else:
+            p32 = prefixes.to(torch.int32)             # low 32 bits = the u32 pattern
+            N.check(self.ctx.handle, N.lib.lbvh_key_histogram_device(self.ctx.handle, C.c_void_p(keys.data_ptr()), keys.numel(),
+                                                                     C.c_void_p(p32.data_ptr()), n_p, prefix_shift, shift,
+                                                                     C.c_void_p(hist.data_ptr())))
         return hist.view(n_p, 256)
 
     def lower_bound(self, sorted_keys, probes):
-        out = torch.empty(len(probes), dtype=torch.int32, device=self.device)
-        arr = (C.c_uint32 * len(probes))(*[int(p) for p in probes])
-        N.check(self.ctx.handle, N.lib.lbvh_lower_bound(self.ctx.handle, C.c_void_p(sorted_keys.data_ptr()),
-                                                        sorted_keys.numel(), arr, len(probes), C.c_void_p(out.data_ptr())))
+        """probes: an int64 DEVICE tensor of u32 values"""
+        out = torch.empty(probes.numel(), dtype=torch.int32, device=self.device)
+        p32 = probes.to(torch.int32)
+        N.check(self.ctx.handle, N.lib.lbvh_lower_bound_device(self.ctx.handle, C.c_void_p(sorted_keys.data_ptr()), sorted_keys.numel(),
+                                                               C.c_void_p(p32.data_ptr()), probes.numel(), C.c_void_p(out.data_ptr())))
         return out
 
     def empty(self, n):
@@ -95,6 +104,17 @@ class _Comm:
         out = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(out, t, group=self.group)
         return [o.tolist() for o in out]
+
+    def all_gather_small(self, t):
+        """Every rank's small 1-D int64 tensor -> [world][len] tensor on the same device (no host visit under RCCL)."""
+        if self.staged and t.is_cuda:
+            h = t.cpu()
+            out = [torch.empty_like(h) for _ in range(self.world)]
+            dist.all_gather(out, h, group=self.group)
+            return torch.stack(out).to(t.device)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return torch.stack(out)
 
     def all_to_all(self, send, send_counts, recv, recv_counts):
         if self.staged:
@@ -166,16 +186,18 @@ class ShardedSorter:
         self.splitters = None
 
     # -- step 2 ------------------------------------------------------------------------------------
-    def find_splitters(self, keys, n_local_counts):
-        """W-1 splitter keys: splitter_q = the key at global sorted position q*N/W (an order statistic,
-        found MSD digit by digit from all-reduced histograms).  Identical on every rank."""
+    def find_splitters(self, keys, total):
+        """W-1 splitter keys: splitter_q = the key at global sorted position q*N/W (an order statistic, found MSD digit
+        by digit from all-reduced histograms).  Identical on every rank.  Everything stays on the device: per round one
+        histogram kernel, one all-reduce of the [W-1][256] table, and the digit selection as a handful of torch
+        operations on that table (cumulative sum, search, gather) — no host round trip (round 2 read the table back to
+        the host in every one of the four rounds).  Returns an int64 tensor of u32 values on the keys' device."""
         W = self.comm.world
+        dev = keys.device
         if W == 1:
-            return []
-        total = int(sum(n_local_counts))
-        targets = [(q * total) // W for q in range(1, W)]           # 0-based global positions
-        prefixes = [0] * (W - 1)
-        remaining = list(targets)
+            return torch.empty(0, dtype=torch.int64, device=dev)
+        remaining = torch.tensor([(q * total) // W for q in range(1, W)], dtype=torch.int64, device=dev)   # 0-based global positions
+        prefixes = torch.zeros(W - 1, dtype=torch.int64, device=dev)
         for level, shift in enumerate(LEVEL_SHIFTS):
             if level == 0:
                 hist = self.ops.key_histogram(keys, None, 32, shift)
@@ -183,17 +205,18 @@ class ShardedSorter:
                 hist = self.ops.key_histogram(keys, prefixes, shift + DIGIT_BITS, shift)
             hist = hist.to(torch.int64) & 0xFFFFFFFF                 # u32 counts; the sum needs 64 bits
             hist = self.comm.all_reduce_sum(hist)                    # RCCL: the global digit histogram
-            h = hist.cpu().numpy()                                   # [n_prefixes][256]
-            for q in range(W - 1):
-                row = h[0] if level == 0 else h[q]
-                cum = np.cumsum(row)
-                d = int(np.searchsorted(cum, remaining[q], side="right"))
-                d = min(d, 255)
-                remaining[q] -= int(cum[d - 1]) if d else 0
-                prefixes[q] = (prefixes[q] << DIGIT_BITS) | d
-        return [_u32(p) for p in prefixes]
+            rows = hist.expand(W - 1, 256) if level == 0 else hist   # [W-1][256]
+            cum = torch.cumsum(rows, dim=1)
+            d = torch.searchsorted(cum.contiguous(), remaining.unsqueeze(1), right=True).squeeze(1).clamp(max=255)
+            below = torch.where(d > 0, cum.gather(1, (d - 1).clamp(min=0).unsqueeze(1)).squeeze(1), torch.zeros_like(remaining))
+            remaining = remaining - below
+            prefixes = (prefixes << DIGIT_BITS) | d
+        return prefixes
 
-    def sort(self, keys, vals):
+    def sort(self, keys, vals, counts=None):
+        """counts: every rank's block length when the caller knows them (a fixed partition such as block_of): saves the
+        one host round trip that gathers them.  Host synchronisations per sort: ONE (the [W][W] table of send counts,
+        which all_to_all_single needs as host integers) + that optional one — round 2 had seven."""
         ops, comm = self.ops, self.comm
         W = comm.world
         n_local = keys.numel()
@@ -201,19 +224,31 @@ class ShardedSorter:
         if W == 1 and not self.always_exchange:
             self.splitters = []
             return keys, vals, [n_local]
-        counts = [c[0] for c in comm.all_gather_host_ints([n_local])]
+        if counts is None:
+            counts = [c[0] for c in comm.all_gather_host_ints([n_local])]
+        assert counts[comm.rank] == n_local
         if sum(counts) == 0:
-            return keys, vals, counts
-        self.splitters = self.find_splitters(keys, counts)                             # 2
-        pos = ops.lower_bound(keys, self.splitters).cpu().tolist()                      # 3
-        edges = [0] + [int(p) & 0xFFFFFFFF for p in pos] + [n_local]
-        send_counts = [edges[i + 1] - edges[i] for i in range(W)]
-        assert min(send_counts) >= 0                                                   # splitters are non-decreasing
-        table = comm.all_gather_host_ints(send_counts)                                 # [src][dst]
+            return keys, vals, list(counts)
+        dev = keys.device
+        splitters = self.find_splitters(keys, int(sum(counts)))                        # 2 (device)
+        pos = ops.lower_bound(keys, splitters).to(torch.int64) & 0xFFFFFFFF if W > 1 else torch.empty(0, dtype=torch.int64, device=dev)   # 3
+        edges = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), pos, torch.full((1,), n_local, dtype=torch.int64, device=dev)])
+        send_dev = edges[1:] - edges[:-1]
+        packed = torch.cat([send_dev, splitters])                                      # one small gather carries both
+        table_dev = comm.all_gather_small(packed)                                      # [src][dst | splitters]
+        table_h = table_dev.cpu()                                                      # the ONE host synchronisation
+        table = table_h[:, :W].tolist()
+        self.splitters = [_u32(x) for x in table_h[comm.rank, W:].tolist()]
+        send_counts = table[comm.rank]
+        assert min(send_counts) >= 0 and sum(send_counts) == n_local                   # splitters are non-decreasing
         recv_counts = [table[src][comm.rank] for src in range(W)]
-        out_keys, out_vals = ops.empty(sum(recv_counts)), ops.empty(sum(recv_counts))
-        comm.all_to_all(keys, send_counts, out_keys, recv_counts)                      # 4
-        comm.all_to_all(vals, send_counts, out_vals, recv_counts)
+        n_recv = sum(recv_counts)
+        # 4: (key, value) pairs cross xGMI as ONE all-to-all of 64-bit words
+        pairs = torch.stack([keys, vals], dim=1).contiguous().view(torch.int64).view(-1)
+        out_pairs = torch.empty(n_recv, dtype=torch.int64, device=dev)
+        comm.all_to_all(pairs, send_counts, out_pairs, recv_counts)
+        kv = out_pairs.view(torch.int32).view(-1, 2)
+        out_keys, out_vals = kv[:, 0].contiguous(), kv[:, 1].contiguous()
         ops.sort_pairs(out_keys, out_vals)                                             # 5 (stable)
         return out_keys, out_vals, [sum(table[src][dst] for src in range(W)) for dst in range(W)]
 
@@ -252,7 +287,8 @@ def sort_container(sorter, container):
     keys = DeviceArray(container.keys.device.value, cap).tensor(dev)
     idx = DeviceArray(container.triangle_index.device.value, cap).tensor(dev)
     lo, hi = block_of(comm.rank, comm.world, cap)
-    k, v, counts = sorter.sort(keys[lo:hi].clone(), idx[lo:hi].clone())
+    blocks = [block_of(r, comm.world, cap) for r in range(comm.world)]
+    k, v, counts = sorter.sort(keys[lo:hi].clone(), idx[lo:hi].clone(), counts=[b[1] - b[0] for b in blocks])
     gk, gv = sorter.gather(k, v, counts)
     keys.copy_(gk)
     idx.copy_(gv)
