@@ -85,8 +85,6 @@ public static class LbvhNative
     // LBVH_TRACE_FAST keeps a dispatch hint from the previous frame; this drops it (the next frame runs as a first frame)
     [DllImport(Lib)] public static extern int lbvh_trace_forget(IntPtr ctx);
     [DllImport(Lib)] public static extern int lbvh_debug_ray_stack_split(IntPtr ctx, uint ldsEntries);
-    // test hook: child boxes of the derived scene not contained in their 32-byte (quantised) counterpart: 0
-    [DllImport(Lib)] public static extern int lbvh_debug_check_ray_nodes(IntPtr ctx, ref Scene scene, out uint violations);
     // measurement helper: shader clock held under a vector-ALU-bound load, MHz
     [DllImport(Lib)] public static extern int lbvh_clock_probe(IntPtr ctx, out float shaderMhz);
     // a context whose work is ordered by a stream the caller owns (hipStream_t), e.g. an interop stream

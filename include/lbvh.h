@@ -393,8 +393,8 @@ typedef struct lbvh_path_state {
 } lbvh_path_state;
 
 /* Closest hit for `count` arbitrary rays taken from the path states (origin, dir; dead paths are skipped and
- * get a miss record): one ray per lane over the derived traversal scene (lbvh_build_fast_scene; its nodes re-encoded
- * in 32 bytes with quantised, conservative child boxes on first use after each build), near-first, t-pruned, per-lane stack of 64 entries like the reference's (Raytracing.compute:113; the first 16 in LDS, deeper
+ * get a miss record): one ray per lane over the derived traversal scene (lbvh_build_fast_scene), near-first,
+ * t-pruned, per-lane stack of 64 entries like the reference's (Raytracing.compute:113; the first 16 in LDS, deeper
  * ones in device memory).  Accept rule = the reference's (own-AABB slab test, Moeller-Trumbore, strict
  * t < best) plus t > t_min, which secondary rays need to leave their surface and the reference lacks
  * (Raytracing.compute:70). */
@@ -408,13 +408,6 @@ lbvh_status lbvh_debug_ray_stack_split(lbvh_context* ctx, uint32_t lds_entries);
 
 /* Camera rays into path states (origin/dir as Raytracing.compute:108-126, throughput 1, radiance 0, alive). */
 lbvh_status lbvh_path_begin(lbvh_context* ctx, const lbvh_camera* h_camera, lbvh_path_state* d_states);
-
-/* Test hook.  The per-ray walker of lbvh_trace_rays / lbvh_path_bounce steps over 32-byte nodes: the child boxes of the
- * derived scene's nodes as 8-bit offsets on a per-node grid, each plane moved outward by two grid steps or more (two
- * 16-byte requests per step instead of four; conservative culling only — which triangles are accepted is decided by the
- * exact Moeller-Trumbore test and t_min < t < best, as before).  This call (re)derives them for the scene if needed and
- * counts the child boxes that are NOT contained in their decoded counterpart with a whole grid step to spare: 0. */
-lbvh_status lbvh_debug_check_ray_nodes(lbvh_context* ctx, const lbvh_scene* h_scene, uint32_t* h_violations);
 
 /* One bounce for every live path given its hit record: a miss adds throughput * sky(dir) and ends the path
  * (sky = (1 - s) * (1,1,1) + s * (0.5,0.7,1), s = 0.5 * (dir.y + 1)); a hit multiplies the throughput by

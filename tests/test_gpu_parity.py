@@ -1169,28 +1169,6 @@ def test_secondary_rays_and_path_trace_bit_exact(ctx):
     pt.drawer.on_destroy()
 
 
-def test_ray_walker_nodes_are_supersets_of_the_exact_child_boxes(ctx):
-    """the per-ray walker steps over 32-byte nodes whose child boxes are 8-bit offsets on a per-node
-    grid.  They only cull (the accept rule is the exact triangle test), so all that is required of them is containment:
-    every exact child box of the derived scene lies inside its decoded counterpart with a whole grid step to spare —
-    checked on the device for random soup, the tiled tori, triangles far outside the scene box, a scene inside one Morton
-    cell, slivers and the 1 M-triangle mesh."""
-    rng = np.random.default_rng(8)
-    big = scenes.random_triangles(3000, seed=3)
-    for f in ("a", "b", "c"):
-        big[f] *= 40.0                                                    # far outside the +-125 scene box
-    tiny = scenes.random_triangles(5000, seed=4, extent=0.01, edge=0.002)  # one Morton cell, boxes near the 0.001 padding
-    sliver = scenes.random_triangles(4000, seed=5)
-    sliver["c"] = sliver["a"] + (sliver["b"] - sliver["a"]) * np.float32(0.5) + rng.normal(0, 1e-6, (4000, 3)).astype(np.float32)
-    for tris in (scenes.random_triangles(4096, seed=1), scenes.tiled_torus(nu=20, nv=12, grid=3), big, tiny, sliver, scenes.tiled_torus()):
-        d = H().RaytracingMeshDrawer(ctx, tris).awake()
-        s = d.container.scene()
-        bad = C.c_uint32(12345)
-        N().check(ctx.handle, N().lib.lbvh_debug_check_ray_nodes(ctx.handle, C.byref(s), C.byref(bad)))
-        assert bad.value == 0
-        d.on_destroy()
-
-
 @pytest.mark.parametrize("lds_entries", [1, 2, 5])
 def test_secondary_rays_deep_stack_in_device_memory(ctx, lds_entries):
     """trace_rays_kernel keeps the first 16 stack entries of a lane in LDS and deeper ones in a device-memory slab.

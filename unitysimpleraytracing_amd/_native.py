@@ -83,7 +83,6 @@ SIGNATURES = {
     "lbvh_debug_sort_ticket_tile": (_U32, [_U32, _U32, _U32, _U32]),
     "lbvh_key_histogram": (_I32, [_P, _P, _U32, _P, _U32, _U32, _U32, _P]),
     "lbvh_lower_bound": (_I32, [_P, _P, _U32, _P, _U32, _P]),
-    "lbvh_debug_check_ray_nodes": (_I32, [_P, _P, _P]),
     "lbvh_key_histogram_device": (_I32, [_P, _P, _U32, _P, _U32, _U32, _U32, _P]),
     "lbvh_lower_bound_device": (_I32, [_P, _P, _U32, _P, _U32, _P]),
     "lbvh_animate": (_I32, [_P, _P, _U32, _P, _P, C.c_float, C.c_float, _P]),

@@ -66,7 +66,6 @@ void lbvh_note_fast_built(lbvh_context* ctx, const lbvh_scene& s)
     ctx->fast_src.triangle_aabb = s.triangle_aabb;
     ctx->fast_src.n = s.n;
     ctx->fast_valid = true;
-    ctx->ray_nodes_valid = false;            // quantised from the fused nodes on the next lbvh_trace_rays / lbvh_path_bounce
 }
 
 int lbvh_require_fast(lbvh_context* ctx, const lbvh_scene& s, const char* who)
@@ -207,7 +206,6 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
     if (ctx->fast_tree) (void)hipFree(ctx->fast_tree);
     if (ctx->hier) (void)hipFree(ctx->hier);
     if (ctx->ray_scratch) (void)hipFree(ctx->ray_scratch);
-    if (ctx->ray_nodes) (void)hipFree(ctx->ray_nodes);
     for (auto& s : ctx->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

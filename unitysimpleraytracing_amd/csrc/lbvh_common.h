@@ -56,19 +56,6 @@ struct alignas(64) lbvh_fast_tri {
 };
 static_assert(sizeof(lbvh_fast_tri) == 64, "fast triangle must be 64 bytes");
 
-// Traversal node of the per-ray walker (lbvh_trace_rays / lbvh_path_bounce), 32 bytes = two 16-byte requests per step
-// instead of four: both child boxes as 8-bit offsets on a per-node grid.  grid[k] holds the grid's origin on axis k as an
-// fp32 whose low mantissa byte is replaced by the biased exponent E of the grid's spacing 2^(E - 127) (decode: origin =
-// bits & 0xFFFFFF00, a value <= the true minimum); plane = origin + q * spacing.  q[0..2] / q[3..5] = left child's min /
-// max planes (x, y, z), q[6..8] / q[9..11] = the right child's.  Written by quantise_nodes_kernel (lbvh_path.hip) from
-// the 64-byte fused nodes with every plane moved OUTWARD by at least two grid steps: a superset box — conservative
-// culling, the accept rule (Moeller-Trumbore on the exact triangle, t > t_min, t < best) is untouched.
-struct alignas(32) lbvh_ray_node {
-    uint32_t grid[3]; uint32_t left;
-    uint8_t q[12];    uint32_t right;
-};
-static_assert(sizeof(lbvh_ray_node) == 32, "ray node must be 32 bytes");
-
 struct lbvh_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -110,10 +97,6 @@ struct lbvh_context {
     // buffers statelessly (Sc/RaytracingMeshDrawer.cs:65-70), so a stale cache must never answer for a scene
     struct { const void *triangles, *sorted_indices, *triangle_aabb; uint32_t n; } fast_src = {nullptr, nullptr, nullptr, 0};
     bool fast_valid = false;
-    // the per-ray walker's 32-byte nodes, derived from fast_nodes on first use after every (re)build of the derived scene
-    lbvh_ray_node* ray_nodes = nullptr;
-    uint32_t ray_nodes_capacity = 0;
-    bool ray_nodes_valid = false;
     // sort: 8 per-XCD ticket queues only on the layout they were designed for (all 256 CUs of an SPX device behind an
     // unmasked stream: workgroups dealt round-robin over the XCDs); anything else takes tiles in ticket order
     uint32_t sort_queues = 1;

@@ -62,83 +62,6 @@ __global__ __launch_bounds__(256) void path_begin_kernel(lbvh_camera cam, lbvh_p
 constexpr int kRayStackLds = 16;
 constexpr int kRayStackDeep = 48;
 
-// ---- 32-byte nodes for the per-ray walker ------------------------------------------------------------------------------
-// The walker below is bound by the divergent requests of its lanes (waves wait 70 % of their cycles with every wave slot
-// taken; L2 sees 14.6 M requests per bounce, 40 % of them miss): the lever is BYTES per step.  A fused 64-byte node holds
-// both child boxes as 12 floats; here they are 12 bytes on a per-node grid (lbvh_common.h), so a step is two 16-byte
-// requests per lane instead of four and two nodes share a cache line.
-// Conservative by construction: grid origin <= the node's minimum (low mantissa byte cleared toward -inf), spacing
-// 2^e >= extent / 250 (and >= 2^-12, so that two grid steps exceed every rounding of the walker's decode:
-// t = q * (spacing * inv) + (origin - o) * inv, three roundings, |error| < 5 * 2^-24 * |t| < 2^-12 * |inv| for |t| * |d| < 400),
-// min planes floor(.) - 2, max planes ceil(.) + 2, all within [0, 255].
-__device__ __forceinline__ uint32_t grid_word(float lo, float hi, float& origin, float& inv_step)
-{
-    uint32_t b = __float_as_uint(lo);
-    if (b & 0x80000000u) { if (b & 0xFFu) b = (b | 0xFFu) + 1u; }       // negative: next magnitude UP with a clear low byte
-    else b &= 0xFFFFFF00u;                                              // positive: magnitude down
-    origin = __uint_as_float(b);                                        // <= lo
-    // spacing 2^e with 250 * 2^e >= hi - origin: e = exponent(extent / 250) + 1 (the quotient rounded up a little)
-    const float y = fmaxf((hi - origin) * (1.0001f / 250.0f), 0.0f);
-    int e = (int)((__float_as_uint(y) >> 23) & 0xFFu) + 1;              // biased; a denormal or zero y gives 1
-    e = max(e, 127 - 12);
-    inv_step = __uint_as_float((uint32_t)(254 - e) << 23);              // 2^-(e - 127)
-    return b | (uint32_t)e;
-}
-
-__global__ __launch_bounds__(256) void quantise_nodes_kernel(const lbvh_fast_node* __restrict__ nodes, uint32_t n_nodes,
-                                                             lbvh_ray_node* __restrict__ out)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n_nodes) return;
-    const float4* nb = reinterpret_cast<const float4*>(&nodes[i]);
-    const float4 lmin = nb[0], lmax = nb[1], rmin = nb[2], rmax = nb[3];
-    const float mn[2][3] = {{lmin.x, lmin.y, lmin.z}, {rmin.x, rmin.y, rmin.z}};
-    const float mx[2][3] = {{lmax.x, lmax.y, lmax.z}, {rmax.x, rmax.y, rmax.z}};
-    uint32_t grid[3], qw[3] = {0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        float origin, inv_step;
-        grid[k] = grid_word(fminf(mn[0][k], mn[1][k]), fmaxf(mx[0][k], mx[1][k]), origin, inv_step);
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const int lo = max((int)floorf((mn[c][k] - origin) * inv_step) - 2, 0);
-            const int hi = min((int)ceilf((mx[c][k] - origin) * inv_step) + 2, 255);
-            const int at_lo = c * 6 + k, at_hi = c * 6 + 3 + k;           // byte positions in q[12]
-            qw[at_lo >> 2] |= (uint32_t)lo << ((at_lo & 3) * 8);
-            qw[at_hi >> 2] |= (uint32_t)hi << ((at_hi & 3) * 8);
-        }
-    }
-    uint4* o = reinterpret_cast<uint4*>(&out[i]);
-    o[0] = make_uint4(grid[0], grid[1], grid[2], __float_as_uint(lmin.w));
-    o[1] = make_uint4(qw[0], qw[1], qw[2], __float_as_uint(lmax.w));
-}
-
-// debug / test: how many child boxes of the fused nodes are NOT inside their decoded 32-byte counterpart (must be 0)
-__global__ __launch_bounds__(256) void check_ray_nodes_kernel(const lbvh_fast_node* __restrict__ nodes, const lbvh_ray_node* __restrict__ rn,
-                                                              uint32_t n_nodes, uint32_t* __restrict__ bad)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n_nodes) return;
-    const float4* nb = reinterpret_cast<const float4*>(&nodes[i]);
-    const float4 b4[4] = {nb[0], nb[1], nb[2], nb[3]};
-    const float box[4][3] = {{b4[0].x, b4[0].y, b4[0].z}, {b4[1].x, b4[1].y, b4[1].z}, {b4[2].x, b4[2].y, b4[2].z}, {b4[3].x, b4[3].y, b4[3].z}};
-    const lbvh_ray_node q = rn[i];
-    uint32_t wrong = (q.left != __float_as_uint(b4[0].w) || q.right != __float_as_uint(b4[1].w)) ? 1u : 0u;
-    for (int k = 0; k < 3; k++) {
-        const float origin = __uint_as_float(q.grid[k] & 0xFFFFFF00u);
-        const float step = __uint_as_float((q.grid[k] & 0xFFu) << 23);
-        for (int c = 0; c < 2; c++) {
-            const float lo = origin + (float)q.q[c * 6 + k] * step, hi = origin + (float)q.q[c * 6 + 3 + k] * step;
-            // outside by at least one whole grid step on each side (the walker's decode rounds differently); a min plane
-            // ON the grid's origin (q = 0) is exact: the walker's t for it is (origin - o) * inv, the reference's own two
-            // roundings on a value <= the true plane — monotone, no margin needed
-            const bool lo_ok = q.q[c * 6 + k] == 0 ? origin <= box[c * 2][k] : lo + step <= box[c * 2][k];
-            if (!lo_ok || !(hi - step >= box[c * 2 + 1][k])) wrong++;
-        }
-    }
-    if (wrong) atomicAdd(bad, wrong);
-}
-
 // Live rays only: alive_rays_kernel writes the miss record of every dead ray and compacts the indices of the live
 // ones (after the first bounce more than half of a frame's paths have left the scene).  (Sorting the live rays by direction octant + Morton code of the origin on top of this was
 // measured: the sort costs 0.15 ms per bounce and the walk does not get faster.)
@@ -179,17 +102,10 @@ static inline size_t deep_bytes(size_t count) { return (size_t)ray_waves_of(coun
 static inline size_t list_bytes(size_t count) { return (count * 4 + 255) & ~(size_t)255; }
 static inline uint32_t* deep_stacks(lbvh_context* ctx, size_t count) { return (uint32_t*)((char*)ctx->ray_scratch + 256 + list_bytes(count)); }
 
-// byte k of a dword as a float (v_cvt_f32_ubyteK)
-__device__ __forceinline__ float ubyte0(uint32_t w) { return (float)(w & 0xFFu); }
-__device__ __forceinline__ float ubyte1(uint32_t w) { return (float)((w >> 8) & 0xFFu); }
-__device__ __forceinline__ float ubyte2(uint32_t w) { return (float)((w >> 16) & 0xFFu); }
-__device__ __forceinline__ float ubyte3(uint32_t w) { return (float)(w >> 24); }
-
 __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* __restrict__ states, const uint32_t* __restrict__ n_alive,
                                                         const uint32_t* __restrict__ list, float t_min,
-                                                        const lbvh_fast_node* __restrict__ nodes,      // the array of 64-byte lines: triangle lines
-                                                        const lbvh_ray_node* __restrict__ rnodes,      // the 32-byte nodes walked
-                                                        lbvh_hit* __restrict__ hits,
+                                                        const lbvh_fast_node* __restrict__ nodes,
+                                                        const lbvh_fast_tri* __restrict__ tris, lbvh_hit* __restrict__ hits,
                                                         uint32_t* __restrict__ deep,     // [gridDim.x][kRayStackDeep][64]
                                                         uint32_t lds_depth)              // <= kRayStackLds
 {
@@ -229,28 +145,12 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* _
         }
         if (!__any(active)) break;
         if (active) {
-            // two 16-byte requests: {grid origin + spacing exponent x 3, left} {12 plane bytes, right}
-            const uint4* nb = reinterpret_cast<const uint4*>(&rnodes[node]);
-            const uint4 g = nb[0], q = nb[1];
-            const uint32_t lref = g.w, rref = q.w;
-            // per axis: t(plane byte) = byte * a + b with a = spacing * inv, b = (origin - o) * inv
-            const float ax = __uint_as_float((g.x & 0xFFu) << 23) * ray.ix, bx = (__uint_as_float(g.x & 0xFFFFFF00u) - ray.ox) * ray.ix;
-            const float ay = __uint_as_float((g.y & 0xFFu) << 23) * ray.iy, by = (__uint_as_float(g.y & 0xFFFFFF00u) - ray.oy) * ray.iy;
-            const float az = __uint_as_float((g.z & 0xFFu) << 23) * ray.iz, bz = (__uint_as_float(g.z & 0xFFFFFF00u) - ray.oz) * ray.iz;
-            // bytes: q.x = {lmin.x, lmin.y, lmin.z, lmax.x}, q.y = {lmax.y, lmax.z, rmin.x, rmin.y}, q.z = {rmin.z, rmax.x, rmax.y, rmax.z}
-            const float l1x = __builtin_fmaf(ubyte0(q.x), ax, bx), l2x = __builtin_fmaf(ubyte3(q.x), ax, bx);
-            const float l1y = __builtin_fmaf(ubyte1(q.x), ay, by), l2y = __builtin_fmaf(ubyte0(q.y), ay, by);
-            const float l1z = __builtin_fmaf(ubyte2(q.x), az, bz), l2z = __builtin_fmaf(ubyte1(q.y), az, bz);
-            const float r1x = __builtin_fmaf(ubyte2(q.y), ax, bx), r2x = __builtin_fmaf(ubyte1(q.z), ax, bx);
-            const float r1y = __builtin_fmaf(ubyte3(q.y), ay, by), r2y = __builtin_fmaf(ubyte2(q.z), ay, by);
-            const float r1z = __builtin_fmaf(ubyte0(q.z), az, bz), r2z = __builtin_fmaf(ubyte3(q.z), az, bz);
-            // the slab test of RayBoxIntersection (Raytracing.compute:75-87) on the decoded (superset) boxes
-            const float tl = fmaxf(fminf(l1x, l2x), fmaxf(fminf(l1y, l2y), fminf(l1z, l2z)));
-            const float fl = fminf(fmaxf(l1x, l2x), fminf(fmaxf(l1y, l2y), fmaxf(l1z, l2z)));
-            const float tr = fmaxf(fminf(r1x, r2x), fmaxf(fminf(r1y, r2y), fminf(r1z, r2z)));
-            const float fr = fminf(fmaxf(r1x, r2x), fminf(fmaxf(r1y, r2y), fmaxf(r1z, r2z)));
-            bool hit_l = fl > tl && fl > 0.0f && !(tl > best_t);
-            bool hit_r = fr > tr && fr > 0.0f && !(tr > best_t);
+            const float4* nb = reinterpret_cast<const float4*>(&nodes[node]);
+            const float4 lmin = nb[0], lmax = nb[1], rmin = nb[2], rmax = nb[3];
+            const uint32_t lref = __float_as_uint(lmin.w), rref = __float_as_uint(lmax.w);
+            float tl, tr;
+            bool hit_l = ray_box(lmin, lmax, ray, tl) && !(tl > best_t);
+            bool hit_r = ray_box(rmin, rmax, ray, tr) && !(tr > best_t);
 #pragma unroll
             for (int side = 0; side < 2; side++) {
                 const bool h = side == 0 ? hit_l : hit_r;
@@ -444,55 +344,6 @@ lbvh_status lbvh_path_begin(lbvh_context* ctx, const lbvh_camera* h_camera, lbvh
     return LBVH_OK;
 }
 
-}  // extern "C"
-
-// the 32-byte nodes of the derived scene the context holds: quantised again after every (re)build of that scene
-static int ensure_ray_nodes(lbvh_context* ctx, uint32_t n)
-{
-    if (ctx->ray_nodes_valid) return LBVH_OK;
-    if (ctx->ray_nodes_capacity < ctx->fast_capacity) {
-        LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->side_stream) LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->side_stream));
-        if (ctx->ray_nodes) { LBVH_HIP_TRY(ctx, hipFree(ctx->ray_nodes)); ctx->ray_nodes = nullptr; }
-        ctx->ray_nodes_capacity = 0;
-        LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->ray_nodes, (size_t)ctx->fast_capacity * sizeof(lbvh_ray_node)));
-        ctx->ray_nodes_capacity = ctx->fast_capacity;
-    }
-    const uint32_t n_nodes = n - 1;
-    LBVH_LAUNCH(ctx, quantise_nodes_kernel, dim3((n_nodes + 255) / 256), dim3(256), ctx->fast_nodes, n_nodes, ctx->ray_nodes);
-    LBVH_HIP_TRY(ctx, hipGetLastError());
-    ctx->ray_nodes_valid = true;
-    return LBVH_OK;
-}
-
-extern "C" {
-
-lbvh_status lbvh_debug_check_ray_nodes(lbvh_context* ctx, const lbvh_scene* h_scene, uint32_t* h_violations)
-{
-    if (!ctx) return LBVH_ERR_INVALID_ARG;
-    LBVH_REQUIRE(ctx, h_scene != nullptr && h_violations != nullptr);
-    {
-        const int frc = lbvh_require_fast(ctx, *h_scene, "lbvh_debug_check_ray_nodes");
-        if (frc != LBVH_OK) return frc;
-    }
-    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_ray_nodes(ctx, h_scene->n);
-    if (rc != LBVH_OK) return rc;
-    uint32_t* d_bad = nullptr;
-    LBVH_HIP_TRY(ctx, hipMalloc((void**)&d_bad, 4));
-    hipError_t e = hipMemsetAsync(d_bad, 0, 4, ctx->cur_stream);
-    const uint32_t n_nodes = h_scene->n - 1;
-    if (e == hipSuccess) {
-        LBVH_LAUNCH(ctx, check_ray_nodes_kernel, dim3((n_nodes + 255) / 256), dim3(256), ctx->fast_nodes, ctx->ray_nodes, n_nodes, d_bad);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(h_violations, d_bad, 4, hipMemcpyDeviceToHost, ctx->cur_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->cur_stream);
-    (void)hipFree(d_bad);
-    LBVH_HIP_TRY(ctx, e);
-    return LBVH_OK;
-}
-
 lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, float t_min,
                             const lbvh_scene* h_scene, lbvh_hit* d_hits)
 {
@@ -509,15 +360,13 @@ lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, 
     // scratch: [live-ray count (256 B) | indices of the live rays]
     int rc = lbvh_reserve(ctx, &ctx->ray_scratch, &ctx->ray_scratch_bytes, 256 + list_bytes(count) + deep_bytes(count));
     if (rc != LBVH_OK) return rc;
-    rc = ensure_ray_nodes(ctx, h_scene->n);
-    if (rc != LBVH_OK) return rc;
     uint32_t* n_alive = (uint32_t*)ctx->ray_scratch;
     uint32_t* list = (uint32_t*)((char*)ctx->ray_scratch + 256);
     LBVH_HIP_TRY(ctx, hipMemsetAsync(n_alive, 0, 4, ctx->cur_stream));
     LBVH_LAUNCH(ctx, alive_rays_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), d_states, count, n_alive, list, d_hits);
     const uint32_t ray_waves = ray_waves_of(count);
     LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive,
-                list, t_min, ctx->fast_nodes, ctx->ray_nodes, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds);
+                list, t_min, ctx->fast_nodes, ctx->fast_tris, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }
@@ -557,8 +406,6 @@ lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = lbvh_reserve(ctx, &ctx->ray_scratch, &ctx->ray_scratch_bytes, 256 + list_bytes(count) + deep_bytes(count));
     if (rc != LBVH_OK) return rc;
-    rc = ensure_ray_nodes(ctx, h_scene->n);
-    if (rc != LBVH_OK) return rc;
     uint32_t* n_alive = (uint32_t*)ctx->ray_scratch;
     uint32_t* list = (uint32_t*)((char*)ctx->ray_scratch + 256);
     LBVH_HIP_TRY(ctx, hipMemsetAsync(n_alive, 0, 4, ctx->cur_stream));
@@ -566,7 +413,7 @@ lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_
                 bounce, seed, albedo, d_states, n_alive, list);
     const uint32_t ray_waves = ray_waves_of(count);
     LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, ctx->fast_nodes,
-                ctx->ray_nodes, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds);
+                ctx->fast_tris, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }
