@@ -25,6 +25,8 @@ for rank in (0, 1, 5, 50, 500, 5000):
         if mode == "cold":
             big.fill_u32(rank, mirror=False)
         ctx.trace_forget()
+        if len(sys.argv) > 1:
+            ctx.clock_probe()            # a full-chip vector-ALU kernel right before: the clock is up when the lone wave starts
         ctx.record(e0)
         N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(cam), x * 8, y * 8, x * 8 + 8, y * 8 + 8, C.byref(s), L.TRACE_FAST, hits.device, None))
         ctx.record(e1)
