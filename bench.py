@@ -157,11 +157,21 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist_mod
-        if args.backend == "nccl":
-            torch.cuda.set_device(device_id)
-            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", device_id))
-        else:
-            dist_mod.init_process_group("gloo")
+        # stdout carries ONE JSON line: whatever the communication libraries print while they connect goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                torch.cuda.set_device(device_id)
+                dist_mod.init_process_group("nccl", device_id=torch.device("cuda", device_id))
+            else:
+                dist_mod.init_process_group("gloo")
+            dist_mod.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         dist = dist_mod
 
     from unitysimpleraytracing_amd import layouts as L
@@ -261,7 +271,29 @@ def main():
     trace_ms_max = reduce_max(trace_ms)
 
     # ---- untimed extras ---------------------------------------------------------------------------
-    def timed_frames(frames, before=None, camera_of=None):
+    tiles_x, tiles_y = (W + TILE_W - 1) // TILE_W, (H + TILE_H - 1) // TILE_H
+    frame_costs = DataBuffer(ctx, tiles_x * tiles_y, np.uint32) if dist is not None else None
+
+    def exchange_costs():
+        """every rank's per-tile step counts of the frame just traced, merged (all-reduce MAX of zero-filled arrays, 130 KB)
+        and handed back: under a moving camera the place a tile came from mostly belongs to another rank"""
+        import torch
+        from unitysimpleraytracing_amd.sharded_sort import DeviceArray
+        frame_costs.fill_u32(0, mirror=False)
+        ctx.trace_costs_export(frame_costs, tiles_x, tiles_y)
+        ctx.sync()
+        t = DeviceArray(frame_costs.device.value, tiles_x * tiles_y).tensor(torch.device("cuda", device_id))
+        if args.backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            torch.cuda.synchronize()
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            t.copy_(h)
+            torch.cuda.synchronize()
+        ctx.trace_costs_import(frame_costs, tiles_x, tiles_y)
+
+    def timed_frames(frames, before=None, camera_of=None, after=None):
         """mean device ms of this rank's share of `frames` frames (HIP events around the trace alone), max over ranks"""
         e0, e1 = ctx.event(), ctx.event()
         total = 0.0
@@ -273,6 +305,8 @@ def main():
             trace_share(c)
             ctx.record(e1)
             total += ctx.elapsed_ms(e0, e1)
+            if after is not None:
+                after()
         ctx.destroy_event(e0); ctx.destroy_event(e1)
         return reduce_max(total / frames)
 
@@ -286,6 +320,9 @@ def main():
         extras["trace_static_scene_ms"] = round(timed_frames(reps), 4)
         extras["trace_cold_ms"] = round(timed_frames(reps, before=ctx.trace_forget), 4)
         extras["trace_moving_ms"] = round(timed_frames(reps, camera_of=lambda k: yawed(cam, 1.0 * (k + 1))), 4)
+        if dist is not None:       # the same with the ranks' per-tile costs exchanged after every frame (lbvh_trace_costs_export / _import)
+            trace_share(); ctx.sync(); exchange_costs()
+            extras["trace_moving_costs_exchanged_ms"] = round(timed_frames(reps, camera_of=lambda k: yawed(cam, 1.0 * (k + 1)), after=exchange_costs), 4)
         trace_share(); ctx.sync()                      # back to the timed camera's history
 
     out = None

@@ -84,6 +84,9 @@ public static class LbvhNative
 
     // LBVH_TRACE_FAST keeps a dispatch hint from the previous frame; this drops it (the next frame runs as a first frame)
     [DllImport(Lib)] public static extern int lbvh_trace_forget(IntPtr ctx);
+    // multi-GPU frames: this context's per-tile costs into a full-frame array / the merged array of all ranks back
+    [DllImport(Lib)] public static extern int lbvh_trace_costs_export(IntPtr ctx, IntPtr dFrameCosts, uint tilesX, uint tilesY);
+    [DllImport(Lib)] public static extern int lbvh_trace_costs_import(IntPtr ctx, IntPtr dFrameCosts, uint tilesX, uint tilesY);
     [DllImport(Lib)] public static extern int lbvh_debug_ray_stack_split(IntPtr ctx, uint ldsEntries);
     // measurement helper: shader clock held under a vector-ALU-bound load, MHz
     [DllImport(Lib)] public static extern int lbvh_clock_probe(IntPtr ctx, out float shaderMhz);

@@ -789,6 +789,70 @@ def test_camera_inside_the_scene_and_negative_t(ctx):
 
 # ---- BASELINE size: 1 M triangles, 1080p -------------------------------------------------------------------
 
+def test_tile_costs_exported_and_imported_between_shards(ctx):
+    """lbvh_trace_costs_export / _import.  Two contexts stand for two ranks tracing the two shards of
+    a frame under a turning camera and exchanging their per-tile step counts after every frame: the export of a shard
+    holds exactly the step counts of its own tiles (against lbvh_trace_tile_costs of the same frame) and leaves the other
+    shard's alone; with the merged array imported every frame's hits still equal the oracle's (the costs are a dispatch
+    hint only); wrong frame sizes are refused."""
+    tris = scenes.tiled_torus(nu=24, nv=16, grid=3)
+    w, h = 328, 200                                            # ragged right / bottom tiles
+    tx, ty = (w + 7) // 8, (h + 7) // 8
+    c2 = H().Context(0)
+    try:
+        ctxs = [ctx, c2]
+        drawers = [H().RaytracingMeshDrawer(c, tris).awake() for c in ctxs]
+        b = O.Built(tris, capacity=drawers[0].container.capacity, threads=8)
+        hits = H().DataBuffer(ctx, w * h, L.HIT)
+        hits2 = H().DataBuffer(c2, w * h, L.HIT)
+        frame = H().DataBuffer(ctx, tx * ty, np.uint32)
+        whole = H().DataBuffer(ctx, tx * ty, np.uint32)
+        stats = H().DataBuffer(ctx, 1, L.TRACE_STATS)
+        from bench import yawed, shard_tiles
+        base = scenes.camera(w, h, (0.0, 0.0, 140.0))
+        for k in range(5):
+            cam = yawed(base, 1.5 * k)
+            ccam = N().Camera.from_dict(cam)
+            for r, (c, d, hb) in enumerate(zip(ctxs, drawers, (hits, hits2))):
+                s = d.container.scene()
+                hb.fill_u32(0x7FC00000, mirror=False)
+                N().check(c.handle, N().lib.lbvh_trace_primary_shard(c.handle, C.byref(ccam), r, 2, C.byref(s), L.TRACE_FAST, hb.device, None))
+                c.sync()
+            oh, _ = O.trace_primary(b, cam, threads=8)
+            g0, g1 = hits.get_data().reshape(h, w), hits2.get_data().reshape(h, w)
+            own0 = np.zeros((h, w), bool)
+            for (x0, y0, x1, y1) in shard_tiles(0, 2, w, h):
+                own0[y0:y1, x0:x1] = True
+            assert (np.where(own0, g0["t"], g1["t"]) == oh["t"]).all()
+            # exchange: each rank writes its own tiles into the zeroed frame array
+            frame.fill_u32(0, mirror=False)
+            ctx.sync()
+            ctx.trace_costs_export(frame, tx, ty)
+            ctx.sync()
+            only0 = frame.get_data().copy()
+            c2.trace_costs_export(frame, tx, ty)
+            c2.sync()
+            merged = frame.get_data().copy()
+            tile_own0 = own0[::8, ::8][:ty, :tx].reshape(-1)
+            assert (only0[~tile_own0] == 0).all() and (only0[tile_own0] > 0).all()
+            assert (merged[tile_own0] == only0[tile_own0]).all() and (merged[~tile_own0] > 0).all()
+            for c in ctxs:
+                c.trace_costs_import(frame, tx, ty)
+                c.sync()
+        # the exported counts are the frame's per-tile node fetches (one-wave tiles; cooperative tiles count all their waves)
+        s0 = drawers[0].container.scene()
+        ccam = N().Camera.from_dict(yawed(base, 1.5 * 4))
+        N().check(ctx.handle, N().lib.lbvh_trace_tile_costs(ctx.handle, C.byref(ccam), C.byref(s0), hits.device, stats.device, whole.device))
+        ref = whole.get_data()
+        assert (ref > 0).all() and np.median(np.abs(ref[tile_own0].astype(np.int64) - merged[tile_own0].astype(np.int64))) == 0
+        assert N().lib.lbvh_trace_costs_export(ctx.handle, frame.device, tx + 1, ty) == -1          # not the traced frame's layout
+        assert N().lib.lbvh_trace_costs_import(ctx.handle, None, tx, ty) == -1
+        for d in drawers:
+            d.on_destroy()
+    finally:
+        c2.close()
+
+
 def test_fast_mode_image_differs_from_reference_mode_only_where_t_ties(ctx, capsys):
     """LBVH_TRACE_FAST resolves hits at EXACTLY equal t to the lowest triangle index, the reference
     to its own visit order (Raytracing.compute:95, strict `<`): a shaded FAST frame may differ from the reference's on those

@@ -83,6 +83,8 @@ SIGNATURES = {
     "lbvh_debug_sort_ticket_tile": (_U32, [_U32, _U32, _U32, _U32]),
     "lbvh_key_histogram": (_I32, [_P, _P, _U32, _P, _U32, _U32, _U32, _P]),
     "lbvh_lower_bound": (_I32, [_P, _P, _U32, _P, _U32, _P]),
+    "lbvh_trace_costs_export": (_I32, [_P, _P, _U32, _U32]),
+    "lbvh_trace_costs_import": (_I32, [_P, _P, _U32, _U32]),
     "lbvh_key_histogram_device": (_I32, [_P, _P, _U32, _P, _U32, _U32, _U32, _P]),
     "lbvh_lower_bound_device": (_I32, [_P, _P, _U32, _P, _U32, _P]),
     "lbvh_animate": (_I32, [_P, _P, _U32, _P, _P, C.c_float, C.c_float, _P]),

@@ -206,6 +206,7 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
     if (ctx->fast_tree) (void)hipFree(ctx->fast_tree);
     if (ctx->hier) (void)hipFree(ctx->hier);
     if (ctx->ray_scratch) (void)hipFree(ctx->ray_scratch);
+    if (ctx->trace_frame_costs) (void)hipFree(ctx->trace_frame_costs);
     for (auto& s : ctx->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -108,10 +108,17 @@ struct lbvh_context {
     size_t trace_queues_bytes = 0;
     uint64_t trace_layout = 0;      // frame layout (tiles, shard, origin) the history belongs to
     uint32_t trace_layout_work = 0;
+    uint32_t trace_shard_index = 0, trace_shard_count = 1, trace_tiles_x = 0, trace_tiles_y = 0;   // of that trace
     bool trace_history = false;
     float fast_centre[3] = {0.0f, 0.0f, 0.0f};   // centre of the scene box the derived scene was built with
     uint32_t trace_counts_turn = 0;  // which of the two class-counter sets the next filing counts into
     lbvh_camera trace_camera = {};   // camera of the trace the history was recorded under
+    // multi-GPU frames: every rank's tile costs of the last frame, merged by the caller (lbvh_trace_costs_import): where a
+    // tile of a moved camera came from usually belongs to another rank
+    uint32_t* trace_frame_costs = nullptr;
+    uint32_t trace_frame_tiles_x = 0, trace_frame_tiles_y = 0;
+    uint32_t trace_frame_capacity = 0;
+    bool trace_frame_valid = false;
     // the traversal tree of the derived scene (aligned keys, own topology and boxes)
     void* fast_tree = nullptr;
     size_t fast_tree_bytes = 0;

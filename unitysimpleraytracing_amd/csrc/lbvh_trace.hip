@@ -1058,9 +1058,12 @@ __device__ __forceinline__ uint32_t item_of_tile(const tile_grid& g, uint32_t ti
     return (grp / g.shard_count) * kShardGroup + tile % kShardGroup;
 }
 
+// `frame` (nullable): the step counts of EVERY tile of the previous frame, whoever traced it (lbvh_trace_costs_import):
+// then a tile's cost is looked up there instead of among this shard's own items only
 __global__ __launch_bounds__(1024) void file_tiles_kernel(const uint32_t* __restrict__ cost, uint32_t n_work,
                                                           uint32_t* __restrict__ counts, uint32_t* __restrict__ lists,
-                                                          uint32_t* __restrict__ next_counts, tile_grid grid)
+                                                          uint32_t* __restrict__ next_counts, tile_grid grid,
+                                                          const uint32_t* __restrict__ frame)
 {
     __shared__ uint32_t s_count[kOrderClasses], s_base[kOrderClasses];
     const uint32_t t = threadIdx.x, lane = lane_id();
@@ -1095,16 +1098,26 @@ __global__ __launch_bounds__(1024) void file_tiles_kernel(const uint32_t* __rest
                     const float ftx = floorf((opx - (float)grid.x0) * 0.125f), fty = floorf((opy - (float)grid.y0) * 0.125f);
                     tx = (int)fminf(fmaxf(ftx, 0.0f), (float)(grid.tiles_x - 1));
                     ty = (int)fminf(fmaxf(fty, 0.0f), (float)(grid.tiles_y - 1));
-                    const uint32_t k0 = item_of_tile(grid, (uint32_t)ty * grid.tiles_x + (uint32_t)tx);
-                    if (k0 < n_work) c = cost[k0];
+                    const uint32_t from = (uint32_t)ty * grid.tiles_x + (uint32_t)tx;
+                    if (frame) {
+                        c = frame[from];
+                    } else {
+                        const uint32_t k0 = item_of_tile(grid, from);
+                        if (k0 < n_work) c = cost[k0];
+                    }
                 }
             }
             for (int dy = -r; dy <= r; dy++)
                 for (int dx = -r; dx <= r; dx++) {
                     const int x = tx + dx, y = ty + dy;
                     if (x < 0 || y < 0 || x >= (int)grid.tiles_x || y >= (int)grid.tiles_y) continue;
-                    const uint32_t k = item_of_tile(grid, (uint32_t)y * grid.tiles_x + (uint32_t)x);
-                    if (k < n_work) c = max(c, cost[k]);
+                    const uint32_t at = (uint32_t)y * grid.tiles_x + (uint32_t)x;
+                    if (frame) {
+                        c = max(c, frame[at]);
+                    } else {
+                        const uint32_t k = item_of_tile(grid, at);
+                        if (k < n_work) c = max(c, cost[k]);
+                    }
                 }
         }
         cls = order_class(c);
@@ -1127,6 +1140,16 @@ __global__ __launch_bounds__(1024) void file_tiles_kernel(const uint32_t* __rest
     // ragged last wave the lanes holding the offsets of the higher classes have no item of their own
     const uint32_t ofs = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((cls & 15u) << 2), (int)wave_ofs);
     if (cls != 0xFFFFFFFFu) lists[(size_t)cls * n_work + s_base[cls] + ofs + mbcnt64(mine)] = i;
+}
+
+// this shard's costs into a full-frame array (tile order), other shards' tiles untouched
+__global__ __launch_bounds__(256) void export_costs_kernel(const uint32_t* __restrict__ cost, uint32_t n_work, uint32_t n_tiles,
+                                                           uint32_t shard_index, uint32_t shard_count, uint32_t* __restrict__ frame)
+{
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= n_work) return;
+    const uint32_t tile = shard_tile(w, shard_index, shard_count);
+    if (tile < n_tiles) frame[tile] = cost[w];
 }
 
 int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_cost)
@@ -1219,7 +1242,10 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     if (have_history) {
         grid.tiles_x = a.tiles_x; grid.tiles_y = a.tiles_y; grid.shard_index = a.shard_index; grid.shard_count = a.shard_count;
         grid.spread = spread;
-        LBVH_LAUNCH(ctx, file_tiles_kernel, dim3((n_work + 1023) / 1024), dim3(1024), cost, n_work, counts, lists, next_counts, grid);
+        // the whole previous frame's costs, if the caller has merged the ranks' (multi-GPU frames under a moving camera)
+        const uint32_t* frame = ctx->trace_frame_valid && ctx->trace_frame_tiles_x == a.tiles_x && ctx->trace_frame_tiles_y == a.tiles_y &&
+                                        spread != 0 ? ctx->trace_frame_costs : nullptr;
+        LBVH_LAUNCH(ctx, file_tiles_kernel, dim3((n_work + 1023) / 1024), dim3(1024), cost, n_work, counts, lists, next_counts, grid, frame);
         ctx->trace_counts_turn ^= 1u;
     }
     // Which tiles are walked cooperatively (known from the last trace).  It costs ~50 % more steps on those tiles (a
@@ -1255,6 +1281,10 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     }
     ctx->trace_layout = layout;
     ctx->trace_layout_work = n_work;
+    ctx->trace_shard_index = a.shard_index;
+    ctx->trace_shard_count = a.shard_count;
+    ctx->trace_tiles_x = a.tiles_x;
+    ctx->trace_tiles_y = a.tiles_y;
     ctx->trace_history = true;
     return LBVH_OK;
 }
@@ -1553,6 +1583,44 @@ lbvh_status lbvh_trace_forget(lbvh_context* ctx)
 {
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     ctx->trace_history = false;
+    ctx->trace_frame_valid = false;
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_trace_costs_export(lbvh_context* ctx, uint32_t* d_frame_costs, uint32_t tiles_x, uint32_t tiles_y)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, d_frame_costs != nullptr && tiles_x > 0 && tiles_y > 0 && (uint64_t)tiles_x * tiles_y <= 0x7FFFFFFFull);
+    // the layout of the last LBVH_TRACE_FAST trace: whole-frame traces and shards starting at the frame's origin
+    if (!ctx->trace_history || ctx->trace_tiles_x != tiles_x || ctx->trace_tiles_y != tiles_y)
+        return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_trace_costs_export", "no LBVH_TRACE_FAST trace of a frame with this many tiles to export");
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n_work = ctx->trace_layout_work;
+    const uint32_t* cost = (const uint32_t*)((const char*)ctx->trace_queues + 256);
+    LBVH_LAUNCH(ctx, export_costs_kernel, dim3((n_work + 255) / 256), dim3(256), cost, n_work, tiles_x * tiles_y, ctx->trace_shard_index,
+                ctx->trace_shard_count, d_frame_costs);
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_trace_costs_import(lbvh_context* ctx, const uint32_t* d_frame_costs, uint32_t tiles_x, uint32_t tiles_y)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, d_frame_costs != nullptr && tiles_x > 0 && tiles_y > 0 && (uint64_t)tiles_x * tiles_y <= 0x7FFFFFFFull);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = tiles_x * tiles_y;
+    if (ctx->trace_frame_capacity < n) {
+        LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->trace_frame_costs) { LBVH_HIP_TRY(ctx, hipFree(ctx->trace_frame_costs)); ctx->trace_frame_costs = nullptr; }
+        ctx->trace_frame_capacity = 0;
+        ctx->trace_frame_valid = false;
+        LBVH_HIP_TRY(ctx, hipMalloc((void**)&ctx->trace_frame_costs, (size_t)n * 4));
+        ctx->trace_frame_capacity = n;
+    }
+    LBVH_HIP_TRY(ctx, hipMemcpyAsync(ctx->trace_frame_costs, d_frame_costs, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->cur_stream));
+    ctx->trace_frame_tiles_x = tiles_x;
+    ctx->trace_frame_tiles_y = tiles_y;
+    ctx->trace_frame_valid = true;
     return LBVH_OK;
 }
 

@@ -79,6 +79,14 @@ class Context:
         """drop the traversal's dispatch history: the next LBVH_TRACE_FAST frame is a cold one"""
         N.check(self.handle, N.lib.lbvh_trace_forget(self.handle))
 
+    def trace_costs_export(self, frame_costs, tiles_x, tiles_y):
+        """this context's per-tile step counts of its last LBVH_TRACE_FAST trace into a full-frame DataBuffer (u32 per tile)"""
+        N.check(self.handle, N.lib.lbvh_trace_costs_export(self.handle, frame_costs.device, tiles_x, tiles_y))
+
+    def trace_costs_import(self, frame_costs, tiles_x, tiles_y):
+        """the merged per-tile step counts of every rank's last trace: the next moved-camera frame's dispatch hint"""
+        N.check(self.handle, N.lib.lbvh_trace_costs_import(self.handle, frame_costs.device, tiles_x, tiles_y))
+
     def copy_probe(self, dst, src, nbytes):
         N.check(self.handle, N.lib.lbvh_copy_bandwidth_probe(self.handle, dst, src, nbytes))
 
