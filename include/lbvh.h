@@ -444,8 +444,8 @@ lbvh_status lbvh_trace_forget(lbvh_context* ctx);
  * rank.  lbvh_trace_costs_export writes this context's per-tile step counts of its last LBVH_TRACE_FAST trace into a
  * full-frame array (one u32 per 8x8-pixel tile, row-major, ceil(W/8) x ceil(H/8); tiles of other shards are left as they
  * are — hand in a zeroed array); the ranks merge their arrays (an all-reduce MAX or SUM of 130 KB at 1080p, e.g. while
- * the next rebuild runs) and give the result back with lbvh_trace_costs_import (copied; valid until the next import or
- * lbvh_trace_forget).  The next trace with a DIFFERENT camera takes its tiles' costs from there.  A hint only: hits do
+ * the next rebuild runs) and give the result back with lbvh_trace_costs_import (copied).  The next trace with a DIFFERENT
+ * camera takes its tiles' costs from there — once: a map is a hint for the frame that follows it, not for later ones.  A hint only: hits do
  * not depend on it.  Both calls are asynchronous on the context's stream. */
 lbvh_status lbvh_trace_costs_export(lbvh_context* ctx, uint32_t* d_frame_costs, uint32_t tiles_x, uint32_t tiles_y);
 lbvh_status lbvh_trace_costs_import(lbvh_context* ctx, const uint32_t* d_frame_costs, uint32_t tiles_x, uint32_t tiles_y);

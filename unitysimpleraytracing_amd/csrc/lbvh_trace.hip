@@ -1246,6 +1246,7 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
         const uint32_t* frame = ctx->trace_frame_valid && ctx->trace_frame_tiles_x == a.tiles_x && ctx->trace_frame_tiles_y == a.tiles_y &&
                                         spread != 0 ? ctx->trace_frame_costs : nullptr;
         LBVH_LAUNCH(ctx, file_tiles_kernel, dim3((n_work + 1023) / 1024), dim3(1024), cost, n_work, counts, lists, next_counts, grid, frame);
+        if (frame) ctx->trace_frame_valid = false;       // one frame old at most: the caller imports after every frame it wants this for
         ctx->trace_counts_turn ^= 1u;
     }
     // Which tiles are walked cooperatively (known from the last trace).  It costs ~50 % more steps on those tiles (a
