@@ -74,3 +74,24 @@ def test_two_ranks_over_gloo(tmp_path):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+def test_bench_starts_its_own_ranks_for_gpus_n():
+    """`python bench.py --gpus N` from a plain launch starts N ranks itself (children with torchrun's
+    environment, created before the parent touches HIP) and ends with their worst return code.  No GPU here: every rank
+    must fail loudly in lbvh_create ("no HIP device") — never fall back to a CPU path — and the parent must report it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is visible: the ranks would run the real benchmark")
+    except ImportError:
+        pass
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "no HIP device" in r.stderr and r.stdout.strip() == ""           # no JSON line from a run that did not run
+    assert r.stderr.count("lbvh_create") >= 1
