@@ -115,6 +115,8 @@ public static class LbvhNative
         float albedo, IntPtr dStates);
     [DllImport(Lib)] public static extern int lbvh_path_bounce(IntPtr ctx, ref Scene scene, IntPtr dStates, IntPtr dHits, UIntPtr count,
         uint bounce, uint seed, float albedo, float tMin);
+    [DllImport(Lib)] public static extern int lbvh_path_first_bounce(IntPtr ctx, ref Camera camera, ref Scene scene, IntPtr dStates, IntPtr dHits,
+        uint seed, float albedo, float tMin);
     [DllImport(Lib)] public static extern int lbvh_path_resolve(IntPtr ctx, IntPtr dStates, UIntPtr count, IntPtr dRgba16f);
 
     // local kernels of the multi-GPU key-range sharded sort (BASELINE configs[3])

@@ -429,6 +429,13 @@ lbvh_status lbvh_path_scatter(lbvh_context* ctx, const lbvh_scene* h_scene, cons
 lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_path_state* d_states, lbvh_hit* d_hits,
                              size_t count, uint32_t bounce, uint32_t seed, float albedo, float t_min);
 
+/* lbvh_path_begin + lbvh_path_bounce(bounce = 0) as one call: d_hits holds the primary hit records of the camera's
+ * W x H frame (lbvh_trace_primary); every pixel's path state is MADE from the camera on the fly — never stored by one
+ * kernel to be loaded by the next (132 MB each way at 1080p) — scattered at its hit, and the first secondary segment is
+ * traced.  States, hit records and the image: identical to the two calls. */
+lbvh_status lbvh_path_first_bounce(lbvh_context* ctx, const lbvh_camera* h_camera, const lbvh_scene* h_scene, lbvh_path_state* d_states,
+                                   lbvh_hit* d_hits, uint32_t seed, float albedo, float t_min);
+
 /* radiance (+ alpha) of the path states as RGBA16F, the reference's render-target format. */
 lbvh_status lbvh_path_resolve(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, uint16_t* d_rgba16f);
 

@@ -1290,6 +1290,36 @@ def test_path_trace_tiny_frames(ctx, res):
     pt.drawer.on_destroy()
 
 
+def test_path_first_bounce_equals_begin_plus_bounce_zero(ctx):
+    """lbvh_path_first_bounce makes every pixel's path state from the camera inside the bounce-0 pass instead of loading what
+    lbvh_path_begin stored: states and next-segment hit records identical to the two calls, word for word (a ragged frame,
+    hits and misses, rays that start inside boxes)."""
+    tris, body, centres = scenes.tiled_torus(nu=24, nv=16, grid=2, with_bodies=True)
+    pt = H().DynamicPathTracer(ctx, tris, body, centres, t_min=1e-3, albedo=0.7, seed=21)
+    w, h = 203, 117
+    count = w * h
+    s = pt.drawer.container.scene()
+    hd, lib = ctx.handle, N().lib
+    for pos in ((0.0, 0.0, 90.0), (1.0, 2.0, 6.0)):
+        ccam = N().Camera.from_dict(scenes.camera(w, h, pos))
+        out = []
+        for fused in (True, False):
+            states = H().DataBuffer(ctx, count, L.PATH_STATE)
+            states.fill_u32(0x7FC00000, mirror=False)                              # nothing may survive from before
+            hits = H().DataBuffer(ctx, count, L.HIT)
+            N().check(hd, lib.lbvh_trace_primary(hd, C.byref(ccam), 0, 0, w, h, C.byref(s), L.TRACE_FAST, hits.device, None))
+            if fused:
+                N().check(hd, lib.lbvh_path_first_bounce(hd, C.byref(ccam), C.byref(s), states.device, hits.device, 21, 0.7, 1e-3))
+            else:
+                N().check(hd, lib.lbvh_path_begin(hd, C.byref(ccam), states.device))
+                N().check(hd, lib.lbvh_path_bounce(hd, C.byref(s), states.device, hits.device, count, 0, 21, 0.7, 1e-3))
+            out.append((states.get_data().copy(), hits.get_data().copy()))
+            states.dispose(); hits.dispose()
+        assert (words(out[0][0]) == words(out[1][0])).all() and (words(out[0][1]) == words(out[1][1])).all()
+        assert out[0][0]["alive"].sum() > 100
+    pt.drawer.on_destroy()
+
+
 def test_path_bounce_zero_treats_prefilled_hit_records_as_misses(ctx):
     """a hit buffer pre-filled with 0xFFFFFFFF words (what lbvh_driver.cpp does) and only partly traced holds
     {t >= MAX_FLOAT, triangle = 0xFFFFFFFF} records that are the CALLER's, not marks of paths that ended earlier: at

@@ -92,6 +92,7 @@ SIGNATURES = {
     "lbvh_path_begin": (_I32, [_P, C.POINTER(Camera), _P]),
     "lbvh_path_scatter": (_I32, [_P, C.POINTER(Scene), _P, _SZ, _U32, _U32, C.c_float, _P]),
     "lbvh_path_bounce": (_I32, [_P, C.POINTER(Scene), _P, _P, _SZ, _U32, _U32, C.c_float, C.c_float]),
+    "lbvh_path_first_bounce": (_I32, [_P, C.POINTER(Camera), C.POINTER(Scene), _P, _P, _U32, C.c_float, C.c_float]),
     "lbvh_path_resolve": (_I32, [_P, _P, _SZ, _P]),
     "lbvh_trace_forget": (_I32, [_P]),
     "lbvh_debug_ray_stack_split": (_I32, [_P, _U32]),

@@ -113,7 +113,9 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* _
     uint32_t* my_deep = deep + (size_t)blockIdx.x * (kRayStackDeep * LBVH_WAVE) + threadIdx.x;
     const uint32_t lane = threadIdx.x;
     const uint32_t total = *n_alive;
-    const uint32_t run = max((total + gridDim.x - 1) / gridDim.x, (uint32_t)LBVH_WAVE);
+    // at least 32 rays per wave: with fewer live rays than lanes on the chip, half-filled waves on every wave slot hide more
+    // latency than full waves on half of them (4 bounces: 1.487 -> 1.443 ms; 64: 1.487, 16: 1.449, 96 / 128 / 192: 1.71 / 1.91 / 2.43)
+    const uint32_t run = max((total + gridDim.x - 1) / gridDim.x, 32u);
     uint32_t next = blockIdx.x * run;                      // scalar: next unclaimed entry of this wave's run
     if (next >= total) return;
     const uint32_t end = min(next + run, total);
@@ -209,40 +211,59 @@ __device__ __forceinline__ float path_rnd(uint32_t seed, uint32_t index, uint32_
 // MARK (lbvh_path_bounce, which owns the hit records between its calls): a path that ends leaves a DEAD record in
 // hits[i] (t = MAX_FLOAT, triangle 0xFFFFFFFF), and a later bounce that finds it skips the path without touching its
 // 64-byte state — after the first bounce most of a frame's paths are dead.
-template <bool MARK>
+// FIRST (lbvh_path_first_bounce): the path state is not read but MADE here from the camera, as path_begin_kernel would
+// have written it: the 132 MB of initial states of a 1080p frame are neither stored by one kernel nor loaded by the next.
+template <bool MARK, bool FIRST>
 __device__ __forceinline__ bool scatter_path(const lbvh_triangle* __restrict__ triangles, const lbvh_hit* hits, size_t i,
-                                             uint32_t bounce, uint32_t seed, float albedo, lbvh_path_state* __restrict__ states);
+                                             uint32_t bounce, uint32_t seed, float albedo, lbvh_path_state* __restrict__ states,
+                                             const lbvh_camera& cam);
 
-// LIST: also append the indices of the paths that go on (one global atomic per workgroup), so that the next
-// segment is traced without a separate pass over all path states
-template <bool LIST>
+// LIST: also append the indices of the paths that go on, so that the next segment is traced without a separate pass over
+// all path states.  A workgroup handles kScatterItems x 256 paths and reserves its run of the list with ONE global atomic:
+// with one path per thread the 8 100 workgroups of a 1080p frame queued on that one counter for most of the kernel's
+// 67 - 91 us (the bounces' own work shrinks with the live paths, the kernel's time did not).
+constexpr int kScatterItems = 8;
+template <bool LIST, bool FIRST = false>
 __global__ __launch_bounds__(256) void path_scatter_kernel(const lbvh_triangle* __restrict__ triangles,
                                                            const lbvh_hit* hits, size_t count, uint32_t bounce,
                                                            uint32_t seed, float albedo, lbvh_path_state* __restrict__ states,
-                                                           uint32_t* __restrict__ n_alive, uint32_t* __restrict__ list)
+                                                           uint32_t* __restrict__ n_alive, uint32_t* __restrict__ list, lbvh_camera cam)
 {
     __shared__ uint32_t s_n, s_base;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (LIST) {
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
     }
-    const bool on = i < count && scatter_path<LIST>(triangles, hits, i, bounce, seed, albedo, states);
+    const size_t i0 = (size_t)blockIdx.x * (256 * kScatterItems) + threadIdx.x;
+    uint32_t ofs[kScatterItems];                      // position inside this wave's run, or ~0u: the path ended
+    uint32_t wave_n = 0;
+#pragma unroll
+    for (int k = 0; k < kScatterItems; k++) {
+        const size_t i = i0 + (size_t)k * 256;
+        const bool on = i < count && scatter_path<LIST, FIRST>(triangles, hits, i, bounce, seed, albedo, states, cam);
+        if (LIST) {
+            const uint64_t m = __ballot(on);
+            ofs[k] = on ? wave_n + mbcnt64(m) : 0xFFFFFFFFu;
+            wave_n += (uint32_t)__popcll(m);
+        }
+    }
     if (LIST) {
-        const uint64_t m = __ballot(on);
-        uint32_t wave_ofs = 0;
-        if (lane_id() == 0 && m) wave_ofs = atomicAdd(&s_n, (uint32_t)__popcll(m));
-        wave_ofs = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_ofs);
+        uint32_t wave_base = 0;
+        if (lane_id() == 0 && wave_n) wave_base = atomicAdd(&s_n, wave_n);
+        wave_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_base);
         __syncthreads();
         if (threadIdx.x == 0 && s_n) s_base = __hip_atomic_fetch_add(n_alive, s_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        if (on) list[s_base + wave_ofs + mbcnt64(m)] = (uint32_t)i;
+#pragma unroll
+        for (int k = 0; k < kScatterItems; k++)
+            if (ofs[k] != 0xFFFFFFFFu) list[s_base + wave_base + ofs[k]] = (uint32_t)(i0 + (size_t)k * 256);
     }
 }
 
-template <bool MARK>
+template <bool MARK, bool FIRST>
 __device__ __forceinline__ bool scatter_path(const lbvh_triangle* __restrict__ triangles, const lbvh_hit* hits, size_t i,
-                                             uint32_t bounce, uint32_t seed, float albedo, lbvh_path_state* __restrict__ states)
+                                             uint32_t bounce, uint32_t seed, float albedo, lbvh_path_state* __restrict__ states,
+                                             const lbvh_camera& cam)
 {
     const float4 h = reinterpret_cast<const float4*>(hits)[i];
     const bool missed = !(h.x < LBVH_MAX_FLOAT);
@@ -250,9 +271,19 @@ __device__ __forceinline__ bool scatter_path(const lbvh_triangle* __restrict__ t
     // the caller's own fill value (an untraced pixel) and is an ordinary miss, as in lbvh_path_scatter
     if (MARK && bounce > 0u && missed && __float_as_uint(h.y) == 0xFFFFFFFFu) return false;
     float4* st = reinterpret_cast<float4*>(&states[i]);
-    float4 o = st[0];
-    if (__float_as_uint(o.w) == 0u) return false;
-    float4 d = st[1], thr = st[2], rad = st[3];
+    float4 o, d, thr, rad;
+    if (FIRST) {                     // path_begin_kernel's state for pixel i, not read but made
+        const uint32_t py = (uint32_t)(i / (size_t)cam.screen_width), px = (uint32_t)(i - (size_t)py * cam.screen_width);
+        const ray_t r = make_ray(cam, px, py);
+        o = make_float4(r.ox, r.oy, r.oz, __uint_as_float(1u));
+        d = make_float4(r.dx, r.dy, r.dz, 0.0f);
+        thr = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    } else {
+        o = st[0];
+        if (__float_as_uint(o.w) == 0u) return false;
+        d = st[1]; thr = st[2]; rad = st[3];
+    }
     if (missed) {
         const float sk = 0.5f * (d.y + 1.0f);
         rad.x = rad.x + thr.x * ((1.0f - sk) * 1.0f + sk * 0.5f);
@@ -261,6 +292,7 @@ __device__ __forceinline__ bool scatter_path(const lbvh_triangle* __restrict__ t
         o.w = __uint_as_float(0u);
         st[0] = o;
         st[3] = rad;
+        if (FIRST) { st[1] = d; st[2] = thr; }
         if (MARK) reinterpret_cast<float4*>(const_cast<lbvh_hit*>(hits))[i] = make_float4(LBVH_MAX_FLOAT, __uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f);
         return false;
     }
@@ -386,14 +418,17 @@ lbvh_status lbvh_path_scatter(lbvh_context* ctx, const lbvh_scene* h_scene, cons
     if (count == 0) return LBVH_OK;
     LBVH_REQUIRE(ctx, h_scene != nullptr && h_scene->triangles != nullptr && d_hits != nullptr && d_states != nullptr);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    LBVH_LAUNCH(ctx, path_scatter_kernel<false>, dim3((unsigned)((count + 255) / 256)), dim3(256), h_scene->triangles, d_hits, count,
-                bounce, seed, albedo, d_states, nullptr, nullptr);
+    LBVH_LAUNCH(ctx, path_scatter_kernel<false>, dim3((unsigned)((count + 256 * kScatterItems - 1) / (256 * kScatterItems))), dim3(256), h_scene->triangles, d_hits, count,
+                bounce, seed, albedo, d_states, nullptr, nullptr, lbvh_camera{});
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }
 
-lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_path_state* d_states, lbvh_hit* d_hits,
-                             size_t count, uint32_t bounce, uint32_t seed, float albedo, float t_min)
+}  // extern "C"
+
+static lbvh_status path_bounce_impl(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_path_state* d_states, lbvh_hit* d_hits,
+                                    size_t count, uint32_t bounce, uint32_t seed, float albedo, float t_min,
+                                    const lbvh_camera* h_first_camera)
 {
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     if (count == 0) return LBVH_OK;
@@ -409,13 +444,35 @@ lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_
     uint32_t* n_alive = (uint32_t*)ctx->ray_scratch;
     uint32_t* list = (uint32_t*)((char*)ctx->ray_scratch + 256);
     LBVH_HIP_TRY(ctx, hipMemsetAsync(n_alive, 0, 4, ctx->cur_stream));
-    LBVH_LAUNCH(ctx, path_scatter_kernel<true>, dim3((unsigned)((count + 255) / 256)), dim3(256), h_scene->triangles, d_hits, count,
-                bounce, seed, albedo, d_states, n_alive, list);
+    const dim3 scatter_grid((unsigned)((count + 256 * kScatterItems - 1) / (256 * kScatterItems)));
+    if (h_first_camera)
+        LBVH_LAUNCH(ctx, (path_scatter_kernel<true, true>), scatter_grid, dim3(256), h_scene->triangles, d_hits, count, 0u, seed, albedo, d_states,
+                    n_alive, list, *h_first_camera);
+    else
+        LBVH_LAUNCH(ctx, (path_scatter_kernel<true, false>), scatter_grid, dim3(256), h_scene->triangles, d_hits, count, bounce, seed, albedo,
+                    d_states, n_alive, list, lbvh_camera{});
     const uint32_t ray_waves = ray_waves_of(count);
     LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, ctx->fast_nodes,
                 ctx->fast_tris, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
+}
+
+extern "C" {
+
+lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_path_state* d_states, lbvh_hit* d_hits,
+                             size_t count, uint32_t bounce, uint32_t seed, float albedo, float t_min)
+{
+    return path_bounce_impl(ctx, h_scene, d_states, d_hits, count, bounce, seed, albedo, t_min, nullptr);
+}
+
+lbvh_status lbvh_path_first_bounce(lbvh_context* ctx, const lbvh_camera* h_camera, const lbvh_scene* h_scene, lbvh_path_state* d_states,
+                                   lbvh_hit* d_hits, uint32_t seed, float albedo, float t_min)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, h_camera != nullptr && h_camera->screen_width > 0 && h_camera->screen_height > 0);
+    return path_bounce_impl(ctx, h_scene, d_states, d_hits, (size_t)h_camera->screen_width * (size_t)h_camera->screen_height, 0u, seed, albedo,
+                            t_min, h_camera);
 }
 
 lbvh_status lbvh_path_resolve(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, uint16_t* d_rgba16f)

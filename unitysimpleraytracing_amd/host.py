@@ -433,9 +433,14 @@ class DynamicPathTracer:
         # in front of it push the scene out of the caches (the frame's primary trace 0.274 -> 0.253 ms)
         N.check(h, N.lib.lbvh_trace_primary(h, C.byref(cam), 0, 0, cam.screen_width, cam.screen_height, C.byref(s),
                                             L.TRACE_FAST, self.hits.device, None))
-        N.check(h, N.lib.lbvh_path_begin(h, C.byref(cam), self.states.device))
-        # bounce b = scatter at the hits of segment b + trace of segment b + 1 (one call); the last bounce only scatters
-        for b in range(bounces):
+        # bounce b = scatter at the hits of segment b + trace of segment b + 1 (one call); the first one also makes the path
+        # states from the camera (lbvh_path_first_bounce = lbvh_path_begin + bounce 0); the last bounce only scatters
+        if bounces == 0:
+            N.check(h, N.lib.lbvh_path_begin(h, C.byref(cam), self.states.device))
+        else:
+            N.check(h, N.lib.lbvh_path_first_bounce(h, C.byref(cam), C.byref(s), self.states.device, self.hits.device, self.seed,
+                                                    self.albedo, self.t_min))
+        for b in range(1, bounces):
             N.check(h, N.lib.lbvh_path_bounce(h, C.byref(s), self.states.device, self.hits.device, count, b, self.seed,
                                               self.albedo, self.t_min))
         N.check(h, N.lib.lbvh_path_scatter(h, C.byref(s), self.hits.device, count, bounces, self.seed, self.albedo,

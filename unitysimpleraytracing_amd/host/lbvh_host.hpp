@@ -372,8 +372,10 @@ public:
         const lbvh_scene s = drawer_.Container().Scene();
         lbvh_path_state* st = (lbvh_path_state*)states_->DeviceBuffer();
         lbvh_hit* hits = (lbvh_hit*)drawer_.Hits().DeviceBuffer();
-        check(ctx_.get(), lbvh_path_begin(ctx_.get(), &cam, st));
-        for (uint32_t b = 0; b < bounces; ++b)          // scatter at segment b's hits + trace of segment b + 1
+        // bounce b = scatter at segment b's hits + trace of segment b + 1; the first one makes the path states from the camera
+        if (bounces == 0) check(ctx_.get(), lbvh_path_begin(ctx_.get(), &cam, st));
+        else check(ctx_.get(), lbvh_path_first_bounce(ctx_.get(), &cam, &s, st, hits, seed_, albedo_, t_min_));
+        for (uint32_t b = 1; b < bounces; ++b)
             check(ctx_.get(), lbvh_path_bounce(ctx_.get(), &s, st, hits, rays, b, seed_, albedo_, t_min_));
         check(ctx_.get(), lbvh_path_scatter(ctx_.get(), &s, hits, rays, bounces, seed_, albedo_, st));
         check(ctx_.get(), lbvh_path_resolve(ctx_.get(), st, rays, (uint16_t*)image_->DeviceBuffer()));
