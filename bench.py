@@ -467,8 +467,8 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import live_counters as LC
             child = [os.path.join(ROOT, "tools", "trace_only.py"), "--reps", "4", "--no-check"]
-            traffic = LC.hbm_traffic(child, "trace_packet_kernel")
-            issue = LC.issue_counters(child, "trace_packet_kernel")
+            traffic = LC.hbm_traffic(child, "trace_")
+            issue = LC.issue_counters(child, "trace_")
         # HBM is the roofline of every stage.  `frac` is the kernel's OWN algorithmic bytes over its live duration
         # against 8 TB/s — small, because the walk prunes (the reference algorithm's bytes priced at this duration would be
         # several times the peak: `reference_equivalent_GBs`) and because the scene it walks is cache-resident.  What the kernel

@@ -682,7 +682,9 @@ __device__ __forceinline__ void tile_rays(const trace_args& a, uint32_t tile, ui
 // together: every wave walks its own chain with a private stack, the packet's 64 best hits live in LDS (64-bit
 // atomic min on (ordered t, line index of the triangle): pruning is shared by all waves), and a wave with spare
 // stack entries hands its OLDEST one (the largest unvisited subtree) to an idle wave through a small LDS list.
-constexpr int kCoopWaves = 8;
+constexpr int kCoopWaves = 8;              // waves of a cooperative workgroup in a share of a frame
+constexpr int kCoopWavesWhole = 4;         // ... in a whole frame (every wave slot taken: workgroups of 4 waves place like the plain kernel's)
+constexpr uint32_t kHeavyClassWhole = 10;   // whole frames: classes >= this (>= 256 steps) are walked cooperatively
 constexpr int kHeavyClass = 7;             // cost classes >= this (>= 96 steps) are walked cooperatively
 constexpr uint32_t kCoopGrain = 32;        // steps of the last trace per cooperating wave
 constexpr uint32_t kCoopMaxWork = 12288;   // tiles per launch up to which every heavy class is walked cooperatively
@@ -730,7 +732,7 @@ __device__ __forceinline__ void coop_unlock(coop_shared& S)
 }
 
 // one heavy tile (work item w) walked by the waves of this workgroup
-template <bool STATS>
+template <bool STATS, int WAVES>
 __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, const lbvh_fast_node* __restrict__ nodes,
                                           const lbvh_fast_tri* __restrict__ tris, uint32_t n_work, uint32_t w,
                                           coop_params heavy_cap, uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits,
@@ -740,7 +742,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
     if (w >= n_work || tile >= a.tiles_x * a.tiles_y) return;        // cannot happen for a heavy item
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     // as many waves as the tile's last step count is worth (about kCoopGrain steps each); the others leave now
-    const uint32_t n_waves = min(max((cost[w] + heavy_cap.grain / 2u) / heavy_cap.grain, 2u), (uint32_t)kCoopWaves);
+    const uint32_t n_waves = min(max((cost[w] + heavy_cap.grain / 2u) / heavy_cap.grain, 2u), (uint32_t)WAVES);
     if (wave >= n_waves) return;
     packet_rays<1> P;
     uint32_t px0, py0;
@@ -983,8 +985,8 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
 //     (workgroups beyond the actual number of heavy tiles leave at once) — at the FRONT of the grid, so they start
 //     first (as a second kernel on another stream they were starved by the light tiles' workgroups);
 //   * the rest: one tile per wave, the w-th tile of the class lists after the heavy ones, heaviest class first.
-template <bool STATS>
-__global__ __launch_bounds__(kCoopWaves * 64) void trace_shared_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
+template <bool STATS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void trace_shared_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
                                                                        const lbvh_fast_tri* __restrict__ tris, uint32_t n_work,
                                                                        const uint32_t* __restrict__ counts,
                                                                        const uint32_t* __restrict__ lists, coop_params heavy_cap,
@@ -999,7 +1001,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void trace_shared_kernel(trace_arg
         if (blockIdx.x >= heavy) return;                         // uniform for the workgroup
         w = blockIdx.x;
     } else {
-        w = (blockIdx.x - heavy_cap.cap) * (uint32_t)kCoopWaves + (threadIdx.x >> 6) + heavy;
+        w = (blockIdx.x - heavy_cap.cap) * (uint32_t)WAVES + (threadIdx.x >> 6) + heavy;
         if (w >= n_work) return;
     }
     if (counts) {        // the w-th item of the class lists, heaviest class first (they partition the work items)
@@ -1009,7 +1011,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void trace_shared_kernel(trace_arg
         w = lists[(size_t)c * n_work + k];
     }
     if (blockIdx.x < heavy_cap.cap) {
-        coop_tile<STATS>(S, a, nodes, tris, n_work, w, heavy_cap, cost, hits, stats, tile_cost);
+        coop_tile<STATS, WAVES>(S, a, nodes, tris, n_work, w, heavy_cap, cost, hits, stats, tile_cost);
         return;
     }
     if (w >= n_work) return;
@@ -1262,14 +1264,30 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     // (1/2, 1/3, 1/4, 1/8 of the frame, yaw 1 degree: 0.209 / 0.197 / 0.187 / 0.174 ms with this rule, 0.361 / 0.275 /
     // 0.232 / 0.174 with cooperative tiles throughout, 0.245 / 0.196 / 0.233 / 0.190 cold).
     const bool stale_coop = spread != 0 && n_work > kMovedCoopMaxWork;
-    if (have_history && n_work <= kSharedMaxWork && !stale_coop) {
+    // Whole frames (round 3): with the lean step the frame is its heaviest packet's chain, so the classes
+    // from 256 steps up (187 of 32 400 tiles at cfg2) are walked cooperatively there too — by workgroups of FOUR waves:
+    // the launch's other workgroups (one tile per wave) then place exactly like the plain kernel's, which the 8-wave form
+    // does not (its light tiles alone cost 8 %: 0.232 against 0.214 ms).  0.213 -> 0.181 ms (classes >= 11: 0.19 - 0.21).
+    // (a moved camera: the plain kernel — the widened costs would make every neighbour of a heavy tile cooperative, 0.27 - 0.29 ms;
+    // marking by the un-widened reprojected cost finds too few of them: 0.20 - 0.22 against 0.21 plain)
+    const bool whole = n_work > kSharedMaxWork && spread == 0;
+    if (have_history && whole) {
+        coop_params hp = {n_work / 4u, kHeavyClassWhole, kCoopGrain};
+        const uint32_t blocks = hp.cap + (n_work + kCoopWavesWhole - 1) / kCoopWavesWhole;
+        if (d_stats)
+            LBVH_LAUNCH(ctx, (trace_shared_kernel<true, kCoopWavesWhole>), dim3(blocks), dim3(kCoopWavesWhole * 64), a, ctx->fast_nodes, ctx->fast_tris,
+                        n_work, counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
+        else
+            LBVH_LAUNCH(ctx, (trace_shared_kernel<false, kCoopWavesWhole>), dim3(blocks), dim3(kCoopWavesWhole * 64), a, ctx->fast_nodes, ctx->fast_tris,
+                        n_work, counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
+    } else if (have_history && n_work <= kSharedMaxWork && !stale_coop) {
         coop_params hp = {n_work / 4u, first_class, kCoopGrain};
         const uint32_t blocks = hp.cap + (n_work + kCoopWaves - 1) / kCoopWaves;
         if (d_stats)
-            LBVH_LAUNCH(ctx, trace_shared_kernel<true>, dim3(blocks), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris, n_work,
+            LBVH_LAUNCH(ctx, (trace_shared_kernel<true, kCoopWaves>), dim3(blocks), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris, n_work,
                         counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
         else
-            LBVH_LAUNCH(ctx, trace_shared_kernel<false>, dim3(blocks), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris, n_work,
+            LBVH_LAUNCH(ctx, (trace_shared_kernel<false, kCoopWaves>), dim3(blocks), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris, n_work,
                         counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
     } else {
         const uint32_t blocks = (n_work + 3) / 4;
