@@ -14,7 +14,7 @@ public static class LbvhNative
 {
     const string Lib = "lbvh";   // liblbvh.so on Linux
 
-    public const int ABI_VERSION = 8;             // LBVH_ABI_VERSION of the include/lbvh.h this file was written against
+    public const int ABI_VERSION = 9;             // LBVH_ABI_VERSION of the include/lbvh.h this file was written against
     public const int TRACE_REFERENCE = 0, TRACE_FAST = 1;
     public const uint BUILD_FAST_SCENE = 1, BUILD_RESET_NODES = 2;      // lbvh_build_scene flags
 
@@ -88,6 +88,7 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern int lbvh_trace_costs_export(IntPtr ctx, IntPtr dFrameCosts, uint tilesX, uint tilesY);
     [DllImport(Lib)] public static extern int lbvh_trace_costs_import(IntPtr ctx, IntPtr dFrameCosts, uint tilesX, uint tilesY);
     [DllImport(Lib)] public static extern int lbvh_debug_ray_stack_split(IntPtr ctx, uint ldsEntries);
+    [DllImport(Lib)] public static extern int lbvh_debug_ray_walker(IntPtr ctx, uint wide);
     // measurement helper: shader clock held under a vector-ALU-bound load, MHz
     [DllImport(Lib)] public static extern int lbvh_clock_probe(IntPtr ctx, out float shaderMhz);
     // a context whose work is ordered by a stream the caller owns (hipStream_t), e.g. an interop stream

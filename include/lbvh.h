@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LBVH_ABI_VERSION 8
+#define LBVH_ABI_VERSION 9
 
 /* ---- status codes ------------------------------------------------------------------------- */
 typedef int32_t lbvh_status;
@@ -393,11 +393,14 @@ typedef struct lbvh_path_state {
 } lbvh_path_state;
 
 /* Closest hit for `count` arbitrary rays taken from the path states (origin, dir; dead paths are skipped and
- * get a miss record): one ray per lane over the derived traversal scene (lbvh_build_fast_scene), near-first,
- * t-pruned, per-lane stack of 64 entries like the reference's (Raytracing.compute:113; the first 16 in LDS, deeper
- * ones in device memory).  Accept rule = the reference's (own-AABB slab test, Moeller-Trumbore, strict
- * t < best) plus t > t_min, which secondary rays need to leave their surface and the reference lacks
- * (Raytracing.compute:70). */
+ * get a miss record): one ray per lane over the derived traversal scene (lbvh_build_fast_scene) in its four-wide
+ * form — every node of that tree with its largest children opened once or twice: up to four child boxes per 128-byte
+ * line, half the steps of the binary walk; made by the first call after a rebuild (collapse_wide_kernel, 0.06 ms at
+ * 1 M triangles) — nearest child first, t-pruned, per-lane stack of 128 entries (three siblings can wait per level;
+ * the reference's binary walk has 64, Raytracing.compute:113; the first 16 in LDS, deeper ones in device memory).
+ * Accept rule = the reference's (own-AABB slab test, Moeller-Trumbore, t < best) plus t > t_min, which secondary
+ * rays need to leave their surface and the reference lacks (Raytracing.compute:70); two triangles hit at the same t:
+ * the lower triangle index, whatever order the walk meets them in (as LBVH_TRACE_FAST). */
 lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, float t_min,
                             const lbvh_scene* h_scene, lbvh_hit* d_hits);
 
@@ -405,6 +408,11 @@ lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, 
  * lbvh_path_bounce spills to its device-memory slab.  Results do not depend on it; tests lower it so the deep part
  * of the stack is exercised by ordinary scenes. */
 lbvh_status lbvh_debug_ray_stack_split(lbvh_context* ctx, uint32_t lds_entries);
+
+/* Test hook: which form of the derived scene lbvh_trace_rays / lbvh_path_bounce walk — 1 (default): four-wide nodes
+ * (each binary node with its largest children opened, made on first use after a rebuild), 0: the binary nodes the
+ * packet walk uses.  Hit records do not depend on it (ties go to the lower triangle index on both). */
+lbvh_status lbvh_debug_ray_walker(lbvh_context* ctx, uint32_t wide);
 
 /* Camera rays into path states (origin/dir as Raytracing.compute:108-126, throughput 1, radiance 0, alive). */
 lbvh_status lbvh_path_begin(lbvh_context* ctx, const lbvh_camera* h_camera, lbvh_path_state* d_states);

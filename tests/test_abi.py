@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(N.lib, name), f"liblbvh.so does not export {name}"
     assert set(N.SIGNATURES) == set(declared_functions())
-    assert N.lib.lbvh_abi_version() == N.ABI_VERSION == 8
+    assert N.lib.lbvh_abi_version() == N.ABI_VERSION == 9
 
 
 def test_struct_layouts_match_the_reference():

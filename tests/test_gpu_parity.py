@@ -1235,7 +1235,7 @@ def test_secondary_rays_and_path_trace_bit_exact(ctx):
 
 @pytest.mark.parametrize("lds_entries", [1, 2, 5])
 def test_secondary_rays_deep_stack_in_device_memory(ctx, lds_entries):
-    """trace_rays_kernel keeps the first 16 stack entries of a lane in LDS and deeper ones in a device-memory slab.
+    """The per-ray walk keeps the first 16 stack entries of a lane in LDS and deeper ones in a device-memory slab.
     With the split lowered to 1 / 2 / 5 entries (lbvh_debug_ray_stack_split) ordinary rays use the slab all the time:
     hit records identical to the default split's, record for record, and `t` identical to the oracle's."""
     tris, body, centres = scenes.tiled_torus(nu=40, nv=24, grid=3, with_bodies=True)
@@ -1268,6 +1268,75 @@ def test_secondary_rays_deep_stack_in_device_memory(ctx, lds_entries):
     oh = O.trace_rays(b, st, 1e-3, threads=8)
     assert (frames[1]["t"] == oh["t"]).all()
     pt.drawer.on_destroy()
+
+
+def _random_ray_states(tris, count, seed):
+    """Rays that start inside the scene's box (on and off its surfaces), random directions — a few of them along the
+    axes (zero direction components: infinite inverse directions in the slab test)."""
+    rng = np.random.default_rng(seed)
+    pts = np.concatenate([tris["a"][:, :3], tris["b"][:, :3], tris["c"][:, :3]]).astype(np.float32)
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    st = np.zeros(count, dtype=L.PATH_STATE)
+    st["origin"] = (lo + (hi - lo) * rng.random((count, 3))).astype(np.float32)
+    on_surface = rng.random(count) < 0.5                       # half of the rays leave a triangle's first vertex
+    st["origin"][on_surface] = tris["a"][rng.integers(0, len(tris), on_surface.sum()), :3]
+    d = rng.normal(size=(count, 3))
+    axis = rng.random(count) < 0.1
+    d[axis] = np.eye(3)[rng.integers(0, 3, axis.sum())] * rng.choice([-1.0, 1.0], axis.sum())[:, None]
+    st["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    st["alive"] = (rng.random(count) < 0.9).astype(np.uint32)
+    return st
+
+
+@pytest.mark.parametrize("scene", ["torus", "soup", "duplicates", "two", "three", "seven"])
+def test_secondary_rays_four_wide_walk_equals_binary_walk(ctx, scene):
+    """lbvh_trace_rays walks the derived scene as four-wide nodes (collapse_wide_kernel: every binary node with its
+    largest children opened). Same leaves, same boxes, ties to the lower triangle index: the hit records equal the binary
+    walk's (lbvh_debug_ray_walker(ctx, 0)) word for word — also with the stack split lowered so that waiting siblings go
+    through the device-memory slab — and `t` equals the oracle's everywhere."""
+    if scene == "torus":
+        tris = scenes.tiled_torus(nu=40, nv=24, grid=3)
+    elif scene == "soup":
+        tris = scenes.random_triangles(n=6000, seed=4, extent=60.0, edge=6.0)
+    elif scene == "duplicates":
+        base = scenes.random_triangles(n=2000, seed=6, extent=40.0, edge=8.0)
+        tris = np.concatenate([base, base[::2]])               # every second triangle twice: exact t ties
+    else:
+        tris = scenes.random_triangles(n={"two": 2, "three": 3, "seven": 7}[scene], seed=8, extent=10.0, edge=6.0)
+    d, c, b = build_both(ctx, tris)
+    d.rebuild(fast=True)
+    st = _random_ray_states(tris, 20000, seed=len(tris))
+    sb = H().DataBuffer(ctx, len(st), L.PATH_STATE)
+    sb.local[:] = st
+    sb.sync()
+    hb = H().DataBuffer(ctx, len(st), L.HIT)
+    s = c.scene()
+    n_ = N()
+    assert n_.lib.lbvh_debug_ray_walker(ctx.handle, 2) == -1
+    frames = {}
+    try:
+        for wide, split in ((0, 16), (1, 16), (1, 1), (1, 3)):
+            n_.check(ctx.handle, n_.lib.lbvh_debug_ray_walker(ctx.handle, wide))
+            n_.check(ctx.handle, n_.lib.lbvh_debug_ray_stack_split(ctx.handle, split))
+            hb.local[:] = np.zeros(1, L.HIT)
+            hb.local["t"] = np.nan
+            hb.sync()
+            n_.check(ctx.handle, n_.lib.lbvh_trace_rays(ctx.handle, sb.device, len(st), 1e-3, C.byref(s), hb.device))
+            frames[(wide, split)] = hb.get_data().copy()
+    finally:
+        n_.check(ctx.handle, n_.lib.lbvh_debug_ray_walker(ctx.handle, 1))
+        n_.check(ctx.handle, n_.lib.lbvh_debug_ray_stack_split(ctx.handle, 16))
+    for key in ((1, 16), (1, 1), (1, 3)):
+        assert (words(frames[(0, 16)]) == words(frames[key])).all(), key
+    oh = O.trace_rays(b, st, 1e-3, threads=8)
+    assert (frames[(1, 16)]["t"] == oh["t"]).all()
+    hit = frames[(1, 16)]["t"] < 1e30
+    assert hit.sum() > (0 if len(tris) < 10 else 1000)
+    if scene == "duplicates":
+        # a ray that meets a duplicated triangle meets its copy at the same t: the record names the lower index
+        dup_of = {2000 + k: 2 * k for k in range(1000)}
+        assert not np.isin(frames[(1, 16)]["tri"][hit], list(dup_of)).any()
+    d.on_destroy()
 
 
 @pytest.mark.parametrize("res", [(1, 1), (5, 3), (63, 1), (65, 9)])

@@ -17,7 +17,7 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_TAG_STALL_sum TCC_BUSY_sum" ; do
   i=$((i+1))
   timeout 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- python3 $R/tools/dynamic_bench.py > $OUT/g$i.log 2>&1
-  echo "group $i rc=$?: $(grep -o '"trace_rays_kernel": [0-9.]*' $OUT/g$i.log | tail -1)"
+  echo "group $i rc=$?: $(grep -o '"trace_rays[a-z_]*kernel": [0-9.]*' $OUT/g$i.log | tail -1)"
 done
 cd $R
 python3 - <<PY
@@ -25,7 +25,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("$OUT/g*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "trace_rays_kernel" in row["Kernel_Name"]:
+        if "trace_rays" in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open("$OUT/summary.txt", "w") as fh:
     for k, v in sorted(acc.items()):

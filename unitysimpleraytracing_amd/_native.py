@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LBVH_LIB: an alternative build of the same library (tools/build_variant.sh: A/B measurements of kernel variants)
 LIB_PATH = os.environ.get("LBVH_LIB") or os.path.join(_HERE, "liblbvh.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -96,6 +96,7 @@ SIGNATURES = {
     "lbvh_path_resolve": (_I32, [_P, _P, _SZ, _P]),
     "lbvh_trace_forget": (_I32, [_P]),
     "lbvh_debug_ray_stack_split": (_I32, [_P, _U32]),
+    "lbvh_debug_ray_walker": (_I32, [_P, _U32]),
     "lbvh_clock_probe": (_I32, [_P, C.POINTER(C.c_float)]),
     "lbvh_trace_tile_costs": (_I32, [_P, C.POINTER(Camera), C.POINTER(Scene), _P, _P, _P]),
     "lbvh_shade": (_I32, [_P, _P, _SZ, _P, _P, _I32, _I32, _P]),

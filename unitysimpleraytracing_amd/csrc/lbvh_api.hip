@@ -66,6 +66,7 @@ void lbvh_note_fast_built(lbvh_context* ctx, const lbvh_scene& s)
     ctx->fast_src.triangle_aabb = s.triangle_aabb;
     ctx->fast_src.n = s.n;
     ctx->fast_valid = true;
+    ctx->wide_valid = false;      // the four-wide form is of the previous tree
 }
 
 int lbvh_require_fast(lbvh_context* ctx, const lbvh_scene& s, const char* who)
@@ -206,6 +207,7 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
     if (ctx->fast_tree) (void)hipFree(ctx->fast_tree);
     if (ctx->hier) (void)hipFree(ctx->hier);
     if (ctx->ray_scratch) (void)hipFree(ctx->ray_scratch);
+    if (ctx->wide_nodes) (void)hipFree(ctx->wide_nodes);
     if (ctx->trace_frame_costs) (void)hipFree(ctx->trace_frame_costs);
     for (auto& s : ctx->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);

@@ -127,6 +127,11 @@ struct lbvh_context {
     void* ray_scratch = nullptr;
     uint32_t ray_stack_lds = 16;              // lbvh_debug_ray_stack_split
     size_t ray_scratch_bytes = 0;
+    // the derived scene as four-wide nodes for the per-ray walk: made by the first lbvh_trace_rays / bounce after a rebuild
+    void* wide_nodes = nullptr;
+    size_t wide_nodes_bytes = 0;
+    bool wide_valid = false;
+    bool ray_wide = true;                     // lbvh_debug_ray_walker
 
     // per-kernel event profiling (lbvh_profile_begin / lbvh_profile_end)
     struct prof_span { const char* name; hipEvent_t a, b; };

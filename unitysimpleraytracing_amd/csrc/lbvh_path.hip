@@ -98,7 +98,7 @@ constexpr uint32_t kRayWaves = 8192;
 // ray scratch: [live-ray count (256 B) | indices of the live rays | deep stack slabs of the launch's waves]
 static inline uint32_t ray_waves_of(size_t count) { return (uint32_t)std::min<size_t>(kRayWaves, (count + LBVH_WAVE - 1) / LBVH_WAVE); }
 // the slab is indexed by blockIdx.x: one launch needs ray_waves_of(count) of them (a 64-ray call: 12 KB, not 96 MB)
-static inline size_t deep_bytes(size_t count) { return (size_t)ray_waves_of(count) * kRayStackDeep * LBVH_WAVE * 4; }
+static inline size_t deep_bytes(size_t count) { return (size_t)ray_waves_of(count) * 112 * LBVH_WAVE * 4; }     // kWideStackDeep entries (>= kRayStackDeep)
 static inline size_t list_bytes(size_t count) { return (count * 4 + 255) & ~(size_t)255; }
 static inline uint32_t* deep_stacks(lbvh_context* ctx, size_t count) { return (uint32_t*)((char*)ctx->ray_scratch + 256 + list_bytes(count)); }
 
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* _
                     unpack_fast_triangle(reinterpret_cast<const float4*>(&nodes[ref & 0x7FFFFFFFu]), v0, v1, v2);   // a triangle line
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_fast_triangle(ray, v0, v1, v2, u, v);
-                    if (dist > t_min && dist < best_t) { best_t = dist; best_tri = __float_as_uint(v0.w); best_u = u; best_v = v; }
+                    const uint32_t tri = __float_as_uint(v0.w);
+                    if (dist > t_min && (dist < best_t || (dist == best_t && tri < best_tri))) { best_t = dist; best_tri = tri; best_u = u; best_v = v; }
                 }
             }
             const bool go_l = hit_l && !(lref & 0x80000000u) && !(tl > best_t);
@@ -177,6 +178,200 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* _
                 node = lref;
             } else if (go_r) {
                 node = rref;
+            } else if (sp != 0) {
+                sp--;
+                node = sp < lds_depth ? s_stack[sp][lane] : my_deep[(sp - lds_depth) * LBVH_WAVE];
+            } else {
+                float4 out;
+                out.x = best_t;
+                out.y = __uint_as_float(best_tri);
+                out.z = best_u;
+                out.w = best_v;
+                reinterpret_cast<float4*>(hits)[i] = out;
+                active = false;
+            }
+        }
+    }
+}
+
+// ---- the per-ray walk over four-wide nodes -------------------------------------------------------------------
+// The per-ray kernel's time follows the number of steps its lanes take (profiles/r3: requests, bytes and L1 traffic per
+// step could be halved without moving it), so the derived scene gets a second, shallower form for rays that do not
+// come in packets: every binary node with its larger children opened once or twice = up to four child boxes in one
+// 128-byte line.  Same leaves, same boxes, same triangle lines: which triangles a ray can meet does not change, and
+// with ties going to the lower triangle index neither does the record it ends with.
+struct alignas(128) lbvh_wide_node {
+    float lo[3][4];          // [axis][slot]
+    float hi[3][4];
+    uint32_t ref[4];         // node index | LEAF + triangle line | kWideEmpty
+    uint32_t pad[4];
+};
+static_assert(sizeof(lbvh_wide_node) == 128, "wide node must be one 128-byte line");
+constexpr uint32_t kWideEmpty = 0xFFFFFFFFu;
+constexpr int kWideStackLds = 16;
+constexpr int kWideStackDeep = 112;      // three siblings can wait per level
+
+struct wide_slot { float mn[3], mx[3]; uint32_t ref; };
+
+__device__ __forceinline__ float half_area(const wide_slot& b)
+{
+    const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__device__ __forceinline__ void children_of(const lbvh_fast_node* __restrict__ nodes, uint32_t i, wide_slot& l, wide_slot& r)
+{
+    const float4* q = reinterpret_cast<const float4*>(&nodes[i]);
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    l.mn[0] = q0.x; l.mn[1] = q0.y; l.mn[2] = q0.z; l.mx[0] = q1.x; l.mx[1] = q1.y; l.mx[2] = q1.z; l.ref = __float_as_uint(q0.w);
+    r.mn[0] = q2.x; r.mn[1] = q2.y; r.mn[2] = q2.z; r.mx[0] = q3.x; r.mx[1] = q3.y; r.mx[2] = q3.z; r.ref = __float_as_uint(q1.w);
+}
+
+// one thread per binary node: its two children, then twice the internal child with the largest surface opened
+__global__ __launch_bounds__(256) void collapse_wide_kernel(const lbvh_fast_node* __restrict__ nodes, uint32_t n_internal,
+                                                            lbvh_wide_node* __restrict__ wide)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_internal) return;
+    wide_slot s[4];
+    children_of(nodes, i, s[0], s[1]);
+    s[2].ref = kWideEmpty; s[3].ref = kWideEmpty;
+#pragma unroll
+    for (int k = 2; k < 4; k++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) { s[k].mn[a] = 0.0f; s[k].mx[a] = 0.0f; }
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+        int open = -1;
+        float open_area = -1.0f;
+#pragma unroll
+        for (int k = 0; k < 2 + round; k++) {
+            const float a = half_area(s[k]);
+            if (!(s[k].ref & 0x80000000u) && (open < 0 || a > open_area)) { open = k; open_area = a; }
+        }
+        if (open < 0) break;
+        uint32_t parent = 0;
+#pragma unroll
+        for (int k = 0; k < 2 + round; k++)
+            if (k == open) parent = s[k].ref;
+        wide_slot l, r;
+        children_of(nodes, parent, l, r);
+#pragma unroll
+        for (int k = 0; k < 2 + round; k++)
+            if (k == open) s[k] = l;
+        s[2 + round] = r;
+    }
+    lbvh_wide_node out;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { out.lo[a][k] = s[k].mn[a]; out.hi[a][k] = s[k].mx[a]; }
+        out.ref[k] = s[k].ref;
+        out.pad[k] = 0u;
+    }
+    float4* dst = reinterpret_cast<float4*>(&wide[i]);
+    const float4* src = reinterpret_cast<const float4*>(&out);
+#pragma unroll
+    for (int k = 0; k < 8; k++) dst[k] = src[k];
+}
+
+__device__ __forceinline__ uint32_t pick4(const uint4 v, uint32_t k) { return k == 0u ? v.x : (k == 1u ? v.y : (k == 2u ? v.z : v.w)); }
+
+// RayBoxIntersection (Raytracing.compute:75-87) on one slot of a wide node: the same six products, minima and maxima
+__device__ __forceinline__ bool wide_box(float lx, float ly, float lz, float hx, float hy, float hz, const ray_t& r, float& tmin_out)
+{
+    return ray_box(make_float4(lx, ly, lz, 0.0f), make_float4(hx, hy, hz, 0.0f), r, tmin_out);
+}
+
+// Same frame as trace_rays_kernel (lane refill from the wave's run of live rays, LDS + device-memory stack).
+__global__ __launch_bounds__(64) void trace_rays_wide_kernel(const lbvh_path_state* __restrict__ states, const uint32_t* __restrict__ n_alive,
+                                                             const uint32_t* __restrict__ list, float t_min,
+                                                             const lbvh_wide_node* __restrict__ wide,
+                                                             const lbvh_fast_node* __restrict__ lines, lbvh_hit* __restrict__ hits,
+                                                             uint32_t* __restrict__ deep,     // [gridDim.x][kWideStackDeep][64]
+                                                             uint32_t lds_depth)              // <= kWideStackLds
+{
+    __shared__ uint32_t s_stack[kWideStackLds][LBVH_WAVE];
+    uint32_t* my_deep = deep + (size_t)blockIdx.x * (kWideStackDeep * LBVH_WAVE) + threadIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t total = *n_alive;
+    const uint32_t run = max((total + gridDim.x - 1) / gridDim.x, 32u);
+    uint32_t next = blockIdx.x * run;
+    if (next >= total) return;
+    const uint32_t end = min(next + run, total);
+
+    bool active = false;
+    size_t i = 0;
+    ray_t ray = {};
+    float best_t = LBVH_MAX_FLOAT, best_u = 0.0f, best_v = 0.0f;
+    uint32_t best_tri = 0, sp = 0, node = 0;
+    auto push = [&](uint32_t ref) {
+        if (sp < lds_depth) { s_stack[sp][lane] = ref; sp++; }
+        else if (sp < lds_depth + (uint32_t)kWideStackDeep) { my_deep[(sp - lds_depth) * LBVH_WAVE] = ref; sp++; }
+    };
+    for (;;) {
+        const uint64_t idle = __ballot(!active);
+        if (idle != 0 && next < end) {
+            if (!active) {
+                const uint32_t k = next + mbcnt64(idle);
+                if (k < end) {
+                    i = list[k];
+                    const float4* st = reinterpret_cast<const float4*>(&states[i]);
+                    const float4 o = st[0], d = st[1];
+                    ray.ox = o.x; ray.oy = o.y; ray.oz = o.z;
+                    ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
+                    ray.ix = 1.0f / d.x; ray.iy = 1.0f / d.y; ray.iz = 1.0f / d.z;
+                    best_t = LBVH_MAX_FLOAT; best_tri = 0; best_u = 0.0f; best_v = 0.0f;
+                    sp = 0; node = 0;
+                    active = true;
+                }
+            }
+            next += (uint32_t)__popcll(idle);
+        }
+        if (!__any(active)) break;
+        if (active) {
+            const float4* w = reinterpret_cast<const float4*>(&wide[node]);
+            const float4 lox = w[0], loy = w[1], loz = w[2], hix = w[3], hiy = w[4], hiz = w[5];
+            const uint4 ref = reinterpret_cast<const uint4*>(w)[6];
+            float t0, t1, t2, t3;
+            const bool h0 = wide_box(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ray, t0) && !(t0 > best_t) && ref.x != kWideEmpty;
+            const bool h1 = wide_box(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ray, t1) && !(t1 > best_t) && ref.y != kWideEmpty;
+            const bool h2 = wide_box(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ray, t2) && !(t2 > best_t) && ref.z != kWideEmpty;
+            const bool h3 = wide_box(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ray, t3) && !(t3 > best_t) && ref.w != kWideEmpty;
+            // leaf slots first: a lane's leaves one after the other, every lane's k-th at the same time
+            uint32_t leaves = (h0 && (ref.x >> 31) ? 1u : 0u) | (h1 && (ref.y >> 31) ? 2u : 0u) | (h2 && (ref.z >> 31) ? 4u : 0u) |
+                              (h3 && (ref.w >> 31) ? 8u : 0u);
+            while (leaves != 0u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(leaves);
+                leaves &= leaves - 1u;
+                float4 v0, v1, v2;
+                unpack_fast_triangle(reinterpret_cast<const float4*>(&lines[pick4(ref, k) & 0x7FFFFFFFu]), v0, v1, v2);
+                float u = 0.0f, v = 0.0f;
+                const float dist = ray_fast_triangle(ray, v0, v1, v2, u, v);
+                const uint32_t tri = __float_as_uint(v0.w);
+                // ties go to the lower triangle index, whatever order the leaves are met in (as in the packet walk)
+                if (dist > t_min && (dist < best_t || (dist == best_t && tri < best_tri))) { best_t = dist; best_tri = tri; best_u = u; best_v = v; }
+            }
+            // nodes to enter, ordered by entry distance: the order key is the distance's bit pattern (non-negative floats
+            // order like integers) with the slot number in its two lowest bits
+            constexpr uint32_t none = 0xFFFFFFFFu;
+            uint32_t k0 = h0 && !(ref.x >> 31) && !(t0 > best_t) ? ((__float_as_uint(fmaxf(t0, 0.0f)) & ~3u) | 0u) : none;
+            uint32_t k1 = h1 && !(ref.y >> 31) && !(t1 > best_t) ? ((__float_as_uint(fmaxf(t1, 0.0f)) & ~3u) | 1u) : none;
+            uint32_t k2 = h2 && !(ref.z >> 31) && !(t2 > best_t) ? ((__float_as_uint(fmaxf(t2, 0.0f)) & ~3u) | 2u) : none;
+            uint32_t k3 = h3 && !(ref.w >> 31) && !(t3 > best_t) ? ((__float_as_uint(fmaxf(t3, 0.0f)) & ~3u) | 3u) : none;
+            {   // five compare-exchanges
+                uint32_t a, b;
+                a = min(k0, k1); b = max(k0, k1); k0 = a; k1 = b;
+                a = min(k2, k3); b = max(k2, k3); k2 = a; k3 = b;
+                a = min(k0, k2); b = max(k0, k2); k0 = a; k2 = b;
+                a = min(k1, k3); b = max(k1, k3); k1 = a; k3 = b;
+                a = min(k1, k2); b = max(k1, k2); k1 = a; k2 = b;
+            }
+            if (k0 != none) {
+                if (k3 != none) push(pick4(ref, k3 & 3u));       // farthest first: the nearest waiting sibling is popped first
+                if (k2 != none) push(pick4(ref, k2 & 3u));
+                if (k1 != none) push(pick4(ref, k1 & 3u));
+                node = pick4(ref, k0 & 3u);
             } else if (sp != 0) {
                 sp--;
                 node = sp < lds_depth ? s_stack[sp][lane] : my_deep[(sp - lds_depth) * LBVH_WAVE];
@@ -345,6 +540,33 @@ __global__ __launch_bounds__(256) void path_resolve_kernel(const lbvh_path_state
 
 static_assert(sizeof(lbvh_path_state) == 64, "path state must be 64 bytes");
 
+// the walk over the live rays of `list`: four-wide nodes (made on first use after a rebuild), or the binary nodes the
+// packet walk uses (lbvh_debug_ray_walker(ctx, 0): the cross-check of the tests)
+static lbvh_status launch_ray_walk(lbvh_context* ctx, const lbvh_path_state* d_states, const uint32_t* n_alive, const uint32_t* list,
+                                   float t_min, lbvh_hit* d_hits, size_t count)
+{
+    const uint32_t ray_waves = ray_waves_of(count);
+    if (ctx->ray_wide) {
+        const uint32_t n_internal = ctx->fast_src.n - 1;
+        if (!ctx->wide_valid) {
+            const int rc = lbvh_reserve(ctx, &ctx->wide_nodes, &ctx->wide_nodes_bytes, (size_t)n_internal * sizeof(lbvh_wide_node));
+            if (rc != LBVH_OK) return (lbvh_status)rc;
+            LBVH_LAUNCH(ctx, collapse_wide_kernel, dim3((n_internal + 255) / 256), dim3(256), ctx->fast_nodes, n_internal,
+                        (lbvh_wide_node*)ctx->wide_nodes);
+            ctx->wide_valid = true;
+        }
+        LBVH_LAUNCH(ctx, trace_rays_wide_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min,
+                    (const lbvh_wide_node*)ctx->wide_nodes, ctx->fast_nodes, d_hits, deep_stacks(ctx, count),
+                    std::min<uint32_t>(ctx->ray_stack_lds, kWideStackLds));
+    } else {
+        LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, ctx->fast_nodes,
+                    ctx->fast_tris, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds);
+    }
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
+}
+
+
 extern "C" {
 
 lbvh_status lbvh_animate(lbvh_context* ctx, const lbvh_triangle* d_rest, uint32_t n, const uint32_t* d_body,
@@ -396,10 +618,14 @@ lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, 
     uint32_t* list = (uint32_t*)((char*)ctx->ray_scratch + 256);
     LBVH_HIP_TRY(ctx, hipMemsetAsync(n_alive, 0, 4, ctx->cur_stream));
     LBVH_LAUNCH(ctx, alive_rays_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), d_states, count, n_alive, list, d_hits);
-    const uint32_t ray_waves = ray_waves_of(count);
-    LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive,
-                list, t_min, ctx->fast_nodes, ctx->fast_tris, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds);
-    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return launch_ray_walk(ctx, d_states, n_alive, list, t_min, d_hits, count);
+}
+
+lbvh_status lbvh_debug_ray_walker(lbvh_context* ctx, uint32_t wide)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, wide <= 1u);
+    ctx->ray_wide = wide != 0u;
     return LBVH_OK;
 }
 
@@ -451,11 +677,7 @@ static lbvh_status path_bounce_impl(lbvh_context* ctx, const lbvh_scene* h_scene
     else
         LBVH_LAUNCH(ctx, (path_scatter_kernel<true, false>), scatter_grid, dim3(256), h_scene->triangles, d_hits, count, bounce, seed, albedo,
                     d_states, n_alive, list, lbvh_camera{});
-    const uint32_t ray_waves = ray_waves_of(count);
-    LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, ctx->fast_nodes,
-                ctx->fast_tris, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds);
-    LBVH_HIP_TRY(ctx, hipGetLastError());
-    return LBVH_OK;
+    return launch_ray_walk(ctx, d_states, n_alive, list, t_min, d_hits, count);
 }
 
 extern "C" {
