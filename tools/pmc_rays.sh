@@ -20,7 +20,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("$OUT/g*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "trace_rays_kernel" in row["Kernel_Name"]:
+        if "trace_rays" in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print(f"{k:32s} launches={len(v)} sum={sum(v):.6g} mean={sum(v)/len(v):.6g}")
