@@ -61,6 +61,9 @@ __global__ __launch_bounds__(256) void path_begin_kernel(lbvh_camera cam, lbvh_p
 // stack (Raytracing.compute:113).
 constexpr int kRayStackLds = 16;
 constexpr int kRayStackDeep = 48;
+// the four-wide walk further down: three siblings can wait per level
+constexpr int kWideStackLds = 16;
+constexpr int kWideStackDeep = 112;
 
 // Live rays only: alive_rays_kernel writes the miss record of every dead ray and compacts the indices of the live
 // ones (after the first bounce more than half of a frame's paths have left the scene).  (Sorting the live rays by direction octant + Morton code of the origin on top of this was
@@ -98,7 +101,7 @@ constexpr uint32_t kRayWaves = 8192;
 // ray scratch: [live-ray count (256 B) | indices of the live rays | deep stack slabs of the launch's waves]
 static inline uint32_t ray_waves_of(size_t count) { return (uint32_t)std::min<size_t>(kRayWaves, (count + LBVH_WAVE - 1) / LBVH_WAVE); }
 // the slab is indexed by blockIdx.x: one launch needs ray_waves_of(count) of them (a 64-ray call: 12 KB, not 96 MB)
-static inline size_t deep_bytes(size_t count) { return (size_t)ray_waves_of(count) * 112 * LBVH_WAVE * 4; }     // kWideStackDeep entries (>= kRayStackDeep)
+static inline size_t deep_bytes(size_t count) { return (size_t)ray_waves_of(count) * std::max(kWideStackDeep, kRayStackDeep) * LBVH_WAVE * 4; }
 static inline size_t list_bytes(size_t count) { return (count * 4 + 255) & ~(size_t)255; }
 static inline uint32_t* deep_stacks(lbvh_context* ctx, size_t count) { return (uint32_t*)((char*)ctx->ray_scratch + 256 + list_bytes(count)); }
 
@@ -208,8 +211,6 @@ struct alignas(128) lbvh_wide_node {
 };
 static_assert(sizeof(lbvh_wide_node) == 128, "wide node must be one 128-byte line");
 constexpr uint32_t kWideEmpty = 0xFFFFFFFFu;
-constexpr int kWideStackLds = 16;
-constexpr int kWideStackDeep = 112;      // three siblings can wait per level
 
 struct wide_slot { float mn[3], mx[3]; uint32_t ref; };
 
