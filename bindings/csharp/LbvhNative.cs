@@ -88,7 +88,7 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern int lbvh_trace_costs_export(IntPtr ctx, IntPtr dFrameCosts, uint tilesX, uint tilesY);
     [DllImport(Lib)] public static extern int lbvh_trace_costs_import(IntPtr ctx, IntPtr dFrameCosts, uint tilesX, uint tilesY);
     [DllImport(Lib)] public static extern int lbvh_debug_ray_stack_split(IntPtr ctx, uint ldsEntries);
-    [DllImport(Lib)] public static extern int lbvh_debug_ray_walker(IntPtr ctx, uint wide);
+    [DllImport(Lib)] public static extern int lbvh_debug_ray_walker(IntPtr ctx, uint walker);
     // measurement helper: shader clock held under a vector-ALU-bound load, MHz
     [DllImport(Lib)] public static extern int lbvh_clock_probe(IntPtr ctx, out float shaderMhz);
     // a context whose work is ordered by a stream the caller owns (hipStream_t), e.g. an interop stream

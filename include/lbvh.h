@@ -409,10 +409,12 @@ lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, 
  * of the stack is exercised by ordinary scenes. */
 lbvh_status lbvh_debug_ray_stack_split(lbvh_context* ctx, uint32_t lds_entries);
 
-/* Test hook: which form of the derived scene lbvh_trace_rays / lbvh_path_bounce walk — 1 (default): four-wide nodes
- * (each binary node with its largest children opened, made on first use after a rebuild), 0: the binary nodes the
- * packet walk uses.  Hit records do not depend on it (ties go to the lower triangle index on both). */
-lbvh_status lbvh_debug_ray_walker(lbvh_context* ctx, uint32_t wide);
+/* Test hook: which walk lbvh_trace_rays / lbvh_path_bounce run — 1 (default): four-wide nodes (each binary node with its
+ * largest children opened, made on first use after a rebuild; from bounce 1 on lbvh_path_bounce takes the kernel that keeps
+ * a step's two fetches in flight at once: few live rays, the launch is the chain of its longest), 2: that kernel for every
+ * launch, 0: the binary nodes the packet walk uses.  Hit records do not depend on it (ties go to the lower triangle index
+ * on all three). */
+lbvh_status lbvh_debug_ray_walker(lbvh_context* ctx, uint32_t walker);
 
 /* Camera rays into path states (origin/dir as Raytracing.compute:108-126, throughput 1, radiance 0, alive). */
 lbvh_status lbvh_path_begin(lbvh_context* ctx, const lbvh_camera* h_camera, lbvh_path_state* d_states);

@@ -1293,7 +1293,8 @@ def test_secondary_rays_four_wide_walk_equals_binary_walk(ctx, scene):
     """lbvh_trace_rays walks the derived scene as four-wide nodes (collapse_wide_kernel: every binary node with its
     largest children opened). Same leaves, same boxes, ties to the lower triangle index: the hit records equal the binary
     walk's (lbvh_debug_ray_walker(ctx, 0)) word for word — also with the stack split lowered so that waiting siblings go
-    through the device-memory slab — and `t` equals the oracle's everywhere."""
+    through the device-memory slab, and with the kernel the later bounces use (walker 2: the next node requested before the
+    step's triangles are tested) — and `t` equals the oracle's everywhere."""
     if scene == "torus":
         tris = scenes.tiled_torus(nu=40, nv=24, grid=3)
     elif scene == "soup":
@@ -1312,10 +1313,10 @@ def test_secondary_rays_four_wide_walk_equals_binary_walk(ctx, scene):
     hb = H().DataBuffer(ctx, len(st), L.HIT)
     s = c.scene()
     n_ = N()
-    assert n_.lib.lbvh_debug_ray_walker(ctx.handle, 2) == -1
+    assert n_.lib.lbvh_debug_ray_walker(ctx.handle, 3) == -1
     frames = {}
     try:
-        for wide, split in ((0, 16), (1, 16), (1, 1), (1, 3)):
+        for wide, split in ((0, 16), (1, 16), (1, 1), (1, 3), (2, 16), (2, 2)):
             n_.check(ctx.handle, n_.lib.lbvh_debug_ray_walker(ctx.handle, wide))
             n_.check(ctx.handle, n_.lib.lbvh_debug_ray_stack_split(ctx.handle, split))
             hb.local[:] = np.zeros(1, L.HIT)
@@ -1326,7 +1327,7 @@ def test_secondary_rays_four_wide_walk_equals_binary_walk(ctx, scene):
     finally:
         n_.check(ctx.handle, n_.lib.lbvh_debug_ray_walker(ctx.handle, 1))
         n_.check(ctx.handle, n_.lib.lbvh_debug_ray_stack_split(ctx.handle, 16))
-    for key in ((1, 16), (1, 1), (1, 3)):
+    for key in ((1, 16), (1, 1), (1, 3), (2, 16), (2, 2)):
         assert (words(frames[(0, 16)]) == words(frames[key])).all(), key
     oh = O.trace_rays(b, st, 1e-3, threads=8)
     assert (frames[(1, 16)]["t"] == oh["t"]).all()

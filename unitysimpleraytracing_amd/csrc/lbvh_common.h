@@ -131,7 +131,7 @@ struct lbvh_context {
     void* wide_nodes = nullptr;
     size_t wide_nodes_bytes = 0;
     bool wide_valid = false;
-    bool ray_wide = true;                     // lbvh_debug_ray_walker
+    uint32_t ray_walker = 1;                  // lbvh_debug_ray_walker: 0 binary nodes, 1 four-wide, 2 four-wide with the few-rays kernel always
 
     // per-kernel event profiling (lbvh_profile_begin / lbvh_profile_end)
     struct prof_span { const char* name; hipEvent_t a, b; };

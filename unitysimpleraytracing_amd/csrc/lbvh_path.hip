@@ -3,6 +3,7 @@
 // primary rays of a static mesh only.  Definitions: include/lbvh.h; bit-exact checker: oracle/.
 // Strict fp32 (-ffp-contract=off), no device trig, counter-based RNG.
 #include <algorithm>
+#include <cstdlib>
 #include "lbvh_common.h"
 #include "lbvh_rt.h"
 
@@ -389,6 +390,138 @@ __global__ __launch_bounds__(64) void trace_rays_wide_kernel(const lbvh_path_sta
     }
 }
 
+// The same walk for launches whose time is the chain of their longest rays (the later bounces of a frame: a few hundred
+// thousand live rays, most of the chip idle for most of the launch): the next node is chosen BEFORE the step's triangles are
+// tested and requested together with the first triangle line, so the two fetches of a step are in flight at once.  84 VGPRs
+// (5 waves per SIMD instead of 8): the price where every wave slot is needed, none where they are not.
+__global__ __launch_bounds__(64) void trace_rays_wide_chain_kernel(const lbvh_path_state* __restrict__ states, const uint32_t* __restrict__ n_alive,
+                                                             const uint32_t* __restrict__ list, float t_min,
+                                                             const lbvh_wide_node* __restrict__ wide,
+                                                             const lbvh_fast_node* __restrict__ lines, lbvh_hit* __restrict__ hits,
+                                                             uint32_t* __restrict__ deep,     // [gridDim.x][kWideStackDeep][64]
+                                                             uint32_t lds_depth)              // <= kWideStackLds
+{
+    __shared__ uint32_t s_stack[kWideStackLds][LBVH_WAVE];
+    uint32_t* my_deep = deep + (size_t)blockIdx.x * (kWideStackDeep * LBVH_WAVE) + threadIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t total = *n_alive;
+    const uint32_t run = max((total + gridDim.x - 1) / gridDim.x, 32u);
+    uint32_t next = blockIdx.x * run;
+    if (next >= total) return;
+    const uint32_t end = min(next + run, total);
+
+    bool active = false, have = false;      // have: the registers below hold this lane's node
+    uint32_t i = 0;                          // (lbvh_trace_rays: count <= 2^32 - 1)
+    ray_t ray = {};
+    float best_t = LBVH_MAX_FLOAT, best_u = 0.0f, best_v = 0.0f;
+    uint32_t best_tri = 0, sp = 0, node = 0;
+    float4 lox = {}, loy = {}, loz = {}, hix = {}, hiy = {}, hiz = {};
+    uint4 ref = {};
+    auto push = [&](uint32_t r) {
+        if (sp < lds_depth) { s_stack[sp][lane] = r; sp++; }
+        else if (sp < lds_depth + (uint32_t)kWideStackDeep) { my_deep[(sp - lds_depth) * LBVH_WAVE] = r; sp++; }
+    };
+    // A step: box tests on the node fetched during the previous step, the next node chosen (against the best hit so far),
+    // then the first leaf's triangle line AND the next node requested together, the triangle tests while both are on their
+    // way.  The two fetches of a step overlap instead of following each other; what a leaf hit would have pruned from the
+    // choice is met by the next step's box tests (its children then fail `entry <= best`).
+    for (;;) {
+        const uint64_t idle = __ballot(!active);
+        if (idle != 0 && next < end) {
+            if (!active) {
+                const uint32_t k = next + mbcnt64(idle);
+                if (k < end) {
+                    i = list[k];
+                    const float4* st = reinterpret_cast<const float4*>(&states[i]);
+                    const float4 o = st[0], d = st[1];
+                    ray.ox = o.x; ray.oy = o.y; ray.oz = o.z;
+                    ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
+                    ray.ix = 1.0f / d.x; ray.iy = 1.0f / d.y; ray.iz = 1.0f / d.z;
+                    best_t = LBVH_MAX_FLOAT; best_tri = 0; best_u = 0.0f; best_v = 0.0f;
+                    sp = 0; node = 0;
+                    active = true; have = false;
+                }
+            }
+            next += (uint32_t)__popcll(idle);
+        }
+        if (!__any(active)) break;
+        uint32_t leaves = 0u;
+        uint4 leaf_ref = {};
+        bool fetch = active, done = false;
+        if (active && have) {
+            float t0, t1, t2, t3;
+            const bool h0 = wide_box(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ray, t0) && !(t0 > best_t) && ref.x != kWideEmpty;
+            const bool h1 = wide_box(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ray, t1) && !(t1 > best_t) && ref.y != kWideEmpty;
+            const bool h2 = wide_box(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ray, t2) && !(t2 > best_t) && ref.z != kWideEmpty;
+            const bool h3 = wide_box(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ray, t3) && !(t3 > best_t) && ref.w != kWideEmpty;
+            leaves = (h0 && (ref.x >> 31) ? 1u : 0u) | (h1 && (ref.y >> 31) ? 2u : 0u) | (h2 && (ref.z >> 31) ? 4u : 0u) |
+                     (h3 && (ref.w >> 31) ? 8u : 0u);
+            leaf_ref = ref;
+            // nodes to enter, ordered by entry distance: the order key is the distance's bit pattern (non-negative floats
+            // order like integers) with the slot number in its two lowest bits
+            constexpr uint32_t none = 0xFFFFFFFFu;
+            uint32_t k0 = h0 && !(ref.x >> 31) ? ((__float_as_uint(fmaxf(t0, 0.0f)) & ~3u) | 0u) : none;
+            uint32_t k1 = h1 && !(ref.y >> 31) ? ((__float_as_uint(fmaxf(t1, 0.0f)) & ~3u) | 1u) : none;
+            uint32_t k2 = h2 && !(ref.z >> 31) ? ((__float_as_uint(fmaxf(t2, 0.0f)) & ~3u) | 2u) : none;
+            uint32_t k3 = h3 && !(ref.w >> 31) ? ((__float_as_uint(fmaxf(t3, 0.0f)) & ~3u) | 3u) : none;
+            {   // five compare-exchanges
+                uint32_t a, b;
+                a = min(k0, k1); b = max(k0, k1); k0 = a; k1 = b;
+                a = min(k2, k3); b = max(k2, k3); k2 = a; k3 = b;
+                a = min(k0, k2); b = max(k0, k2); k0 = a; k2 = b;
+                a = min(k1, k3); b = max(k1, k3); k1 = a; k3 = b;
+                a = min(k1, k2); b = max(k1, k2); k1 = a; k2 = b;
+            }
+            if (k0 != none) {
+                if (k3 != none) push(pick4(ref, k3 & 3u));       // farthest first: the nearest waiting sibling is popped first
+                if (k2 != none) push(pick4(ref, k2 & 3u));
+                if (k1 != none) push(pick4(ref, k1 & 3u));
+                node = pick4(ref, k0 & 3u);
+            } else if (sp != 0) {
+                sp--;
+                node = sp < lds_depth ? s_stack[sp][lane] : my_deep[(sp - lds_depth) * LBVH_WAVE];
+            } else {
+                fetch = false;
+                done = true;              // after this step's leaves
+            }
+        }
+        // the first leaf's line, then the next node: requested back to back
+        // (a triangle line: {v0, index} | e2.x in dword 7 | {e1, e2.y} | e2.z in dword 15)
+        float4 q0 = {}, q1 = {}, q2 = {}, q3 = {};
+        if (leaves != 0u) {
+            const float4* line = reinterpret_cast<const float4*>(&lines[pick4(leaf_ref, (uint32_t)__builtin_ctz(leaves)) & 0x7FFFFFFFu]);
+            q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3];
+        }
+        if (fetch) {
+            const float4* w = reinterpret_cast<const float4*>(&wide[node]);
+            lox = w[0]; loy = w[1]; loz = w[2]; hix = w[3]; hiy = w[4]; hiz = w[5];
+            ref = reinterpret_cast<const uint4*>(w)[6];
+            have = true;
+        }
+        while (leaves != 0u) {
+            leaves &= leaves - 1u;
+            float u = 0.0f, v = 0.0f;
+            const float dist = ray_triangle_edges(ray, q0, q2.x, q2.y, q2.z, q1.w, q2.w, q3.w, u, v);
+            const uint32_t tri = __float_as_uint(q0.w);
+            // ties go to the lower triangle index, whatever order the leaves are met in (as in the packet walk)
+            if (dist > t_min && (dist < best_t || (dist == best_t && tri < best_tri))) { best_t = dist; best_tri = tri; best_u = u; best_v = v; }
+            if (leaves != 0u) {
+                const float4* line = reinterpret_cast<const float4*>(&lines[pick4(leaf_ref, (uint32_t)__builtin_ctz(leaves)) & 0x7FFFFFFFu]);
+                q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3];
+            }
+        }
+        if (done) {
+            float4 out;
+            out.x = best_t;
+            out.y = __uint_as_float(best_tri);
+            out.z = best_u;
+            out.w = best_v;
+            reinterpret_cast<float4*>(hits)[i] = out;
+            active = false;
+        }
+    }
+}
+
 // ---- bounce ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t pcg_hash(uint32_t v)
 {
@@ -541,13 +674,14 @@ __global__ __launch_bounds__(256) void path_resolve_kernel(const lbvh_path_state
 
 static_assert(sizeof(lbvh_path_state) == 64, "path state must be 64 bytes");
 
-// the walk over the live rays of `list`: four-wide nodes (made on first use after a rebuild), or the binary nodes the
-// packet walk uses (lbvh_debug_ray_walker(ctx, 0): the cross-check of the tests)
+// the walk over the live rays of `list`: four-wide nodes (made on first use after a rebuild) — few_rays: with the kernel that
+// keeps two fetches of a step in flight (the later bounces of a frame) —, or the binary nodes the packet walk uses
+// (lbvh_debug_ray_walker(ctx, 0): the cross-check of the tests; 2: the few-rays kernel for every launch)
 static lbvh_status launch_ray_walk(lbvh_context* ctx, const lbvh_path_state* d_states, const uint32_t* n_alive, const uint32_t* list,
-                                   float t_min, lbvh_hit* d_hits, size_t count)
+                                   float t_min, lbvh_hit* d_hits, size_t count, bool few_rays = false)
 {
     const uint32_t ray_waves = ray_waves_of(count);
-    if (ctx->ray_wide) {
+    if (ctx->ray_walker != 0u) {
         const uint32_t n_internal = ctx->fast_src.n - 1;
         if (!ctx->wide_valid) {
             const int rc = lbvh_reserve(ctx, &ctx->wide_nodes, &ctx->wide_nodes_bytes, (size_t)n_internal * sizeof(lbvh_wide_node));
@@ -556,9 +690,14 @@ static lbvh_status launch_ray_walk(lbvh_context* ctx, const lbvh_path_state* d_s
                         (lbvh_wide_node*)ctx->wide_nodes);
             ctx->wide_valid = true;
         }
-        LBVH_LAUNCH(ctx, trace_rays_wide_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min,
-                    (const lbvh_wide_node*)ctx->wide_nodes, ctx->fast_nodes, d_hits, deep_stacks(ctx, count),
-                    std::min<uint32_t>(ctx->ray_stack_lds, kWideStackLds));
+        if (few_rays || ctx->ray_walker == 2u)
+            LBVH_LAUNCH(ctx, trace_rays_wide_chain_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min,
+                        (const lbvh_wide_node*)ctx->wide_nodes, ctx->fast_nodes, d_hits, deep_stacks(ctx, count),
+                        std::min<uint32_t>(ctx->ray_stack_lds, kWideStackLds));
+        else
+            LBVH_LAUNCH(ctx, trace_rays_wide_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min,
+                        (const lbvh_wide_node*)ctx->wide_nodes, ctx->fast_nodes, d_hits, deep_stacks(ctx, count),
+                        std::min<uint32_t>(ctx->ray_stack_lds, kWideStackLds));
     } else {
         LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, ctx->fast_nodes,
                     ctx->fast_tris, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds);
@@ -622,11 +761,11 @@ lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, 
     return launch_ray_walk(ctx, d_states, n_alive, list, t_min, d_hits, count);
 }
 
-lbvh_status lbvh_debug_ray_walker(lbvh_context* ctx, uint32_t wide)
+lbvh_status lbvh_debug_ray_walker(lbvh_context* ctx, uint32_t walker)
 {
     if (!ctx) return LBVH_ERR_INVALID_ARG;
-    LBVH_REQUIRE(ctx, wide <= 1u);
-    ctx->ray_wide = wide != 0u;
+    LBVH_REQUIRE(ctx, walker <= 2u);
+    ctx->ray_walker = walker;
     return LBVH_OK;
 }
 
@@ -678,7 +817,7 @@ static lbvh_status path_bounce_impl(lbvh_context* ctx, const lbvh_scene* h_scene
     else
         LBVH_LAUNCH(ctx, (path_scatter_kernel<true, false>), scatter_grid, dim3(256), h_scene->triangles, d_hits, count, bounce, seed, albedo,
                     d_states, n_alive, list, lbvh_camera{});
-    return launch_ray_walk(ctx, d_states, n_alive, list, t_min, d_hits, count);
+    return launch_ray_walk(ctx, d_states, n_alive, list, t_min, d_hits, count, bounce >= 1u);
 }
 
 extern "C" {
