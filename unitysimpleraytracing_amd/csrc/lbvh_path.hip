@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void path_begin_kernel(lbvh_camera cam, lbvh_p
 // stack (Raytracing.compute:113).
 constexpr int kRayStackLds = 16;
 constexpr int kRayStackDeep = 48;
-// the four-wide walk further down: three siblings can wait per level
+// the four-wide walk further down: three siblings can wait per level.  (Neither stack can overflow on a tree of this library:
+// the derived tree is a radix tree over unique 32-bit keys, at most 32 levels deep — 32 waiting entries for the binary walk,
+// 3 x 32 for the four-wide one, whose levels are binary levels or pairs of them.)
 constexpr int kWideStackLds = 16;
 constexpr int kWideStackDeep = 112;
 
