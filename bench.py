@@ -75,6 +75,10 @@ def parse():
     # test hooks: run the N-rank path on fewer GPUs (ranks share --device, gloo instead of RCCL)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--device", type=int, default=None)
+    # N > 1: how every rank's hit records reach rank 0's full-frame buffer inside the timed step (frame_gather.py):
+    # peer = traced straight into rank 0's memory (IPC-mapped, xGMI stores) + device-side completion flags;
+    # packed = contiguous shares + one torch.distributed gather + lbvh_frame_unpack; auto = peer if its self-test passes
+    ap.add_argument("--gather", choices=["auto", "peer", "packed"], default="auto")
     return ap.parse_args()
 
 
@@ -111,17 +115,19 @@ def self_launch(n):
     """`python bench.py --gpus N` from a plain launch: start the N ranks as CHILD processes (one per GPU, the environment
     torch.distributed.run would give them) and exit with their worst return code.  Nothing in this parent has touched HIP
     or torch at this point (no exec of a GPU-initialised process anywhere); rank 0's JSON line goes straight to stdout."""
-    import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
+    import tempfile
+    # rendezvous through a file the ranks share (torch.distributed's file:// store), not through a TCP port picked here and
+    # released before rank 0 binds it (ADVICE r3: another process could take it in between)
+    rdv_dir = tempfile.mkdtemp(prefix="lbvh_bench_rdv_")
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   LBVH_BENCH_RENDEZVOUS_FILE=os.path.join(rdv_dir, "store"))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        # stdout carries ONE JSON line, rank 0's: whatever another rank prints goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
     worst = 0
     try:
         pending = list(procs)
@@ -140,6 +146,8 @@ def self_launch(n):
         for p_ in procs:
             if p_.poll() is None:
                 p_.kill()
+        import shutil
+        shutil.rmtree(rdv_dir, ignore_errors=True)
     raise SystemExit(worst)
 
 
@@ -162,11 +170,13 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
+            rdv = os.environ.get("LBVH_BENCH_RENDEZVOUS_FILE")          # set by self_launch; torchrun gives MASTER_ADDR / PORT
+            how = dict(init_method="file://" + rdv, rank=rank, world_size=world) if rdv else {}
             if args.backend == "nccl":
                 torch.cuda.set_device(device_id)
-                dist_mod.init_process_group("nccl", device_id=torch.device("cuda", device_id))
+                dist_mod.init_process_group("nccl", device_id=torch.device("cuda", device_id), **how)
             else:
-                dist_mod.init_process_group("gloo")
+                dist_mod.init_process_group("gloo", **how)
             dist_mod.barrier()
         finally:
             sys.stdout.flush()
@@ -230,9 +240,19 @@ def main():
     hit_buf = DataBuffer(ctx, W * H, L.HIT)             # full-frame layout on every rank
     from unitysimpleraytracing_amd import _native as N
     ccam = N.Camera.from_dict(cam)
+    # N > 1: the step ends with ONE whole frame in rank 0's buffer (the reference renders one image per Update(),
+    # RaytracingMeshDrawer.cs:76-89): every rank's records travel to rank 0 inside the timed region
+    gather = None
+    if dist is not None:
+        from unitysimpleraytracing_amd.frame_gather import FrameGather
+        if args.backend == "nccl":
+            import torch
+            torch.cuda.set_device(device_id)
+        gather = FrameGather(ctx, dist, rank, world, W, H, device_id, staged=(args.backend == "gloo"), mode=args.gather)
 
     def trace_share(camera=None, stats=None):
-        # this rank's share of the frame (every world-th group of 8 adjacent 8x8-pixel tiles), one launch
+        # this rank's share of the frame (every world-th group of 8 adjacent 8x8-pixel tiles), one launch, into this
+        # rank's own buffer: the untimed extras (what a share costs alone)
         s = drawer.container.scene()
         N.check(ctx.handle, N.lib.lbvh_trace_primary_shard(ctx.handle, C.byref(camera if camera is not None else ccam), rank, world,
                                                            C.byref(s), mode, hit_buf.device, stats))
@@ -241,7 +261,10 @@ def main():
         rebuild()
         if ev:
             ctx.record(ev[0])       # rebuild | trace
-        trace_share()
+        if gather is None:
+            trace_share()
+        else:                       # the share + its way into rank 0's frame (+ on rank 0: the wait for everybody's)
+            gather.trace_share(ccam, drawer.container.scene(), mode, own_done_event=ev[2] if ev else None)
         if ev:
             ctx.record(ev[1])       # end of the step = start of the next one's rebuild
 
@@ -251,7 +274,7 @@ def main():
 
     # two event records per step (each costs the stream a few microseconds): a step's rebuild starts where the
     # previous step's trace ended
-    events = [(ctx.event(), ctx.event()) for _ in range(args.steps)]
+    events = [(ctx.event(), ctx.event()) + ((ctx.event(),) if gather is not None else ()) for _ in range(args.steps)]
     ev_start = ctx.event()
     barrier()
     ctx.sync()
@@ -269,6 +292,41 @@ def main():
     wall_ms = reduce_max((t1 - t0) * 1e3 / args.steps)
     build_ms_max = reduce_max(build_ms)
     trace_ms_max = reduce_max(trace_ms)
+    # N > 1: trace_ms contains the records' way to rank 0 (on rank 0: the wait for every rank's share); the traversal alone:
+    own_trace_ms_max = reduce_max(float(np.mean([ctx.elapsed_ms(e[0], e[2]) for e in events]))) if gather is not None else trace_ms_max
+
+    # ---- N > 1: the assembled frame, word for word (untimed) ------------------------------------------
+    frame_check = None
+    if gather is not None:
+        # a fresh frame into a POISONED buffer: every record must arrive in this very frame
+        if rank == 0:
+            gather.frame.fill_u32(0x7FC00000, mirror=False)
+        ctx.sync()
+        barrier()
+        gather.trace_share(ccam, drawer.container.scene(), mode)
+        ctx.sync()
+        barrier()
+        if rank == 0:
+            assembled = gather.frame.get_data().copy()
+            s_c = drawer.container.scene()
+            alone = DataBuffer(ctx, W * H, L.HIT)
+            N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s_c), mode, alone.device, None))
+            one_gpu = alone.get_data().copy()
+            N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s_c), L.TRACE_REFERENCE, alone.device, None))
+            ref = alone.get_data().copy()
+            alone.dispose()
+            words_equal = bool((assembled.view(np.uint32) == one_gpu.view(np.uint32)).all())
+            t_equal = bool((assembled["t"].view(np.uint32) == ref["t"].view(np.uint32)).all())
+            tie_pixels = int(np.count_nonzero(assembled["tri"] != ref["tri"]))
+            frame_check = {"transport": gather.mode, "peer_unavailable_because": gather.peer_error,
+                           "assembled_equals_one_gpu_frame_word_for_word": words_equal,
+                           "t_equals_reference_mode_bit_for_bit": t_equal,
+                           "pixels_where_the_triangle_differs_from_reference_mode": tie_pixels,
+                           "note": "a fresh frame assembled in rank 0's NaN-poisoned buffer from every rank's share, compared with the "
+                                   "frame rank 0 traces alone (same mode: every word) and with LBVH_TRACE_REFERENCE (t: every bit; the "
+                                   "triangle differs only where two are hit at exactly the same t — DESIGN 9)"}
+            if not (words_equal and t_equal):
+                raise SystemExit(f"the assembled {world}-GPU frame differs from the one-GPU frame: {frame_check}")
 
     # ---- untimed extras ---------------------------------------------------------------------------
     tiles_x, tiles_y = (W + TILE_W - 1) // TILE_W, (H + TILE_H - 1) // TILE_H
@@ -473,7 +531,8 @@ def main():
         # against 8 TB/s — small, because the walk prunes (the reference algorithm's bytes priced at this duration would be
         # several times the peak: `reference_equivalent_GBs`) and because the scene it walks is cache-resident.  What the kernel
         # is close to is vector-instruction issue, carried beside it under its own name (`valu_issue`).
-        roofline = {"kernel": kname, "kernel_ms": round(trace_kernel_ms, 4), "bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS,
+        roofline = {"roofline_version": 3,        # 3 (round 3 on): frac = HBM fraction of the kernel's own bytes; valu_issue against the 2-cycle rate
+                    "kernel": kname, "kernel_ms": round(trace_kernel_ms, 4), "bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": hbm["frac"],
                     "algorithmic_bytes": round(bytes_per_ray * W * H), "bytes_per_ray": hbm["bytes_per_ray"],
                     "bytes_per_ray_basis": hbm["bytes_per_ray_basis"], "measured_copy_GBs": hbm["measured_copy_GBs"],
@@ -532,6 +591,9 @@ def main():
             "build_ms": round(build_ms_max, 4), "trace_ms": round(trace_ms_max, 4),
             "build_reference_stages_ms": round(ref_build_ms, 4),
             "build_reference_stages_Mtri_s": round(n_tris / (ref_build_ms * 1e-3) / 1e6, 2),
+            "value_without_gather": round(W * H / (own_trace_ms_max * 1e-3) / 1e6, 2),
+            "trace_without_gather_ms": round(own_trace_ms_max, 4),
+            "frame_gather": frame_check,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "scaling_note": "strong scaling of ONE 1080p frame: `value` = rays of the whole frame / the slowest rank's trace part.  The "
                             "rebuild is replicated (every rank builds the whole BVH: north_star's 'BVH replicated, no collectives'), so "
@@ -548,7 +610,10 @@ def main():
                                    "camera (0,0,250) fov 60; full LBVH rebuild + frame trace per step",
                        "triangles": n_tris, "rays": W * H, "trace_mode": args.mode,
                        "sharding": f"rays in interleaved groups of 8 tiles over {world} GPU(s) (one launch per GPU), BVH replicated, "
-                                   "no collective",
+                                   "no collective in the traversal" + ("" if gather is None else
+                                   "; every step ends with the whole frame in rank 0's buffer: " +
+                                   ("shares traced straight into rank 0's memory (IPC-mapped, xGMI stores) + device-side completion flags"
+                                    if gather.mode == "peer" else "packed shares + one torch.distributed gather + lbvh_frame_unpack")),
                        "hit_fraction": round(hit_fraction, 4)},
             "roofline": roofline,
             "roofline_sort_scatter": sort_roofline,
@@ -568,6 +633,8 @@ def main():
     for e in events + [(ev_start,)]:
         for x in e:
             ctx.destroy_event(x)
+    if gather is not None:
+        gather.close()
     drawer.on_destroy()
     ctx.close()
     if dist is not None:

@@ -14,7 +14,7 @@ public static class LbvhNative
 {
     const string Lib = "lbvh";   // liblbvh.so on Linux
 
-    public const int ABI_VERSION = 9;             // LBVH_ABI_VERSION of the include/lbvh.h this file was written against
+    public const int ABI_VERSION = 10;             // LBVH_ABI_VERSION of the include/lbvh.h this file was written against
     public const int TRACE_REFERENCE = 0, TRACE_FAST = 1;
     public const uint BUILD_FAST_SCENE = 1, BUILD_RESET_NODES = 2;      // lbvh_build_scene flags
 
@@ -89,6 +89,24 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern int lbvh_trace_costs_import(IntPtr ctx, IntPtr dFrameCosts, uint tilesX, uint tilesY);
     [DllImport(Lib)] public static extern int lbvh_debug_ray_stack_split(IntPtr ctx, uint ldsEntries);
     [DllImport(Lib)] public static extern int lbvh_debug_ray_walker(IntPtr ctx, uint walker);
+    [DllImport(Lib)] public static extern int lbvh_debug_ray_stack_limit(IntPtr ctx, uint deepEntries);
+
+    // one frame from N GPUs (BASELINE configs[2]): peer-mapped frame buffer, ordering between contexts of this process
+    // (sync events) or between processes (IPC handle of the buffer + completion flags waited for on the device), and
+    // packed shares for transports that want one contiguous block per GPU
+    [DllImport(Lib)] public static extern int lbvh_peer_enable(IntPtr ctx, int peerDevice);
+    [DllImport(Lib)] public static extern int lbvh_sync_event_create(IntPtr ctx, out IntPtr ev);
+    [DllImport(Lib)] public static extern int lbvh_event_wait(IntPtr ctx, IntPtr ev);
+    [DllImport(Lib)] public static extern int lbvh_ipc_export(IntPtr ctx, IntPtr dPtr, [Out] byte[] handle64);
+    [DllImport(Lib)] public static extern int lbvh_ipc_import(IntPtr ctx, byte[] handle64, out IntPtr dPtr);
+    [DllImport(Lib)] public static extern int lbvh_ipc_close(IntPtr ctx, IntPtr dPtr);
+    [DllImport(Lib)] public static extern int lbvh_frame_signal(IntPtr ctx, IntPtr dFlags, uint slot, uint value);
+    [DllImport(Lib)] public static extern int lbvh_frame_wait(IntPtr ctx, IntPtr dFlags, uint nSlots, uint value);
+    [DllImport(Lib)] public static extern int lbvh_trace_primary_shard_packed(IntPtr ctx, ref Camera camera, uint shardIndex, uint shardCount,
+        ref Scene scene, int mode, IntPtr dPacked, IntPtr dStats);
+    [DllImport(Lib)] public static extern ulong lbvh_shard_records(int width, int height, uint shardIndex, uint shardCount);
+    [DllImport(Lib)] public static extern int lbvh_frame_unpack(IntPtr ctx, IntPtr dPacked, ulong shareStride, uint firstShard, uint nShards,
+        uint shardCount, int width, int height, IntPtr dFrameHits);
     // measurement helper: shader clock held under a vector-ALU-bound load, MHz
     [DllImport(Lib)] public static extern int lbvh_clock_probe(IntPtr ctx, out float shaderMhz);
     // a context whose work is ordered by a stream the caller owns (hipStream_t), e.g. an interop stream

@@ -23,10 +23,16 @@ public sealed class NativeBuffer : IDisposable
         Pointer = p;
     }
 
+    /// Bytes of a managed array handed to SetData / GetData: from the ARRAY's element type, never from this buffer's
+    /// stride — the drawer reads its RGBA16F image (stride 8) back into a ushort[4 W H] (ADVICE r3: `Length * stride`
+    /// priced that array at four times its size and threw on every frame).  The array may be smaller than the buffer
+    /// (a prefix transfer, as ComputeBuffer allows); it may not be larger, and it must hold whole elements.
     long Bytes(Array data)
     {
-        long bytes = (long)data.Length * stride;
+        Type element = data.GetType().GetElementType();
+        long bytes = element.IsPrimitive ? Buffer.ByteLength(data) : (long)data.Length * Marshal.SizeOf(element);
         if (bytes > (long)count * stride) throw new ArgumentException("NativeBuffer: array larger than the buffer");
+        if (bytes % stride != 0) throw new ArgumentException("NativeBuffer: array does not hold whole buffer elements");
         return bytes;
     }
 

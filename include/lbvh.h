@@ -18,7 +18,7 @@
  *   - all stage calls are asynchronous and ordered on the context's HIP stream;
  *     lbvh_buffer_download and lbvh_sync block (= ComputeBuffer.GetData, Sc/DataBuffer.cs:50-54).
  *   - a context is bound to one GPU and is not thread-safe; multi-GPU = one context per device
- *     (one process per GPU in bench.py).
+ *     (one process per GPU in bench.py; one process driving N contexts in host/lbvh_host.hpp MultiGpuDrawer).
  *   - buffer layouts are the reference's, bit for bit (Sh/Constants.cginc:9-54,
  *     Sc/SceneDataTypes.cs:4-89).
  */
@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LBVH_ABI_VERSION 9
+#define LBVH_ABI_VERSION 10
 
 /* ---- status codes ------------------------------------------------------------------------- */
 typedef int32_t lbvh_status;
@@ -347,6 +347,63 @@ lbvh_status lbvh_trace_primary_shard(lbvh_context* ctx, const lbvh_camera* h_cam
                                      uint32_t shard_count, const lbvh_scene* h_scene, int32_t mode,
                                      lbvh_hit* d_hits, lbvh_trace_stats* d_stats);
 
+/* ---- one frame from N GPUs (BASELINE configs[2]; SURVEY 8(e): "hit records gathered to GPU 0") ----------------------- *
+ * The reference renders ONE image per Update() (Sc/RaytracingMeshDrawer.cs:76-89).  With the rays sharded over N GPUs
+ * (lbvh_trace_primary_shard, BVH replicated) the frame is whole only once every share's records sit in one full-frame
+ * buffer on the GPU that shades / displays it.  Two ways to get them there, no collective on either:
+ *   peer-mapped stores   d_hits of lbvh_trace_primary_shard may be memory of ANOTHER GPU of the node (the frame buffer of
+ *                        GPU 0): after lbvh_peer_enable the trace kernel's stores travel over xGMI as the tiles finish — no
+ *                        second pass, the transfer overlaps the walk.  One process: the owner waits with lbvh_event_wait on
+ *                        the tracing contexts' events.  One process per GPU: the buffer crosses with lbvh_ipc_export /
+ *                        lbvh_ipc_import and completion with lbvh_frame_signal / lbvh_frame_wait (flag words in the
+ *                        owner's memory, written over xGMI, waited for on the device — no host round trip per frame);
+ *   packed shares        lbvh_trace_primary_shard_packed writes a share contiguously (work-item order, 64 records per
+ *                        8x8 tile) so that any transport can move it as one block (hipMemcpyPeerAsync, an RCCL
+ *                        send / recv); lbvh_frame_unpack on the owner puts every share's records at their pixels. */
+
+/* Kernels of this context may read and write memory that lives on `peer_device` (hipDeviceEnablePeerAccess; a no-op for
+ * the context's own device or when already enabled).  LBVH_ERR_HIP when the two GPUs cannot reach each other. */
+lbvh_status lbvh_peer_enable(lbvh_context* ctx, int32_t peer_device);
+
+/* An event for ORDERING work between contexts (lbvh_event_create's are for timing: they skip the system-scope release
+ * that makes a GPU's stores visible to another one).  Recorded with lbvh_event_record, destroyed with lbvh_event_destroy;
+ * lbvh_event_elapsed_ms does not take it. */
+lbvh_status lbvh_sync_event_create(lbvh_context* ctx, void** out_event);
+/* The context's stream waits (on the device, the host does not block) for `event` — an event of lbvh_sync_event_create
+ * recorded with lbvh_event_record on ANY context of this process, e.g. the end of another GPU's share of the frame. */
+lbvh_status lbvh_event_wait(lbvh_context* ctx, void* event);
+
+/* Cross-process handle of a buffer of lbvh_buffer_alloc (hipIpcGetMemHandle, 64 bytes, to be sent to the other process by
+ * any means) / the same memory mapped into this process and usable as a d_ pointer on this context (after
+ * lbvh_peer_enable when it lives on another GPU) / unmapped again.  The exporting process keeps ownership. */
+#define LBVH_IPC_HANDLE_BYTES 64
+lbvh_status lbvh_ipc_export(lbvh_context* ctx, void* d_ptr, uint8_t h_handle[LBVH_IPC_HANDLE_BYTES]);
+lbvh_status lbvh_ipc_import(lbvh_context* ctx, const uint8_t h_handle[LBVH_IPC_HANDLE_BYTES], void** out_d_ptr);
+lbvh_status lbvh_ipc_close(lbvh_context* ctx, void* d_ptr);
+
+/* d_flags[slot] := value once everything enqueued on this context so far has finished and its stores are visible system
+ * wide (a release store at system scope; d_flags may be another GPU's memory).  Values of one slot must grow (frame numbers). */
+lbvh_status lbvh_frame_signal(lbvh_context* ctx, uint32_t* d_flags, uint32_t slot, uint32_t value);
+/* Work enqueued on this context after the call starts only when d_flags[s] >= value (as signed distance: wrap-around safe)
+ * for every s < n_slots — e.g. every other rank has signalled this frame.  The wait runs on the device and is bounded: if a
+ * flag never arrives the next lbvh_sync / lbvh_buffer_download returns LBVH_ERR_HIP, the GPU does not hang.  n_slots <= 64. */
+lbvh_status lbvh_frame_wait(lbvh_context* ctx, const uint32_t* d_flags, uint32_t n_slots, uint32_t value);
+
+/* lbvh_trace_primary_shard with the share written CONTIGUOUSLY: record of lane l (pixel (l & 7, l >> 3) of the tile) of the
+ * share's k-th work item at d_packed[k * 64 + l]; work item k is tile ((k / 8) * shard_count + shard_index) * 8 + k % 8 of the
+ * full frame in row-major tile order.  lbvh_shard_records gives the number of records a share occupies (whole tiles: lanes
+ * outside the screen and tiles past the frame's last one are never written). */
+lbvh_status lbvh_trace_primary_shard_packed(lbvh_context* ctx, const lbvh_camera* h_camera, uint32_t shard_index,
+                                            uint32_t shard_count, const lbvh_scene* h_scene, int32_t mode,
+                                            lbvh_hit* d_packed, lbvh_trace_stats* d_stats);
+/* Records of shard `shard_index`'s packed share of a width x height frame (pure function; the same for every call site). */
+uint64_t lbvh_shard_records(int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count);
+/* Packed shares -> the full frame: share s (s in [first_shard, first_shard + n_shards)) starts at
+ * d_packed[(s - first_shard) * share_stride] (share_stride in records, >= lbvh_shard_records of any of them); its records
+ * go to d_frame_hits[y * width + x].  Pixels of other shards are not touched. */
+lbvh_status lbvh_frame_unpack(lbvh_context* ctx, const lbvh_hit* d_packed, uint64_t share_stride, uint32_t first_shard,
+                              uint32_t n_shards, uint32_t shard_count, int32_t width, int32_t height, lbvh_hit* d_frame_hits);
+
 /* ---- stage a-9, tail: shading -------------------------------------------------------------------- */
 
 /* Replaces the rest of kernel Raytracing's body (Sh/Raytracing/Raytracing.compute:178-184) for `count`
@@ -408,6 +465,12 @@ lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, 
  * lbvh_path_bounce spills to its device-memory slab.  Results do not depend on it; tests lower it so the deep part
  * of the stack is exercised by ordinary scenes. */
 lbvh_status lbvh_debug_ray_stack_split(lbvh_context* ctx, uint32_t lds_entries);
+
+/* Test hook: how many entries of the device-memory part of a ray's stack the walkers may use (0 = all of it: 48 for the
+ * binary walk, 112 for the four-wide one — more than any tree of this library can ask for).  A stack that runs out does not
+ * drop the entry silently: the launch sets the context's fault word and the next lbvh_sync / lbvh_buffer_download returns
+ * LBVH_ERR_HIP ("a per-ray traversal stack ran out of entries").  Tests lower the limit to see exactly that. */
+lbvh_status lbvh_debug_ray_stack_limit(lbvh_context* ctx, uint32_t deep_entries);
 
 /* Test hook: which walk lbvh_trace_rays / lbvh_path_bounce run — 1 (default): four-wide nodes (each binary node with its
  * largest children opened, made on first use after a rebuild; from bounce 1 on lbvh_path_bounce takes the kernel that keeps

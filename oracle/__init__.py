@@ -14,13 +14,16 @@ LIB_PATH = os.path.join(_HERE, "liblbvh_oracle.so")
 
 
 def build():
+    """gcc only (`make` = liblbvh_oracle.so): the CPU checker does not need the GPU toolchain; the rocPRIM cross-check of the
+    sort is `make gpu-checkers`, built by __graft_entry__.build()."""
     subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
 
 
 if not os.path.exists(LIB_PATH):
     build()
 
-_lib = C.CDLL(LIB_PATH)
+# LBVH_ORACLE_LIB: another build of the same oracle (the sanitizer job loads liblbvh_oracle_asan.so / _tsan.so)
+_lib = C.CDLL(os.environ.get("LBVH_ORACLE_LIB") or LIB_PATH)
 _P, _U32, _I32 = C.c_void_p, C.c_uint32, C.c_int32
 _F3 = C.POINTER(C.c_float)
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_functions():
         assert hasattr(N.lib, name), f"liblbvh.so does not export {name}"
     assert set(N.SIGNATURES) == set(declared_functions())
-    assert N.lib.lbvh_abi_version() == N.ABI_VERSION == 9
+    assert N.lib.lbvh_abi_version() == N.ABI_VERSION == 10
 
 
 def test_struct_layouts_match_the_reference():
@@ -143,7 +143,7 @@ def test_csharp_binding_declares_every_entry_point_with_the_headers_arity():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "lbvh.h")).read(), flags=re.S)
-    protos = re.findall(r"\b(?:lbvh_status|int32_t|uint32_t|const char\*)\s+(lbvh_\w+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S)
+    protos = re.findall(r"\b(?:lbvh_status|int32_t|uint32_t|uint64_t|const char\*)\s+(lbvh_\w+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S)
     c = {name: (0 if args.strip() in ("", "void") else len(args.split(","))) for name, args in protos}
     cs = re.sub(r"//.*", "", open(os.path.join(root, "bindings", "csharp", "LbvhNative.cs")).read())
     imports = re.findall(r"\[DllImport\(Lib\)\]\s*public static extern \w+\s+(lbvh_\w+)\s*\(([^;]*?)\)\s*;", cs, flags=re.S)

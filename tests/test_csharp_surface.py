@@ -93,3 +93,64 @@ def test_camera_struct_matches_the_c_layout():
     from unitysimpleraytracing_amd import _native as N
     import ctypes as C
     assert C.sizeof(N.Camera) == 4 * len(fields) == 80
+
+
+# ---- array bytes vs buffer bytes at every NativeBuffer.SetData / GetData call site ------------------------
+# NativeBuffer.Bytes() once priced a managed array at `Length * stride` — the BUFFER's element size — so the drawer's
+# `_image.GetData(ushort[4 W H])` on a stride-8 buffer asked for four times the buffer and threw on every frame.  No C#
+# compiler is here to run it; the check below evaluates, for sample frame sizes, what each call site hands over.
+CS_SIZEOF = {"ushort": 2, "short": 2, "uint": 4, "int": 4, "float": 4, "ulong": 8, "long": 8, "byte": 1, "Color32": 4,
+             "LbvhNative.Hit": 16, "T": 24}          # T: DataBuffer<T>'s element, any one size on both sides
+
+
+def _cs_eval(expr, env):
+    expr = re.sub(r"Marshal\.SizeOf\(typeof\(([\w\.]+)\)\)", lambda m: str(CS_SIZEOF[m.group(1)]), expr.strip())
+    expr = re.sub(r"\b([A-Za-z_][\w\.]*)\b", lambda m: str(env[m.group(1)]) if m.group(1) in env else m.group(1), expr)
+    assert re.fullmatch(r"[\d\s\*\+\-\(\)/]+", expr), expr
+    return int(eval(expr))
+
+
+def _transfer_sites(text, env):
+    """(buffer, array, array_bytes, buffer_bytes, stride) for every `buf.SetData(arr)` / `buf.GetData(arr)` whose operands
+    are allocated in the same file as `buf = new NativeBuffer(count, stride)` and `arr = new T[len]` / `T[] arr = ...`"""
+    text = re.sub(r"//[^\n]*", "", text)
+    buffers = {m.group(1): (m.group(2), m.group(3)) for m in
+               re.finditer(r"(\w+)\s*=\s*new NativeBuffer\(\s*([^,]+),\s*((?:[^()]|\([^()]*(?:\([^()]*\))?[^()]*\))+)\)\s*;", text)}
+    arrays = {m.group(1): (m.group(2), m.group(3)) for m in re.finditer(r"(\w+)\s*=\s*new\s+([\w\.]+)\[([^\]]+)\]\s*;", text)}
+    for m in re.finditer(r"([\w\.]+)\[\]\s+(\w+)\s*=\s*[^;]*GetPixels32\(\)\s*;", text):      # Color32[] px = tex.GetPixels32()
+        arrays[m.group(2)] = (m.group(1), "%s_Length" % m.group(2))
+    sites = []
+    for m in re.finditer(r"(\w+)\.(SetData|GetData)\((\w+)\)", text):
+        buf, arr = m.group(1), m.group(3)
+        if buf not in buffers or arr not in arrays:
+            continue
+        e = dict(env)
+        e[arr + ".Length"] = e.setdefault(arr + "_Length", 1000)
+        count, stride = (_cs_eval(x, e) for x in buffers[buf])
+        etype, length = arrays[arr]
+        sites.append((buf, arr, CS_SIZEOF[etype] * _cs_eval(length, e), count * stride, stride))
+    return sites
+
+
+def test_array_sizes_match_buffer_strides_at_every_transfer():
+    seen = 0
+    for f in sorted(os.listdir(CS)):
+        text = open(os.path.join(CS, f)).read()
+        for w, h in ((7, 5), (1920, 1080)):
+            env = {"width": w, "height": h, "_keys.count": 4096, "size": 3072}
+            for buf, arr, abytes, bbytes, stride in _transfer_sites(text, env):
+                seen += 1
+                assert abytes <= bbytes and abytes % stride == 0, (f, buf, arr, abytes, bbytes, stride)
+    assert seen >= 8        # the drawer's texture upload, the sorter's validation read-back, DataBuffer<T>'s two, x 2 sizes
+    # and the helper prices an array by ITS element type
+    nb = re.sub(r"//[^\n]*", "", open(os.path.join(CS, "NativeBuffer.cs")).read())
+    body = re.search(r"long Bytes\(Array data\)\s*\{(.*?)\n    \}", nb, flags=re.S).group(1)
+    assert "GetElementType()" in body and not re.search(r"data\.Length\s*\*\s*stride", body)
+
+
+def test_transfer_check_catches_the_round_three_bug():
+    """the same scan on the drawer as it was (ushort[4 W H] priced at the buffer's stride) must fail"""
+    src = "_image = new NativeBuffer(width * height, 8);\n_imageHost = new ushort[width * height * 4];\n_image.GetData(_imageHost);"
+    (buf, arr, abytes, bbytes, stride), = _transfer_sites(src, {"width": 7, "height": 5})
+    assert (abytes, bbytes, stride) == (7 * 5 * 4 * 2, 7 * 5 * 8, 8)                 # what the fixed helper computes
+    assert 7 * 5 * 4 * stride > bbytes                                             # what `Length * stride` asked for

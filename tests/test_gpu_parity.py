@@ -847,6 +847,13 @@ def test_tile_costs_exported_and_imported_between_shards(ctx):
         assert (ref > 0).all() and np.median(np.abs(ref[tile_own0].astype(np.int64) - merged[tile_own0].astype(np.int64))) == 0
         assert N().lib.lbvh_trace_costs_export(ctx.handle, frame.device, tx + 1, ty) == -1          # not the traced frame's layout
         assert N().lib.lbvh_trace_costs_import(ctx.handle, None, tx, ty) == -1
+        # a sub-rectangle with the SAME tile counts but another origin is not a frame to export (its costs would
+        # land shifted by a tile)
+        big = N().Camera.from_dict(scenes.camera(w + 8, h + 8, (0.0, 0.0, 140.0)))
+        N().check(ctx.handle, N().lib.lbvh_trace_primary(ctx.handle, C.byref(big), 8, 8, w + 8, h + 8, C.byref(s0), L.TRACE_FAST, hits.device, None))
+        assert N().lib.lbvh_trace_costs_export(ctx.handle, frame.device, tx, ty) == -1
+        assert b"(0, 0)" in N().lib.lbvh_last_error(ctx.handle)
+        ctx.sync()
         for d in drawers:
             d.on_destroy()
     finally:

@@ -1,0 +1,231 @@
+"""One frame from N GPUs (BASELINE configs[2]), on the one GPU a test box has: N logical ranks —
+contexts of one process, or processes — share cuda:0.  What is checked is everything except the xGMI wire: the share
+layouts, the peer-mapped frame buffer, the completion protocols (sync events inside a process; IPC-mapped flags waited
+for on the device between processes), the packed transport and its unpack kernel, and bench.py's N-rank step ending in
+ONE frame that equals the one-GPU frame word for word."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as O
+from unitysimpleraytracing_amd import layouts as L
+from unitysimpleraytracing_amd import scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+POISON = 0x7FC00000
+
+
+def _yawed(cam, deg):
+    from bench import yawed
+    return yawed(cam, deg)
+
+
+@pytest.mark.parametrize("ranks", [1, 2, 3, 8])
+def test_one_process_n_contexts_assemble_the_frame_on_the_owner(ranks):
+    """host.MultiGpuDrawer (twin of lbvh_host.hpp's): every context traces its share straight into the owner's frame
+    buffer, the owner's stream waits for the others' events on the device.  Frames: two from one camera (the second is
+    dispatched by the first one's costs), a turned camera, a rebuilt scene — both modes — each into a poisoned buffer and
+    equal, word for word, to the frame one context traces alone; t equal to the oracle's."""
+    from unitysimpleraytracing_amd import host as Hh
+    tris = scenes.tiled_torus(nu=24, nv=16, grid=2)
+    W, Ht = 250, 131
+    multi = Hh.MultiGpuDrawer([0] * ranks, tris).awake()
+    one_ctx = Hh.Context(0)
+    single = Hh.RaytracingMeshDrawer(one_ctx, tris).awake()
+    b = O.Built(tris, capacity=single.container.capacity, threads=8)
+    cam0 = scenes.camera(W, Ht, (0.0, 0.0, 120.0))
+    for mode in (L.TRACE_FAST, L.TRACE_REFERENCE):
+        for f in range(4):
+            cam = cam0 if f < 2 else _yawed(cam0, 3.0 * f)
+            if f == 3:
+                multi.rebuild()
+                single.rebuild()
+            if multi.frame is not None:
+                multi.frame.fill_u32(POISON, mirror=False)
+            multi.update(cam, mode=mode)
+            got = multi.hits()                     # on the owner's stream: behind the device-side gather
+            single.update(cam, mode=mode)
+            want = single.hits()
+            assert (got.view(np.uint32) == want.view(np.uint32)).all(), (ranks, mode, f)
+            if f in (0, 2):
+                oh, _ = O.trace_primary(b, cam, threads=8)
+                assert (got["t"].view(np.uint32) == oh["t"].view(np.uint32)).all()
+    multi.on_destroy()
+    single.on_destroy()
+    one_ctx.close()
+
+
+@pytest.mark.parametrize("shards", [1, 2, 3, 8])
+@pytest.mark.parametrize("size", [(250, 131), (64, 8), (13, 5)])
+def test_packed_shares_and_unpack(ctx, shards, size):
+    """lbvh_trace_primary_shard_packed writes a share as frame_gather.pack_share lays it out (lanes outside the screen and
+    slots past the last tile untouched); lbvh_frame_unpack of all shares — in one call, and share by share — is the frame."""
+    from unitysimpleraytracing_amd import _native as N
+    from unitysimpleraytracing_amd import frame_gather as G
+    from unitysimpleraytracing_amd import host as Hh
+    W, Ht = size
+    tris = scenes.random_triangles(4096, seed=1)
+    d = Hh.RaytracingMeshDrawer(ctx, tris).awake()
+    cam = scenes.camera(W, Ht, (0.0, 0.0, 300.0))
+    ccam = N.Camera.from_dict(cam)
+    s = d.container.scene()
+    for mode in (L.TRACE_FAST, L.TRACE_REFERENCE):
+        d.update(cam, mode=mode)
+        full = d.hits()
+        stride = int(N.lib.lbvh_shard_records(W, Ht, 0, shards))
+        packed = Hh.DataBuffer(ctx, stride * shards, L.HIT)
+        for frame in range(2):                     # the second pass runs on the shares' dispatch history
+            packed.fill_u32(POISON, mirror=False)
+            for r in range(shards):
+                at = C.c_void_p(packed.device.value + r * stride * 16)
+                N.check(ctx.handle, N.lib.lbvh_trace_primary_shard_packed(ctx.handle, C.byref(ccam), r, shards, C.byref(s), mode, at, None))
+            got = packed.get_data().copy()
+            for r in range(shards):
+                want = G.pack_share(full, r, shards)
+                mine = got[r * stride: r * stride + len(want)]
+                marked = np.zeros((Ht, W), dtype=np.uint32) + 1
+                valid = G.pack_share(marked, r, shards) == 1            # lanes that are pixels of the frame
+                assert (mine[valid].view(np.uint32) == want[valid].view(np.uint32)).all()
+                assert (mine[~valid].view(np.uint32) == POISON).all()   # never written
+        frame_buf = Hh.DataBuffer(ctx, W * Ht, L.HIT)
+        frame_buf.fill_u32(POISON, mirror=False)
+        N.check(ctx.handle, N.lib.lbvh_frame_unpack(ctx.handle, packed.device, stride, 0, shards, shards, W, Ht, frame_buf.device))
+        assert (frame_buf.get_data().reshape(Ht, W).view(np.uint32) == full.view(np.uint32)).all()
+        frame_buf.fill_u32(POISON, mirror=False)
+        for r in range(shards):                    # one share at a time (a transport that delivers them separately)
+            at = C.c_void_p(packed.device.value + r * stride * 16)
+            N.check(ctx.handle, N.lib.lbvh_frame_unpack(ctx.handle, at, stride, r, 1, shards, W, Ht, frame_buf.device))
+        assert (frame_buf.get_data().reshape(Ht, W).view(np.uint32) == full.view(np.uint32)).all()
+        frame_buf.dispose()
+        packed.dispose()
+    # argument errors
+    with pytest.raises(N.LbvhError):
+        N.check(ctx.handle, N.lib.lbvh_frame_unpack(ctx.handle, d._hits.device, 1, 0, shards, shards, W, Ht, d._hits.device))   # stride too small
+    with pytest.raises(N.LbvhError):
+        N.check(ctx.handle, N.lib.lbvh_frame_unpack(ctx.handle, d._hits.device, 1 << 20, 1, shards, shards, W, Ht, d._hits.device))  # past the last shard
+    d.on_destroy()
+
+
+_CHILD = r"""
+import ctypes as C, sys, os
+sys.path.insert(0, sys.argv[1])
+from unitysimpleraytracing_amd import _native as N
+from unitysimpleraytracing_amd.host import Context
+h_frame, h_flags = bytes.fromhex(sys.argv[2]), bytes.fromhex(sys.argv[3])
+slot, frames = int(sys.argv[4]), int(sys.argv[5])
+with Context(0) as ctx:
+    ctx.peer_enable(0)
+    frame = ctx.ipc_import(h_frame)
+    flags = ctx.ipc_import(h_flags)
+    for f in range(1, frames + 1):
+        # this "rank" owns words [slot * 4096, (slot + 1) * 4096) of the frame buffer
+        at = C.c_void_p(frame.value + slot * 4096 * 4)
+        N.check(ctx.handle, N.lib.lbvh_buffer_fill_u32(ctx.handle, at, (slot << 16) + f, 4096))
+        ctx.frame_signal(flags, slot, f)
+    ctx.sync()
+    ctx.ipc_close(frame)
+    ctx.ipc_close(flags)
+print("child ok")
+"""
+
+
+def test_ipc_mapped_frame_buffer_and_device_side_flags_between_processes(ctx):
+    """The one-process-per-GPU transport (frame_gather 'peer'): the owner exports its frame buffer and flag words, two other
+    PROCESSES map them, store into them and signal frame numbers; the owner's lbvh_frame_wait (on the device) lets its
+    download through only when both have signalled the last frame — which then holds both processes' last patterns."""
+    from unitysimpleraytracing_amd import host as Hh
+    frames = 5
+    frame = Hh.DataBuffer(ctx, 2 * 4096, np.uint32, 0)
+    flags = Hh.DataBuffer(ctx, 64, np.uint32, 0)
+    ctx.sync()
+    hf, hg = ctx.ipc_export(frame.device).hex(), ctx.ipc_export(flags.device).hex()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, "-c", _CHILD, ROOT, hf, hg, str(slot), str(frames)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for slot in range(2)]
+    ctx.frame_wait(flags.device, 2, frames)        # enqueued at once: the children have not even started
+    got = frame.get_data().copy()                  # behind the wait on the stream
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0 and "child ok" in out, err[-2000:]
+    for slot in range(2):
+        assert (got[slot * 4096:(slot + 1) * 4096] == (slot << 16) + frames).all()
+    assert (flags.get_data()[:2] == frames).all()
+    # a flag that is already there: the wait returns at once; wrap-around-safe comparison
+    ctx.frame_wait(flags.device, 2, frames - 2)
+    ctx.sync()
+    frame.dispose()
+    flags.dispose()
+
+
+def test_cpp_multi_gpu_drawer():
+    """host/lbvh_host.hpp MultiGpuDrawer through the compiled driver: 3 logical ranks, 8 frames (two modes x static, static,
+    turned, rebuilt) assembled in the owner's poisoned buffer == the frames one context traces alone."""
+    exe = os.path.join(ROOT, "unitysimpleraytracing_amd", "host", "lbvh_driver")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    for ranks in (1, 3, 8):
+        r = subprocess.run([exe, "multi", str(ranks), "4096", "250", "131"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-500:]
+        res = json.loads(r.stdout)
+        assert res["frames"] == 8 and res["frames_equal"] == 8 and res["ranks"] == ranks and res["hits"] > 0
+
+
+@pytest.mark.parametrize("transport", ["peer", "packed"])
+def test_bench_two_ranks_end_every_step_with_one_whole_frame(transport):
+    """bench.py's N-rank step on one GPU (two processes sharing cuda:0, gloo in place of RCCL): the timed step carries every
+    rank's records into rank 0's frame; the line says which transport ran and that the assembled cfg2 frame (1 M triangles,
+    1080p) equals the one-GPU frame word for word and the reference mode's t bit for bit."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device", "0", "--steps", "3",
+                        "--warmup", "1", "--gather", transport, "--no-sort-bench", "--no-cpu-baseline", "--no-dynamic", "--no-live-counters"],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    fg = line["frame_gather"]
+    assert line["n_gpus"] == 2 and fg["transport"] == transport
+    assert fg["assembled_equals_one_gpu_frame_word_for_word"] is True and fg["t_equals_reference_mode_bit_for_bit"] is True
+    assert fg["pixels_where_the_triangle_differs_from_reference_mode"] < 64
+    assert line["value"] > 0 and line["value_without_gather"] >= line["value"] * 0.999
+
+
+def test_ray_stack_that_runs_out_is_reported_not_dropped(ctx):
+    """the per-ray walkers used to drop a stack entry silently when their stack was full.  No tree of this
+    library can fill it (<= 32 levels), so the test hook shrinks it: one entry in LDS, one in device memory -> the launch
+    sets the fault word, the next sync says so ONCE, and the same rays trace correctly again with the default stack."""
+    from unitysimpleraytracing_amd import _native as N
+    from unitysimpleraytracing_amd import host as Hh
+    tris = scenes.tiled_torus(nu=24, nv=16, grid=2)
+    d = Hh.RaytracingMeshDrawer(ctx, tris).awake()
+    W, Ht = 96, 64
+    cam = N.Camera.from_dict(scenes.camera(W, Ht, (0.0, 0.0, 120.0)))
+    states = Hh.DataBuffer(ctx, W * Ht, L.PATH_STATE)
+    hits = Hh.DataBuffer(ctx, W * Ht, L.HIT)
+    s = d.container.scene()
+    N.check(ctx.handle, N.lib.lbvh_path_begin(ctx.handle, C.byref(cam), states.device))
+    N.check(ctx.handle, N.lib.lbvh_trace_rays(ctx.handle, states.device, W * Ht, 0.0, C.byref(s), hits.device))
+    good = hits.get_data().copy()
+    assert (good["t"] < L.MAX_FLOAT).sum() > 100
+    try:
+        for walker in (1, 0):                      # the four-wide walk and the binary one
+            N.check(ctx.handle, N.lib.lbvh_debug_ray_walker(ctx.handle, walker))
+            N.check(ctx.handle, N.lib.lbvh_debug_ray_stack_split(ctx.handle, 1))
+            N.check(ctx.handle, N.lib.lbvh_debug_ray_stack_limit(ctx.handle, 1))
+            N.check(ctx.handle, N.lib.lbvh_trace_rays(ctx.handle, states.device, W * Ht, 0.0, C.byref(s), hits.device))
+            with pytest.raises(N.LbvhError, match="stack ran out"):
+                ctx.sync()
+            ctx.sync()                             # reported once
+            N.check(ctx.handle, N.lib.lbvh_debug_ray_stack_limit(ctx.handle, 0))
+            N.check(ctx.handle, N.lib.lbvh_trace_rays(ctx.handle, states.device, W * Ht, 0.0, C.byref(s), hits.device))
+            assert (hits.get_data().view(np.uint32) == good.view(np.uint32)).all()      # deep part of the stack in use, all entries kept
+    finally:
+        N.check(ctx.handle, N.lib.lbvh_debug_ray_stack_limit(ctx.handle, 0))
+        N.check(ctx.handle, N.lib.lbvh_debug_ray_stack_split(ctx.handle, 16))
+        N.check(ctx.handle, N.lib.lbvh_debug_ray_walker(ctx.handle, 1))
+    states.dispose(); hits.dispose()
+    d.on_destroy()

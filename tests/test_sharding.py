@@ -76,6 +76,85 @@ def test_two_ranks_over_gloo(tmp_path):
     assert open(out).read() == "ok"
 
 
+# ---- the gather: every rank's records into ONE frame on rank 0 -----------------------------------
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("size", [(8, 8), (250, 131), (1920, 1080), (1921, 1083)])
+def test_packed_share_layout_mirrors_the_library(world, size):
+    """frame_gather's numpy mirror of the packed layout agrees with the library's pure size function, shares partition the
+    frame's tiles, and pack -> unpack is the identity on every pixel (odd sizes: partial tiles at the right / bottom edge)."""
+    from unitysimpleraytracing_amd import _native as N
+    from unitysimpleraytracing_amd import frame_gather as G
+    width, height = size
+    n_tiles = ((width + 7) // 8) * ((height + 7) // 8)
+    seen = []
+    for r in range(world):
+        items = G.share_items(r, world, width, height)
+        assert len(items) * 64 == G.shard_records(width, height, r, world) == N.lib.lbvh_shard_records(width, height, r, world)
+        seen += [int(t) for t in items if t >= 0]
+    assert sorted(seen) == list(range(n_tiles))
+    assert N.lib.lbvh_shard_records(width, height, world, world) == 0 and N.lib.lbvh_shard_records(0, height, 0, world) == 0
+    if width * height <= 300 * 200:
+        rng = np.random.default_rng(5)
+        frame = rng.integers(1, 1 << 30, size=(height, width)).astype(np.uint32)
+        shares = [G.pack_share(frame, r, world) for r in range(world)]
+        assert (G.unpack_shares(shares, world, width, height) == frame).all()
+
+
+def _gather_worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+
+    import oracle as O
+    from unitysimpleraytracing_amd import frame_gather as G
+    from unitysimpleraytracing_amd import layouts as L
+    from unitysimpleraytracing_amd import scenes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H = 101, 77                                         # partial tiles on both edges, a ragged last group
+    tris = scenes.random_triangles(2000, seed=9)
+    b = O.Built(tris, capacity=2048)
+    cam = scenes.camera(W, H, (0.0, 0.0, 300.0))
+    mine = np.zeros((H, W), dtype=L.HIT)
+    mine.view(np.uint32)[:] = 0x7FC00000                   # what this rank does not own is poison
+    for x0, y0, x1, y1 in shard_tiles(rank, world, W, H):
+        hits, _ = O.trace_primary(b, cam, rect=(x0, y0, x1, y1))
+        mine[y0:y1, x0:x1] = hits
+    packed = G.pack_share(mine, rank, world)
+    stride = G.shard_records(W, H, 0, world)               # the largest share: equal blocks for the collective
+    block = np.zeros(stride, dtype=L.HIT)
+    block[:len(packed)] = packed
+    t = torch.from_numpy(block.view(np.uint32).reshape(-1).copy().view(np.int32))
+    parts = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, parts, dst=0)                           # what bench.py's packed transport does over RCCL
+    if rank == 0:
+        shares = [p.numpy().view(np.uint32).view(L.HIT) for p in parts]
+        frame = np.zeros((H, W), dtype=L.HIT)
+        frame.view(np.uint32)[:] = 0x7FC00000
+        G.unpack_shares(shares, world, W, H, frame=frame)
+        full, _ = O.trace_primary(b, cam)
+        ok = bool((frame.view(np.uint32) == full.view(np.uint32)).all())
+        with open(out_path, "w") as f:
+            f.write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_gather_one_whole_frame_over_gloo(tmp_path, world):
+    """The N > 1 step ends with ONE frame on rank 0: every rank's share, packed, through one gather, unpacked at its
+    pixels == the frame traced whole, every word of every record (oracle as the tracer; the same layout functions the
+    GPU kernels are tested against in test_gpu_parity.py)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "gather.txt")
+    mp.spawn(_gather_worker, args=(world, port, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
+
+
 def test_bench_starts_its_own_ranks_for_gpus_n():
     """`python bench.py --gpus N` from a plain launch starts N ranks itself (children with torchrun's
     environment, created before the parent touches HIP) and ends with their worst return code.  No GPU here: every rank

@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LBVH_LIB: an alternative build of the same library (tools/build_variant.sh: A/B measurements of kernel variants)
 LIB_PATH = os.environ.get("LBVH_LIB") or os.path.join(_HERE, "liblbvh.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -97,6 +97,18 @@ SIGNATURES = {
     "lbvh_trace_forget": (_I32, [_P]),
     "lbvh_debug_ray_stack_split": (_I32, [_P, _U32]),
     "lbvh_debug_ray_walker": (_I32, [_P, _U32]),
+    "lbvh_debug_ray_stack_limit": (_I32, [_P, _U32]),
+    "lbvh_peer_enable": (_I32, [_P, _I32]),
+    "lbvh_sync_event_create": (_I32, [_P, C.POINTER(_P)]),
+    "lbvh_event_wait": (_I32, [_P, _P]),
+    "lbvh_ipc_export": (_I32, [_P, _P, C.POINTER(C.c_uint8)]),
+    "lbvh_ipc_import": (_I32, [_P, C.POINTER(C.c_uint8), C.POINTER(_P)]),
+    "lbvh_ipc_close": (_I32, [_P, _P]),
+    "lbvh_frame_signal": (_I32, [_P, _P, _U32, _U32]),
+    "lbvh_frame_wait": (_I32, [_P, _P, _U32, _U32]),
+    "lbvh_trace_primary_shard_packed": (_I32, [_P, C.POINTER(Camera), _U32, _U32, C.POINTER(Scene), _I32, _P, _P]),
+    "lbvh_shard_records": (C.c_uint64, [_I32, _I32, _U32, _U32]),
+    "lbvh_frame_unpack": (_I32, [_P, _P, C.c_uint64, _U32, _U32, _U32, _I32, _I32, _P]),
     "lbvh_clock_probe": (_I32, [_P, C.POINTER(C.c_float)]),
     "lbvh_trace_tile_costs": (_I32, [_P, C.POINTER(Camera), C.POINTER(Scene), _P, _P, _P]),
     "lbvh_shade": (_I32, [_P, _P, _SZ, _P, _P, _I32, _I32, _P]),

@@ -90,7 +90,10 @@ int lbvh_check_fault(lbvh_context* ctx)
     const uint32_t code = __atomic_exchange_n(ctx->fault_host, 0u, __ATOMIC_RELAXED);
     if (code == 0) return LBVH_OK;
     char msg[128];
-    snprintf(msg, sizeof msg, "a bounded inter-workgroup wait gave up (fault %u): results enqueued before this call are invalid", code);
+    snprintf(msg, sizeof msg, "%s (fault %u): results enqueued before this call are invalid",
+             code == LBVH_FAULT_RAY_STACK    ? "a per-ray traversal stack ran out of entries"
+             : code == LBVH_FAULT_FRAME_WAIT ? "lbvh_frame_wait: a rank's completion flag never arrived"
+                                             : "a bounded inter-workgroup wait gave up", code);
     return lbvh_set_error(ctx, LBVH_ERR_HIP, "device-side protocol fault", msg);
 }
 
@@ -327,6 +330,126 @@ lbvh_status lbvh_event_elapsed_ms(lbvh_context* ctx, void* start, void* stop, fl
     LBVH_REQUIRE(ctx, start != nullptr && stop != nullptr && out_ms != nullptr);
     LBVH_HIP_TRY(ctx, hipEventSynchronize((hipEvent_t)stop));
     LBVH_HIP_TRY(ctx, hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return LBVH_OK;
+}
+
+// ---- one frame from N GPUs: peer access, cross-context / cross-process completion ----------------------------------------
+
+lbvh_status lbvh_peer_enable(lbvh_context* ctx, int32_t peer_device)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    int n = 0;
+    LBVH_HIP_TRY(ctx, hipGetDeviceCount(&n));
+    LBVH_REQUIRE(ctx, peer_device >= 0 && peer_device < n);
+    if (peer_device == ctx->device) return LBVH_OK;
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int can = 0;
+    LBVH_HIP_TRY(ctx, hipDeviceCanAccessPeer(&can, ctx->device, peer_device));
+    if (!can) return lbvh_set_error(ctx, LBVH_ERR_HIP, "lbvh_peer_enable", "the two GPUs cannot access each other's memory");
+    const hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
+    if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return LBVH_OK; }
+    LBVH_HIP_TRY(ctx, e);
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_sync_event_create(lbvh_context* ctx, void** out_event)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, out_event != nullptr);
+    // an ORDERING event: its record is a system-scope release (what the timing events of lbvh_event_create leave out), so
+    // whoever waits for it — another GPU's stream included — sees every store enqueued before it
+    hipEvent_t ev;
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    *out_event = (void*)ev;
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_event_wait(lbvh_context* ctx, void* event)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, event != nullptr);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LBVH_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)event, 0));
+    return LBVH_OK;
+}
+
+static_assert(sizeof(hipIpcMemHandle_t) == LBVH_IPC_HANDLE_BYTES, "lbvh.h promises 64-byte IPC handles");
+
+lbvh_status lbvh_ipc_export(lbvh_context* ctx, void* d_ptr, uint8_t h_handle[LBVH_IPC_HANDLE_BYTES])
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, d_ptr != nullptr && h_handle != nullptr);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipIpcMemHandle_t h;
+    LBVH_HIP_TRY(ctx, hipIpcGetMemHandle(&h, d_ptr));
+    memcpy(h_handle, &h, sizeof h);
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_ipc_import(lbvh_context* ctx, const uint8_t h_handle[LBVH_IPC_HANDLE_BYTES], void** out_d_ptr)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, h_handle != nullptr && out_d_ptr != nullptr);
+    *out_d_ptr = nullptr;
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, h_handle, sizeof h);
+    LBVH_HIP_TRY(ctx, hipIpcOpenMemHandle(out_d_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_ipc_close(lbvh_context* ctx, void* d_ptr)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    if (!d_ptr) return LBVH_OK;
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    LBVH_HIP_TRY(ctx, hipIpcCloseMemHandle(d_ptr));
+    return LBVH_OK;
+}
+
+// Completion flags between GPUs that share no process (bench.py: one rank per GPU).  The signalling kernel runs after the
+// stream's earlier kernels have ended (their stores have left this GPU's caches: the end-of-kernel release) and publishes
+// with a system-scope release store; flag and data take the same xGMI path to the owner's memory.  The waiting kernel polls
+// with system-scope acquire loads — its own HBM, written by the peers — and ends when every flag has reached the frame
+// number; what the stream runs after it starts with the usual kernel-start invalidate and reads the peers' records.
+__global__ void frame_signal_kernel(uint32_t* flag, uint32_t value)
+{
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(64) void frame_wait_kernel(const uint32_t* flags, uint32_t n_slots, uint32_t value, uint32_t* fault)
+{
+    const uint32_t lane = threadIdx.x;
+    bool here = lane >= n_slots;
+    for (uint32_t spin = 0; spin < LBVH_SPIN_LIMIT; spin++) {
+        if (!here) here = (int32_t)(__hip_atomic_load(flags + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) >= 0;
+        if (__builtin_amdgcn_ballot_w64(!here) == 0) return;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    if (lane == 0) __hip_atomic_store(fault, LBVH_FAULT_FRAME_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+lbvh_status lbvh_frame_signal(lbvh_context* ctx, uint32_t* d_flags, uint32_t slot, uint32_t value)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, d_flags != nullptr && ((uintptr_t)d_flags & 3) == 0);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LBVH_LAUNCH(ctx, frame_signal_kernel, dim3(1), dim3(1), d_flags + slot, value);
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_frame_wait(lbvh_context* ctx, const uint32_t* d_flags, uint32_t n_slots, uint32_t value)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, n_slots <= 64u);
+    if (n_slots == 0) return LBVH_OK;
+    LBVH_REQUIRE(ctx, d_flags != nullptr && ((uintptr_t)d_flags & 3) == 0);
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LBVH_LAUNCH(ctx, frame_wait_kernel, dim3(1), dim3(64), d_flags, n_slots, value, ctx->fault_dev);
+    LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }
 

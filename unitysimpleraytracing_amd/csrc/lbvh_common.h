@@ -21,6 +21,10 @@ static_assert(sizeof(lbvh_hit) == 16, "hit record must be 16 bytes");
 
 // device-side fault codes (ctx->fault_host): a bounded spin of an inter-workgroup protocol gave up
 #define LBVH_FAULT_SORT_LOOKBACK 1u
+// a per-ray traversal stack ran out of entries (lbvh_trace_rays / lbvh_path_bounce): hits of that launch are invalid
+#define LBVH_FAULT_RAY_STACK 2u
+// lbvh_frame_wait gave up: another rank's completion flag for this frame never arrived
+#define LBVH_FAULT_FRAME_WAIT 3u
 // polls before a spin gives up: each poll is a round trip to the coherence point (>= 0.5 us), so this is seconds —
 // orders of magnitude beyond any legitimate wait (a predecessor tile's run time), and never a hung GPU
 #define LBVH_SPIN_LIMIT (1u << 22)
@@ -109,6 +113,7 @@ struct lbvh_context {
     uint64_t trace_layout = 0;      // frame layout (tiles, shard, origin) the history belongs to
     uint32_t trace_layout_work = 0;
     uint32_t trace_shard_index = 0, trace_shard_count = 1, trace_tiles_x = 0, trace_tiles_y = 0;   // of that trace
+    int32_t trace_origin_x = 0, trace_origin_y = 0;                                                // ... and its rectangle's origin
     bool trace_history = false;
     float fast_centre[3] = {0.0f, 0.0f, 0.0f};   // centre of the scene box the derived scene was built with
     uint32_t trace_counts_turn = 0;  // which of the two class-counter sets the next filing counts into
@@ -126,6 +131,7 @@ struct lbvh_context {
     // lbvh_trace_rays: live-ray list
     void* ray_scratch = nullptr;
     uint32_t ray_stack_lds = 16;              // lbvh_debug_ray_stack_split
+    uint32_t ray_stack_deep = 0xFFFFFFFFu;    // lbvh_debug_ray_stack_limit: entries of the device-memory part the walkers may use
     size_t ray_scratch_bytes = 0;
     // the derived scene as four-wide nodes for the per-ray walk: made by the first lbvh_trace_rays / bounce after a rebuild
     void* wide_nodes = nullptr;

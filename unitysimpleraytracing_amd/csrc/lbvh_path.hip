@@ -108,7 +108,9 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* _
                                                         const lbvh_fast_node* __restrict__ nodes,
                                                         const lbvh_fast_tri* __restrict__ tris, lbvh_hit* __restrict__ hits,
                                                         uint32_t* __restrict__ deep,     // [gridDim.x][kRayStackDeep][64]
-                                                        uint32_t lds_depth)              // <= kRayStackLds
+                                                        uint32_t lds_depth,              // <= kRayStackLds
+                                                        uint32_t deep_cap,               // <= kRayStackDeep (lbvh_debug_ray_stack_limit lowers it)
+                                                        uint32_t* __restrict__ fault)    // mapped host word: a stack that ran out says so here
 {
     __shared__ uint32_t s_stack[kRayStackLds][LBVH_WAVE];
     uint32_t* my_deep = deep + (size_t)blockIdx.x * (kRayStackDeep * LBVH_WAVE) + threadIdx.x;
@@ -174,7 +176,8 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* _
                 node = l_near ? lref : rref;
                 const uint32_t far = l_near ? rref : lref;
                 if (sp < lds_depth) { s_stack[sp][lane] = far; sp++; }
-                else if (sp < lds_depth + (uint32_t)kRayStackDeep) { my_deep[(sp - lds_depth) * LBVH_WAVE] = far; sp++; }
+                else if (sp < lds_depth + deep_cap) { my_deep[(sp - lds_depth) * LBVH_WAVE] = far; sp++; }
+                else __hip_atomic_store(fault, LBVH_FAULT_RAY_STACK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // never on this library's trees (see kWideStackDeep)
             } else if (go_l) {
                 node = lref;
             } else if (go_r) {
@@ -288,7 +291,9 @@ __global__ __launch_bounds__(64) void trace_rays_wide_kernel(const lbvh_path_sta
                                                              const lbvh_wide_node* __restrict__ wide,
                                                              const lbvh_fast_node* __restrict__ lines, lbvh_hit* __restrict__ hits,
                                                              uint32_t* __restrict__ deep,     // [gridDim.x][kWideStackDeep][64]
-                                                             uint32_t lds_depth)              // <= kWideStackLds
+                                                             uint32_t lds_depth,              // <= kWideStackLds
+                                                             uint32_t deep_cap,               // <= kWideStackDeep
+                                                             uint32_t* __restrict__ fault)
 {
     __shared__ uint32_t s_stack[kWideStackLds][LBVH_WAVE];
     uint32_t* my_deep = deep + (size_t)blockIdx.x * (kWideStackDeep * LBVH_WAVE) + threadIdx.x;
@@ -306,7 +311,10 @@ __global__ __launch_bounds__(64) void trace_rays_wide_kernel(const lbvh_path_sta
     uint32_t best_tri = 0, sp = 0, node = 0;
     auto push = [&](uint32_t ref) {
         if (sp < lds_depth) { s_stack[sp][lane] = ref; sp++; }
-        else if (sp < lds_depth + (uint32_t)kWideStackDeep) { my_deep[(sp - lds_depth) * LBVH_WAVE] = ref; sp++; }
+        else if (sp < lds_depth + deep_cap) { my_deep[(sp - lds_depth) * LBVH_WAVE] = ref; sp++; }
+        // a dropped entry would be a silently wrong hit: report it.  Cannot happen on this library's trees (a radix
+        // tree over unique 32-bit keys is <= 32 levels deep, 3 waiting siblings per level); lbvh_debug_ray_stack_limit provokes it
+        else __hip_atomic_store(fault, LBVH_FAULT_RAY_STACK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
     for (;;) {
         const uint64_t idle = __ballot(!active);
@@ -396,7 +404,9 @@ __global__ __launch_bounds__(64) void trace_rays_wide_chain_kernel(const lbvh_pa
                                                              const lbvh_wide_node* __restrict__ wide,
                                                              const lbvh_fast_node* __restrict__ lines, lbvh_hit* __restrict__ hits,
                                                              uint32_t* __restrict__ deep,     // [gridDim.x][kWideStackDeep][64]
-                                                             uint32_t lds_depth)              // <= kWideStackLds
+                                                             uint32_t lds_depth,              // <= kWideStackLds
+                                                             uint32_t deep_cap,               // <= kWideStackDeep
+                                                             uint32_t* __restrict__ fault)
 {
     __shared__ uint32_t s_stack[kWideStackLds][LBVH_WAVE];
     uint32_t* my_deep = deep + (size_t)blockIdx.x * (kWideStackDeep * LBVH_WAVE) + threadIdx.x;
@@ -416,7 +426,10 @@ __global__ __launch_bounds__(64) void trace_rays_wide_chain_kernel(const lbvh_pa
     uint4 ref = {};
     auto push = [&](uint32_t r) {
         if (sp < lds_depth) { s_stack[sp][lane] = r; sp++; }
-        else if (sp < lds_depth + (uint32_t)kWideStackDeep) { my_deep[(sp - lds_depth) * LBVH_WAVE] = r; sp++; }
+        else if (sp < lds_depth + deep_cap) { my_deep[(sp - lds_depth) * LBVH_WAVE] = r; sp++; }
+        // a dropped entry would be a silently wrong hit: report it.  Cannot happen on this library's trees (a radix
+        // tree over unique 32-bit keys is <= 32 levels deep, 3 waiting siblings per level); lbvh_debug_ray_stack_limit provokes it
+        else __hip_atomic_store(fault, LBVH_FAULT_RAY_STACK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
     // A step: box tests on the node fetched during the previous step, the next node chosen (against the best hit so far),
     // then the first leaf's triangle line AND the next node requested together, the triangle tests while both are on their
@@ -690,14 +703,14 @@ static lbvh_status launch_ray_walk(lbvh_context* ctx, const lbvh_path_state* d_s
         if (few_rays || ctx->ray_walker == 2u)
             LBVH_LAUNCH(ctx, trace_rays_wide_chain_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min,
                         (const lbvh_wide_node*)ctx->wide_nodes, ctx->fast_nodes, d_hits, deep_stacks(ctx, count),
-                        std::min<uint32_t>(ctx->ray_stack_lds, kWideStackLds));
+                        std::min<uint32_t>(ctx->ray_stack_lds, kWideStackLds), std::min<uint32_t>(ctx->ray_stack_deep, kWideStackDeep), ctx->fault_dev);
         else
             LBVH_LAUNCH(ctx, trace_rays_wide_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min,
                         (const lbvh_wide_node*)ctx->wide_nodes, ctx->fast_nodes, d_hits, deep_stacks(ctx, count),
-                        std::min<uint32_t>(ctx->ray_stack_lds, kWideStackLds));
+                        std::min<uint32_t>(ctx->ray_stack_lds, kWideStackLds), std::min<uint32_t>(ctx->ray_stack_deep, kWideStackDeep), ctx->fault_dev);
     } else {
         LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, ctx->fast_nodes,
-                    ctx->fast_tris, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds);
+                    ctx->fast_tris, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds, std::min<uint32_t>(ctx->ray_stack_deep, kRayStackDeep), ctx->fault_dev);
     }
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
@@ -771,6 +784,13 @@ lbvh_status lbvh_debug_ray_stack_split(lbvh_context* ctx, uint32_t lds_entries)
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     LBVH_REQUIRE(ctx, lds_entries >= 1 && lds_entries <= (uint32_t)kRayStackLds);
     ctx->ray_stack_lds = lds_entries;
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_debug_ray_stack_limit(lbvh_context* ctx, uint32_t deep_entries)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    ctx->ray_stack_deep = deep_entries == 0u ? 0xFFFFFFFFu : deep_entries;       // the kernels clamp it to their slab's size
     return LBVH_OK;
 }
 

@@ -17,6 +17,7 @@
 // LBVH_TRACE_REFERENCE: one wave (8x8 pixels) per workgroup, per-lane stack in LDS as [entry][lane]
 // (bank-conflict-free, no scratch memory), no barriers.  LBVH_TRACE_FAST: one wave per 8x8-pixel packet with
 // a wave-shared stack in one VGPR (v_writelane / v_readlane), no LDS at all (see the packet section below).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,6 +36,7 @@ struct trace_args {
     uint32_t tiles_x, tiles_y;
     uint32_t shard_index, shard_count;   // this launch traces every shard_count-th GROUP of tiles
     uint32_t line_bytes;                 // size of the node + triangle line array if it is below 4 GB, else 0
+    uint32_t packed;                     // 1: records go to hits[work item * 64 + lane] (lbvh_trace_primary_shard_packed)
 };
 
 constexpr int kOrderClasses = 16;         // cost classes of the packet dispatch order
@@ -74,6 +76,14 @@ __device__ __forceinline__ bool tile_pixel(const trace_args& a, uint32_t tile, u
     px = (uint32_t)a.x0 + tx * 8 + (lane & 7);
     py = (uint32_t)a.y0 + ty * 8 + (lane >> 3);
     return px < (uint32_t)a.x1 && py < (uint32_t)a.y1;
+}
+
+// where the record of lane `lane` (pixel px, py) of work item w goes: at its pixel of the traced rectangle, or — packed
+// shares, one contiguous block per GPU for whatever carries it to the frame's owner — behind the share's earlier tiles
+__device__ __forceinline__ size_t hit_slot(const trace_args& a, uint32_t w, uint32_t lane, uint32_t px, uint32_t py)
+{
+    if (a.packed) return (size_t)w * 64u + lane;
+    return (size_t)(py - (uint32_t)a.y0) * (uint32_t)(a.x1 - a.x0) + (px - (uint32_t)a.x0);
 }
 
 __device__ __forceinline__ void add_stats(lbvh_trace_stats* stats, uint32_t pops, uint32_t box_hits,
@@ -154,13 +164,12 @@ __global__ __launch_bounds__(64) void trace_reference_kernel(trace_args a, lbvh_
             }
             if (sp > (uint32_t)kStackDepth) sp = kStackDepth;   // unreachable for unique keys
         }
-        const uint32_t rw = (uint32_t)(a.x1 - a.x0);
         float4 out;
         out.x = best_t;
         out.y = __uint_as_float(best_tri);
         out.z = best_u;
         out.w = best_v;
-        reinterpret_cast<float4*>(hits)[(size_t)(py - (uint32_t)a.y0) * rw + (px - (uint32_t)a.x0)] = out;
+        reinterpret_cast<float4*>(hits)[hit_slot(a, blockIdx.x, lane, px, py)] = out;
         if (STATS && best_t < LBVH_MAX_FLOAT) n_hit = 1;
     }
     if (STATS) add_stats(stats, n_pops, n_box, n_leaf, n_tri, n_hit);
@@ -907,8 +916,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                 out = make_float4(dist, v0.w, u, v);
                 if (STATS) n_hit++;
             }
-            const uint32_t rw = (uint32_t)(a.x1 - a.x0);
-            reinterpret_cast<float4*>(hits)[(size_t)(py0 - (uint32_t)a.y0) * rw + (px0 - (uint32_t)a.x0)] = out;
+            reinterpret_cast<float4*>(hits)[hit_slot(a, w, lane, px0, py0)] = out;
         }
     }
     if (STATS) add_stats(stats, C.pops, C.box, C.leaf, C.tri, n_hit);
@@ -926,7 +934,6 @@ __device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_
         if (lane == 0) cost[w] = 0;
         return;
     }
-    const uint32_t rw = (uint32_t)(a.x1 - a.x0);
     packet_rays<1> P;
     uint32_t px0, py0;
     tile_rays<1, 1>(a, tile, lane, P, px0, py0);
@@ -953,7 +960,7 @@ __device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_
         out.y = __uint_as_float(P.best_tri[0]);
         out.z = P.best_u[0];
         out.w = P.best_v[0];
-        reinterpret_cast<float4*>(hits)[(size_t)(py0 - (uint32_t)a.y0) * rw + (px0 - (uint32_t)a.x0)] = out;
+        reinterpret_cast<float4*>(hits)[hit_slot(a, w, lane, px0, py0)] = out;
         if (STATS && P.best_t[0] < LBVH_MAX_FLOAT) n_hit++;
     }
     if (STATS) add_stats(stats, C.pops, C.box, C.leaf, C.tri, n_hit);
@@ -1154,6 +1161,24 @@ __global__ __launch_bounds__(256) void export_costs_kernel(const uint32_t* __res
     if (tile < n_tiles) frame[tile] = cost[w];
 }
 
+// packed shares -> their pixels of the full frame (the owner's side of lbvh_trace_primary_shard_packed): one wave per
+// (share, work item), 16 bytes per lane both ways
+__global__ __launch_bounds__(256) void frame_unpack_kernel(const lbvh_hit* __restrict__ packed, uint64_t share_stride, uint32_t first_shard,
+                                                           uint32_t shard_count, uint32_t items_per_share, uint32_t tiles_x, uint32_t n_tiles,
+                                                           uint32_t width, uint32_t height, lbvh_hit* __restrict__ frame)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6), s = blockIdx.y;
+    if (k >= items_per_share) return;
+    const uint32_t tile = shard_tile(k, first_shard + s, shard_count);
+    if (tile >= n_tiles) return;
+    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
+    if (px >= width || py >= height) return;
+    reinterpret_cast<float4*>(frame)[(size_t)py * width + px] =
+        reinterpret_cast<const float4*>(packed)[(size_t)s * share_stride + (size_t)k * 64u + lane];
+}
+
 int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_cost)
 {
     a.tiles_x = (uint32_t)(a.x1 - a.x0 + 7) / 8;
@@ -1248,9 +1273,11 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
         const uint32_t* frame = ctx->trace_frame_valid && ctx->trace_frame_tiles_x == a.tiles_x && ctx->trace_frame_tiles_y == a.tiles_y &&
                                         spread != 0 ? ctx->trace_frame_costs : nullptr;
         LBVH_LAUNCH(ctx, file_tiles_kernel, dim3((n_work + 1023) / 1024), dim3(1024), cost, n_work, counts, lists, next_counts, grid, frame);
-        if (frame) ctx->trace_frame_valid = false;       // one frame old at most: the caller imports after every frame it wants this for
         ctx->trace_counts_turn ^= 1u;
     }
+    // an imported cost map is a hint for the ONE frame that follows it, used or not (an unused map — static camera,
+    // another layout — used to stay valid and could steer a frame traced much later)
+    ctx->trace_frame_valid = false;
     // Which tiles are walked cooperatively (known from the last trace).  It costs ~50 % more steps on those tiles (a
     // subtree handed to another wave is walked before the near hits that would have pruned it are known), so it is
     // for under-filled launches — one GPU's share of a multi-GPU frame: every tile of 96 steps or more up to
@@ -1304,6 +1331,8 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     ctx->trace_shard_count = a.shard_count;
     ctx->trace_tiles_x = a.tiles_x;
     ctx->trace_tiles_y = a.tiles_y;
+    ctx->trace_origin_x = a.x0;
+    ctx->trace_origin_y = a.y0;
     ctx->trace_history = true;
     return LBVH_OK;
 }
@@ -1538,7 +1567,8 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
 
 static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, int32_t x0, int32_t y0, int32_t x1,
                               int32_t y1, uint32_t shard_index, uint32_t shard_count, const lbvh_scene* h_scene,
-                              int32_t mode, lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_cost = nullptr)
+                              int32_t mode, lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_cost = nullptr,
+                              bool packed = false)
 {
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     LBVH_REQUIRE(ctx, h_camera != nullptr && h_scene != nullptr);
@@ -1557,6 +1587,8 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
     a.cam = cam;
     a.x0 = x0; a.y0 = y0; a.x1 = x1; a.y1 = y1;
     a.shard_index = shard_index; a.shard_count = shard_count;
+    a.line_bytes = 0;
+    a.packed = packed ? 1u : 0u;
     a.tiles_x = (uint32_t)(x1 - x0 + 7) / 8;
     a.tiles_y = (uint32_t)(y1 - y0 + 7) / 8;
     const uint32_t n_tiles = shard_work(a.tiles_x * a.tiles_y, shard_index, shard_count);
@@ -1611,8 +1643,10 @@ lbvh_status lbvh_trace_costs_export(lbvh_context* ctx, uint32_t* d_frame_costs, 
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     LBVH_REQUIRE(ctx, d_frame_costs != nullptr && tiles_x > 0 && tiles_y > 0 && (uint64_t)tiles_x * tiles_y <= 0x7FFFFFFFull);
     // the layout of the last LBVH_TRACE_FAST trace: whole-frame traces and shards starting at the frame's origin
-    if (!ctx->trace_history || ctx->trace_tiles_x != tiles_x || ctx->trace_tiles_y != tiles_y)
-        return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_trace_costs_export", "no LBVH_TRACE_FAST trace of a frame with this many tiles to export");
+    // ... and only those: a sub-rectangle with the same tile counts but another origin would export its costs shifted
+    if (!ctx->trace_history || ctx->trace_tiles_x != tiles_x || ctx->trace_tiles_y != tiles_y || ctx->trace_origin_x != 0 || ctx->trace_origin_y != 0)
+        return lbvh_set_error(ctx, LBVH_ERR_INVALID_ARG, "lbvh_trace_costs_export",
+                              "the last LBVH_TRACE_FAST trace was not a frame (or a shard of one) with this many tiles starting at pixel (0, 0)");
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t n_work = ctx->trace_layout_work;
     const uint32_t* cost = (const uint32_t*)((const char*)ctx->trace_queues + 256);
@@ -1661,6 +1695,47 @@ lbvh_status lbvh_trace_primary_shard(lbvh_context* ctx, const lbvh_camera* h_cam
     LBVH_REQUIRE(ctx, shard_count >= 1 && shard_index < shard_count);
     return trace_impl(ctx, h_camera, 0, 0, h_camera->screen_width, h_camera->screen_height, shard_index, shard_count,
                       h_scene, mode, d_hits, d_stats);
+}
+
+lbvh_status lbvh_trace_primary_shard_packed(lbvh_context* ctx, const lbvh_camera* h_camera, uint32_t shard_index,
+                                            uint32_t shard_count, const lbvh_scene* h_scene, int32_t mode,
+                                            lbvh_hit* d_packed, lbvh_trace_stats* d_stats)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, h_camera != nullptr);
+    LBVH_REQUIRE(ctx, shard_count >= 1 && shard_index < shard_count);
+    return trace_impl(ctx, h_camera, 0, 0, h_camera->screen_width, h_camera->screen_height, shard_index, shard_count,
+                      h_scene, mode, d_packed, d_stats, nullptr, true);
+}
+
+uint64_t lbvh_shard_records(int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count)
+{
+    if (width <= 0 || height <= 0 || shard_count == 0 || shard_index >= shard_count) return 0;
+    const uint64_t tiles = (uint64_t)((width + 7) / 8) * (uint64_t)((height + 7) / 8);
+    if (tiles > 0x7FFFFFFFull) return 0;
+    return (uint64_t)shard_work((uint32_t)tiles, shard_index, shard_count) * 64u;
+}
+
+lbvh_status lbvh_frame_unpack(lbvh_context* ctx, const lbvh_hit* d_packed, uint64_t share_stride, uint32_t first_shard,
+                              uint32_t n_shards, uint32_t shard_count, int32_t width, int32_t height, lbvh_hit* d_frame_hits)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, width > 0 && height > 0 && shard_count >= 1 && n_shards <= 65535u);
+    LBVH_REQUIRE(ctx, (uint64_t)first_shard + n_shards <= shard_count);
+    if (n_shards == 0) return LBVH_OK;
+    LBVH_REQUIRE(ctx, d_packed != nullptr && d_frame_hits != nullptr && ((uintptr_t)d_packed & 15) == 0 && ((uintptr_t)d_frame_hits & 15) == 0);
+    const uint64_t tiles64 = (uint64_t)((width + 7) / 8) * (uint64_t)((height + 7) / 8);
+    LBVH_REQUIRE(ctx, tiles64 <= 0x7FFFFFFFull);
+    const uint32_t n_tiles = (uint32_t)tiles64;
+    uint32_t items = 0;          // the largest share of those handed in
+    for (uint32_t s = 0; s < n_shards; s++) items = std::max(items, shard_work(n_tiles, first_shard + s, shard_count));
+    LBVH_REQUIRE(ctx, share_stride >= (uint64_t)items * 64u);
+    if (items == 0) return LBVH_OK;
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    LBVH_LAUNCH(ctx, frame_unpack_kernel, dim3((items + 3) / 4, n_shards), dim3(256), d_packed, share_stride, first_shard, shard_count, items,
+                (uint32_t)((width + 7) / 8), n_tiles, (uint32_t)width, (uint32_t)height, d_frame_hits);
+    LBVH_HIP_TRY(ctx, hipGetLastError());
+    return LBVH_OK;
 }
 
 }  // extern "C"

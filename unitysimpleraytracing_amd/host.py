@@ -90,6 +90,45 @@ class Context:
     def copy_probe(self, dst, src, nbytes):
         N.check(self.handle, N.lib.lbvh_copy_bandwidth_probe(self.handle, dst, src, nbytes))
 
+    # -- one frame from N GPUs (include/lbvh.h, "one frame from N GPUs") ---------------------------------
+    def peer_enable(self, peer_device):
+        """kernels of this context may store into memory of `peer_device` (the frame's owner)"""
+        N.check(self.handle, N.lib.lbvh_peer_enable(self.handle, int(peer_device)))
+
+    def sync_event(self):
+        """an ORDERING event (system-scope release at its record), for wait_event of another context"""
+        e = C.c_void_p()
+        N.check(self.handle, N.lib.lbvh_sync_event_create(self.handle, C.byref(e)))
+        return e
+
+    def wait_event(self, ev):
+        """this context's stream waits on the device for an event recorded on any context of the process"""
+        N.check(self.handle, N.lib.lbvh_event_wait(self.handle, ev))
+
+    def ipc_export(self, device_ptr):
+        """64-byte cross-process handle of a buffer of this context (hipIpcGetMemHandle)"""
+        h = (C.c_uint8 * 64)()
+        N.check(self.handle, N.lib.lbvh_ipc_export(self.handle, device_ptr, h))
+        return bytes(h)
+
+    def ipc_import(self, handle_bytes):
+        """the exporting process's buffer mapped here: a device pointer usable on this context"""
+        h = (C.c_uint8 * 64).from_buffer_copy(handle_bytes)
+        p = C.c_void_p()
+        N.check(self.handle, N.lib.lbvh_ipc_import(self.handle, h, C.byref(p)))
+        return p
+
+    def ipc_close(self, device_ptr):
+        N.check(self.handle, N.lib.lbvh_ipc_close(self.handle, device_ptr))
+
+    def frame_signal(self, flags_ptr, slot, value):
+        """flags[slot] := value (system-scope release) once everything enqueued so far has finished"""
+        N.check(self.handle, N.lib.lbvh_frame_signal(self.handle, flags_ptr, slot, value))
+
+    def frame_wait(self, flags_ptr, n_slots, value):
+        """later work on this context starts only when flags[0..n_slots) have all reached `value` (bounded device-side wait)"""
+        N.check(self.handle, N.lib.lbvh_frame_wait(self.handle, flags_ptr, n_slots, value))
+
 
 class DataBuffer:
     """Assets/_Scripts/DataBuffer.cs: a device buffer (ComputeBuffer) + a host mirror (T[])."""
@@ -389,6 +428,80 @@ class RaytracingMeshDrawer:
         for b in (self._hits, self._stats):
             if b is not None:
                 b.dispose()
+
+
+class MultiGpuDrawer:
+    """One frame from N GPUs driven by one process (twin of host/lbvh_host.hpp MultiGpuDrawer; BASELINE configs[2]): one
+    Context + one replica of the scene per entry of `devices` (a device may repeat: logical ranks on one GPU), every build
+    call enqueued round-robin, and update() = every context traces its share straight into ONE full-frame buffer on the
+    first device (peer-mapped stores, no second pass) + the first context's stream waits for the others' completion events
+    on the device.  The reference renders one image per Update() (Assets/_Scripts/RaytracingMeshDrawer.cs:76-89): this is
+    where the N shares become that image."""
+
+    def __init__(self, devices, triangles, capacity=None):
+        self.contexts = [Context(d) for d in devices]
+        self.drawers = [RaytracingMeshDrawer(c, triangles, capacity) for c in self.contexts]
+        self.done = [c.sync_event() for c in self.contexts]
+        self.consumed = self.contexts[0].sync_event()
+        for c in self.contexts[1:]:
+            c.peer_enable(devices[0])
+        self.frame = None
+        self._shape = None
+
+    @property
+    def owner(self):
+        return self.contexts[0]
+
+    def awake(self, fast=True):
+        for d in self.drawers:                       # replicas: the same deterministic build on every GPU
+            d.awake(fast=fast)
+        return self
+
+    def rebuild(self, fast=True):
+        for d in self.drawers:
+            d.rebuild(fast=fast)
+
+    def update(self, camera, mode=L.TRACE_FAST):
+        cam = N.Camera.from_dict(camera)
+        count = cam.screen_width * cam.screen_height
+        if self.frame is None or self.frame.size < count:
+            self.sync()                              # nobody may still be writing the old buffer
+            if self.frame is not None:
+                self.frame.dispose()
+            self.frame = DataBuffer(self.owner, count, L.HIT)
+        self._shape = (cam.screen_height, cam.screen_width)
+        n = len(self.contexts)
+        self.owner.record(self.consumed)             # the owner's reads of the previous frame end here
+        for c in self.contexts[1:]:
+            c.wait_event(self.consumed)
+        for r, (c, d) in enumerate(zip(self.contexts, self.drawers)):
+            s = d.container.scene()
+            N.check(c.handle, N.lib.lbvh_trace_primary_shard(c.handle, C.byref(cam), r, n, C.byref(s), mode, self.frame.device, None))
+            if r:
+                c.record(self.done[r])
+        for r in range(1, n):
+            self.owner.wait_event(self.done[r])      # the gather: a device-side wait, nothing is copied
+        return self.frame
+
+    def hits(self):
+        h, w = self._shape
+        return self.frame.get_data()[: h * w].reshape(h, w).copy()
+
+    def sync(self):
+        for c in self.contexts:
+            c.sync()
+
+    def on_destroy(self):
+        self.sync()
+        if self.frame is not None:
+            self.frame.dispose()
+        for d in self.drawers:
+            d.on_destroy()
+        for c, e in zip(self.contexts, self.done):
+            c.destroy_event(e)
+        self.owner.destroy_event(self.consumed)
+        for c in self.contexts:
+            c.close()
 
 
 class DynamicPathTracer:

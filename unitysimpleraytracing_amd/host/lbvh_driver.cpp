@@ -3,6 +3,9 @@
 // timings and checksums the parity tests compare with the oracle.  Links only liblbvh.so.
 //     lbvh_driver [n] [w] [h] [dynamic]          seeded random triangles (cfg1)
 //     lbvh_driver obj <file.obj> [w] [h] [z]     mesh ingest (lbvh_mesh.hpp) -> Awake -> Update, camera at (0, 0, z)
+//     lbvh_driver multi <ranks> [n] [w] [h]      one process, <ranks> contexts (MultiGpuDrawer; rank r on device r % device
+//                                                count): frames assembled in rank 0's buffer by peer-mapped stores,
+//                                                compared word for word with one context's whole frame
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -20,8 +23,86 @@ static uint64_t splitmix64(uint64_t& s)
 }
 static float uniform(uint64_t& s, float lo, float hi) { return lo + (hi - lo) * (float)((splitmix64(s) >> 40) * (1.0 / 16777216.0)); }
 
+static std::vector<lbvh_triangle> random_mesh(uint32_t n)
+{
+    std::vector<lbvh_triangle> mesh(n);
+    uint64_t seed = 1;
+    for (auto& t : mesh) {
+        std::memset(&t, 0, sizeof t);
+        for (int k = 0; k < 3; k++) {
+            const float c = uniform(seed, -100.0f, 100.0f);
+            t.a[k] = c;
+            t.b[k] = c + uniform(seed, -2.0f, 2.0f);
+            t.c[k] = c + uniform(seed, -2.0f, 2.0f);
+        }
+        t.b_uv[0] = 1.0f; t.c_uv[1] = 1.0f;
+    }
+    return mesh;
+}
+
+static lbvh_camera camera_at(int w, int h, float z, float yaw_deg = 0.0f)
+{
+    lbvh_camera cam;
+    cam.screen_width = w; cam.screen_height = h;
+    cam.camera_fov = (float)std::tan(60.0 * 3.14159265358979323846 / 180.0 / 2.0);   // Mathf.Tan(fov * Deg2Rad / 2)
+    cam.near_plane = 0.3f;
+    const float c = (float)std::cos(yaw_deg * 3.14159265358979323846 / 180.0), s = (float)std::sin(yaw_deg * 3.14159265358979323846 / 180.0);
+    const float m[16] = {-c, 0, s, 0, 0, 1, 0, 0, s, 0, c, z, 0, 0, 0, 1};
+    std::memcpy(cam.camera_to_world, m, sizeof m);
+    return cam;
+}
+
+// BASELINE configs[2] through the one-process host: every frame of every camera / mode assembled from <ranks> shares must
+// equal the frame one context traces alone, the assembled buffer poisoned before each frame
+static int multi_main(int argc, char** argv)
+{
+    const int ranks = argc > 2 ? atoi(argv[2]) : 2;
+    const uint32_t n = argc > 3 ? (uint32_t)atoi(argv[3]) : 4096;
+    const int w = argc > 4 ? atoi(argv[4]) : 256, h = argc > 5 ? atoi(argv[5]) : 256;
+    const std::vector<lbvh_triangle> mesh = random_mesh(n);
+    try {
+        const int n_dev = lbvh::Context::device_count();
+        if (n_dev <= 0) { std::fprintf(stderr, "no HIP device visible\n"); return 1; }
+        std::vector<int> devices;
+        for (int r = 0; r < ranks; r++) devices.push_back(r % n_dev);
+        lbvh::MultiGpuDrawer multi(devices, mesh);
+        multi.Awake();
+        lbvh::Context one(0);
+        lbvh::RaytracingMeshDrawer single(one, mesh);
+        single.Awake();
+        int frames = 0, equal = 0;
+        size_t hits = 0;
+        for (int mode : {LBVH_TRACE_FAST, LBVH_TRACE_REFERENCE})
+            for (int f = 0; f < 4; f++) {
+                // two frames from one camera (the second is dispatched by the first one's costs), then a turned one, then a
+                // rebuilt scene
+                const lbvh_camera cam = camera_at(w, h, 300.0f, f < 2 ? 0.0f : 2.0f * f);
+                if (f == 3) { multi.Rebuild(); single.Rebuild(); }
+                if (frames) multi.Hits().Fill(0x7FC00000u, false);            // poison: a missing tile cannot pass on old values
+                multi.Update(cam, mode);
+                single.Update(cam, mode);
+                multi.Hits().GetData();                                      // on the owner's stream: behind the device-side gather
+                single.Hits().GetData();
+                const bool same = std::memcmp(multi.Hits().LocalBuffer().data(), single.Hits().LocalBuffer().data(),
+                                              (size_t)w * h * sizeof(lbvh_hit)) == 0;
+                frames++;
+                equal += same ? 1 : 0;
+                if (mode == LBVH_TRACE_REFERENCE && f == 0)
+                    for (size_t i = 0; i < (size_t)w * h; i++) hits += multi.Hits().LocalBuffer()[i].t < LBVH_MAX_FLOAT ? 1 : 0;
+            }
+        multi.Sync();
+        std::printf("{\"ranks\": %d, \"devices\": %d, \"triangles\": %u, \"rays\": %d, \"frames\": %d, \"frames_equal\": %d, \"hits\": %zu}\n",
+                    ranks, n_dev, n, w * h, frames, equal, hits);
+        return equal == frames ? 0 : 2;
+    } catch (const lbvh::Error& e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+}
+
 int main(int argc, char** argv)
 {
+    if (argc > 1 && std::strcmp(argv[1], "multi") == 0) return multi_main(argc, argv);
     const bool from_obj = argc > 2 && std::strcmp(argv[1], "obj") == 0;
     uint32_t n = !from_obj && argc > 1 ? (uint32_t)atoi(argv[1]) : 4096;
     const int w = from_obj ? (argc > 3 ? atoi(argv[3]) : 256) : (argc > 2 ? atoi(argv[2]) : 256);

@@ -79,6 +79,21 @@ private:
     void* ev_ = nullptr;
 };
 
+// An ORDERING event (lbvh_sync_event_create): recorded on one context's stream, waited for by another's, on the device.
+class SyncEvent {
+public:
+    explicit SyncEvent(Context& ctx) : ctx_(ctx) { check(ctx_.get(), lbvh_sync_event_create(ctx_.get(), &ev_)); }
+    ~SyncEvent() { if (ev_) lbvh_event_destroy(ctx_.get(), ev_); }
+    SyncEvent(const SyncEvent&) = delete;
+    SyncEvent& operator=(const SyncEvent&) = delete;
+    void record() { check(ctx_.get(), lbvh_event_record(ctx_.get(), ev_)); }
+    // everything enqueued on `waiter` after this call starts after the work recorded before record()
+    void make_wait(Context& waiter) { check(waiter.get(), lbvh_event_wait(waiter.get(), ev_)); }
+private:
+    Context& ctx_;
+    void* ev_ = nullptr;
+};
+
 // Assets/_Scripts/DataBuffer.cs
 template <typename T>
 class DataBuffer {
@@ -324,6 +339,13 @@ public:
                                            (lbvh_leaf_node*)c.BvhLeafNode().DeviceBuffer(), (lbvh_aabb*)c.BvhData().DeviceBuffer(),
                                            LBVH_BUILD_FAST_SCENE | LBVH_BUILD_RESET_NODES));
     }
+    // this GPU's share of the frame written into `frame` — a full-frame buffer that may live on ANOTHER GPU (peer-mapped:
+    // lbvh_peer_enable on this context first): the records travel as the tiles finish, nothing is copied afterwards
+    void UpdateShardInto(const lbvh_camera& cam, uint32_t shard_index, uint32_t shard_count, lbvh_hit* frame, int mode = LBVH_TRACE_FAST)
+    {
+        const lbvh_scene s = container_->Scene();
+        check(ctx_.get(), lbvh_trace_primary_shard(ctx_.get(), &cam, shard_index, shard_count, &s, mode, frame, nullptr));
+    }
     DataBuffer<uint64_t>& Image() { return *image_; }
     MeshBufferContainer& Container() { return *container_; }
     DataBuffer<lbvh_hit>& Hits() { return *hits_; }
@@ -337,6 +359,67 @@ private:
     std::unique_ptr<DataBuffer<uint32_t>> tex_;
     std::unique_ptr<DataBuffer<uint64_t>> image_;
     int tex_w_ = 0, tex_h_ = 0;
+};
+
+// One frame from N GPUs driven by ONE process — what a Unity MonoBehaviour is (Assets/_Scripts/RaytracingMeshDrawer.cs:30-84
+// runs Awake / Update on the main thread of one process) and BASELINE configs[2] asks for: BVH replicated, rays sharded, no
+// collective.  One Context per entry of `devices` (a device may appear more than once: logical ranks on one GPU, which is
+// how the tests run it on a one-GPU box), each with its own replica of the scene; Awake() / Rebuild() enqueue every
+// replica's build round-robin (all calls are asynchronous, so the N GPUs build side by side); Update() has every context
+// trace its share of the frame straight into ONE full-frame hit buffer that lives on the first device — peer-mapped
+// stores over xGMI while the tiles finish, no second pass — and makes the first context's stream wait for the others'
+// completion events on the device.  Whatever the first context enqueues next (lbvh_shade, a download, Unity's blit) sees a
+// whole frame; the host never blocks inside Update().  The next Update() may only overwrite the buffer once the owner is
+// done reading the previous frame: the owner records `consumed_` at the top of Update() and every other stream waits for it.
+class MultiGpuDrawer {
+public:
+    MultiGpuDrawer(const std::vector<int>& devices, const std::vector<lbvh_triangle>& mesh)
+    {
+        if (devices.empty()) throw Error(LBVH_ERR_INVALID_ARG, "MultiGpuDrawer: no devices");
+        for (int d : devices) {
+            contexts_.emplace_back(new Context(d));
+            drawers_.emplace_back(new RaytracingMeshDrawer(*contexts_.back(), mesh));
+            done_.emplace_back(new SyncEvent(*contexts_.back()));
+        }
+        consumed_.reset(new SyncEvent(*contexts_[0]));
+        for (size_t r = 1; r < contexts_.size(); ++r)            // rank r stores into the owner's memory
+            check(contexts_[r]->get(), lbvh_peer_enable(contexts_[r]->get(), devices[0]));
+    }
+    ~MultiGpuDrawer()
+    {
+        try { Sync(); } catch (const Error&) {}                            // no rank may still be storing into the frame buffer
+    }
+    size_t Ranks() const { return contexts_.size(); }
+    Context& Owner() { return *contexts_[0]; }
+    RaytracingMeshDrawer& Drawer(size_t rank) { return *drawers_[rank]; }
+    void Awake() { for (auto& d : drawers_) d->Awake(); }                  // replicas: deterministic, bit-identical trees
+    void Rebuild() { for (auto& d : drawers_) d->Rebuild(); }              // per-frame rebuilds of dynamic scenes
+    void Update(const lbvh_camera& cam, int mode = LBVH_TRACE_FAST)
+    {
+        const size_t rays = (size_t)cam.screen_width * cam.screen_height;
+        if (!frame_ || frame_->Size() < rays) {
+            Sync();                                                        // nobody may still be writing the old buffer
+            frame_.reset(new DataBuffer<lbvh_hit>(*contexts_[0], rays));
+        }
+        const uint32_t n = (uint32_t)contexts_.size();
+        consumed_->record();                                               // the owner's reads of the previous frame end here
+        for (uint32_t r = 1; r < n; ++r) consumed_->make_wait(*contexts_[r]);
+        for (uint32_t r = 0; r < n; ++r) {                                 // round-robin enqueue: N GPUs trace side by side
+            drawers_[r]->UpdateShardInto(cam, r, n, (lbvh_hit*)frame_->DeviceBuffer(), mode);
+            if (r != 0) done_[r]->record();
+        }
+        for (uint32_t r = 1; r < n; ++r) done_[r]->make_wait(*contexts_[0]);   // the gather: a device-side wait, no copy
+    }
+    // the whole frame, on the first device; valid for work enqueued on Owner() after Update()
+    DataBuffer<lbvh_hit>& Hits() { return *frame_; }
+    void Sync() { for (auto& c : contexts_) c->sync(); }
+private:
+    // (destruction order: buffers and events before their contexts)
+    std::vector<std::unique_ptr<Context>> contexts_;
+    std::vector<std::unique_ptr<RaytracingMeshDrawer>> drawers_;
+    std::vector<std::unique_ptr<SyncEvent>> done_;
+    std::unique_ptr<SyncEvent> consumed_;
+    std::unique_ptr<DataBuffer<lbvh_hit>> frame_;
 };
 
 // BASELINE configs[4] (extension): rigid bodies rotate every frame, the LBVH is rebuilt, primary rays + `bounces`
