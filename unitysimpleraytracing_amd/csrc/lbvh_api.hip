@@ -93,7 +93,6 @@ int lbvh_check_fault(lbvh_context* ctx)
     snprintf(msg, sizeof msg, "%s (fault %u): results enqueued before this call are invalid",
              code == LBVH_FAULT_RAY_STACK    ? "a per-ray traversal stack ran out of entries"
              : code == LBVH_FAULT_FRAME_WAIT ? "lbvh_frame_wait: a rank's completion flag never arrived"
-             : code == LBVH_FAULT_TRACE_BOARD ? "a posting on the traversal's offer board never arrived"
                                              : "a bounded inter-workgroup wait gave up", code);
     return lbvh_set_error(ctx, LBVH_ERR_HIP, "device-side protocol fault", msg);
 }
@@ -208,7 +207,6 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->fast_nodes) (void)hipFree(ctx->fast_nodes);
     if (ctx->trace_queues) (void)hipFree(ctx->trace_queues);
-    if (ctx->trace_board) (void)hipFree(ctx->trace_board);
     if (ctx->fast_tree) (void)hipFree(ctx->fast_tree);
     if (ctx->hier) (void)hipFree(ctx->hier);
     if (ctx->ray_scratch) (void)hipFree(ctx->ray_scratch);

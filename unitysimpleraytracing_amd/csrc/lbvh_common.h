@@ -25,8 +25,6 @@ static_assert(sizeof(lbvh_hit) == 16, "hit record must be 16 bytes");
 #define LBVH_FAULT_RAY_STACK 2u
 // lbvh_frame_wait gave up: another rank's completion flag for this frame never arrived
 #define LBVH_FAULT_FRAME_WAIT 3u
-// a posting on the traversal's offer board was reserved and never written (trace_offer_kernel)
-#define LBVH_FAULT_TRACE_BOARD 4u
 // polls before a spin gives up: each poll is a round trip to the coherence point (>= 0.5 us), so this is seconds —
 // orders of magnitude beyond any legitimate wait (a predecessor tile's run time), and never a hung GPU
 #define LBVH_SPIN_LIMIT (1u << 22)
@@ -112,10 +110,6 @@ struct lbvh_context {
     // packet traversal scheduling: step count of every tile in the last trace + the dispatch order made from it
     void* trace_queues = nullptr;
     size_t trace_queues_bytes = 0;
-    // in-flight cooperation: two offer boards taking turns + one record per work item (lbvh_trace.hip trace_offer_kernel)
-    void* trace_board = nullptr;
-    size_t trace_board_bytes = 0;
-    uint32_t trace_epoch = 0;
     uint64_t trace_layout = 0;      // frame layout (tiles, shard, origin) the history belongs to
     uint32_t trace_layout_work = 0;
     uint32_t trace_shard_index = 0, trace_shard_count = 1, trace_tiles_x = 0, trace_tiles_y = 0;   // of that trace

@@ -585,17 +585,8 @@ __device__ __forceinline__ bool lean_triangle(const ray_t& r, const lean_tri& T,
     return !(det < 1e-8f && det > -1e-8f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f);
 }
 
-// A lean walk stopped at the head of a step by its step cap (CAPPED): what walk_heavy continues from.
-struct lean_handoff {
-    int w_node;               // the line of the node the next step processes (sign-ordered fetch pattern)
-    int stack;                // the wave-shared stack register: entries [0, sp) in lanes 0 .. sp - 1
-    uint32_t sp;
-    bool pending;             // false: the walk ran to its end, nothing is handed over
-};
-
-template <bool BUF, bool CAPPED = false>
-__device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, packet_rays<1>& P, uint32_t neg, uint32_t cap = 0,
-                                                     lean_handoff* out = nullptr)
+template <bool BUF>
+__device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, packet_rays<1>& P, uint32_t neg)
 {
     const uint32_t lane = lane_id();
     const ray_t r = P.ray[0];
@@ -608,12 +599,7 @@ __device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, pac
     uint32_t best_tri = P.best_tri[0];
     float best_u = P.best_u[0], best_v = P.best_v[0];
     int w_node = fetch_line<BUF>(src, 0u, node_bytes);
-    if (CAPPED) out->pending = false;
     for (;;) {
-        if (CAPPED && steps == cap) {          // one scalar compare per step: everything else of a heavy tile's life is walk_heavy's
-            out->w_node = w_node; out->stack = stack; out->sp = sp; out->pending = true;
-            break;
-        }
         const uint32_t lref = (uint32_t)__builtin_amdgcn_readlane(w_node, 3), rref = (uint32_t)__builtin_amdgcn_readlane(w_node, 7);
         const bool leaf_l = (int)lref < 0, leaf_r = (int)rref < 0;
         const int w_l = fetch_line<BUF>(src, lref, node_bytes);        // both children in flight before the tests
@@ -980,352 +966,6 @@ __device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_
     if (STATS) add_stats(stats, C.pops, C.box, C.leaf, C.tri, n_hit);
 }
 
-// ---- in-flight cooperation through a global offer board: no history needed ---------------------------------------------
-// Which tiles are heavy is only known once they have been walked: a first frame, a camera that turned, a scene that was
-// rebuilt, another GPU's share of the last frame — every case in which the cost-ordered dispatch has nothing to go by
-// (a cold frame 0.26 ms against 0.17 warm; a frame's run time is the dependent chain of its heaviest tiles).
-// The decision is therefore taken WHILE the frame runs, and nobody ever waits:
-//   * every wave walks its tile with the lean step exactly as before — with a step cap (one scalar compare per step);
-//   * a tile that reaches the cap is heavy: its wave goes on in walk_heavy — the same step — and, every few steps, POSTS its
-//     oldest stack entry (the largest unvisited subtree) on a board in device memory: (tile, subtree, direction signs);
-//   * EVERY wave of the launch, when its own tile is done, looks at the board before it ends (the look was requested when
-//     the wave started: no latency added to a light tile) and, if something is posted, takes it: sets up that tile's rays,
-//     starts from the tile's best hits at the time of the posting, walks the subtree privately — posting in turn if it is
-//     long — and merges its hits into the tile's record (64-bit atomic min on (ordered t, triangle line): ties to the
-//     lowest index, as everywhere);
-//   * a tile's record counts its unfinished walks (the owner's + every posted subtree); whoever brings the count to zero
-//     writes the tile's hit records.  A wave that posted looks at the board once more before it ends, so every posting is
-//     taken by somebody (at worst by its own poster): no wave waits for another, no slot is held idle.
-// Under-filled launches (a GPU's share of a frame) need nothing special: the waves of light tiles finish early and help.
-// Only packets the lean step takes (one origin, ordered signs: every primary packet off the image's centre lines) are shared.
-// ONE board would be two hot words for the whole chip: measured, 75 000 postings per frame through one head / tail pair
-// take 52 ms (0.7 us each, serialised at the memory side — the tile queues of round 1 again).  So there are kBoards of
-// them, each a short list of its own: a workgroup posts to and takes from board (workgroup index mod kBoards); a board
-// accepts kBoardSlots postings per launch (then its workgroups keep their subtrees), so nothing ever wraps.
-constexpr uint32_t kBoards = 512;
-constexpr uint32_t kBoardSlots = 504;              // eight-byte slots (+ the 64-byte header: 4 KB per board)
-#ifndef LBVH_OFFER_CAP
-#define LBVH_OFFER_CAP 64          // steps a tile walks before it is treated as heavy
-#endif
-#ifndef LBVH_OFFER_EVERY
-#define LBVH_OFFER_EVERY 32        // steps between two postings of one walk (a posting costs its taker ~20 steps of set-up)
-#endif
-
-// No fences anywhere in this protocol: an agent-scope release / acquire on this chip writes back / invalidates the whole
-// L2 of the XCD (measured: a frame with ~15 000 postings took 2.3 ms — every fence threw the BVH out of a cache).  Instead
-// every word that crosses waves is read and written with agent-scope (cache-bypassing) accesses, a posting is ONE 64-bit
-// word that is its own "ready" flag (0 = not written yet: the boards of the next launch are cleared by this one), and a
-// writer waits for its earlier write-through stores to be acknowledged (s_waitcnt vmcnt(0)) before the word that publishes
-// them — the sort's look-back works the same way (lbvh_sort.hip).
-struct alignas(64) share_board {
-    uint32_t head, tail;
-    uint32_t unfinished;             // tiles of this board's workgroups that are not complete yet (lingering launches)
-    uint32_t pad[13];
-    unsigned long long entry[kBoardSlots];      // bit 63 | direction signs << 60 | work item << 30 | node
-};
-static_assert(sizeof(share_board) == 4096, "a board is 4 KB: workgroup k of a launch clears board k of the next one, 16 bytes per thread");
-__device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-struct alignas(16) tile_record {
-    unsigned long long best[64];     // per ray: ordered t << 32 | line index of the triangle
-    uint32_t pending;                // walks of this tile that have not ended: the owner's + posted subtrees
-    uint32_t steps;
-    uint32_t board;                  // of the tile's owner (whoever completes the tile checks it out there)
-    uint32_t pad1;
-};
-
-struct offer_ctx {
-    share_board* boards;             // of this launch
-    uint32_t n_boards;
-    uint32_t linger;                 // 1: a launch that cannot fill the chip — waves whose tile is done stay while tiles of
-                                     // their board are unfinished (their slots are wanted by nobody)
-    uint32_t my_board;
-    share_board* board;              // of this workgroup
-    tile_record* records;
-    uint32_t cap, every;
-    uint32_t leaf_base;
-    uint32_t* fault;
-};
-
-
-// walk_heavy: the lean step for a tile that turned out heavy — the owner past its cap, or a wave that took a posted subtree.
-// Private stack and private best hits; every `every` steps, with two or more entries on the stack, the oldest one is posted.
-// At the end the walk's hits are merged into the tile's record (if the tile was ever shared) and the walk is checked out;
-// the last one out writes the tile's records.  Returns true if this walk posted anything.
-template <bool BUF>
-__device__ __forceinline__ bool walk_heavy(const line_source& src, const trace_args& a, const offer_ctx& oc, const lbvh_fast_node* __restrict__ nodes,
-                                           uint32_t item, const ray_t& r, uint32_t neg, uint32_t px0, uint32_t py0, bool act,
-                                           int w_node, int stack, uint32_t sp, uint32_t steps_before, float best_t, uint32_t best_tri,
-                                           float best_u, float best_v, bool record_live, uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits)
-{
-    const uint32_t lane = lane_id();
-    const uint32_t node_bytes = node_line_bytes(lane, true, neg);
-    const uint32_t axis = lane & 3u;
-    const float o_lane = axis == 0u ? r.ox : (axis == 1u ? r.oy : (axis == 2u ? r.oz : 0.0f));
-    tile_record& rec = oc.records[item];
-    uint32_t base = 0, steps = 0, since = oc.every;      // (the owner posts at its first chance)
-    bool posted = false, board_full = false;
-    for (;;) {
-        if (since >= oc.every && sp - base >= 2u) {
-            // post my oldest entry.  The tile's record first, if this is the tile's first posting: my hits so far (a miss carries
-            // line 0, which never wins; a lane without a ray -inf, which prunes everything) and one walk — mine — checked in
-            // one round trip: a slot of my workgroup's board (none left: the board has taken its share of this launch)
-            uint32_t idx = kNone;
-            if (lane == 0 && !board_full) idx = __hip_atomic_fetch_add(&oc.board->tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
-            if (idx < kBoardSlots) {
-                if (!record_live) {
-                    __hip_atomic_store(&rec.best[lane], ((unsigned long long)ordered_key(best_t) << 32) |
-                                                            (best_t < LBVH_MAX_FLOAT && act ? (unsigned long long)(oc.leaf_base + best_tri) : 0ull),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (lane == 0) {
-                        __hip_atomic_store(&rec.pending, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // my walk + this posting
-                        __hip_atomic_store(&rec.steps, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&rec.board, oc.my_board, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                } else if (lane == 0) {
-                    __hip_atomic_fetch_add(&rec.pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                record_live = true;
-                const uint32_t node = (uint32_t)__builtin_amdgcn_readlane(stack, base & 63u);
-                vm_drain();                                                 // the record (all lanes' write-through stores) before the posting
-                if (lane == 0)
-                    __hip_atomic_store(&oc.board->entry[idx], (1ull << 63) | ((unsigned long long)neg << 60) | ((unsigned long long)item << 30) | node,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                base++;
-                posted = true;
-            } else {
-                board_full = true;
-            }
-            since = 0;
-        }
-        const uint32_t lref = (uint32_t)__builtin_amdgcn_readlane(w_node, 3), rref = (uint32_t)__builtin_amdgcn_readlane(w_node, 7);
-        const bool leaf_l = (int)lref < 0, leaf_r = (int)rref < 0;
-        const int w_l = fetch_line<BUF>(src, lref, node_bytes);        // both children in flight before the tests
-        const int w_r = fetch_line<BUF>(src, rref, node_bytes);
-        steps++;
-        since++;
-        const int d = __float_as_int(__int_as_float(w_node) - o_lane);     // every plane minus the origin, once
-        const float tl = fmaxf(row_dword<0>(d) * r.ix, fmaxf(row_dword<1>(d) * r.iy, row_dword<2>(d) * r.iz));
-        const float fl = fminf(row_dword<4>(d) * r.ix, fminf(row_dword<5>(d) * r.iy, row_dword<6>(d) * r.iz));
-        const float tr = fmaxf(row_dword<8>(d) * r.ix, fmaxf(row_dword<9>(d) * r.iy, row_dword<10>(d) * r.iz));
-        const float fr = fminf(row_dword<12>(d) * r.ix, fminf(row_dword<13>(d) * r.iy, row_dword<14>(d) * r.iz));
-        const bool box_l = fl > max_zero(tl), box_r = fr > max_zero(tr);
-        const bool near_l = !(tl > best_t), near_r = !(tr > best_t);
-        bool hit_l = box_l && near_l, hit_r = box_r && near_r;
-        uint64_t ml = __builtin_amdgcn_ballot_w64(box_l) & __builtin_amdgcn_ballot_w64(near_l);
-        uint64_t mr = __builtin_amdgcn_ballot_w64(box_r) & __builtin_amdgcn_ballot_w64(near_r);
-        if (leaf_l) {
-            if (ml != 0) {
-                const lean_tri T = uniform_tri(w_l, o_lane);
-                float t, u, v;
-                if (lean_triangle(r, T, t, u, v) && hit_l && closer(t, T.index, best_t, best_tri)) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
-                const bool still_r = !(tr > best_t);
-                hit_r = hit_r && still_r;
-                mr &= __builtin_amdgcn_ballot_w64(still_r);
-            }
-            ml = 0;
-        }
-        if (leaf_r) {
-            if (mr != 0) {
-                const lean_tri T = uniform_tri(w_r, o_lane);
-                float t, u, v;
-                if (lean_triangle(r, T, t, u, v) && hit_r && closer(t, T.index, best_t, best_tri)) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
-                ml &= __builtin_amdgcn_ballot_w64(!(tl > best_t));
-            }
-            mr = 0;
-        }
-        if (ml != 0 && mr != 0) {
-            const uint64_t both = ml & mr, le = __builtin_amdgcn_ballot_w64(tl <= tr);
-            const int by_votes = lanes_in(both & le) - lanes_in(both & ~le), by_lanes = lanes_in(ml) - lanes_in(mr);
-            const bool l_near = (by_votes != 0 ? by_votes : by_lanes) >= 0;
-            push_slot(stack, (uint32_t)__builtin_amdgcn_readfirstlane((int)(l_near ? rref : lref)),
-                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(sp & 63u)));
-            sp++;
-            w_node = select_line(w_l, w_r, l_near);
-        } else if (ml != 0) {
-            w_node = w_l;
-        } else if (mr != 0) {
-            w_node = w_r;
-        } else {
-            if (sp == base) break;
-            sp--;
-            w_node = fetch_line<BUF>(src, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), node_bytes);
-        }
-    }
-    const uint32_t walked = steps_before + steps;
-    if (!record_live) {
-        // never shared: the records from my registers, like any light tile
-        if (lane == 0) cost[item] = walked;
-        if (act) reinterpret_cast<float4*>(hits)[hit_slot(a, item, lane, px0, py0)] = make_float4(best_t, __uint_as_float(best_tri), best_u, best_v);
-        if (oc.linger && lane == 0) __hip_atomic_fetch_sub(&oc.board->unfinished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return posted;
-    }
-    // merge my hits into the tile's record and check this walk out; the last one out writes the tile's records
-    if (act && best_t < LBVH_MAX_FLOAT)
-        __hip_atomic_fetch_min(&rec.best[lane], ((unsigned long long)ordered_key(best_t) << 32) | (unsigned long long)(oc.leaf_base + best_tri),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t left = 1;
-    if (lane == 0) __hip_atomic_fetch_add(&rec.steps, walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    vm_drain();                  // my merges have been performed at the memory side before I check out
-    if (lane == 0) left = __hip_atomic_fetch_sub(&rec.pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
-    left = (uint32_t)__builtin_amdgcn_readfirstlane((int)left);
-    if (left == 0u) {
-        if (oc.linger && lane == 0)
-            __hip_atomic_fetch_sub(&oc.boards[__hip_atomic_load(&rec.board, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)].unfinished, 1u,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 0) cost[item] = __hip_atomic_load(&rec.steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (act) {
-            const unsigned long long key = __hip_atomic_load(&rec.best[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float t = key_value((uint32_t)(key >> 32));
-            float4 out = make_float4(LBVH_MAX_FLOAT, __uint_as_float(0u), 0.0f, 0.0f);
-            if (t < LBVH_MAX_FLOAT) {
-                // barycentrics (and the original index) from the winning triangle: the same arithmetic as in the walk
-                float4 v0, v1, v2;
-                unpack_fast_triangle(reinterpret_cast<const float4*>(&nodes[(uint32_t)key]), v0, v1, v2);   // a triangle line
-                float u = 0.0f, v = 0.0f;
-                const float dist = ray_fast_triangle(r, v0, v1, v2, u, v);
-                out = make_float4(dist, v0.w, u, v);
-            }
-            reinterpret_cast<float4*>(hits)[hit_slot(a, item, lane, px0, py0)] = out;
-        }
-    }
-    return posted;
-}
-
-// One tile per wave, four per workgroup, dealt as trace_packet_kernel deals them; heavy tiles post subtrees, finishing waves
-// take them.
-template <bool BUF>
-__device__ __forceinline__ void offer_wave(const trace_args& a, const offer_ctx& oc, const lbvh_fast_node* __restrict__ nodes, uint32_t n_work,
-                                           const uint32_t* __restrict__ counts, const uint32_t* __restrict__ lists,
-                                           uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits)
-{
-    const uint32_t lane = lane_id();
-    line_source src;
-    src.lines = nodes;
-    src.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<lbvh_fast_node*>(nodes), 0, (int)a.line_bytes, 0x00020000);
-    // is anything posted?  Asked now, looked at when my tile is done: the answer is a tile's run time old and costs it nothing
-    const uint32_t head0 = __hip_atomic_load(&oc.board->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t tail0 = __hip_atomic_load(&oc.board->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bool posted = false;
-    uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
-    bool valid = w < n_work;
-    if (valid && counts) {        // the w-th item of the class lists, heaviest class first (they partition the work items)
-        uint32_t k = w;
-        int c = kOrderClasses - 1;
-        for (; c > 0 && k >= counts[c]; c--) k -= counts[c];
-        w = lists[(size_t)c * n_work + k];
-    }
-    if (valid && shard_tile(w, a.shard_index, a.shard_count) >= a.tiles_x * a.tiles_y) {      // tail of the last group
-        if (lane == 0) cost[w] = 0;
-        valid = false;
-    }
-    if (valid) {
-        if (oc.linger && lane == 0) __hip_atomic_fetch_add(&oc.board->unfinished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        packet_rays<1> P;
-        uint32_t px0, py0, neg = 0;
-        tile_rays<1, 1>(a, shard_tile(w, a.shard_index, a.shard_count), lane, P, px0, py0);
-        P.best_t[0] = LBVH_MAX_FLOAT; P.best_tri[0] = 0; P.best_u[0] = 0.0f; P.best_v[0] = 0.0f;
-        const bool ordered = packet_signs(P, neg);
-        if (ordered && packet_one_origin(P)) {
-            lean_handoff ho;
-            const uint32_t steps = walk_packet_lean<BUF, true>(src, P, neg, oc.cap, &ho);
-            if (!ho.pending) {
-                if (lane == 0) cost[w] = steps;
-                if (P.act[0])
-                    reinterpret_cast<float4*>(hits)[hit_slot(a, w, lane, px0, py0)] =
-                        make_float4(P.best_t[0], __uint_as_float(P.best_tri[0]), P.best_u[0], P.best_v[0]);
-                if (oc.linger && lane == 0) __hip_atomic_fetch_sub(&oc.board->unfinished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                posted = walk_heavy<BUF>(src, a, oc, nodes, w, P.ray[0], neg, px0, py0, P.act[0], ho.w_node, ho.stack, ho.sp, steps,
-                                         P.act[0] ? P.best_t[0] : -INFINITY, P.best_tri[0], P.best_u[0], P.best_v[0], false, cost, hits);
-            }
-        } else {            // the image's centre lines: the generic walker, alone
-            walk_counters C = {0, 0, 0, 0};
-            const uint32_t steps = ordered ? walk_packet<false, 1, true, BUF>(src, P, C, neg) : walk_packet<false, 1, false, BUF>(src, P, C, 0u);
-            if (lane == 0) cost[w] = steps;
-            if (P.act[0])
-                reinterpret_cast<float4*>(hits)[hit_slot(a, w, lane, px0, py0)] =
-                    make_float4(P.best_t[0], __uint_as_float(P.best_tri[0]), P.best_u[0], P.best_v[0]);
-            if (oc.linger && lane == 0) __hip_atomic_fetch_sub(&oc.board->unfinished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    // my tile is done: anything on the board?  (the early answer unless I posted myself: then my postings may still be there)
-    bool maybe = head0 < min(tail0, kBoardSlots) || posted || oc.linger != 0;
-    while (maybe) {
-        uint32_t idx = kNone;
-        if (lane == 0) {
-            for (int tries = 0; tries < 8; tries++) {
-                const uint32_t h = __hip_atomic_load(&oc.board->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t t = min(__hip_atomic_load(&oc.board->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kBoardSlots);
-                if (h >= t) {
-                    // nothing posted.  A lingering launch: tiles of my board still running may post yet — wait for that
-                    if (oc.linger && __hip_atomic_load(&oc.board->unfinished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                        __builtin_amdgcn_s_sleep(64);
-                        tries = 0;
-                        continue;
-                    }
-                    break;
-                }
-                uint32_t expect = h;
-                if (__hip_atomic_compare_exchange_strong(&oc.board->head, &expect, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    idx = h;
-                    break;
-                }
-            }
-        }
-        idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
-        if (idx == kNone) break;
-        // the posting (its writer reserved the slot before filling it: wait for the sequence word — a running wave writes it)
-        uint32_t item = kNone, node = 0, eneg = 0;
-        if (lane == 0) {
-            unsigned long long e = 0;
-            for (uint32_t spin = 0; spin <= LBVH_SPIN_LIMIT; spin++) {
-                e = __hip_atomic_load(&oc.board->entry[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (e != 0) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (e != 0) {
-                item = (uint32_t)(e >> 30) & 0x3FFFFFFFu;
-                node = (uint32_t)e & 0x3FFFFFFFu;
-                eneg = (uint32_t)(e >> 60) & 7u;
-            } else {
-                __hip_atomic_store(oc.fault, LBVH_FAULT_TRACE_BOARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
-        node = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
-        eneg = (uint32_t)__builtin_amdgcn_readfirstlane((int)eneg);
-        if (item == kNone) break;
-        // that tile's rays, its best hits as of now, and the subtree
-        packet_rays<1> P;
-        uint32_t px0, py0;
-        tile_rays<1, 1>(a, shard_tile(item, a.shard_index, a.shard_count), lane, P, px0, py0);
-        const unsigned long long key = __hip_atomic_load(&oc.records[item].best[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float t0 = key_value((uint32_t)(key >> 32));
-        const uint32_t node_bytes = node_line_bytes(lane, true, eneg);
-        const int w_node = fetch_line<BUF>(src, node, node_bytes);
-        // (best_tri of the snapshot: the record holds the line; a helper only merges hits of its own, strictly better or tying lower)
-        const uint32_t tri0 = (uint32_t)key >= oc.leaf_base ? (uint32_t)key - oc.leaf_base : 0u;
-        posted = walk_heavy<BUF>(src, a, oc, nodes, item, P.ray[0], eneg, px0, py0, P.act[0], w_node, 0, 0u, 0u, P.act[0] ? t0 : -INFINITY, tri0,
-                                 0.0f, 0.0f, true, cost, hits) || posted;
-        maybe = true;            // look again: more may have been posted meanwhile (and mine must not be left behind)
-    }
-}
-
-__global__ __launch_bounds__(256) void trace_offer_kernel(trace_args a, offer_ctx oc, share_board* next_boards, const lbvh_fast_node* __restrict__ nodes,
-                                                          uint32_t n_work, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ lists,
-                                                          uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits)
-{
-    // the boards of the NEXT launch of this context start empty (launches of a context are stream-ordered)
-    // (workgroup k clears board k: 4 KB = 256 threads x 16 bytes; grids smaller than kBoards clear several each)
-    for (uint32_t k = blockIdx.x; k < kBoards; k += gridDim.x)
-        reinterpret_cast<uint4*>(&next_boards[k])[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
-    oc.my_board = blockIdx.x % oc.n_boards;
-    oc.board = oc.boards + oc.my_board;
-    if (a.line_bytes != 0) offer_wave<true>(a, oc, nodes, n_work, counts, lists, cost, hits);
-    else offer_wave<false>(a, oc, nodes, n_work, counts, lists, cost, hits);
-}
-
 // A full chip (a whole frame on one GPU): one wave per tile, 4 tiles per workgroup, the w-th tile of the class
 // lists, heaviest class first.  No cooperative tiles: with every wave slot taken they do not pay (287 -> 304 us).
 template <bool STATS>
@@ -1658,41 +1298,7 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     // (a moved camera: the plain kernel — the widened costs would make every neighbour of a heavy tile cooperative, 0.27 - 0.29 ms;
     // marking by the un-widened reprojected cost finds too few of them: 0.20 - 0.22 against 0.21 plain)
     const bool whole = n_work > kSharedMaxWork && spread == 0;
-    static const int adapt_env = getenv("LBVH_ADAPT") ? atoi(getenv("LBVH_ADAPT")) : 1;                 // measurement switches
-    static const uint32_t offer_cap = getenv("LBVH_OFFER_CAP") ? (uint32_t)atoi(getenv("LBVH_OFFER_CAP")) : (uint32_t)LBVH_OFFER_CAP;
-    static const uint32_t offer_every = getenv("LBVH_OFFER_EVERY") ? (uint32_t)atoi(getenv("LBVH_OFFER_EVERY")) : (uint32_t)LBVH_OFFER_EVERY;
-    static const int adapt_order = getenv("LBVH_ADAPT_ORDER") ? atoi(getenv("LBVH_ADAPT_ORDER")) : 1;
-    if (adapt_env && !d_stats && n_work < (1u << 30)) {      // (a posting packs the work item into 30 bits)
-        // in-flight cooperation (trace_offer_kernel): who shares is decided while the frame runs; the history, when there is
-        // one, only orders the dispatch
-        const size_t board_bytes = 2 * (size_t)kBoards * sizeof(share_board), rec_bytes = (size_t)n_work * sizeof(tile_record);
-        void* before_board = ctx->trace_board;
-        rc = lbvh_reserve(ctx, &ctx->trace_board, &ctx->trace_board_bytes, board_bytes + rec_bytes);
-        if (rc != LBVH_OK) return rc;
-        if (ctx->trace_board != before_board)          // new memory: both sets of boards start empty (afterwards each launch clears the next one's)
-            LBVH_HIP_TRY(ctx, hipMemsetAsync(ctx->trace_board, 0, board_bytes, ctx->cur_stream));
-        ctx->trace_epoch++;
-        share_board* boards = (share_board*)ctx->trace_board;
-        offer_ctx oc;
-        oc.boards = boards + (size_t)(ctx->trace_epoch & 1u) * kBoards;
-        oc.board = oc.boards;
-        oc.my_board = 0;
-        {
-            // a launch that cannot fill the chip (a GPU's share of a frame): nobody wants the slot of a wave whose tile is done,
-            // so it stays and helps; fewer boards then, so that a posting is seen by more of them
-            static const int linger_env = getenv("LBVH_OFFER_LINGER") ? atoi(getenv("LBVH_OFFER_LINGER")) : 1;
-            const uint32_t blocks_ = (n_work + 3) / 4;
-            oc.linger = linger_env && blocks_ <= 1536u ? 1u : 0u;
-            oc.n_boards = oc.linger ? std::max(1u, std::min(kBoards, blocks_ / 8u)) : kBoards;
-        }
-        oc.records = (tile_record*)((char*)ctx->trace_board + board_bytes);
-        oc.cap = offer_cap; oc.every = offer_every;
-        oc.leaf_base = ctx->fast_capacity;
-        oc.fault = ctx->fault_dev;
-        const uint32_t blocks = (n_work + 3) / 4;
-        LBVH_LAUNCH(ctx, trace_offer_kernel, dim3(blocks), dim3(256), a, oc, boards + (size_t)((ctx->trace_epoch & 1u) ^ 1u) * kBoards, ctx->fast_nodes, n_work,
-                    have_history && adapt_order ? counts : nullptr, lists, cost, d_hits);
-    } else if (have_history && whole) {
+    if (have_history && whole) {
         coop_params hp = {n_work / 4u, kHeavyClassWhole, kCoopGrain};
         const uint32_t blocks = hp.cap + (n_work + kCoopWavesWhole - 1) / kCoopWavesWhole;
         if (d_stats)
