@@ -579,7 +579,7 @@ def main():
         if world == 1 and not args.no_dynamic and not cfg4:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import dynamic_bench                               # cfg5: animate + rebuild + primary + 4 bounces per frame
-            dynamic = dynamic_bench.run(ctx, frames=10, warmup=2)
+            dynamic = dynamic_bench.run(ctx, frames=10, warmup=2, live=live)
 
         out = {
             "metric": "LBVH build Mtri/s + primary Mrays/s at 1080p on 1M-tri synthetic mesh",

@@ -90,6 +90,8 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern int lbvh_debug_ray_stack_split(IntPtr ctx, uint ldsEntries);
     [DllImport(Lib)] public static extern int lbvh_debug_ray_walker(IntPtr ctx, uint walker);
     [DllImport(Lib)] public static extern int lbvh_debug_ray_stack_limit(IntPtr ctx, uint deepEntries);
+    // measurement: the four-wide per-ray walkers add {rays, node lines fetched, triangles tested} (3 x ulong) while set
+    [DllImport(Lib)] public static extern int lbvh_ray_stats_target(IntPtr ctx, IntPtr dStats);
 
     // one frame from N GPUs (BASELINE configs[2]): peer-mapped frame buffer, ordering between contexts of this process
     // (sync events) or between processes (IPC handle of the buffer + completion flags waited for on the device), and
@@ -128,6 +130,9 @@ public static class LbvhNative
     // dynamic scene + secondary rays (BASELINE configs[4]; extension, no reference counterpart)
     [DllImport(Lib)] public static extern int lbvh_animate(IntPtr ctx, IntPtr dRestTriangles, uint n, IntPtr dBodyIds, IntPtr dBodyCentres,
         float cosAngle, float sinAngle, IntPtr dTrianglesOut);
+    [DllImport(Lib)] public static extern int lbvh_animate_build_scene(IntPtr ctx, IntPtr dRestTriangles, IntPtr dBodyIds, IntPtr dBodyCentres,
+        float cosAngle, float sinAngle, IntPtr dTriangles, uint n, uint capacity, float[] boxMin, float[] boxMax, IntPtr dKeys, IntPtr dIndices,
+        IntPtr dAabb, IntPtr dInternal, IntPtr dLeaf, IntPtr dBvh, uint flags);
     [DllImport(Lib)] public static extern int lbvh_path_begin(IntPtr ctx, ref Camera camera, IntPtr dStates);
     [DllImport(Lib)] public static extern int lbvh_trace_rays(IntPtr ctx, IntPtr dStates, UIntPtr count, float tMin, ref Scene scene, IntPtr dHits);
     [DllImport(Lib)] public static extern int lbvh_path_scatter(IntPtr ctx, ref Scene scene, IntPtr dHits, UIntPtr count, uint bounce, uint seed,

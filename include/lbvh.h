@@ -441,6 +441,15 @@ lbvh_status lbvh_animate(lbvh_context* ctx, const lbvh_triangle* d_rest, uint32_
                          const float* d_centres /* n_bodies x 4 floats (xyz, pad) */, float cos_angle, float sin_angle,
                          lbvh_triangle* d_out);
 
+/* lbvh_animate followed by lbvh_build_scene as one call, with identical results: the moved triangles go to d_triangles AND
+ * straight into the Morton / AABB stage (one kernel: as two, the 128-byte records were written and read back for the 36 bytes
+ * of their positions).  The per-frame chain of a dynamic scene (BASELINE configs[4]); every other argument as lbvh_build_scene. */
+lbvh_status lbvh_animate_build_scene(lbvh_context* ctx, const lbvh_triangle* d_rest, const uint32_t* d_body, const float* d_centres,
+                                     float cos_angle, float sin_angle, lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
+                                     const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
+                                     lbvh_aabb* d_aabb, lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh,
+                                     uint32_t flags);
+
 /* One path vertex per pixel: 64 bytes. */
 typedef struct lbvh_path_state {
     float origin[3];     uint32_t alive;     /* 1 while the path continues                      */
@@ -465,6 +474,17 @@ lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, 
  * lbvh_path_bounce spills to its device-memory slab.  Results do not depend on it; tests lower it so the deep part
  * of the stack is exercised by ordinary scenes. */
 lbvh_status lbvh_debug_ray_stack_split(lbvh_context* ctx, uint32_t lds_entries);
+
+/* Measurement aid (cfg5's roofline): while d_stats is non-NULL, every launch of the four-wide per-ray walk (lbvh_trace_rays,
+ * lbvh_path_bounce, lbvh_path_first_bounce) ADDS what it did to it: rays walked, 128-byte four-wide node lines fetched (one per
+ * ray-step), triangle lines fetched and tested.  Zero it yourself; NULL switches the counting off (the default: the counting
+ * kernels are separate instantiations, the product's carry none of it). */
+typedef struct lbvh_ray_stats {
+    uint64_t rays;
+    uint64_t node_fetches;
+    uint64_t triangle_tests;
+} lbvh_ray_stats;
+lbvh_status lbvh_ray_stats_target(lbvh_context* ctx, lbvh_ray_stats* d_stats);
 
 /* Test hook: how many entries of the device-memory part of a ray's stack the walkers may use (0 = all of it: 48 for the
  * binary walk, 112 for the four-wide one — more than any tree of this library can ask for).  A stack that runs out does not

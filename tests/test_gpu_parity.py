@@ -1240,6 +1240,123 @@ def test_secondary_rays_and_path_trace_bit_exact(ctx):
     pt.drawer.on_destroy()
 
 
+def test_animate_build_scene_equals_animate_plus_rebuild(ctx):
+    """lbvh_animate_build_scene (one fused animate + Morton kernel in front of the replayed chain) leaves every array exactly as
+    lbvh_animate + lbvh_build_scene do: moved triangles, keys, indices, boxes, nodes — and the traced frame; over several
+    frames (the second call on captures the graph, later ones replay it) and a triangle count off the workgroup size."""
+    tris, body, centres = scenes.tiled_torus(nu=36, nv=22, grid=3, with_bodies=True)
+    tris, body = tris[:-37], body[:-37]
+    a = H().DynamicPathTracer(ctx, tris, body, centres, seed=3)
+    c2 = H().Context(0)
+    try:
+        b = H().DynamicPathTracer(c2, tris, body, centres, seed=3)
+        cam = scenes.camera(200, 120, (0.0, 0.0, 150.0))
+        for f in range(4):
+            a.animate(0.07 * (f + 1))                    # fused
+            b.animate(0.07 * (f + 1), fused=False)       # two calls
+            ca, cb = a.drawer.container, b.drawer.container
+            ca.get_all_gpu_data(); cb.get_all_gpu_data()
+            n = ca.triangles_length
+            for x, y in ((ca.triangle_data, cb.triangle_data), (ca.keys, cb.keys), (ca.triangle_index, cb.triangle_index),
+                         (ca.bvh_internal_node, cb.bvh_internal_node), (ca.bvh_leaf_node, cb.bvh_leaf_node)):
+                assert (words(x.local) == words(y.local)).all()
+            assert (words(ca.triangle_aabb.local[:n]) == words(cb.triangle_aabb.local[:n])).all()
+            assert (words(ca.bvh_data.local[: n - 1]) == words(cb.bvh_data.local[: n - 1])).all()
+            moved = O.animate(tris, body, centres, 0.07 * (f + 1))
+            assert (words(ca.triangle_data.local[:n]) == words(moved)).all()
+            a.render(cam, bounces=2); b.render(cam, bounces=2)
+            assert (a.image().view(np.uint16) == b.image().view(np.uint16)).all()
+        b.drawer.on_destroy()
+    finally:
+        c2.close()
+    a.drawer.on_destroy()
+
+
+def test_cfg5_full_size_frame_against_the_oracle(ctx):
+    """BASELINE configs[4] at its own size: 1 000 000 triangles in 125 rotating bodies, 1920 x 1080, primary
+    rays + 4 bounces — the frame DynamicPathTracer renders after an animated rebuild, against the oracle's path states on every
+    16th pixel (a 4 x 4 grid of the frame; the oracle walks those paths only, the others are dead from the start).  As in the
+    small scenes: a path that met two triangles at exactly the same t may continue from the other one; every other sampled
+    path must agree bit for bit in origin, direction, throughput, radiance and in its RGBA16F pixel."""
+    W, Ht = 1920, 1080
+    tris, body, centres = scenes.tiled_torus(with_bodies=True)
+    assert len(tris) == 1_000_000
+    pt = H().DynamicPathTracer(ctx, tris, body, centres, t_min=1e-3, albedo=0.7, seed=9)
+    angle = 0.03
+    pt.animate(angle)
+    cam = scenes.camera(W, Ht, (0.0, 0.0, 250.0))
+    pt.render(cam, bounces=4)
+    gst = pt.states.get_data()[: W * Ht].reshape(Ht, W)
+    img = pt.image()
+    # the rebuilt tree itself, at size, word for word
+    moved = O.animate(tris, body, centres, angle)
+    b = O.Built(moved, capacity=pt.drawer.container.capacity, threads=8)
+    c = pt.drawer.container
+    c.get_all_gpu_data()
+    assert (c.keys.local == b.keys).all() and (c.triangle_index.local == b.indices).all()
+    assert (words(c.bvh_internal_node.local) == words(b.internal)).all()
+    # the oracle's paths on the grid x = 1, 5, 9, ...; y = 2, 6, 10, ...
+    st = O.path_begin(cam).reshape(Ht, W)
+    sampled = np.zeros((Ht, W), dtype=bool)
+    sampled[2::4, 1::4] = True
+    st["alive"][~sampled] = 0
+    ph, _ = O.trace_primary(b, cam, rect=(1, 2, W, Ht), step=(4, 4), threads=8)
+    hits = np.zeros((Ht, W), dtype=L.HIT)
+    hits["t"] = L.MAX_FLOAT
+    hits[2::4, 1::4] = ph
+    flat = st.reshape(-1)
+    O.path_scatter(b, hits.reshape(-1), flat, 0, 9, 0.7)
+    for k in range(1, 5):
+        h = O.trace_rays(b, flat, 1e-3, threads=8)
+        O.path_scatter(b, h, flat, k, 9, 0.7)
+    oimg = O.path_resolve(flat).reshape(Ht, W, 4)
+    g, o = gst[sampled], st[sampled]
+    same = (g["origin"] == o["origin"]).all(axis=1) & (g["dir"] == o["dir"]).all(axis=1)
+    assert len(g) == 270 * 480 and same.mean() > 0.995, same.mean()
+    for field in ("throughput", "radiance"):
+        assert (g[field][same].view(np.uint32) == o[field][same].view(np.uint32)).all(), field
+    assert (g["alpha"][same] == o["alpha"][same]).all() and (g["alive"][same] == o["alive"][same]).all()
+    assert (img[sampled].view(np.uint16)[same] == oimg[sampled].view(np.uint16)[same]).all()
+    assert 0.3 < float((img[..., 3] > 0).mean()) < 0.6             # the primary hit fraction of cfg2's camera
+    pt.drawer.on_destroy()
+
+
+def test_ray_walk_statistics(ctx):
+    """lbvh_ray_stats_target: the four-wide walkers' own counters (the algorithmic bytes of cfg5's roofline) — every live ray
+    counted once, at least one node line per ray, counts identical for both four-wide kernels' instantiations with and
+    without the counting (hit records unchanged), nothing counted once the target is cleared."""
+    tris = scenes.tiled_torus(nu=24, nv=16, grid=2)
+    d = H().RaytracingMeshDrawer(ctx, tris).awake()
+    W, Ht = 160, 96
+    cam = N().Camera.from_dict(scenes.camera(W, Ht, (0.0, 0.0, 120.0)))
+    states = H().DataBuffer(ctx, W * Ht, L.PATH_STATE)
+    hits = H().DataBuffer(ctx, W * Ht, L.HIT)
+    stats = H().DataBuffer(ctx, 1, L.RAY_STATS)
+    s = d.container.scene()
+    N().check(ctx.handle, N().lib.lbvh_path_begin(ctx.handle, C.byref(cam), states.device))
+    N().check(ctx.handle, N().lib.lbvh_trace_rays(ctx.handle, states.device, W * Ht, 0.0, C.byref(s), hits.device))
+    plain = hits.get_data().copy()
+    try:
+        for walker in (1, 2):
+            N().check(ctx.handle, N().lib.lbvh_debug_ray_walker(ctx.handle, walker))
+            stats.fill_u32(0)
+            N().check(ctx.handle, N().lib.lbvh_ray_stats_target(ctx.handle, stats.device))
+            N().check(ctx.handle, N().lib.lbvh_trace_rays(ctx.handle, states.device, W * Ht, 0.0, C.byref(s), hits.device))
+            N().check(ctx.handle, N().lib.lbvh_ray_stats_target(ctx.handle, None))
+            st = stats.get_data()[0].copy()
+            assert int(st["rays"]) == W * Ht and int(st["node_fetches"]) >= W * Ht
+            assert int(st["triangle_tests"]) >= int((plain["t"] < L.MAX_FLOAT).sum())
+            assert (words(hits.get_data()) == words(plain)).all()
+            N().check(ctx.handle, N().lib.lbvh_trace_rays(ctx.handle, states.device, W * Ht, 0.0, C.byref(s), hits.device))
+            assert (words(stats.get_data()) == words(np.array([st]))).all()        # target cleared: nothing added
+    finally:
+        N().check(ctx.handle, N().lib.lbvh_ray_stats_target(ctx.handle, None))
+        N().check(ctx.handle, N().lib.lbvh_debug_ray_walker(ctx.handle, 1))
+    for bfr in (states, hits, stats):
+        bfr.dispose()
+    d.on_destroy()
+
+
 @pytest.mark.parametrize("lds_entries", [1, 2, 5])
 def test_secondary_rays_deep_stack_in_device_memory(ctx, lds_entries):
     """The per-ray walk keeps the first 16 stack entries of a lane in LDS and deeper ones in a device-memory slab.

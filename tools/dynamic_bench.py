@@ -13,9 +13,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(ctx, frames=20, warmup=3, bounces=4, w=1920, h=1080, profile=True):
+HBM_PEAK_GBS = 8000.0
+
+
+def run(ctx, frames=20, warmup=3, bounces=4, w=1920, h=1080, profile=True, live=False):
+    import ctypes as C
+    from unitysimpleraytracing_amd import _native as N
+    from unitysimpleraytracing_amd import layouts as L
     from unitysimpleraytracing_amd import scenes
-    from unitysimpleraytracing_amd.host import DynamicPathTracer
+    from unitysimpleraytracing_amd.host import DataBuffer, DynamicPathTracer
     tris, body, centres = scenes.tiled_torus(with_bodies=True)
     cam = scenes.camera(w, h, (0.0, 0.0, 250.0))
     pt = DynamicPathTracer(ctx, tris, body, centres)
@@ -37,7 +43,40 @@ def run(ctx, frames=20, warmup=3, bounces=4, w=1920, h=1080, profile=True):
         for f in range(5):
             pt.animate(0.01 * f)
             pt.render(cam, bounces)
-        out["kernels_ms_per_frame"] = {k: round(v[1] / 5.0, 4) for k, v in ctx.profile_end().items()}
+        prof = ctx.profile_end()
+        out["kernels_ms_per_frame"] = {k: round(v[1] / 5.0, 4) for k, v in prof.items()}
+        # ---- roofline of the frame's dominant kernels: the per-ray walk of the four bounces (HBM is the roofline of
+        # every stage).  Algorithmic bytes from the walk's own counters of one more frame (lbvh_ray_stats_target): 128 B per
+        # four-wide node line a ray fetches + 64 B per triangle line it tests + 64 B of path state in + 16 B hit record out per ray.
+        stats = DataBuffer(ctx, 1, L.RAY_STATS)
+        stats.fill_u32(0)
+        N.check(ctx.handle, N.lib.lbvh_ray_stats_target(ctx.handle, stats.device))
+        pt.animate(0.01 * 2)
+        pt.render(cam, bounces)
+        N.check(ctx.handle, N.lib.lbvh_ray_stats_target(ctx.handle, None))
+        st = stats.get_data()[0]
+        stats.dispose()
+        walk_ms = sum(v[1] for k, v in prof.items() if "trace_rays_wide" in k) / 5.0
+        alg = 128.0 * float(st["node_fetches"]) + 64.0 * float(st["triangle_tests"]) + 80.0 * float(st["rays"])
+        achieved = alg / (walk_ms * 1e-3) / 1e9
+        traffic = None
+        if live:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import live_counters as LC
+            child = [os.path.join(ROOT, "tools", "dynamic_bench.py"), "--frames", "3", "--no-profile"]
+            per_launch = LC.hbm_traffic(child, "trace_rays_wide", pick="mean")
+            if per_launch:            # mean per launch of either walker x the frame's four launches
+                traffic = {k: (round(v * bounces) if isinstance(v, (int, float)) else v) for k, v in per_launch.items()}
+                traffic["basis"] = "mean per launch of trace_rays_wide_kernel / trace_rays_wide_chain_kernel x %d launches per frame" % bounces
+        out["roofline"] = {"kernel": "trace_rays_wide_kernel + trace_rays_wide_chain_kernel (the %d bounces of a frame)" % bounces,
+                           "kernel_ms": round(walk_ms, 4), "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes": round(alg),
+                           "rays": int(st["rays"]), "node_fetches_per_ray": round(float(st["node_fetches"]) / max(float(st["rays"]), 1.0), 1),
+                           "triangle_tests_per_ray": round(float(st["triangle_tests"]) / max(float(st["rays"]), 1.0), 2),
+                           "bytes_basis": "128 B per four-wide node line + 64 B per triangle line + 64 B path state + 16 B hit record per ray, "
+                                          "this frame's counters (lbvh_ray_stats_target); divergent per-ray fetches: the lines come mostly from L2, "
+                                          "`traffic` is what reached HBM",
+                           "traffic": traffic}
     img = pt.image()
     out["alpha_fraction"] = round(float((img[..., 3] > 0).mean()), 4)
     out["mean_rgb"] = [round(float(x), 4) for x in img[..., :3].astype(np.float32).mean(axis=(0, 1))]
@@ -46,6 +85,12 @@ def run(ctx, frames=20, warmup=3, bounces=4, w=1920, h=1080, profile=True):
 
 
 if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=20)
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--live", action="store_true", help="FETCH_SIZE / WRITE_SIZE child passes for the roofline's traffic")
+    a = ap.parse_args()
     from unitysimpleraytracing_amd.host import Context
     with Context(0) as ctx:
-        print(json.dumps(run(ctx)))
+        print(json.dumps(run(ctx, frames=a.frames, profile=not a.no_profile, live=a.live)))

@@ -88,6 +88,7 @@ SIGNATURES = {
     "lbvh_key_histogram_device": (_I32, [_P, _P, _U32, _P, _U32, _U32, _U32, _P]),
     "lbvh_lower_bound_device": (_I32, [_P, _P, _U32, _P, _U32, _P]),
     "lbvh_animate": (_I32, [_P, _P, _U32, _P, _P, C.c_float, C.c_float, _P]),
+    "lbvh_animate_build_scene": (_I32, [_P, _P, _P, _P, C.c_float, C.c_float, _P, _U32, _U32, _F3, _F3, _P, _P, _P, _P, _P, _P, _U32]),
     "lbvh_trace_rays": (_I32, [_P, _P, _SZ, C.c_float, C.POINTER(Scene), _P]),
     "lbvh_path_begin": (_I32, [_P, C.POINTER(Camera), _P]),
     "lbvh_path_scatter": (_I32, [_P, C.POINTER(Scene), _P, _SZ, _U32, _U32, C.c_float, _P]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "lbvh_debug_ray_stack_split": (_I32, [_P, _U32]),
     "lbvh_debug_ray_walker": (_I32, [_P, _U32]),
     "lbvh_debug_ray_stack_limit": (_I32, [_P, _U32]),
+    "lbvh_ray_stats_target": (_I32, [_P, _P]),
     "lbvh_peer_enable": (_I32, [_P, _I32]),
     "lbvh_sync_event_create": (_I32, [_P, C.POINTER(_P)]),
     "lbvh_event_wait": (_I32, [_P, _P]),

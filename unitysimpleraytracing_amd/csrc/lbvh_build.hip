@@ -28,6 +28,42 @@ __device__ __forceinline__ uint32_t quantize(float x)          // MeshBufferCont
     return (uint32_t)x;
 }
 
+// one triangle's Morton code, index, padded AABB (and, for lbvh_build_scene, its 64-byte traversal line) from its three
+// positions: the loop body of MeshBufferContainer.cs:123-146.  Key and index go to memory, box and line to the workgroup's
+// LDS staging (the caller stores them as whole records).
+__device__ __forceinline__ void morton_of_triangle(const float4 a, const float4 b, const float4 c, uint32_t i, const box3& scene,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ indices, float4* s_box,
+                                                   float4* s_line, bool with_line)
+{
+    const float ax[3] = {a.x, a.y, a.z}, bx[3] = {b.x, b.y, b.z}, cx[3] = {c.x, c.y, c.z};
+    float mn[3], mx[3];
+    uint32_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        mn[k] = fminf(fminf(ax[k], bx[k]), cx[k]) - 0.001f;      // GetCentroidAndAABB :54-63
+        mx[k] = fmaxf(fmaxf(ax[k], bx[k]), cx[k]) + 0.001f;
+        float cen = (mn[k] + mx[k]) * 0.5f;                      // :65
+        cen = cen - scene.mn[k];                                 // NormalizeCentroid :76-81
+        cen = cen / (scene.mx[k] - scene.mn[k]);
+        q[k] = quantize(cen);
+    }
+    keys[i] = expand_bits(q[0]) * 4u + expand_bits(q[1]) * 2u + expand_bits(q[2]);   // :46-49
+    indices[i] = i;
+    s_box[threadIdx.x * 2 + 0] = make_float4(mn[0], mn[1], mn[2], 0.0f);
+    s_box[threadIdx.x * 2 + 1] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+    if (with_line) {
+        // lbvh_build_scene: the derived scene's triangle line (lbvh_common.h lbvh_fast_tri: first vertex, the two edge
+        // vectors of Raytracing.compute:41-42, the triangle's index), in ORIGINAL order — the positions are in
+        // registers here, so no kernel has to gather the 128-byte records again after the sort
+        const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
+        const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
+        s_line[threadIdx.x * 4 + 0] = make_float4(a.x, a.y, a.z, __uint_as_float(i));
+        s_line[threadIdx.x * 4 + 1] = make_float4(a.x, a.y, a.z, e2x);
+        s_line[threadIdx.x * 4 + 2] = make_float4(e1x, e1y, e1z, e2y);
+        s_line[threadIdx.x * 4 + 3] = make_float4(e1x, e1y, e1z, e2z);
+    }
+}
+
 __global__ __launch_bounds__(256) void morton_aabb_kernel(const lbvh_triangle* __restrict__ tris,
                                                           uint32_t n, uint32_t capacity, box3 scene,
                                                           uint32_t* __restrict__ keys,
@@ -51,34 +87,7 @@ __global__ __launch_bounds__(256) void morton_aabb_kernel(const lbvh_triangle* _
     if (i < n) {
         // only the three padded positions (48 of the 128 bytes) are read
         const float4* p = reinterpret_cast<const float4*>(&tris[i]);
-        const float4 a = p[0], b = p[1], c = p[2];
-        const float ax[3] = {a.x, a.y, a.z}, bx[3] = {b.x, b.y, b.z}, cx[3] = {c.x, c.y, c.z};
-        float mn[3], mx[3];
-        uint32_t q[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            mn[k] = fminf(fminf(ax[k], bx[k]), cx[k]) - 0.001f;      // GetCentroidAndAABB :54-63
-            mx[k] = fmaxf(fmaxf(ax[k], bx[k]), cx[k]) + 0.001f;
-            float cen = (mn[k] + mx[k]) * 0.5f;                      // :65
-            cen = cen - scene.mn[k];                                 // NormalizeCentroid :76-81
-            cen = cen / (scene.mx[k] - scene.mn[k]);
-            q[k] = quantize(cen);
-        }
-        keys[i] = expand_bits(q[0]) * 4u + expand_bits(q[1]) * 2u + expand_bits(q[2]);   // :46-49
-        indices[i] = i;
-        s_box[threadIdx.x * 2 + 0] = make_float4(mn[0], mn[1], mn[2], 0.0f);
-        s_box[threadIdx.x * 2 + 1] = make_float4(mx[0], mx[1], mx[2], 0.0f);
-        if (lines) {
-            // lbvh_build_scene: the derived scene's triangle line (lbvh_common.h lbvh_fast_tri: first vertex, the two edge
-            // vectors of Raytracing.compute:41-42, the triangle's index), in ORIGINAL order — the positions are in
-            // registers here, so no kernel has to gather the 128-byte records again after the sort
-            const float e1x = b.x - a.x, e1y = b.y - a.y, e1z = b.z - a.z;
-            const float e2x = c.x - a.x, e2y = c.y - a.y, e2z = c.z - a.z;
-            s_line[threadIdx.x * 4 + 0] = make_float4(a.x, a.y, a.z, __uint_as_float(i));
-            s_line[threadIdx.x * 4 + 1] = make_float4(a.x, a.y, a.z, e2x);
-            s_line[threadIdx.x * 4 + 2] = make_float4(e1x, e1y, e1z, e2y);
-            s_line[threadIdx.x * 4 + 3] = make_float4(e1x, e1y, e1z, e2z);
-        }
+        morton_of_triangle(p[0], p[1], p[2], i, scene, keys, indices, s_box, s_line, lines != nullptr);
     }
     __syncthreads();
     const uint32_t live = n > b0 ? min(n - b0, 256u) : 0u;          // triangles of this block
@@ -93,6 +102,72 @@ __global__ __launch_bounds__(256) void morton_aabb_kernel(const lbvh_triangle* _
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) {
             const uint32_t f = k * 256u + threadIdx.x;
+            if (f < live * 4u) ol[f] = s_line[f];
+        }
+    }
+}
+
+// lbvh_animate + the kernel above in one pass (lbvh_animate_build_scene: the per-frame chain of a dynamic scene).  As two
+// kernels the moved triangles were written (128 B each) and read straight back for the 36 bytes of their positions: 128 MB
+// per million triangles fetched for nothing.  Here a workgroup moves its 256 triangles — one thread per 16-byte quarter row,
+// loads and stores of a wave covering 1 KB of consecutive bytes, as animate_kernel — keeps the moved positions in LDS, and
+// every thread then takes one triangle's Morton code, box and line from there.  Same floats in the same order as the two
+// kernels: the results are identical word for word.
+__global__ __launch_bounds__(256) void animate_morton_kernel(const lbvh_triangle* __restrict__ rest, const uint32_t* __restrict__ body,
+                                                             const float4* __restrict__ centres, float cs, float sn,
+                                                             lbvh_triangle* __restrict__ tris, uint32_t n, uint32_t capacity, box3 scene,
+                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ indices,
+                                                             lbvh_aabb* __restrict__ aabb, uint32_t* __restrict__ zero, uint32_t zero_words,
+                                                             lbvh_fast_tri* __restrict__ lines)
+{
+    const uint32_t b0 = blockIdx.x * 256u, i = b0 + threadIdx.x;
+    for (uint32_t w = i; w < zero_words; w += gridDim.x * 256u) zero[w] = 0u;
+    __shared__ float4 s_pos[256 * 3];
+    __shared__ float4 s_box[256 * 2];
+    __shared__ float4 s_line[256 * 4];
+    if (i < capacity && i >= n) {
+        keys[i] = 0xFFFFFFFFu;
+        indices[i] = 0xFFFFFFFFu;
+    }
+    // quarter row k of the triangles (j * 32 + t / 8), j = 0 .. 7: k = t & 7 is the same for all eight (256 % 8 == 0)
+    const uint32_t k = threadIdx.x & 7u;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+        const uint32_t local = j * 32u + (threadIdx.x >> 3), tri = b0 + local;
+        if (tri < n) {
+            const size_t g = (size_t)tri * 8u + k;
+            float4 p = reinterpret_cast<const float4*>(rest)[g];
+            if (k < 3u) {                                        // positions a, b, c
+                const float4 ctr = centres[body[tri]];
+                const float x = p.x - ctr.x, z = p.z - ctr.z;
+                p.x = (cs * x + sn * z) + ctr.x;                 // rotation about Y through the body centre (animate_kernel)
+                p.z = (cs * z - sn * x) + ctr.z;
+                s_pos[local * 3u + k] = p;
+            } else if (k >= 5u) {                                // normals (k = 3, 4: uv, copied)
+                const float nx = p.x, nz = p.z;
+                p.x = cs * nx + sn * nz;
+                p.z = cs * nz - sn * nx;
+            }
+            reinterpret_cast<float4*>(tris)[g] = p;
+        }
+    }
+    __syncthreads();
+    if (i < n)
+        morton_of_triangle(s_pos[threadIdx.x * 3 + 0], s_pos[threadIdx.x * 3 + 1], s_pos[threadIdx.x * 3 + 2], i, scene, keys, indices, s_box,
+                           s_line, lines != nullptr);
+    __syncthreads();
+    const uint32_t live = n > b0 ? min(n - b0, 256u) : 0u;
+    float4* ob = reinterpret_cast<float4*>(aabb + b0);
+#pragma unroll
+    for (uint32_t q = 0; q < 2; q++) {
+        const uint32_t f = q * 256u + threadIdx.x;
+        if (f < live * 2u) ob[f] = s_box[f];
+    }
+    if (lines) {
+        float4* ol = reinterpret_cast<float4*>(lines + b0);
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t f = q * 256u + threadIdx.x;
             if (f < live * 4u) ol[f] = s_line[f];
         }
     }
@@ -1196,6 +1271,18 @@ int lbvh_launch_morton(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint
     const uint32_t blocks = (capacity + 255) / 256;
     LBVH_LAUNCH(ctx, morton_aabb_kernel, dim3(blocks), dim3(256), d_triangles, n, capacity, scene, d_keys, d_indices, d_aabb,
                 d_zero, zero_words, d_lines);
+    return LBVH_OK;
+}
+
+int lbvh_launch_animate_morton(lbvh_context* ctx, const lbvh_anim& anim, lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
+                               const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
+                               lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines)
+{
+    box3 scene;
+    for (int k = 0; k < 3; k++) { scene.mn[k] = h_box_min[k]; scene.mx[k] = h_box_max[k]; }
+    const uint32_t blocks = (capacity + 255) / 256;
+    LBVH_LAUNCH(ctx, animate_morton_kernel, dim3(blocks), dim3(256), anim.rest, anim.body, (const float4*)anim.centres, anim.cos_angle,
+                anim.sin_angle, d_triangles, n, capacity, scene, d_keys, d_indices, d_aabb, d_zero, zero_words, d_lines);
     return LBVH_OK;
 }
 

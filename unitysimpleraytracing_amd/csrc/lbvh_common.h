@@ -137,6 +137,7 @@ struct lbvh_context {
     void* wide_nodes = nullptr;
     size_t wide_nodes_bytes = 0;
     bool wide_valid = false;
+    lbvh_ray_stats* ray_stats = nullptr;      // lbvh_ray_stats_target: the four-wide walkers add their counters here while set
     uint32_t ray_walker = 1;                  // lbvh_debug_ray_walker: 0 binary nodes, 1 four-wide, 2 four-wide with the few-rays kernel always
 
     // per-kernel event profiling (lbvh_profile_begin / lbvh_profile_end)
@@ -191,6 +192,11 @@ int lbvh_launch_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, lbvh
 int lbvh_launch_morton(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
                        const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
                        lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines);
+// lbvh_animate fused into the Morton kernel (lbvh_animate_build_scene): the rest pose is moved into d_triangles on the way
+struct lbvh_anim { const lbvh_triangle* rest; const uint32_t* body; const float* centres; float cos_angle, sin_angle; };
+int lbvh_launch_animate_morton(lbvh_context* ctx, const lbvh_anim& anim, lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
+                               const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
+                               lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines);
 // the sort with its scratch described / already cleared by the caller
 int lbvh_sort_scratch(lbvh_context* ctx, uint32_t count, uint32_t** d_zero, uint32_t* zero_words);
 int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t count, bool scratch_cleared);

@@ -285,7 +285,22 @@ __device__ __forceinline__ bool wide_box(float lx, float ly, float lz, float hx,
     return ray_box(make_float4(lx, ly, lz, 0.0f), make_float4(hx, hy, hz, 0.0f), r, tmin_out);
 }
 
+// what a launch of the per-ray walk did (lbvh_ray_stats_target: the algorithmic bytes of cfg5's roofline): wave reduction,
+// one atomic per counter per wave at the end of the kernel
+__device__ __forceinline__ void add_ray_stats(lbvh_ray_stats* stats, uint32_t rays, uint32_t steps, uint32_t tris)
+{
+    uint32_t v[3] = {rays, steps, tris};
+#pragma unroll
+    for (int k = 0; k < 3; k++) v[k] = wave_total_from_inclusive(wave_inclusive_sum(v[k]));
+    if (lane_id() == 0) {
+        atomicAdd((unsigned long long*)&stats->rays, (unsigned long long)v[0]);
+        atomicAdd((unsigned long long*)&stats->node_fetches, (unsigned long long)v[1]);
+        atomicAdd((unsigned long long*)&stats->triangle_tests, (unsigned long long)v[2]);
+    }
+}
+
 // Same frame as trace_rays_kernel (lane refill from the wave's run of live rays, LDS + device-memory stack).
+template <bool STATS>
 __global__ __launch_bounds__(64) void trace_rays_wide_kernel(const lbvh_path_state* __restrict__ states, const uint32_t* __restrict__ n_alive,
                                                              const uint32_t* __restrict__ list, float t_min,
                                                              const lbvh_wide_node* __restrict__ wide,
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(64) void trace_rays_wide_kernel(const lbvh_path_sta
                                                              uint32_t* __restrict__ deep,     // [gridDim.x][kWideStackDeep][64]
                                                              uint32_t lds_depth,              // <= kWideStackLds
                                                              uint32_t deep_cap,               // <= kWideStackDeep
-                                                             uint32_t* __restrict__ fault)
+                                                             uint32_t* __restrict__ fault, lbvh_ray_stats* stats)
 {
     __shared__ uint32_t s_stack[kWideStackLds][LBVH_WAVE];
     uint32_t* my_deep = deep + (size_t)blockIdx.x * (kWideStackDeep * LBVH_WAVE) + threadIdx.x;
@@ -303,6 +318,7 @@ __global__ __launch_bounds__(64) void trace_rays_wide_kernel(const lbvh_path_sta
     uint32_t next = blockIdx.x * run;
     if (next >= total) return;
     const uint32_t end = min(next + run, total);
+    uint32_t n_rays = 0, n_steps = 0, n_tris = 0;
 
     bool active = false;
     size_t i = 0;
@@ -331,12 +347,14 @@ __global__ __launch_bounds__(64) void trace_rays_wide_kernel(const lbvh_path_sta
                     best_t = LBVH_MAX_FLOAT; best_tri = 0; best_u = 0.0f; best_v = 0.0f;
                     sp = 0; node = 0;
                     active = true;
+                    if (STATS) n_rays++;
                 }
             }
             next += (uint32_t)__popcll(idle);
         }
         if (!__any(active)) break;
         if (active) {
+            if (STATS) n_steps++;
             const float4* w = reinterpret_cast<const float4*>(&wide[node]);
             const float4 lox = w[0], loy = w[1], loz = w[2], hix = w[3], hiy = w[4], hiz = w[5];
             const uint4 ref = reinterpret_cast<const uint4*>(w)[6];
@@ -351,6 +369,7 @@ __global__ __launch_bounds__(64) void trace_rays_wide_kernel(const lbvh_path_sta
             while (leaves != 0u) {
                 const uint32_t k = (uint32_t)__builtin_ctz(leaves);
                 leaves &= leaves - 1u;
+                if (STATS) n_tris++;
                 float4 v0, v1, v2;
                 unpack_fast_triangle(reinterpret_cast<const float4*>(&lines[pick4(ref, k) & 0x7FFFFFFFu]), v0, v1, v2);
                 float u = 0.0f, v = 0.0f;
@@ -393,12 +412,14 @@ __global__ __launch_bounds__(64) void trace_rays_wide_kernel(const lbvh_path_sta
             }
         }
     }
+    if (STATS) add_ray_stats(stats, n_rays, n_steps, n_tris);
 }
 
 // The same walk for launches whose time is the chain of their longest rays (the later bounces of a frame: a few hundred
 // thousand live rays, most of the chip idle for most of the launch): the next node is chosen BEFORE the step's triangles are
 // tested and requested together with the first triangle line, so the two fetches of a step are in flight at once.  84 VGPRs
 // (5 waves per SIMD instead of 8): the price where every wave slot is needed, none where they are not.
+template <bool STATS>
 __global__ __launch_bounds__(64) void trace_rays_wide_chain_kernel(const lbvh_path_state* __restrict__ states, const uint32_t* __restrict__ n_alive,
                                                              const uint32_t* __restrict__ list, float t_min,
                                                              const lbvh_wide_node* __restrict__ wide,
@@ -406,7 +427,7 @@ __global__ __launch_bounds__(64) void trace_rays_wide_chain_kernel(const lbvh_pa
                                                              uint32_t* __restrict__ deep,     // [gridDim.x][kWideStackDeep][64]
                                                              uint32_t lds_depth,              // <= kWideStackLds
                                                              uint32_t deep_cap,               // <= kWideStackDeep
-                                                             uint32_t* __restrict__ fault)
+                                                             uint32_t* __restrict__ fault, lbvh_ray_stats* stats)
 {
     __shared__ uint32_t s_stack[kWideStackLds][LBVH_WAVE];
     uint32_t* my_deep = deep + (size_t)blockIdx.x * (kWideStackDeep * LBVH_WAVE) + threadIdx.x;
@@ -416,6 +437,7 @@ __global__ __launch_bounds__(64) void trace_rays_wide_chain_kernel(const lbvh_pa
     uint32_t next = blockIdx.x * run;
     if (next >= total) return;
     const uint32_t end = min(next + run, total);
+    uint32_t n_rays = 0, n_steps = 0, n_tris = 0;
 
     bool active = false, have = false;      // have: the registers below hold this lane's node
     uint32_t i = 0;                          // (lbvh_trace_rays: count <= 2^32 - 1)
@@ -450,6 +472,7 @@ __global__ __launch_bounds__(64) void trace_rays_wide_chain_kernel(const lbvh_pa
                     best_t = LBVH_MAX_FLOAT; best_tri = 0; best_u = 0.0f; best_v = 0.0f;
                     sp = 0; node = 0;
                     active = true; have = false;
+                    if (STATS) n_rays++;
                 }
             }
             next += (uint32_t)__popcll(idle);
@@ -503,6 +526,7 @@ __global__ __launch_bounds__(64) void trace_rays_wide_chain_kernel(const lbvh_pa
             q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3];
         }
         if (fetch) {
+            if (STATS) n_steps++;
             const float4* w = reinterpret_cast<const float4*>(&wide[node]);
             lox = w[0]; loy = w[1]; loz = w[2]; hix = w[3]; hiy = w[4]; hiz = w[5];
             ref = reinterpret_cast<const uint4*>(w)[6];
@@ -510,6 +534,7 @@ __global__ __launch_bounds__(64) void trace_rays_wide_chain_kernel(const lbvh_pa
         }
         while (leaves != 0u) {
             leaves &= leaves - 1u;
+            if (STATS) n_tris++;
             float u = 0.0f, v = 0.0f;
             const float dist = ray_triangle_edges(ray, q0, q2.x, q2.y, q2.z, q1.w, q2.w, q3.w, u, v);
             const uint32_t tri = __float_as_uint(q0.w);
@@ -530,6 +555,7 @@ __global__ __launch_bounds__(64) void trace_rays_wide_chain_kernel(const lbvh_pa
             active = false;
         }
     }
+    if (STATS) add_ray_stats(stats, n_rays, n_steps, n_tris);
 }
 
 // ---- bounce ----------------------------------------------------------------------------------------------
@@ -700,14 +726,20 @@ static lbvh_status launch_ray_walk(lbvh_context* ctx, const lbvh_path_state* d_s
                         (lbvh_wide_node*)ctx->wide_nodes);
             ctx->wide_valid = true;
         }
-        if (few_rays || ctx->ray_walker == 2u)
-            LBVH_LAUNCH(ctx, trace_rays_wide_chain_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min,
-                        (const lbvh_wide_node*)ctx->wide_nodes, ctx->fast_nodes, d_hits, deep_stacks(ctx, count),
-                        std::min<uint32_t>(ctx->ray_stack_lds, kWideStackLds), std::min<uint32_t>(ctx->ray_stack_deep, kWideStackDeep), ctx->fault_dev);
-        else
-            LBVH_LAUNCH(ctx, trace_rays_wide_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min,
-                        (const lbvh_wide_node*)ctx->wide_nodes, ctx->fast_nodes, d_hits, deep_stacks(ctx, count),
-                        std::min<uint32_t>(ctx->ray_stack_lds, kWideStackLds), std::min<uint32_t>(ctx->ray_stack_deep, kWideStackDeep), ctx->fault_dev);
+        const uint32_t lds = std::min<uint32_t>(ctx->ray_stack_lds, kWideStackLds), deep_cap = std::min<uint32_t>(ctx->ray_stack_deep, kWideStackDeep);
+        lbvh_ray_stats* st = ctx->ray_stats;
+        const lbvh_wide_node* wn = (const lbvh_wide_node*)ctx->wide_nodes;
+        if (few_rays || ctx->ray_walker == 2u) {
+            if (st) LBVH_LAUNCH(ctx, trace_rays_wide_chain_kernel<true>, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, wn, ctx->fast_nodes,
+                                d_hits, deep_stacks(ctx, count), lds, deep_cap, ctx->fault_dev, st);
+            else LBVH_LAUNCH(ctx, trace_rays_wide_chain_kernel<false>, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, wn, ctx->fast_nodes,
+                             d_hits, deep_stacks(ctx, count), lds, deep_cap, ctx->fault_dev, st);
+        } else {
+            if (st) LBVH_LAUNCH(ctx, trace_rays_wide_kernel<true>, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, wn, ctx->fast_nodes,
+                                d_hits, deep_stacks(ctx, count), lds, deep_cap, ctx->fault_dev, st);
+            else LBVH_LAUNCH(ctx, trace_rays_wide_kernel<false>, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, wn, ctx->fast_nodes,
+                             d_hits, deep_stacks(ctx, count), lds, deep_cap, ctx->fault_dev, st);
+        }
     } else {
         LBVH_LAUNCH(ctx, trace_rays_kernel, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, ctx->fast_nodes,
                     ctx->fast_tris, d_hits, deep_stacks(ctx, count), ctx->ray_stack_lds, std::min<uint32_t>(ctx->ray_stack_deep, kRayStackDeep), ctx->fault_dev);
@@ -784,6 +816,14 @@ lbvh_status lbvh_debug_ray_stack_split(lbvh_context* ctx, uint32_t lds_entries)
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     LBVH_REQUIRE(ctx, lds_entries >= 1 && lds_entries <= (uint32_t)kRayStackLds);
     ctx->ray_stack_lds = lds_entries;
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_ray_stats_target(lbvh_context* ctx, lbvh_ray_stats* d_stats)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, ((uintptr_t)d_stats & 7) == 0);
+    ctx->ray_stats = d_stats;
     return LBVH_OK;
 }
 

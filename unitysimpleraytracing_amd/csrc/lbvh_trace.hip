@@ -1410,10 +1410,13 @@ lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene, 
 }  // extern "C"
 
 // RaytracingMeshDrawer.Awake()'s whole build chain, as two concurrent lanes after the sort.
+// morton_done: the Morton kernel (keys, indices, triangle AABBs, triangle lines, the sort's cleared scratch) has been enqueued by
+// the caller already — lbvh_animate_build_scene's fused animate + Morton kernel, whose arguments change every frame and
+// therefore stay outside the replayed graph
 static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
                                        const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
                                        lbvh_aabb* d_aabb, lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh,
-                                       uint32_t flags)
+                                       uint32_t flags, bool morton_done = false)
 {
     {
         const int src = lbvh_ensure_side(ctx);
@@ -1439,7 +1442,8 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
             if ((rc = ensure_fast_lines(ctx, n)) != LBVH_OK) return rc;
             lines = ctx->fast_tris;
         }
-        lbvh_launch_morton(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, zero, zero_words, lines);
+        if (!morton_done)
+            lbvh_launch_morton(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, zero, zero_words, lines);
         if ((rc = (lbvh_status)lbvh_launch_sort(ctx, d_keys, d_indices, capacity, zero != nullptr)) != LBVH_OK) return rc;
     }
     const bool fast = (flags & LBVH_BUILD_FAST_SCENE) != 0;
@@ -1481,10 +1485,13 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
 
 extern "C" {
 
-lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
-                             const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
-                             lbvh_aabb* d_aabb, lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh,
-                             uint32_t flags)
+}  // extern "C"
+
+// lbvh_build_scene, and lbvh_animate_build_scene (anim != nullptr): the same chain behind a fused animate + Morton kernel
+static lbvh_status build_scene_impl(lbvh_context* ctx, const lbvh_anim* anim, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
+                                    const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
+                                    lbvh_aabb* d_aabb, lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh,
+                                    uint32_t flags)
 {
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     LBVH_REQUIRE(ctx, n >= 2 && capacity >= n);
@@ -1497,7 +1504,7 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
     auto mix = [&](uint64_t v) { for (int i = 0; i < 8; i++) { key ^= (v >> (8 * i)) & 0xFFu; key *= 1099511628211ull; } };
     mix((uint64_t)(uintptr_t)d_triangles); mix(n); mix(capacity); mix((uint64_t)(uintptr_t)d_keys); mix((uint64_t)(uintptr_t)d_indices);
     mix((uint64_t)(uintptr_t)d_aabb); mix((uint64_t)(uintptr_t)d_internal); mix((uint64_t)(uintptr_t)d_leaf);
-    mix((uint64_t)(uintptr_t)d_bvh); mix(flags);
+    mix((uint64_t)(uintptr_t)d_bvh); mix(flags); mix(anim ? 1u : 0u);
     for (int k = 0; k < 3; k++) { uint32_t b; memcpy(&b, &h_box_min[k], 4); mix(b); memcpy(&b, &h_box_max[k], 4); mix(b); }
     auto mix_scratch = [&](decltype(mix)& m) {      // every context-owned buffer the captured kernels point into
         m((uint64_t)(uintptr_t)ctx->fast_nodes); m((uint64_t)(uintptr_t)ctx->fast_tris); m((uint64_t)(uintptr_t)ctx->fast_tree);
@@ -1520,6 +1527,24 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
     lbvh_note_write(ctx, d_indices, (size_t)capacity * 4);
     lbvh_note_write(ctx, d_aabb, (size_t)n * sizeof(lbvh_aabb));
     if (fast_flag) ctx->fast_valid = false;
+    if (anim) {
+        // the fused animate + Morton kernel: a plain launch in front of the (replayed) rest of the chain — its angle changes
+        // every frame.  The sort's scratch it clears and the triangle lines it writes are sized here, before any capture
+        lbvh_note_write(ctx, d_triangles, (size_t)n * sizeof(lbvh_triangle));
+        uint32_t* zero = nullptr;
+        uint32_t zero_words = 0;
+        lbvh_status src = (lbvh_status)lbvh_sort_scratch(ctx, capacity, &zero, &zero_words);
+        if (src != LBVH_OK) return src;
+        lbvh_fast_tri* lines = nullptr;
+        if (fast_flag) {
+            if ((src = ensure_fast_lines(ctx, n)) != LBVH_OK) return src;
+            lines = ctx->fast_tris;
+        }
+        LBVH_REQUIRE(ctx, ((uintptr_t)d_triangles & 15) == 0 && ((uintptr_t)d_aabb & 15) == 0);
+        lbvh_launch_animate_morton(ctx, *anim, const_cast<lbvh_triangle*>(d_triangles), n, capacity, h_box_min, h_box_max, d_keys, d_indices,
+                                   d_aabb, zero, zero_words, lines);
+    }
+    const bool morton_done = anim != nullptr;
     if (graphs && ctx->build_graph && ctx->build_graph_key == key) {
         LBVH_HIP_TRY(ctx, hipGraphLaunch(ctx->build_graph, ctx->stream));
         if (fast_flag) lbvh_note_fast_built(ctx, built);
@@ -1534,7 +1559,7 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             const lbvh_status rc = build_scene_enqueue(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb,
-                                                       d_internal, d_leaf, d_bvh, flags);
+                                                       d_internal, d_leaf, d_bvh, flags, morton_done);
             const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
             if (rc == LBVH_OK && e == hipSuccess && graph &&
                 hipGraphInstantiate(&ctx->build_graph, graph, nullptr, nullptr, 0) == hipSuccess) {
@@ -1553,7 +1578,7 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
         ctx->cur_stream = ctx->stream;
     }
     const lbvh_status rc = build_scene_enqueue(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb,
-                                               d_internal, d_leaf, d_bvh, flags);
+                                               d_internal, d_leaf, d_bvh, flags, morton_done);
     // the key includes the scratch pointers as they are AFTER this call
     key = args_key;
     mix_scratch(mix);
@@ -1561,6 +1586,32 @@ lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles
     ctx->build_seen_key = rc == LBVH_OK ? key2 : 0;
     if (rc == LBVH_OK && fast_flag) lbvh_note_fast_built(ctx, built);
     return rc;
+}
+
+extern "C" {
+
+lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
+                             const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
+                             lbvh_aabb* d_aabb, lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh,
+                             uint32_t flags)
+{
+    return build_scene_impl(ctx, nullptr, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, d_internal, d_leaf,
+                            d_bvh, flags);
+}
+
+lbvh_status lbvh_animate_build_scene(lbvh_context* ctx, const lbvh_triangle* d_rest, const uint32_t* d_body, const float* d_centres,
+                                     float cos_angle, float sin_angle, lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
+                                     const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
+                                     lbvh_aabb* d_aabb, lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh,
+                                     uint32_t flags)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, d_rest != nullptr && d_body != nullptr && d_centres != nullptr && d_triangles != nullptr);
+    LBVH_REQUIRE(ctx, d_rest != d_triangles);
+    LBVH_REQUIRE(ctx, ((uintptr_t)d_rest & 15) == 0 && ((uintptr_t)d_triangles & 15) == 0 && ((uintptr_t)d_centres & 15) == 0);
+    lbvh_anim anim = {d_rest, d_body, d_centres, cos_angle, sin_angle};
+    return build_scene_impl(ctx, &anim, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, d_internal, d_leaf, d_bvh,
+                            flags);
 }
 
 }  // extern "C"

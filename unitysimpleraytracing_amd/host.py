@@ -526,12 +526,22 @@ class DynamicPathTracer:
         self.t_min, self.albedo, self.seed = float(t_min), float(albedo), int(seed)
         self.states = self.hits = self.image_buf = None
 
-    def animate(self, angle):
+    def animate(self, angle, fused=True):
+        """the bodies turned to `angle` and the whole LBVH rebuilt: lbvh_animate_build_scene (one call; fused=False: lbvh_animate +
+        the rebuild as two — same results)"""
         c = self.drawer.container
-        N.check(self.ctx.handle, N.lib.lbvh_animate(
-            self.ctx.handle, self.rest.device, c.triangles_length, self.body.device, self.centres.device,
-            float(np.float32(np.cos(angle))), float(np.float32(np.sin(angle))), c.triangle_data.device))
-        self.drawer.rebuild(fast=True)
+        cs, sn = float(np.float32(np.cos(angle))), float(np.float32(np.sin(angle)))
+        if not fused:
+            N.check(self.ctx.handle, N.lib.lbvh_animate(
+                self.ctx.handle, self.rest.device, c.triangles_length, self.body.device, self.centres.device, cs, sn, c.triangle_data.device))
+            self.drawer.rebuild(fast=True)
+            return
+        f3 = C.POINTER(C.c_float)
+        N.check(self.ctx.handle, N.lib.lbvh_animate_build_scene(
+            self.ctx.handle, self.rest.device, self.body.device, self.centres.device, cs, sn, c.triangle_data.device, c.triangles_length,
+            c.capacity, c.box_min.ctypes.data_as(f3), c.box_max.ctypes.data_as(f3), c.keys.device, c.triangle_index.device,
+            c.triangle_aabb.device, c.bvh_internal_node.device, c.bvh_leaf_node.device, c.bvh_data.device,
+            L.BUILD_RESET_NODES | L.BUILD_FAST_SCENE))
 
     def render(self, camera, bounces=4):
         cam = N.Camera.from_dict(camera)

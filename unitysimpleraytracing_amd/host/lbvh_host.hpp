@@ -436,13 +436,18 @@ public:
         body_.LocalBuffer() = body_ids;             body_.Sync();
         centres_.LocalBuffer() = body_centres_xyzw; centres_.Sync();
     }
+    // the bodies turned to `angle` and the whole LBVH rebuilt, one call (= lbvh_animate + RaytracingMeshDrawer::Rebuild)
     void Animate(float angle)
     {
         MeshBufferContainer& c = drawer_.Container();
-        check(ctx_.get(), lbvh_animate(ctx_.get(), (const lbvh_triangle*)rest_.DeviceBuffer(), c.TrianglesLength(),
-                                       (const uint32_t*)body_.DeviceBuffer(), (const float*)centres_.DeviceBuffer(),
-                                       std::cos(angle), std::sin(angle), (lbvh_triangle*)c.TriangleData().DeviceBuffer()));
-        drawer_.Rebuild();
+        const float mn[3] = {-125.0f, -125.0f, -125.0f}, mx[3] = {125.0f, 125.0f, 125.0f};   // MeshBufferContainer.Whole
+        check(ctx_.get(), lbvh_animate_build_scene(ctx_.get(), (const lbvh_triangle*)rest_.DeviceBuffer(), (const uint32_t*)body_.DeviceBuffer(),
+                                                   (const float*)centres_.DeviceBuffer(), std::cos(angle), std::sin(angle),
+                                                   (lbvh_triangle*)c.TriangleData().DeviceBuffer(), c.TrianglesLength(), c.Capacity(), mn, mx,
+                                                   (uint32_t*)c.Keys().DeviceBuffer(), (uint32_t*)c.TriangleIndex().DeviceBuffer(),
+                                                   (lbvh_aabb*)c.TriangleAABB().DeviceBuffer(), (lbvh_internal_node*)c.BvhInternalNode().DeviceBuffer(),
+                                                   (lbvh_leaf_node*)c.BvhLeafNode().DeviceBuffer(), (lbvh_aabb*)c.BvhData().DeviceBuffer(),
+                                                   LBVH_BUILD_FAST_SCENE | LBVH_BUILD_RESET_NODES));
     }
     void Render(const lbvh_camera& cam, uint32_t bounces = 4)
     {

@@ -26,6 +26,7 @@ TRACE_STATS = np.dtype([("pops", "<u8"), ("box_hits", "<u8"), ("leaf_tests", "<u
 
 BUILD_FAST_SCENE, BUILD_RESET_NODES = 1, 2      # lbvh_build_scene flags
 
+RAY_STATS = np.dtype([("rays", "<u8"), ("node_fetches", "<u8"), ("triangle_tests", "<u8")])
 PATH_STATE = np.dtype([("origin", "<f4", 3), ("alive", "<u4"), ("dir", "<f4", 3), ("pad0", "<f4"),
                        ("throughput", "<f4", 3), ("pad1", "<f4"), ("radiance", "<f4", 3), ("alpha", "<f4")])
 assert PATH_STATE.itemsize == 64
