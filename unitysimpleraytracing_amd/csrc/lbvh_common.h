@@ -198,15 +198,8 @@ int lbvh_launch_animate_morton(lbvh_context* ctx, const lbvh_anim& anim, lbvh_tr
                                const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
                                lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines);
 // the sort with its scratch described / already cleared by the caller
-// (morton: the plan of lbvh_launch_sort_morton; d_in_keys / d_in_values: the sort's own scratch pair, where that sort reads)
-int lbvh_sort_scratch(lbvh_context* ctx, uint32_t count, uint32_t** d_zero, uint32_t* zero_words, bool morton = false,
-                      uint32_t** d_in_keys = nullptr, uint32_t** d_in_values = nullptr);
+int lbvh_sort_scratch(lbvh_context* ctx, uint32_t count, uint32_t** d_zero, uint32_t* zero_words);
 int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t count, bool scratch_cleared);
-// lbvh_build_scene's sort of 30-bit Morton keys (+ 0xFFFFFFFF pads): three 10-bit passes instead of four 8-bit ones, the same
-// order; input in the scratch pair (d_in_keys / d_in_values above), result in d_keys / d_values.  lbvh_sort_morton_form: the
-// sizes this form is used for.
-bool lbvh_sort_morton_form(uint32_t count);
-int lbvh_launch_sort_morton(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t count, bool scratch_cleared);
 // the frontier counter lbvh_launch_refit(n) will use on the current lane (sizes the scratch)
 int lbvh_refit_counter(lbvh_context* ctx, uint32_t n, uint32_t** d_counter);
 // the stand-alone refit (lbvh_refit): d_sorted_indices may be nullptr (boxes already in leaf order)

@@ -34,21 +34,13 @@
 // reaches memory as two masked partial writes; on one XCD the halves merge in its L2.  So tickets are
 // per XCD and hand out kGroup CONSECUTIVE tiles to each XCD in turn (measured on the access pattern
 // alone, tools/ubench/tilecopy.hip: 2.9 -> 4.0 TB/s for unaligned 128-B runs).
-#include <cstdlib>
 #include "lbvh_common.h"
 
 namespace {
 
 constexpr int kThreads = 256;          // 4 waves
-constexpr int kRadix = 256;            // the reference's digit (Constants.cginc:1-2): lbvh_sort_pairs, any 32-bit keys
+constexpr int kRadix = 256;
 constexpr int kPasses = 4;
-// lbvh_build_scene's keys are 30-bit Morton codes (+ 0xFFFFFFFF pads behind them): THREE passes of 10 bits give the same
-// stable order — a pad and a code of 30 one-bits tie on the 30 bits sorted and keep their input order, pads last — and at
-// the sizes where a pass is its look-back chain's latency, not bandwidth (<= 2 M keys: every tile on a CU of its own),
-// one pass less is 15 us of the rebuild.  1 024 rank cells per wave = 128 KB of LDS per tile: one tile per CU.
-constexpr int kMortonBits = 10;
-constexpr int kMortonPasses = 3;
-constexpr int kMaxRadix = 1 << kMortonBits;
 
 constexpr uint32_t kFlagAgg = 1u << 30;    // value = this tile's (this group's) digit count
 constexpr uint32_t kFlagIncl = 2u << 30;   // group words: value = digit count of groups 0..this
@@ -56,17 +48,14 @@ constexpr uint32_t kValueMask = (1u << 30) - 1u;
 constexpr int kLook = 2;                   // group words inspected per look-back step
 constexpr int kLbGroup = 8;                // tiles per look-back group
 
-// ---- all digit histograms in one read of the keys ------------------------------------------------
-template <int RBITS, int PASSES>
+// ---- all four digit histograms in one read of the keys ------------------------------------------
 __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t* __restrict__ keys,
                                                                   uint32_t count, uint32_t* __restrict__ ghist)
 {
-    constexpr int RADIX = 1 << RBITS;
-    __shared__ uint32_t s_hist[PASSES][RADIX];
+    __shared__ uint32_t s_hist[kPasses][kRadix];
     const uint32_t t = threadIdx.x;
 #pragma unroll
-    for (int p = 0; p < PASSES; p++)
-        for (int d = (int)t; d < RADIX; d += kThreads) s_hist[p][d] = 0;
+    for (int p = 0; p < kPasses; p++) s_hist[p][t] = 0;
     __syncthreads();
     // grid-stride over 16-B vectors (4 keys per lane per load), 2 loads in flight per thread
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -79,9 +68,9 @@ __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t
     const u32x4* vkeys = reinterpret_cast<const u32x4*>(keys + head);
     const uint32_t stride = gridDim.x * kThreads;
     auto add_key = [&](uint32_t k) {
-        // a wave whose 64 keys agree on a digit would serialise 64 LDS atomics on one counter (top digits of
+        // a wave whose 64 keys agree on a digit would serialise 64 LDS atomics on one counter (top bytes of
         // clustered Morton codes, 0xFFFFFFFF pads, already-sorted input): one lane adds 64 instead.  Only the two
-        // high digits are checked — the low digits of distinct keys differ — plus whole-key equality.
+        // high digits are checked — the low bytes of distinct keys differ — plus whole-key equality.
         const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
         const uint64_t active = __ballot(1);
         const bool first = lane_id() == (uint32_t)__builtin_ctzll(active);
@@ -89,16 +78,16 @@ __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t
         if (__all(k == k0)) {
             if (first) {
 #pragma unroll
-                for (int p = 0; p < PASSES; p++) atomicAdd(&s_hist[p][(k0 >> (RBITS * p)) & (RADIX - 1)], nactive);
+                for (int p = 0; p < kPasses; p++) atomicAdd(&s_hist[p][(k0 >> (8 * p)) & 255u], nactive);
             }
             return;
         }
+        atomicAdd(&s_hist[0][k & 255u], 1u);
+        atomicAdd(&s_hist[1][(k >> 8) & 255u], 1u);
 #pragma unroll
-        for (int p = 0; p < PASSES - 2; p++) atomicAdd(&s_hist[p][(k >> (RBITS * p)) & (RADIX - 1)], 1u);
-#pragma unroll
-        for (int p = PASSES - 2; p < PASSES; p++) {
-            const uint32_t d = (k >> (RBITS * p)) & (RADIX - 1);
-            const uint32_t d0 = (k0 >> (RBITS * p)) & (RADIX - 1);
+        for (int p = 2; p < kPasses; p++) {
+            const uint32_t d = (k >> (8 * p)) & 255u;
+            const uint32_t d0 = (k0 >> (8 * p)) & 255u;
             if (__all(d == d0)) {
                 if (first) atomicAdd(&s_hist[p][d0], nactive);
             } else {
@@ -126,16 +115,15 @@ __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t
         if (t < 4u ? t < head : idx < count) {
             const uint32_t k = keys[idx];
 #pragma unroll
-            for (int p = 0; p < PASSES; p++) atomicAdd(&s_hist[p][(k >> (RBITS * p)) & (RADIX - 1)], 1u);
+            for (int p = 0; p < kPasses; p++) atomicAdd(&s_hist[p][(k >> (8 * p)) & 255u], 1u);
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < PASSES; p++)
-        for (int d = (int)t; d < RADIX; d += kThreads) {
-            const uint32_t c = s_hist[p][d];
-            if (c) atomicAdd(&ghist[p * RADIX + d], c);
-        }
+    for (int p = 0; p < kPasses; p++) {
+        const uint32_t c = s_hist[p][t];
+        if (c) atomicAdd(&ghist[p * kRadix + t], c);
+    }
 }
 
 // Ticket k of queue x -> tile.  queues == 8: queue x holds the tiles whose (tile / group) % 8 == x in increasing
@@ -145,57 +133,38 @@ __host__ __device__ __forceinline__ uint32_t ticket_tile(uint32_t k, uint32_t x,
     return (k / group) * (queues * group) + x * group + (k % group);
 }
 
-// block-wide exclusive prefix of one value per thread (s_wsum: one word per wave; two barriers)
-template <int WAVES>
-__device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t* s_wsum, uint32_t w, uint32_t lane)
-{
-    const uint32_t incl = wave_inclusive_sum(v);
-    __syncthreads();                               // s_wsum reuse
-    if (lane == 63) s_wsum[w] = incl;
-    __syncthreads();
-    uint32_t wave_prefix = 0;
-#pragma unroll
-    for (int i = 0; i < WAVES; i++) wave_prefix += (uint32_t)i < w ? s_wsum[i] : 0u;
-    return incl - v + wave_prefix;
-}
-
 // ---- one pass: rank + look-back + scatter ----------------------------------------------------------
-// RBITS = 8: the reference's digit.  RBITS = 10 (Morton keys, see kMortonBits): every thread of the 512 owns TWO digits
-// (DPT) where the 8-bit form has the first 256 threads own one each.
-template <int THREADS, int ITEMS, bool STREAM, int RBITS>
+template <int THREADS, int ITEMS, bool STREAM>
 __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t count, uint32_t shift,
-    const uint32_t* __restrict__ ghist,   // [RADIX] digit totals of this pass
-    uint32_t* status,                     // [tiles][RADIX] tile words of this pass (zeroed per sort)
-    uint32_t* gstatus,                    // [ceil(tiles / kLbGroup)][RADIX] group words of this pass (zeroed per sort)
+    const uint32_t* __restrict__ ghist,   // [256] digit totals of this pass
+    uint32_t* status,                     // [tiles][256] tile words of this pass (zeroed per sort)
+    uint32_t* gstatus,                    // [ceil(tiles / kLbGroup)][256] group words of this pass (zeroed per sort)
     uint32_t* tickets,                    // [8] per-XCD tile tickets of this pass (zeroed per sort)
     uint32_t tiles, uint32_t group,       // group = consecutive tiles handed to one XCD
     uint32_t queues,                      // 8 = per-XCD ticket queues, 1 = tiles in ticket order
     uint32_t* fault)                      // mapped host word: a bounded spin that gave up says so here
 {
-    constexpr int RADIX = 1 << RBITS;
     constexpr int TILE = THREADS * ITEMS;
-    constexpr int DPT = RADIX > THREADS ? RADIX / THREADS : 1;      // digits a thread owns: digits t * DPT .. t * DPT + DPT - 1
-    constexpr int OWNERS = RADIX / DPT;                             // threads 0 .. OWNERS - 1 own digits
     // STREAM (sorts from 8 M pairs: beyond what the L2s hold): every key and value is read exactly once per pass, and
     // loaded as streaming data (sc1 nt: not kept in L2) they leave the L2 to the scatter's partial lines, which wait
     // there for the tile that completes them — 1.24 -> 1.19 ms per 2^26 pairs, 0.367 -> 0.346 at 2^24; at 2^22 (32 MB of
     // pairs) the default policy is the faster one (0.129 against 0.134 ms).
     constexpr int kLoadPolicy = STREAM ? 6 : 0;
     constexpr int WAVES = THREADS / LBVH_WAVE;
+    constexpr int DWAVES = kRadix / LBVH_WAVE;   // waves that own the 256 digits
     // tile exchange buffer: keys first, then values; during ranking it holds the per-wave rank cells
-    constexpr int XCHG_WORDS = TILE > WAVES * RADIX * 4 ? TILE : WAVES * RADIX * 4;
+    constexpr int XCHG_WORDS = TILE > WAVES * kRadix * 4 ? TILE : WAVES * kRadix * 4;
     __shared__ __attribute__((aligned(16))) uint32_t s_xchg[XCHG_WORDS];
-    __shared__ uint16_t s_wcnt[WAVES][RADIX];    // per-wave local bases (<= TILE <= 8192)
-    __shared__ uint32_t s_gofs[RADIX];           // global base of digit d minus its local start
-    __shared__ uint32_t s_wsum[WAVES + 1];
+    __shared__ uint16_t s_wcnt[WAVES][kRadix];   // per-wave local bases (<= TILE <= 8192)
+    __shared__ uint32_t s_gofs[kRadix];          // global base of digit d minus its local start
+    __shared__ uint32_t s_wsum[DWAVES + 1];
     __shared__ uint32_t s_tile;
 
     const uint32_t t = threadIdx.x;
     const uint32_t w = t >> 6;
     const uint32_t lane = lane_id();
-    const bool owner = t < (uint32_t)OWNERS;
     if (t == 0) {
         // when the home queue is drained take from the others.  grid == tiles and every workgroup takes exactly
         // one, so one is found.
@@ -210,22 +179,24 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         s_tile = tile;
     }
     // rank cells {peer mask lo, hi, count, -} per (wave, digit), 16 B each, all zero
-    for (int i = t; i < WAVES * RADIX; i += THREADS) reinterpret_cast<uint4*>(s_xchg)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = t; i < WAVES * kRadix; i += THREADS) reinterpret_cast<uint4*>(s_xchg)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint32_t base = tile * (uint32_t)TILE;
     const uint32_t nvalid = min((uint32_t)TILE, count - base);
 
     // exclusive scan of the pass's digit totals = first output index of each digit (every tile
-    // recomputes it from the L2-resident counters: cheaper than a launch)
-    uint32_t digit_start[DPT];
+    // recomputes it from 1 KB of L2-resident counters: cheaper than a launch)
+    uint32_t digit_start = 0;
     {
-        uint32_t total[DPT], sum = 0;
+        const uint32_t total = t < (uint32_t)kRadix ? ghist[t] : 0u;
+        const uint32_t incl = wave_inclusive_sum(total);
+        if (lane == 63 && w < (uint32_t)DWAVES) s_wsum[w] = incl;
+        __syncthreads();
+        uint32_t wave_prefix = 0;
 #pragma unroll
-        for (int q = 0; q < DPT; q++) { total[q] = owner ? ghist[t * DPT + q] : 0u; sum += total[q]; }
-        uint32_t run = block_exclusive<WAVES>(sum, s_wsum, w, lane);
-#pragma unroll
-        for (int q = 0; q < DPT; q++) { digit_start[q] = run; run += total[q]; }
+        for (int i = 0; i < DWAVES; i++) wave_prefix += (uint32_t)i < w ? s_wsum[i] : 0u;
+        digit_start = incl - total + wave_prefix;
     }
 
     // wave-striped load: wave w owns keys [base + w*64*ITEMS, +64*ITEMS), item i = 64 consecutive
@@ -248,7 +219,7 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         key[i] = idx < count ? k : 0xFFFFFFFFu;
     }
 
-    // Ranking.  The wave's 64 keys of one item are matched on the whole digit THROUGH LDS: every lane ORs its
+    // Ranking.  The wave's 64 keys of one item are matched on the whole 8-bit digit THROUGH LDS: every lane ORs its
     // lane bit into the 64-bit peer mask of cell (wave, digit) and reads the cell back — LDS executes a wave's
     // instructions in order, so the read sees all 64 ORs.  rank = count of the same digit in earlier items (kept in
     // the cell) + same-digit lanes below me (v_mbcnt of the mask); the lowest peer lane clears the mask and adds
@@ -256,11 +227,11 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     // was as much VALU-bound (196 us of wave64 issue per 2^26 pairs) as HBM-bound.
     {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4* cells = reinterpret_cast<u32x4*>(s_xchg) + w * RADIX;
+        u32x4* cells = reinterpret_cast<u32x4*>(s_xchg) + w * kRadix;
         const unsigned long long lane_bit = 1ull << lane;
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
-            const uint32_t d = (key[i] >> shift) & (RADIX - 1);
+            const uint32_t d = (key[i] >> shift) & (kRadix - 1);
             u32x4* cell = cells + d;
             __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(cell), lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const u32x4 c = *reinterpret_cast<volatile u32x4*>(cell);
@@ -276,11 +247,18 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     }
     __syncthreads();
 
-    uint32_t ltotal[DPT] = {};
-    uint32_t gv[DPT][kLook] = {};                      // look-back state carried across the LDS exchange
-    uint32_t lb_group = 0, lb_partial[DPT] = {}, lb_total[DPT] = {};
+    uint32_t ltotal = 0;
+    uint32_t gv[kLook] = {};                           // look-back state carried across the LDS exchange
+    uint32_t lb_group = 0, lb_partial = 0, lb_total = 0;
     bool lb_leader = false;
-    if (owner) {   // thread t = digits t * DPT ...
+    if (t < (uint32_t)kRadix) {   // thread t = digit t
+        uint32_t total = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) total += s_xchg[(i * kRadix + t) * 4 + 2];
+        ltotal = total;                                // including padding slots (they sit last)
+        // the padding slots of a partial last tile all landed on digit 255: they are not keys
+        if (t == kRadix - 1) total -= (uint32_t)TILE - nvalid;
+
         // Two-level look-back.  A tile publishes its digit counts (tile words) and needs the counts of all
         // earlier tiles.  With single-level decoupled look-back the walk length is (tiles finishing per
         // round trip to the coherence point) ~ 30 words on this chip (41 tiles/us x 0.7 us), 14 dependent
@@ -291,85 +269,64 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         // ~2 dependent round trips per tile.
         constexpr uint32_t G = (uint32_t)kLbGroup;
         const uint32_t g = tile / G, gi = tile % G;
-        const bool leader = gi == G - 1u;               // a partial last group has no leader: nothing follows it
-#pragma unroll
-        for (int q = 0; q < DPT; q++) {
-            const uint32_t dd = t * DPT + q;
-            uint32_t total = 0;
-#pragma unroll
-            for (int i = 0; i < WAVES; i++) total += s_xchg[(i * RADIX + dd) * 4 + 2];
-            ltotal[q] = total;                             // including padding slots (they sit last)
-            // the padding slots of a partial last tile all landed on the largest digit: they are not keys
-            if (dd == RADIX - 1) total -= (uint32_t)TILE - nvalid;
-            __hip_atomic_store(status + (size_t)tile * RADIX + dd, kFlagAgg | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lb_total[q] = total;
-        }
-        // (the owned digits in lockstep: all their loads of a round are in flight together — one after the other the 10-bit
-        // form paid every round trip twice)
-        uint32_t v[DPT][kLbGroup - 1];
-#pragma unroll
-        for (int q = 0; q < DPT; q++) {
-            const uint32_t* row0 = status + (size_t)(g * G) * RADIX + t * DPT + q;
+        __hip_atomic_store(status + (size_t)tile * kRadix + t, kFlagAgg | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t in_group = 0;
+        {
+            const uint32_t* row0 = status + (size_t)(g * G) * kRadix + t;
+            uint32_t v[kLbGroup - 1];
 #pragma unroll
             for (int j = 0; j < kLbGroup - 1; j++)
-                if ((uint32_t)j < gi) v[q][j] = __hip_atomic_load(row0 + (size_t)j * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int q = 0; q < DPT; q++) {
-            const uint32_t dd = t * DPT + q;
-            const uint32_t* row0 = status + (size_t)(g * G) * RADIX + dd;
-            uint32_t in_group = 0;
+                if ((uint32_t)j < gi) v[j] = __hip_atomic_load(row0 + (size_t)j * kRadix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int j = 0; j < kLbGroup - 1; j++) {
                 if ((uint32_t)j >= gi) continue;
-                for (uint32_t spins = 0; (v[q][j] & ~kValueMask) == 0; spins++) {
+                for (uint32_t spins = 0; (v[j] & ~kValueMask) == 0; spins++) {
                     if (spins > LBVH_SPIN_LIMIT) {
                         __hip_atomic_store(fault, LBVH_FAULT_SORT_LOOKBACK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
-                    v[q][j] = __hip_atomic_load(row0 + (size_t)j * RADIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v[j] = __hip_atomic_load(row0 + (size_t)j * kRadix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                in_group += v[q][j] & kValueMask;
+                in_group += v[j] & kValueMask;
             }
-            uint32_t* gmine = gstatus + (size_t)g * RADIX + dd;
-            if (leader)
-                __hip_atomic_store(gmine, (g == 0 ? kFlagIncl : kFlagAgg) | ((in_group + lb_total[q]) & kValueMask), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            lb_partial[q] = in_group;
         }
+        const bool leader = gi == G - 1u;               // a partial last group has no leader: nothing follows it
+        uint32_t* gmine = gstatus + (size_t)g * kRadix + t;
+        if (leader)
+            __hip_atomic_store(gmine, (g == 0 ? kFlagIncl : kFlagAgg) | ((in_group + total) & kValueMask), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         // the group-level words are requested now and consumed after the tile's LDS exchange below: the
         // round trips to the coherence point overlap with work that does not need the global offsets
 #pragma unroll
-        for (int q = 0; q < DPT; q++)
-#pragma unroll
-            for (int j = 0; j < kLook; j++) {
-                const uint32_t qq = g - 1u - (uint32_t)j;
-                gv[q][j] = (uint32_t)j < g ? __hip_atomic_load(gstatus + (size_t)qq * RADIX + t * DPT + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                           : kFlagIncl;         // before group 0: inclusive prefix 0
-            }
+        for (int j = 0; j < kLook; j++) {
+            const uint32_t q = g - 1u - (uint32_t)j;
+            gv[j] = (uint32_t)j < g ? __hip_atomic_load(gstatus + (size_t)q * kRadix + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : kFlagIncl;         // before group 0: inclusive prefix 0
+        }
         lb_group = g;
         lb_leader = leader;
+        lb_partial = in_group;
+        lb_total = total;
     }
-    uint32_t gbase[DPT] = {};                          // first output index of a digit minus its local start
+    uint32_t gbase = 0;                                // first output index of digit t minus its local start
     {   // local layout: digits in order, waves in order inside a digit
-        uint32_t sum = 0;
+        const uint32_t incl = wave_inclusive_sum(ltotal);
+        __syncthreads();                               // s_wsum reuse
+        if (lane == 63 && w < (uint32_t)DWAVES) s_wsum[w] = incl;
+        __syncthreads();
+        if (t < (uint32_t)kRadix) {
+            uint32_t wave_prefix = 0;
 #pragma unroll
-        for (int q = 0; q < DPT; q++) sum += ltotal[q];
-        uint32_t dstart = block_exclusive<WAVES>(sum, s_wsum, w, lane);
-        if (owner) {
+            for (int i = 0; i < DWAVES; i++) wave_prefix += (uint32_t)i < w ? s_wsum[i] : 0u;
+            const uint32_t dstart = incl - ltotal + wave_prefix;
+            uint32_t run = dstart;
 #pragma unroll
-            for (int q = 0; q < DPT; q++) {
-                const uint32_t dd = t * DPT + q;
-                uint32_t run = dstart;
-#pragma unroll
-                for (int i = 0; i < WAVES; i++) {
-                    const uint32_t c = s_xchg[(i * RADIX + dd) * 4 + 2];
-                    s_wcnt[i][dd] = (uint16_t)run;
-                    run += c;
-                }
-                gbase[q] = digit_start[q] - dstart;
-                dstart += ltotal[q];
+            for (int i = 0; i < WAVES; i++) {
+                const uint32_t c = s_xchg[(i * kRadix + t) * 4 + 2];
+                s_wcnt[i][t] = (uint16_t)run;
+                run += c;
             }
+            gbase = digit_start - dstart;
         }
     }
     __syncthreads();
@@ -377,7 +334,7 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     // Keys and values go through the SAME LDS buffer one after the other: half the LDS per tile.
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
-        const uint32_t d = (key[i] >> shift) & (RADIX - 1);
+        const uint32_t d = (key[i] >> shift) & (kRadix - 1);
         const uint32_t r = (i & 1) ? rank2[i / 2] >> 16 : rank2[i / 2] & 0xFFFFu;
         const uint32_t lpos = (uint32_t)s_wcnt[w][d] + r;            // local position in the digit-sorted tile
         if (i & 1) rank2[i / 2] = (rank2[i / 2] & 0xFFFFu) | (lpos << 16); else rank2[i / 2] = (rank2[i / 2] & 0xFFFF0000u) | lpos;
@@ -393,51 +350,38 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         for (int i = 0; i < ITEMS; i++)
             val[i] = __builtin_amdgcn_raw_buffer_load_b32(vals_in_rsrc, (wave_base + (uint32_t)i * LBVH_WAVE + lane) * 4u, 0, kLoadPolicy);
     }
-    if (owner) {   // finish the look-back: decoupled walk over the group words, nearest first (owned digits in lockstep)
-        uint32_t before[DPT] = {}, p[DPT];
-        bool done[DPT];
-#pragma unroll
-        for (int q = 0; q < DPT; q++) { p[q] = lb_group; done[q] = lb_group == 0; }     // next word to consume belongs to group p - 1
-        for (uint32_t spins = 0;; spins++) {
-            bool all_done = true;
-#pragma unroll
-            for (int q = 0; q < DPT; q++) {
-#pragma unroll
-                for (int j = 0; j < kLook; j++) {
-                    if (done[q]) continue;
-                    const uint32_t f = gv[q][j] & ~kValueMask;
-                    if (f == 0) break;                   // not published yet: re-read from here
-                    before[q] += gv[q][j] & kValueMask;
-                    p[q]--;
-                    if (f == kFlagIncl) done[q] = true;
-                }
-                all_done = all_done && done[q];
-            }
-            if (all_done) break;
+    if (t < (uint32_t)kRadix) {   // finish the look-back: decoupled walk over the group words, nearest first
+        uint32_t before = 0;
+        uint32_t p = lb_group;                       // next word to consume belongs to group p - 1
+        bool done = p == 0;
+        for (uint32_t spins = 0; !done; spins++) {
             if (spins > LBVH_SPIN_LIMIT) {
                 __hip_atomic_store(fault, LBVH_FAULT_SORT_LOOKBACK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
 #pragma unroll
-            for (int q = 0; q < DPT; q++) {
-                if (done[q]) continue;
+            for (int j = 0; j < kLook; j++) {
+                if (done) continue;
+                const uint32_t f = gv[j] & ~kValueMask;
+                if (f == 0) break;                   // not published yet: re-read from here
+                before += gv[j] & kValueMask;
+                p--;
+                if (f == kFlagIncl) done = true;
+            }
+            if (!done) {
 #pragma unroll
                 for (int j = 0; j < kLook; j++) {
-                    const uint32_t qq = p[q] - 1u - (uint32_t)j;
-                    gv[q][j] = (uint32_t)j < p[q] ? __hip_atomic_load(gstatus + (size_t)qq * RADIX + t * DPT + q, __ATOMIC_RELAXED,
-                                                                      __HIP_MEMORY_SCOPE_AGENT)
-                                                  : kFlagIncl;
+                    const uint32_t q = p - 1u - (uint32_t)j;
+                    gv[j] = (uint32_t)j < p ? __hip_atomic_load(gstatus + (size_t)q * kRadix + t, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT)
+                                            : kFlagIncl;
                 }
             }
         }
-#pragma unroll
-        for (int q = 0; q < DPT; q++) {
-            const uint32_t dd = t * DPT + q;
-            if (lb_leader && lb_group > 0)
-                __hip_atomic_store(gstatus + (size_t)lb_group * RADIX + dd, kFlagIncl | ((before[q] + lb_partial[q] + lb_total[q]) & kValueMask),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_gofs[dd] = gbase[q] + before[q] + lb_partial[q];
-        }
+        if (lb_leader && lb_group > 0)
+            __hip_atomic_store(gstatus + (size_t)lb_group * kRadix + t, kFlagIncl | ((before + lb_partial + lb_total) & kValueMask),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_gofs[t] = gbase + before + lb_partial;
     }
     __syncthreads();
 
@@ -446,15 +390,13 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     // (count < 2^30, so offsets fit), which is what keeps 16 stores in flight inside the register budget.
     const __amdgpu_buffer_rsrc_t keys_rsrc = __builtin_amdgcn_make_buffer_rsrc(keys_out, 0, (int)(count * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t vals_rsrc = __builtin_amdgcn_make_buffer_rsrc(vals_out, 0, (int)(count * 4u), 0x00020000);
-    constexpr int DPR = RBITS <= 8 ? 4 : 2;            // digits of the sorted keys kept per register
-    constexpr int DBITS = 32 / DPR;
-    uint32_t digs[ITEMS / DPR];
+    uint32_t dig4[ITEMS / 4];
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {
         const uint32_t pos = (uint32_t)j * THREADS + t;
         const uint32_t k = s_xchg[pos];
-        const uint32_t d = (k >> shift) & (RADIX - 1);
-        if (j % DPR) digs[j / DPR] |= d << (DBITS * (j % DPR)); else digs[j / DPR] = d;
+        const uint32_t d = (k >> shift) & (kRadix - 1);
+        if (j & 3) dig4[j / 4] |= d << (8 * (j & 3)); else dig4[j / 4] = d;
         const uint32_t dst = s_gofs[d] + pos;
         if (pos < nvalid) __builtin_amdgcn_raw_buffer_store_b32(k, keys_rsrc, dst * 4u, 0, 0);
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -466,22 +408,22 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {
         const uint32_t pos = (uint32_t)j * THREADS + t;
-        const uint32_t dst = s_gofs[(digs[j / DPR] >> (DBITS * (j % DPR))) & (RADIX - 1)] + pos;
+        const uint32_t dst = s_gofs[(dig4[j / 4] >> (8 * (j & 3))) & 255u] + pos;
         if (pos < nvalid) __builtin_amdgcn_raw_buffer_store_b32(s_xchg[pos], vals_rsrc, dst * 4u, 0, 0);
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int THREADS, int ITEMS, bool STREAM, int RBITS>
-void launch_passes(lbvh_context* ctx, uint32_t* ks, uint32_t* vs, uint32_t* kd, uint32_t* vd, uint32_t passes,
+template <int THREADS, int ITEMS, bool STREAM>
+void launch_passes(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t* alt_keys, uint32_t* alt_vals,
                    uint32_t count, uint32_t tiles, uint32_t* ghist, uint32_t* status, uint32_t* gstatus, uint32_t groups,
                    uint32_t* tickets, uint32_t group)
 {
-    constexpr uint32_t RADIX = 1u << RBITS;
-    for (uint32_t p = 0; p < passes; p++) {   // ComputeBufferSorter.cs:102
-        LBVH_LAUNCH(ctx, (sort_onesweep_kernel<THREADS, ITEMS, STREAM, RBITS>), dim3(tiles), dim3(THREADS), ks, vs, kd, vd, count,
-                    (uint32_t)RBITS * p, ghist + p * RADIX, status + (size_t)p * tiles * RADIX,
-                    gstatus + (size_t)p * groups * RADIX, tickets + 8u * p, tiles, group, ctx->sort_queues, ctx->fault_dev);
+    uint32_t *ks = d_keys, *vs = d_values, *kd = alt_keys, *vd = alt_vals;
+    for (uint32_t p = 0; p < (uint32_t)kPasses; p++) {   // ComputeBufferSorter.cs:102
+        LBVH_LAUNCH(ctx, (sort_onesweep_kernel<THREADS, ITEMS, STREAM>), dim3(tiles), dim3(THREADS), ks, vs, kd, vd, count,
+                    8u * p, ghist + p * kRadix, status + (size_t)p * tiles * kRadix,
+                    gstatus + (size_t)p * groups * kRadix, tickets + 8u * p, tiles, group, ctx->sort_queues, ctx->fault_dev);
         uint32_t* tmp;
         tmp = ks; ks = kd; kd = tmp;
         tmp = vs; vs = vd; vd = tmp;
@@ -499,30 +441,19 @@ struct sort_plan {
 };
 }
 
-// Which sorts take the three 10-bit passes when their keys are known to be Morton codes (lbvh_build_scene): those whose
-// passes are latency, not bandwidth — up to 2 M keys (512 tiles of 4 096 on 256 CUs; beyond, the 16-byte digit runs of
-// 1 024 digits per 8 192-key tile would meet HBM).
-bool lbvh_sort_morton_form(uint32_t count)
-{
-    static const int env = getenv("LBVH_SORT_M30") ? atoi(getenv("LBVH_SORT_M30")) : 1;      // measurement switch
-    return env != 0 && count >= 2u && count <= (1u << 21);
-}
-
-// morton: the plan of the three 10-bit passes (lbvh_launch_sort_morton) instead of the four 8-bit ones
-static int sort_prepare(lbvh_context* ctx, uint32_t count, sort_plan* pl, bool morton = false)
+static int sort_prepare(lbvh_context* ctx, uint32_t count, sort_plan* pl)
 {
     // tile = 512 threads x 16 keys (8192) for big inputs: long digit runs = fuller cache lines in the
     // scatter and short look-back chains (measured best of 256..1024 threads x 4..16 keys at 2^24..2^28);
     // 512 x 8 below 2 M keys so every CU still gets tiles
-    const int threads = 512, items = count >= (1u << 21) && !morton ? 16 : 8;
-    const uint32_t radix = morton ? (uint32_t)kMaxRadix : (uint32_t)kRadix, passes = morton ? (uint32_t)kMortonPasses : (uint32_t)kPasses;
+    const int threads = 512, items = count >= (1u << 21) ? 16 : 8;
     const uint32_t tile = (uint32_t)threads * (uint32_t)items;
     const uint32_t tiles = (uint32_t)(((uint64_t)count + tile - 1) / tile);
     const size_t pair_bytes = (((size_t)count * 4) + 255) & ~(size_t)255;
-    // [ghist passes x radix | tickets (passes x 8 XCDs, padded to 256 B) | tile words passes x tiles x radix | group words] is zeroed per sort
-    const size_t head_bytes = (size_t)passes * radix * 4 + 256;
+    // [ghist 4x256 | tickets (4 passes x 8 XCDs, padded to 256 B) | tile words 4 x tiles x 256 | group words] is zeroed per sort
+    const size_t head_bytes = (size_t)kPasses * kRadix * 4 + 256;
     const uint32_t groups = (tiles + (uint32_t)kLbGroup - 1u) / (uint32_t)kLbGroup;
-    const size_t status_bytes = (size_t)passes * ((size_t)tiles + groups) * radix * 4;
+    const size_t status_bytes = (size_t)kPasses * ((size_t)tiles + groups) * kRadix * 4;
     int rc = lbvh_reserve(ctx, &ctx->sort_scratch, &ctx->sort_scratch_bytes, 2 * pair_bytes + head_bytes + status_bytes);
     if (rc != LBVH_OK) return rc;
     char* p = (char*)ctx->sort_scratch;
@@ -532,26 +463,21 @@ static int sort_prepare(lbvh_context* ctx, uint32_t count, sort_plan* pl, bool m
     pl->alt_keys = (uint32_t*)p;
     pl->alt_vals = (uint32_t*)(p + pair_bytes);
     pl->ghist = (uint32_t*)(p + 2 * pair_bytes);
-    pl->tickets = pl->ghist + passes * radix;
+    pl->tickets = pl->ghist + kPasses * kRadix;
     pl->status = (uint32_t*)(p + 2 * pair_bytes + head_bytes);
-    pl->gstatus = pl->status + (size_t)passes * tiles * radix;
+    pl->gstatus = pl->status + (size_t)kPasses * tiles * kRadix;
     pl->zero_bytes = head_bytes + status_bytes;
     return LBVH_OK;
 }
 
-int lbvh_sort_scratch(lbvh_context* ctx, uint32_t count, uint32_t** d_zero, uint32_t* zero_words, bool morton, uint32_t** d_in_keys,
-                      uint32_t** d_in_values)
+int lbvh_sort_scratch(lbvh_context* ctx, uint32_t count, uint32_t** d_zero, uint32_t* zero_words)
 {
     *d_zero = nullptr;
     *zero_words = 0;
-    if (d_in_keys) *d_in_keys = nullptr;
-    if (d_in_values) *d_in_values = nullptr;
     if (count < 2) return LBVH_OK;
     sort_plan pl;
-    const int rc = sort_prepare(ctx, count, &pl, morton);
+    const int rc = sort_prepare(ctx, count, &pl);
     if (rc != LBVH_OK) return rc;
-    if (d_in_keys) *d_in_keys = pl.alt_keys;
-    if (d_in_values) *d_in_values = pl.alt_vals;
     if (pl.zero_bytes / 4 > 0xFFFFFFFFull) return LBVH_OK;      // the caller's sort clears it itself
     *d_zero = pl.ghist;
     *zero_words = (uint32_t)(pl.zero_bytes / 4);
@@ -576,39 +502,17 @@ int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, ui
     // 1024 global atomics each block ends with do not pile up on the same counters
     uint32_t hblocks = (count + 8191u) / 8192u;
     if (hblocks > 256u * 8u) hblocks = 256u * 8u;
-    LBVH_LAUNCH(ctx, (sort_histogram_kernel<8, kPasses>), dim3(hblocks), dim3(kThreads), d_keys, count, ghist);
+    LBVH_LAUNCH(ctx, sort_histogram_kernel, dim3(hblocks), dim3(kThreads), d_keys, count, ghist);
     // consecutive tiles per XCD: 16 when every XCD still gets several groups, fewer for small sorts
     const uint32_t group = tiles >= 1024u ? 16u : tiles >= 128u ? 8u : 1u;
     if (items == 16 && count >= (1u << 23))
-        launch_passes<512, 16, true, 8>(ctx, d_keys, d_values, alt_keys, alt_vals, kPasses, count, tiles, ghist, status, gstatus, groups, tickets, group);
+        launch_passes<512, 16, true>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     else if (items == 16)
-        launch_passes<512, 16, false, 8>(ctx, d_keys, d_values, alt_keys, alt_vals, kPasses, count, tiles, ghist, status, gstatus, groups, tickets, group);
+        launch_passes<512, 16, false>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     else
-        launch_passes<512, 8, false, 8>(ctx, d_keys, d_values, alt_keys, alt_vals, kPasses, count, tiles, ghist, status, gstatus, groups, tickets, group);
+        launch_passes<512, 8, false>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;   // 4 passes: the result is back in d_keys / d_values
-}
-
-// The sort of lbvh_build_scene for keys that are 30-bit Morton codes (pads 0xFFFFFFFF behind them): three 10-bit passes.
-// An odd number of passes ends in the other buffer pair, so the INPUT is expected in the sort's own scratch pair
-// (lbvh_sort_scratch's d_in_keys / d_in_values: the Morton kernel writes there) and the result lands in d_keys / d_values.
-int lbvh_launch_sort_morton(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t count, bool scratch_cleared)
-{
-    if (count < 2) return LBVH_OK;
-    sort_plan pl;
-    {
-        const int rc = sort_prepare(ctx, count, &pl, true);
-        if (rc != LBVH_OK) return rc;
-    }
-    if (!scratch_cleared) LBVH_HIP_TRY(ctx, hipMemsetAsync(pl.ghist, 0, pl.zero_bytes, ctx->cur_stream));
-    uint32_t hblocks = (count + 8191u) / 8192u;
-    if (hblocks > 256u * 8u) hblocks = 256u * 8u;
-    LBVH_LAUNCH(ctx, (sort_histogram_kernel<kMortonBits, kMortonPasses>), dim3(hblocks), dim3(kThreads), pl.alt_keys, count, pl.ghist);
-    const uint32_t group = pl.tiles >= 1024u ? 16u : pl.tiles >= 128u ? 8u : 1u;
-    launch_passes<512, 8, false, kMortonBits>(ctx, pl.alt_keys, pl.alt_vals, d_keys, d_values, kMortonPasses, count, pl.tiles, pl.ghist, pl.status,
-                                              pl.gstatus, pl.groups, pl.tickets, group);
-    LBVH_HIP_TRY(ctx, hipGetLastError());
-    return LBVH_OK;
 }
 
 extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values,

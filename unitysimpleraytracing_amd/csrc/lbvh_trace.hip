@@ -1436,22 +1436,15 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
         // three fill kernels less in the chain
         uint32_t* zero = nullptr;
         uint32_t zero_words = 0;
-        // Morton keys are 30 bits: up to 2 M of them are sorted by three 10-bit passes (lbvh_sort.hip), which read their
-        // input from the sort's own scratch pair — the Morton kernel writes keys and indices there
-        const bool m30 = lbvh_sort_morton_form(capacity);
-        uint32_t *in_keys = nullptr, *in_vals = nullptr;
-        if ((rc = (lbvh_status)lbvh_sort_scratch(ctx, capacity, &zero, &zero_words, m30, &in_keys, &in_vals)) != LBVH_OK) return rc;
+        if ((rc = (lbvh_status)lbvh_sort_scratch(ctx, capacity, &zero, &zero_words)) != LBVH_OK) return rc;
         lbvh_fast_tri* lines = nullptr;
         if (flags & LBVH_BUILD_FAST_SCENE) {        // the derived scene's triangle lines ride on the Morton kernel
             if ((rc = ensure_fast_lines(ctx, n)) != LBVH_OK) return rc;
             lines = ctx->fast_tris;
         }
         if (!morton_done)
-            lbvh_launch_morton(ctx, d_triangles, n, capacity, h_box_min, h_box_max, m30 ? in_keys : d_keys, m30 ? in_vals : d_indices, d_aabb, zero,
-                               zero_words, lines);
-        rc = m30 ? (lbvh_status)lbvh_launch_sort_morton(ctx, d_keys, d_indices, capacity, zero != nullptr)
-                 : (lbvh_status)lbvh_launch_sort(ctx, d_keys, d_indices, capacity, zero != nullptr);
-        if (rc != LBVH_OK) return rc;
+            lbvh_launch_morton(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, zero, zero_words, lines);
+        if ((rc = (lbvh_status)lbvh_launch_sort(ctx, d_keys, d_indices, capacity, zero != nullptr)) != LBVH_OK) return rc;
     }
     const bool fast = (flags & LBVH_BUILD_FAST_SCENE) != 0;
     if (fast) {
@@ -1540,9 +1533,7 @@ static lbvh_status build_scene_impl(lbvh_context* ctx, const lbvh_anim* anim, co
         lbvh_note_write(ctx, d_triangles, (size_t)n * sizeof(lbvh_triangle));
         uint32_t* zero = nullptr;
         uint32_t zero_words = 0;
-        const bool m30 = lbvh_sort_morton_form(capacity);
-        uint32_t *in_keys = nullptr, *in_vals = nullptr;
-        lbvh_status src = (lbvh_status)lbvh_sort_scratch(ctx, capacity, &zero, &zero_words, m30, &in_keys, &in_vals);
+        lbvh_status src = (lbvh_status)lbvh_sort_scratch(ctx, capacity, &zero, &zero_words);
         if (src != LBVH_OK) return src;
         lbvh_fast_tri* lines = nullptr;
         if (fast_flag) {
@@ -1550,8 +1541,8 @@ static lbvh_status build_scene_impl(lbvh_context* ctx, const lbvh_anim* anim, co
             lines = ctx->fast_tris;
         }
         LBVH_REQUIRE(ctx, ((uintptr_t)d_triangles & 15) == 0 && ((uintptr_t)d_aabb & 15) == 0);
-        lbvh_launch_animate_morton(ctx, *anim, const_cast<lbvh_triangle*>(d_triangles), n, capacity, h_box_min, h_box_max, m30 ? in_keys : d_keys,
-                                   m30 ? in_vals : d_indices, d_aabb, zero, zero_words, lines);
+        lbvh_launch_animate_morton(ctx, *anim, const_cast<lbvh_triangle*>(d_triangles), n, capacity, h_box_min, h_box_max, d_keys, d_indices,
+                                   d_aabb, zero, zero_words, lines);
     }
     const bool morton_done = anim != nullptr;
     if (graphs && ctx->build_graph && ctx->build_graph_key == key) {
