@@ -15,6 +15,7 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--mode", default="fast")
 ap.add_argument("--no-check", action="store_true")
 ap.add_argument("--cam-z", type=float, default=250.0)
+ap.add_argument("--cold", action="store_true", help="drop the dispatch history before every frame (the plain packet kernel, row-major)")
 args = ap.parse_args()
 W, H = 1920, 1080
 tris = scenes.tiled_torus()
@@ -28,6 +29,8 @@ import numpy as np
 if args.no_check:
     e0, e1 = ctx.event(), ctx.event()
     for r in range(args.reps):
+        if args.cold:
+            ctx.trace_forget()
         ctx.record(e0)
         N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(cam), 0, 0, W, H, C.byref(s), mode, hits.device, None))
         ctx.record(e1)
