@@ -7,7 +7,7 @@ WT=$(mktemp -d /tmp/lbvh_head.XXXX)
 git -C $R worktree add -f $WT HEAD -q
 mkdir -p $R/build_exp/obj_head
 for f in lbvh_api lbvh_sort lbvh_build lbvh_trace lbvh_shade lbvh_path; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-mfma-vgpr-form -c $WT/unitysimpleraytracing_amd/csrc/$f.hip -o $R/build_exp/obj_head/$f.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -c $WT/unitysimpleraytracing_amd/csrc/$f.hip -o $R/build_exp/obj_head/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_exp/liblbvh_head.so $R/build_exp/obj_head/*.o

@@ -9,7 +9,7 @@ CS=$R/unitysimpleraytracing_amd/csrc
 OUT=$R/build_exp
 mkdir -p $OUT/obj_$NAME
 for f in lbvh_api lbvh_sort lbvh_build lbvh_trace lbvh_shade lbvh_path; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form "$@" \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function "$@" \
       -c $CS/$f.hip -o $OUT/obj_$NAME/$f.o &
 done
 wait

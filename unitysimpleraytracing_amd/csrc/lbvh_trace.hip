@@ -658,110 +658,6 @@ __device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, pac
     return steps;
 }
 
-// ---- the lean step with its products on the matrix pipe --------------------------------------------------------------
-// The walk is bound by vector-instruction issue (pipes busy 0.91), and 12 of the lean step's ~54 vector
-// instructions are the slab products (plane - origin) x inverse direction: for every ray, four planes (left near / far,
-// right near / far) per axis — an OUTER PRODUCT of four wave-uniform values with a per-lane one, which is exactly what
-// v_mfma_f32_4x4x1_16b_f32 computes for each block of four lanes: lane n receives A[m] x B[n] for the A values of the four
-// lanes of its block.  The node line arrives as in the lean step (lane k holds dword k & 15; `plane - origin` is ONE
-// subtraction over the line); a cross-lane gather on the LDS crossbar (ds_bpermute_b32: no LDS memory, no vector-pipe slot)
-// puts, per axis, the four planes of that axis into the four lanes of every block — near / far already chosen by the
-// gather's lane indices, which know the packet's direction signs — and THREE matrix instructions (A = those differences,
-// B = the lane's inverse direction component, C = 0) leave all twelve products in the lane's registers, computed beside
-// the vector pipe instead of on it.  A x B + 0 on the matrix pipe is the product v_mul_f32 gives, bit for bit —
-// tools/ubench/mfmacheck.hip compares 4 x 2^30 random pairs (normal, denormal, overflowing, zeros, infinities, NaNs): 0
-// differ — so tmin / tmax, and with them every decision of the walk, are walk_packet_lean's.
-// (First form, measured and dropped: every lane loading float4 (lane & 3) of the line — the matrix instruction's operand
-// layout straight from memory, no gather — is 12 % SLOWER than the lean step, 202 against 181 us per frame: four times the
-// bytes come back from L1 for every line.)
-typedef float lbvh_f4 __attribute__((ext_vector_type(4)));
-
-// source lane (as a byte address for ds_bpermute) of plane m = lane & 3 of `axis` in this lane's 16-lane row:
-// m = 0 / 1: the left box's near / far plane, 2 / 3: the right box's
-__device__ __forceinline__ int plane_gather_address(uint32_t lane, uint32_t axis, uint32_t neg)
-{
-    const uint32_t m = lane & 3u, box = m >> 1, far = (m & 1u) ^ ((neg >> axis) & 1u);      // far: the box's max plane on this axis
-    return (int)(((lane & 48u) + box * 8u + far * 4u + axis) * 4u);
-}
-
-template <bool BUF>
-__device__ __forceinline__ uint32_t walk_packet_matrix(const line_source& src, packet_rays<1>& P, uint32_t neg)
-{
-    const uint32_t lane = lane_id();
-    const ray_t r = P.ray[0];
-    int stack = 0;            // wave-shared stack: slot k lives in lane k of this VGPR
-    uint32_t sp = 0, steps = 0;
-    const uint32_t node_bytes = (lane & 15u) * 4u;          // (plain order: the gather below picks near and far)
-    const uint32_t axis = lane & 3u;          // dword k of a line is a plane (or a vertex coordinate) of axis k & 3; 3: no plane
-    const float o_lane = axis == 0u ? r.ox : (axis == 1u ? r.oy : (axis == 2u ? r.oz : 0.0f));
-    const int gx = plane_gather_address(lane, 0u, neg), gy = plane_gather_address(lane, 1u, neg), gz = plane_gather_address(lane, 2u, neg);
-    const lbvh_f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    float best_t = P.act[0] ? P.best_t[0] : -INFINITY;
-    uint32_t best_tri = P.best_tri[0];
-    float best_u = P.best_u[0], best_v = P.best_v[0];
-    int w_node = fetch_line<BUF>(src, 0u, node_bytes);
-    for (;;) {
-        const uint32_t lref = (uint32_t)__builtin_amdgcn_readlane(w_node, 3), rref = (uint32_t)__builtin_amdgcn_readlane(w_node, 7);
-        const bool leaf_l = (int)lref < 0, leaf_r = (int)rref < 0;
-        const int w_l = fetch_line<BUF>(src, lref, node_bytes);        // both children in flight before the tests
-        const int w_r = fetch_line<BUF>(src, rref, node_bytes);
-        steps++;
-        const int d = __float_as_int(__int_as_float(w_node) - o_lane);     // every plane minus the origin, once
-        // per axis: {left near, left far, right near, right far} into the four lanes of every block, then the outer product
-        const lbvh_f4 px = __builtin_amdgcn_mfma_f32_4x4x1f32(__int_as_float(__builtin_amdgcn_ds_bpermute(gx, d)), r.ix, zero, 0, 0, 0);
-        const lbvh_f4 py = __builtin_amdgcn_mfma_f32_4x4x1f32(__int_as_float(__builtin_amdgcn_ds_bpermute(gy, d)), r.iy, zero, 0, 0, 0);
-        const lbvh_f4 pz = __builtin_amdgcn_mfma_f32_4x4x1f32(__int_as_float(__builtin_amdgcn_ds_bpermute(gz, d)), r.iz, zero, 0, 0, 0);
-        const float tl = fmaxf(px[0], fmaxf(py[0], pz[0]));
-        const float fl = fminf(px[1], fminf(py[1], pz[1]));
-        const float tr = fmaxf(px[2], fmaxf(py[2], pz[2]));
-        const float fr = fminf(px[3], fminf(py[3], pz[3]));
-        const bool box_l = fl > max_zero(tl), box_r = fr > max_zero(tr);
-        const bool near_l = !(tl > best_t), near_r = !(tr > best_t);
-        bool hit_l = box_l && near_l, hit_r = box_r && near_r;
-        uint64_t ml = __builtin_amdgcn_ballot_w64(box_l) & __builtin_amdgcn_ballot_w64(near_l);
-        uint64_t mr = __builtin_amdgcn_ballot_w64(box_r) & __builtin_amdgcn_ballot_w64(near_r);
-        // leaves first: their hits tighten best_t before anything is entered
-        if (leaf_l) {
-            if (ml != 0) {
-                const lean_tri T = uniform_tri(w_l, o_lane);
-                float t, u, v;            // every lane computes; the lanes that hit the leaf's box may keep the result
-                if (lean_triangle(r, T, t, u, v) && hit_l && closer(t, T.index, best_t, best_tri)) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
-                const bool still_r = !(tr > best_t);
-                hit_r = hit_r && still_r;
-                mr &= __builtin_amdgcn_ballot_w64(still_r);
-            }
-            ml = 0;
-        }
-        if (leaf_r) {
-            if (mr != 0) {
-                const lean_tri T = uniform_tri(w_r, o_lane);
-                float t, u, v;
-                if (lean_triangle(r, T, t, u, v) && hit_r && closer(t, T.index, best_t, best_tri)) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
-                ml &= __builtin_amdgcn_ballot_w64(!(tl > best_t));
-            }
-            mr = 0;
-        }
-        if (ml != 0 && mr != 0) {
-            const uint64_t both = ml & mr, le = __builtin_amdgcn_ballot_w64(tl <= tr);
-            const int by_votes = lanes_in(both & le) - lanes_in(both & ~le), by_lanes = lanes_in(ml) - lanes_in(mr);
-            const bool l_near = (by_votes != 0 ? by_votes : by_lanes) >= 0;
-            push_slot(stack, l_near ? rref : lref, sp & 63u);
-            sp++;
-            w_node = select_line(w_l, w_r, l_near);
-        } else if (ml != 0) {
-            w_node = w_l;
-        } else if (mr != 0) {
-            w_node = w_r;
-        } else {
-            if (sp == 0) break;
-            sp--;
-            w_node = fetch_line<BUF>(src, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), node_bytes);
-        }
-    }
-    P.best_t[0] = best_t; P.best_tri[0] = best_tri; P.best_u[0] = best_u; P.best_v[0] = best_v;
-    return steps;
-}
-
 // do all active rays of the packet leave the same point (primary rays of a pinhole camera do)?
 __device__ __forceinline__ bool packet_one_origin(const packet_rays<1>& P)
 {
@@ -1050,11 +946,7 @@ __device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_
     src.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<lbvh_fast_node*>(nodes), 0, (int)a.line_bytes, 0x00020000);
     uint32_t steps;
     if (!STATS && ordered && packet_one_origin(P))
-#ifdef LBVH_LEAN_VALU_PRODUCTS          // (A/B: the products on the vector pipe, as until round 3)
         steps = a.line_bytes != 0 ? walk_packet_lean<true>(src, P, neg) : walk_packet_lean<false>(src, P, neg);
-#else
-        steps = a.line_bytes != 0 ? walk_packet_matrix<true>(src, P, neg) : walk_packet_matrix<false>(src, P, neg);
-#endif
     else if (a.line_bytes != 0)
         steps = ordered ? walk_packet<STATS, 1, true, true>(src, P, C, neg) : walk_packet<STATS, 1, false, true>(src, P, C, 0u);
     else
