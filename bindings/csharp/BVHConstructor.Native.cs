@@ -41,14 +41,14 @@ public class BVHConstructor : IDisposable
 
     public void ConstructTree()
     {
-        IntPtr ctx = LbvhContext.Handle;
+        IntPtr ctx = _internalNodes.Context;             // the GPU the tree's buffers live on
         LbvhNative.Check(ctx, LbvhNative.lbvh_build_tree(ctx, _trianglesCount, _sortedMortonCodes.Pointer, _internalNodes.Pointer,
                                                          _leafNodes.Pointer));
     }
 
     public void ConstructBVH()
     {
-        IntPtr ctx = LbvhContext.Handle;
+        IntPtr ctx = _internalNodes.Context;
         LbvhNative.Check(ctx, LbvhNative.lbvh_refit(ctx, _trianglesCount, _internalNodes.Pointer, _leafNodes.Pointer, _triangleAABB.Pointer,
                                                     _sortedTriangleIndices.Pointer, _bvhData.Pointer));
     }

@@ -34,7 +34,7 @@ public class ComputeBufferSorter<TKey, TValue> : IDisposable where TKey : struct
 
     public void Sort()
     {
-        IntPtr ctx = LbvhContext.Handle;
+        IntPtr ctx = _keys.Context;                      // the GPU the pairs live on
         LbvhNative.Check(ctx, LbvhNative.lbvh_sort_pairs(ctx, _keys.Pointer, _values.Pointer, (uint)_keys.count));
         if (ValidateAfterSort) ValidateSortedData();
     }

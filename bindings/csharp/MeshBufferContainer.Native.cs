@@ -83,14 +83,14 @@ public class MeshBufferContainer : IDisposable
         }
         _triangleDataBuffer.Sync();
 
-        IntPtr ctx = LbvhContext.Handle;
+        IntPtr ctx = Keys.Context;                       // the GPU that was current when the buffers above were made
         LbvhNative.Check(ctx, LbvhNative.lbvh_morton_aabb(ctx, TriangleData.Pointer, _trianglesLength, (uint)capacity, WholeMin, WholeMax,
                                                           Keys.Pointer, TriangleIndex.Pointer, TriangleAABB.Pointer));
     }
 
     public void DistributeKeys()
     {
-        IntPtr ctx = LbvhContext.Handle;
+        IntPtr ctx = Keys.Context;
         LbvhNative.Check(ctx, LbvhNative.lbvh_distribute_keys(ctx, Keys.Pointer, _trianglesLength));
     }
 

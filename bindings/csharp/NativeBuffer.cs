@@ -12,6 +12,10 @@ public sealed class NativeBuffer : IDisposable
     public IntPtr Pointer { get; private set; }
     public int count { get; }
     public int stride { get; }
+    /// The native context (= GPU) this buffer lives on: the one that was current when it was created (LbvhContext.Current).
+    /// The re-hosted classes take the context of their calls from their buffers, so a replica built while GPU k was current
+    /// keeps working on GPU k whatever is current later.
+    public IntPtr Context { get; }
 
     public NativeBuffer(int count, int stride)
     {
@@ -19,6 +23,7 @@ public sealed class NativeBuffer : IDisposable
         this.count = count;
         this.stride = stride;
         IntPtr ctx = LbvhContext.Handle;
+        Context = ctx;
         LbvhNative.Check(ctx, LbvhNative.lbvh_buffer_alloc(ctx, (UIntPtr)(ulong)count, (UIntPtr)(ulong)stride, out IntPtr p));
         Pointer = p;
     }
@@ -39,7 +44,7 @@ public sealed class NativeBuffer : IDisposable
     /// Host array -> device (ComputeBuffer.SetData); blocking like Unity's.
     public void SetData(Array data)
     {
-        IntPtr ctx = LbvhContext.Handle;
+        IntPtr ctx = Context;
         GCHandle h = GCHandle.Alloc(data, GCHandleType.Pinned);
         try { LbvhNative.Check(ctx, LbvhNative.lbvh_buffer_upload(ctx, Pointer, h.AddrOfPinnedObject(), (UIntPtr)(ulong)Bytes(data))); }
         finally { h.Free(); }
@@ -48,7 +53,7 @@ public sealed class NativeBuffer : IDisposable
     /// Device -> host array (ComputeBuffer.GetData): waits for the work enqueued so far, the reference's only sync point.
     public void GetData(Array data)
     {
-        IntPtr ctx = LbvhContext.Handle;
+        IntPtr ctx = Context;
         GCHandle h = GCHandle.Alloc(data, GCHandleType.Pinned);
         try { LbvhNative.Check(ctx, LbvhNative.lbvh_buffer_download(ctx, h.AddrOfPinnedObject(), Pointer, (UIntPtr)(ulong)Bytes(data))); }
         finally { h.Free(); }
@@ -57,14 +62,14 @@ public sealed class NativeBuffer : IDisposable
     /// Every 32-bit word of the buffer = value (the fill constructors' uint.MaxValue / NullLeaf patterns), on the device.
     public void Fill(uint value)
     {
-        IntPtr ctx = LbvhContext.Handle;
+        IntPtr ctx = Context;
         LbvhNative.Check(ctx, LbvhNative.lbvh_buffer_fill_u32(ctx, Pointer, value, (UIntPtr)(ulong)((long)count * stride / 4)));
     }
 
     public void Release()
     {
         if (Pointer == IntPtr.Zero) return;
-        LbvhNative.lbvh_buffer_free(LbvhContext.Handle, Pointer);
+        LbvhNative.lbvh_buffer_free(Context, Pointer);
         Pointer = IntPtr.Zero;
     }
 
