@@ -28,9 +28,11 @@ part of a step; `ms_per_step` is the whole step (build + trace), wall clock, max
       frac = achieved / peak — a small number: the walk prunes and the scene it walks is cache-resident;
   roofline.traffic: HBM-side bytes per launch from live FETCH_SIZE / WRITE_SIZE child passes (or null — never replayed
       from a committed file);
-  roofline.valu_issue: what the kernel IS close to — wave64 vector instructions per second (SQ_INSTS_VALU of a live
+  roofline.valu_issue: the busiest unit of the kernel — wave64 vector instructions per second (SQ_INSTS_VALU of a live
       rocprofv3 child pass of this very run) against 1024 SIMDs x the measured shader clock / 2 cycles (the guide's
-      v_fma_f32 rate with other waves resident), and the share of SIMD cycles with a vector instruction executing.
+      v_fma_f32 rate with other waves resident), and the share of SIMD cycles with a vector instruction executing.  Not
+      "the" bound: with 17 % of these instructions moved to the matrix pipe the frame is 0 - 2 % shorter (DESIGN 13.3,
+      profiles/r4/d_*): a step is a dependent chain across the vector pipe, the scalar unit and the memory system.
 """
 import argparse
 import ctypes as C
@@ -529,8 +531,8 @@ def main():
             issue = LC.issue_counters(child, "trace_")
         # HBM is the roofline of every stage.  `frac` is the kernel's OWN algorithmic bytes over its live duration
         # against 8 TB/s — small, because the walk prunes (the reference algorithm's bytes priced at this duration would be
-        # several times the peak: `reference_equivalent_GBs`) and because the scene it walks is cache-resident.  What the kernel
-        # is close to is vector-instruction issue, carried beside it under its own name (`valu_issue`).
+        # several times the peak: `reference_equivalent_GBs`) and because the scene it walks is cache-resident.  The busiest unit
+        # of the kernel is the vector pipe, carried beside it under its own name (`valu_issue`); DESIGN 13.3 for what binds a step.
         roofline = {"roofline_version": 3,        # 3 (round 3 on): frac = HBM fraction of the kernel's own bytes; valu_issue against the 2-cycle rate
                     "kernel": kname, "kernel_ms": round(trace_kernel_ms, 4), "bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": hbm["frac"],
@@ -550,7 +552,9 @@ def main():
                          "instruction (MI355X_MICROARCH.md: v_fma_f32 2 cycles on the SIMD-32 with other waves resident).  Only v_mul / "
                          "v_add / v_fma / v_mov reach that rate on this chip; the walk's v_cmp, min3 / max3, DPP-operand and v_readlane "
                          "instructions issue in 4.3 cycles (profiles/r3/b_instcost.txt): `pipe_busy_frac` is the share of the kernel's "
-                         "SIMD cycles with a vector instruction executing (SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles)",
+                         "SIMD cycles with a vector instruction executing (SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles).  The busiest unit, not "
+                         "the whole bound: 17 % fewer of these instructions (slab products on the matrix pipe) shorten the frame by "
+                         "0 - 2 % (profiles/r4/d_matrix_pipe_products.txt)",
                 "pipe_busy_frac": round(4.0 * issue.get("SQ_ACTIVE_INST_VALU", 0.0) / simd_cycles, 3),
                 "cycles_per_valu": round(4.0 * issue.get("SQ_ACTIVE_INST_VALU", 0.0) / valu, 2),
                 "valu_per_step": round(valu / steps, 1), "salu_per_step": round(issue.get("SQ_INSTS_SALU", 0.0) / steps, 1),
@@ -595,12 +599,13 @@ def main():
             "trace_without_gather_ms": round(own_trace_ms_max, 4),
             "frame_gather": frame_check,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "scaling_note": "strong scaling of ONE 1080p frame: `value` = rays of the whole frame / the slowest rank's trace part.  The "
-                            "rebuild is replicated (every rank builds the whole BVH: north_star's 'BVH replicated, no collectives'), so "
+            "scaling_note": "strong scaling of ONE 1080p frame: `value` = rays of the whole frame / the slowest rank's trace part — for N > 1 "
+                            "that part ends with the whole frame in rank 0's buffer (`frame_gather`; `value_without_gather`: the traversal "
+                            "alone).  The rebuild is replicated (every rank builds the whole BVH: north_star's 'BVH replicated, no collectives'), so "
                             f"ms_per_step cannot fall below build_ms ({build_ms_max:.3f} ms here) however many GPUs trace: at 8 GPUs the step "
                             "is at best ~1.4x faster than on one.  A share's trace time is the dependent chain of its heaviest 8x8 tile "
                             "(~0.4 us per step), not throughput: expect ~0.8 / 0.45 / 0.3 efficiency at 2 / 4 / 8 GPUs for `value` "
-                            "(DESIGN.md section 6, profiles/r3/*shard_times*)",
+                            "(DESIGN.md sections 6 and 13.1, profiles/r4/n_shard_times_one_gpu.txt)",
             "dtype": "f32+u32", "data": "synthetic",
             "config": {"workload": ("cfg4: 16,000,000-triangle tiled bumpy torus (400x160 quads x 125 tiles, seed 2), sort "
                                     + (f"key-range sharded over {world} GPUs (RCCL digit-histogram all-reduce + one all-to-all), "
