@@ -348,6 +348,10 @@ def test_build_scene_one_call_equals_the_staged_chain(ctx, scene):
     for rep in range(3):
         c.bvh_data.fill_u32(0x7FC00000, mirror=False)
         c.keys.fill_u32(0, mirror=False)
+        # LBVH_BUILD_RESET_NODES refills only what the tree kernel does not write (slots past the tree, the root's parent):
+        # whatever stood in the arrays before, every word of all capacity slots must come out as a fresh build's
+        c.bvh_internal_node.fill_u32(0x1234567 + rep, mirror=False)
+        c.bvh_leaf_node.fill_u32(0x89ABCDE + rep, mirror=False)
         d.rebuild()                                   # lbvh_build_scene
         assert_build_equal(c, b)
         d.update(cam, mode=L.TRACE_FAST)

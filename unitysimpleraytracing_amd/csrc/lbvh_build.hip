@@ -28,6 +28,22 @@ __device__ __forceinline__ uint32_t quantize(float x)          // MeshBufferCont
     return (uint32_t)x;
 }
 
+// LBVH_BUILD_RESET_NODES without two fills of 32 MB in front of the chain: the tree kernel that follows writes EVERY word of
+// internal nodes [0, n - 1) and leaves [0, n) — a node's own five words by its thread, its parent word by its parent's —
+// except the root's parent word, so refilling the node arrays with 0xFFFFFFFF (Sc/MeshBufferContainer.cs:114-115) comes down
+// to the slots past the tree and that one word: thread i of the Morton kernel does slot i.
+struct node_reset { uint32_t* internal; uint32_t* leaf; };      // nullptr: no reset
+__device__ __forceinline__ void reset_node_slot(const node_reset& r, uint32_t i, uint32_t n, uint32_t capacity)
+{
+    if (!r.internal || i >= capacity) return;
+    if (i + 1u >= n) {          // internal slots n - 1 .. capacity - 1
+#pragma unroll
+        for (int k = 0; k < 6; k++) r.internal[(size_t)i * 6u + k] = 0xFFFFFFFFu;
+    }
+    if (i >= n) { r.leaf[(size_t)i * 2u] = 0xFFFFFFFFu; r.leaf[(size_t)i * 2u + 1u] = 0xFFFFFFFFu; }
+    if (i == 0u) r.internal[4] = 0xFFFFFFFFu;          // the root's parent: never written by TreeConstructor (BVH.compute:94-149)
+}
+
 // one triangle's Morton code, index, padded AABB (and, for lbvh_build_scene, its 64-byte traversal line) from its three
 // positions: the loop body of MeshBufferContainer.cs:123-146.  Key and index go to memory, box and line to the workgroup's
 // LDS staging (the caller stores them as whole records).
@@ -70,12 +86,13 @@ __global__ __launch_bounds__(256) void morton_aabb_kernel(const lbvh_triangle* _
                                                           uint32_t* __restrict__ indices,
                                                           lbvh_aabb* __restrict__ aabb,
                                                           uint32_t* __restrict__ zero, uint32_t zero_words,
-                                                          lbvh_fast_tri* __restrict__ lines)
+                                                          lbvh_fast_tri* __restrict__ lines, node_reset reset)
 {
     const uint32_t b0 = blockIdx.x * 256u, i = b0 + threadIdx.x;
     // lbvh_build_scene: the sort that follows wants its counters and look-back words cleared; doing it here saves
     // a fill kernel in the chain
     for (uint32_t w = i; w < zero_words; w += gridDim.x * 256u) zero[w] = 0u;
+    reset_node_slot(reset, i, n, capacity);
     // records leave through LDS: a thread produces one triangle's 32-byte AABB and 64-byte line, the workgroup stores
     // them as consecutive float4 (a wave's store = 1 KB of whole records instead of 64 half / quarter lines)
     __shared__ float4 s_box[256 * 2];
@@ -118,10 +135,11 @@ __global__ __launch_bounds__(256) void animate_morton_kernel(const lbvh_triangle
                                                              lbvh_triangle* __restrict__ tris, uint32_t n, uint32_t capacity, box3 scene,
                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ indices,
                                                              lbvh_aabb* __restrict__ aabb, uint32_t* __restrict__ zero, uint32_t zero_words,
-                                                             lbvh_fast_tri* __restrict__ lines)
+                                                             lbvh_fast_tri* __restrict__ lines, node_reset reset)
 {
     const uint32_t b0 = blockIdx.x * 256u, i = b0 + threadIdx.x;
     for (uint32_t w = i; w < zero_words; w += gridDim.x * 256u) zero[w] = 0u;
+    reset_node_slot(reset, i, n, capacity);
     __shared__ float4 s_pos[256 * 3];
     __shared__ float4 s_box[256 * 2];
     __shared__ float4 s_line[256 * 4];
@@ -1264,25 +1282,29 @@ int lbvh_launch_tree_fused(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys
 
 int lbvh_launch_morton(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
                        const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
-                       lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines)
+                       lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines,
+                       lbvh_internal_node* d_reset_internal, lbvh_leaf_node* d_reset_leaf)
 {
     box3 scene;
     for (int k = 0; k < 3; k++) { scene.mn[k] = h_box_min[k]; scene.mx[k] = h_box_max[k]; }
     const uint32_t blocks = (capacity + 255) / 256;
+    const node_reset reset = {reinterpret_cast<uint32_t*>(d_reset_internal), reinterpret_cast<uint32_t*>(d_reset_leaf)};
     LBVH_LAUNCH(ctx, morton_aabb_kernel, dim3(blocks), dim3(256), d_triangles, n, capacity, scene, d_keys, d_indices, d_aabb,
-                d_zero, zero_words, d_lines);
+                d_zero, zero_words, d_lines, reset);
     return LBVH_OK;
 }
 
 int lbvh_launch_animate_morton(lbvh_context* ctx, const lbvh_anim& anim, lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
                                const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
-                               lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines)
+                               lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines,
+                               lbvh_internal_node* d_reset_internal, lbvh_leaf_node* d_reset_leaf)
 {
     box3 scene;
     for (int k = 0; k < 3; k++) { scene.mn[k] = h_box_min[k]; scene.mx[k] = h_box_max[k]; }
     const uint32_t blocks = (capacity + 255) / 256;
+    const node_reset reset = {reinterpret_cast<uint32_t*>(d_reset_internal), reinterpret_cast<uint32_t*>(d_reset_leaf)};
     LBVH_LAUNCH(ctx, animate_morton_kernel, dim3(blocks), dim3(256), anim.rest, anim.body, (const float4*)anim.centres, anim.cos_angle,
-                anim.sin_angle, d_triangles, n, capacity, scene, d_keys, d_indices, d_aabb, d_zero, zero_words, d_lines);
+                anim.sin_angle, d_triangles, n, capacity, scene, d_keys, d_indices, d_aabb, d_zero, zero_words, d_lines, reset);
     return LBVH_OK;
 }
 

@@ -187,16 +187,19 @@ int lbvh_set_error(lbvh_context* ctx, int code, const char* what, const char* de
 // d_zero_word (may be nullptr): a word the tree kernel clears on the way — the counter of the refit that follows
 int lbvh_launch_tree(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys, lbvh_internal_node* d_internal,
                      lbvh_leaf_node* d_leaf, uint32_t* d_zero_word);
-// Morton / AABB kernel that also clears d_zero[0 .. zero_words) (the scratch of the sort that follows) and, with
-// d_lines, writes the derived scene's 64-byte triangle lines (original order)
+// Morton / AABB kernel that also clears d_zero[0 .. zero_words) (the scratch of the sort that follows), with
+// d_lines writes the derived scene's 64-byte triangle lines (original order), and with d_reset_internal / d_reset_leaf refills
+// what LBVH_BUILD_RESET_NODES has to refill of the node arrays: the slots past the tree and the root's parent word
 int lbvh_launch_morton(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
                        const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
-                       lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines);
+                       lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines,
+                       lbvh_internal_node* d_reset_internal = nullptr, lbvh_leaf_node* d_reset_leaf = nullptr);
 // lbvh_animate fused into the Morton kernel (lbvh_animate_build_scene): the rest pose is moved into d_triangles on the way
 struct lbvh_anim { const lbvh_triangle* rest; const uint32_t* body; const float* centres; float cos_angle, sin_angle; };
 int lbvh_launch_animate_morton(lbvh_context* ctx, const lbvh_anim& anim, lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
                                const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
-                               lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines);
+                               lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines,
+                               lbvh_internal_node* d_reset_internal = nullptr, lbvh_leaf_node* d_reset_leaf = nullptr);
 // the sort with its scratch described / already cleared by the caller
 int lbvh_sort_scratch(lbvh_context* ctx, uint32_t count, uint32_t** d_zero, uint32_t* zero_words);
 int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t count, bool scratch_cleared);

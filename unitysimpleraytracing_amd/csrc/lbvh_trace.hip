@@ -1423,10 +1423,10 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
         if (src != LBVH_OK) return src;
     }
     lbvh_status rc;
-    if (flags & LBVH_BUILD_RESET_NODES) {        // NullLeaf / uint.MaxValue fills, Sc/MeshBufferContainer.cs:114-115
-        LBVH_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_internal, 0xFFFFFFFFu, (size_t)capacity * 6, ctx->stream));
-        LBVH_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_leaf, 0xFFFFFFFFu, (size_t)capacity * 2, ctx->stream));
-    }
+    // LBVH_BUILD_RESET_NODES (NullLeaf / uint.MaxValue fills, Sc/MeshBufferContainer.cs:114-115): the tree kernel rewrites every word
+    // of the nodes below n, so only the slots past the tree and the root's parent word are refilled — by the Morton kernel, on
+    // its way (two fills of 24 + 8 MB stood in front of the chain: 13 us of the rebuild)
+    const bool reset = (flags & LBVH_BUILD_RESET_NODES) != 0;
     // (argument checks of the public stage functions are repeated here only where lbvh_build_scene's own do not cover them)
     LBVH_REQUIRE(ctx, ((uintptr_t)d_triangles & 15) == 0 && ((uintptr_t)d_aabb & 15) == 0);
     LBVH_REQUIRE(ctx, ((uintptr_t)d_internal & 7) == 0 && ((uintptr_t)d_leaf & 7) == 0 && ((uintptr_t)d_bvh & 15) == 0);
@@ -1443,7 +1443,8 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
             lines = ctx->fast_tris;
         }
         if (!morton_done)
-            lbvh_launch_morton(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, zero, zero_words, lines);
+            lbvh_launch_morton(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, zero, zero_words, lines,
+                               reset ? d_internal : nullptr, reset ? d_leaf : nullptr);
         if ((rc = (lbvh_status)lbvh_launch_sort(ctx, d_keys, d_indices, capacity, zero != nullptr)) != LBVH_OK) return rc;
     }
     const bool fast = (flags & LBVH_BUILD_FAST_SCENE) != 0;
@@ -1542,7 +1543,8 @@ static lbvh_status build_scene_impl(lbvh_context* ctx, const lbvh_anim* anim, co
         }
         LBVH_REQUIRE(ctx, ((uintptr_t)d_triangles & 15) == 0 && ((uintptr_t)d_aabb & 15) == 0);
         lbvh_launch_animate_morton(ctx, *anim, const_cast<lbvh_triangle*>(d_triangles), n, capacity, h_box_min, h_box_max, d_keys, d_indices,
-                                   d_aabb, zero, zero_words, lines);
+                                   d_aabb, zero, zero_words, lines, (flags & LBVH_BUILD_RESET_NODES) ? d_internal : nullptr,
+                                   (flags & LBVH_BUILD_RESET_NODES) ? d_leaf : nullptr);
     }
     const bool morton_done = anim != nullptr;
     if (graphs && ctx->build_graph && ctx->build_graph_key == key) {
