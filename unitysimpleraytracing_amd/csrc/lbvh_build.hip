@@ -236,12 +236,13 @@ __device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* s_
     return incl - v + prefix;
 }
 
-__global__ __launch_bounds__(kDistThreads) void distribute_reduce_kernel(
-    const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ chunk_sums,
-    uint32_t* __restrict__ boundary)
+// (kernel bodies take their workgroup's index as an argument: lbvh_build_scene runs two of them side by side in ONE launch —
+// "merged launches" further down)
+__device__ __forceinline__ void distribute_reduce_body(uint32_t block, const uint32_t* __restrict__ keys, uint32_t n,
+                                                       uint32_t* __restrict__ chunk_sums, uint32_t* __restrict__ boundary)
 {
     __shared__ uint32_t s_wave[kDistThreads / LBVH_WAVE];
-    const uint32_t base = blockIdx.x * (uint32_t)kDistChunk;
+    const uint32_t base = block * (uint32_t)kDistChunk;
     const uint32_t j0 = base + threadIdx.x * (uint32_t)kDistItems;
     const uint32_t prev = (j0 > 0 && j0 - 1 < n) ? keys[j0 - 1] : 0u;
     uint32_t f[kDistItems];
@@ -252,9 +253,16 @@ __global__ __launch_bounds__(kDistThreads) void distribute_reduce_kernel(
     uint32_t total;
     (void)block_exclusive_sum(s, s_wave, &total);
     if (threadIdx.x == 0) {
-        chunk_sums[blockIdx.x] = total;
-        boundary[blockIdx.x] = prev;   // old key just before this chunk: the apply pass must not
+        chunk_sums[block] = total;
+        boundary[block] = prev;        // old key just before this chunk: the apply pass must not
     }                                   // re-read it, the previous chunk overwrites it in place
+}
+
+__global__ __launch_bounds__(kDistThreads) void distribute_reduce_kernel(
+    const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ chunk_sums,
+    uint32_t* __restrict__ boundary)
+{
+    distribute_reduce_body(blockIdx.x, keys, n, chunk_sums, boundary);
 }
 
 __global__ __launch_bounds__(kDistThreads) void distribute_scan_kernel(uint32_t* __restrict__ chunk_sums,
@@ -278,24 +286,23 @@ __global__ __launch_bounds__(kDistThreads) void distribute_scan_kernel(uint32_t*
 constexpr uint32_t kSelfScanChunks = 2048;
 
 template <bool SELF>
-__global__ __launch_bounds__(kDistThreads) void distribute_apply_kernel(
-    uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ chunk_sums,
-    const uint32_t* __restrict__ boundary)
+__device__ __forceinline__ void distribute_apply_body(uint32_t block, uint32_t* __restrict__ keys, uint32_t n,
+                                                      const uint32_t* __restrict__ chunk_sums, const uint32_t* __restrict__ boundary)
 {
     __shared__ uint32_t s_wave[kDistThreads / LBVH_WAVE];
     __shared__ uint32_t s_before[kDistThreads / LBVH_WAVE];
     uint32_t before = 0;
     if (SELF) {
         uint32_t part = 0;
-        for (uint32_t c = threadIdx.x; c < blockIdx.x; c += kDistThreads) part += chunk_sums[c];
+        for (uint32_t c = threadIdx.x; c < block; c += kDistThreads) part += chunk_sums[c];
         (void)block_exclusive_sum(part, s_before, &before);
     } else {
-        before = chunk_sums[blockIdx.x];
+        before = chunk_sums[block];
     }
-    const uint32_t base = blockIdx.x * (uint32_t)kDistChunk;
+    const uint32_t base = block * (uint32_t)kDistChunk;
     const uint32_t j0 = base + threadIdx.x * (uint32_t)kDistItems;
     uint32_t prev = 0;
-    if (threadIdx.x == 0) prev = boundary[blockIdx.x];
+    if (threadIdx.x == 0) prev = boundary[block];
     else if (j0 - 1 < n) prev = keys[j0 - 1];
     uint32_t f[kDistItems];
     dist_load(keys, n, j0, prev, f);
@@ -310,6 +317,14 @@ __global__ __launch_bounds__(kDistThreads) void distribute_apply_kernel(
         const uint32_t j = j0 + (uint32_t)c;
         if (j < n) keys[j] = carry + f[c];
     }
+}
+
+template <bool SELF>
+__global__ __launch_bounds__(kDistThreads) void distribute_apply_kernel(
+    uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ chunk_sums,
+    const uint32_t* __restrict__ boundary)
+{
+    distribute_apply_body<SELF>(blockIdx.x, keys, n, chunk_sums, boundary);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -510,22 +525,22 @@ enum { TREE_TOPOLOGY = 0, TREE_REFERENCE = 1, TREE_FUSED = 2 };
 // TREE_TOPOLOGY   lbvh_build_tree: the reference's node arrays only
 // TREE_REFERENCE  + bvh[i] = box of the node's range (BVHData, BVH.compute:215)
 // TREE_FUSED      the derived traversal tree: nothing but the 64-byte traversal node (both child boxes + child references)
+// s_keys[kTreeWindow], s_out[kTreeThreads * kQuads of the mode]: the calling kernel's LDS (tree_pair_kernel runs two modes
+// in one launch on ONE set)
 template <int MODE>
-__global__ __launch_bounds__(kTreeThreads) void tree_kernel(const uint32_t* __restrict__ codes, uint32_t n,
-                                                            lbvh_internal_node* __restrict__ internal,
-                                                            lbvh_leaf_node* __restrict__ leaf, uint32_t* __restrict__ zero_word,
-                                                            hier_t hier, lbvh_aabb* __restrict__ bvh,
-                                                            lbvh_fast_node* __restrict__ fused, uint32_t leaf_base,
-                                                            const uint32_t* __restrict__ sorted_indices)
+__device__ __forceinline__ void tree_body(uint32_t block, uint32_t* s_keys, float4* s_out, const uint32_t* __restrict__ codes,
+                                          uint32_t n, lbvh_internal_node* __restrict__ internal, lbvh_leaf_node* __restrict__ leaf,
+                                          uint32_t* __restrict__ zero_word, hier_t hier, lbvh_aabb* __restrict__ bvh,
+                                          lbvh_fast_node* __restrict__ fused, uint32_t leaf_base,
+                                          const uint32_t* __restrict__ sorted_indices)
 {
-    __shared__ uint32_t s_keys[kTreeWindow];
-    const uint32_t thread_id = blockIdx.x * kTreeThreads + threadIdx.x;
+    const uint32_t thread_id = block * kTreeThreads + threadIdx.x;
     if (thread_id == 0 && zero_word) *zero_word = 0u;      // lbvh_build_tree + lbvh_refit: the refit's frontier counter
     key_window win;
     win.lds = (lds_u32*)s_keys;
     win.num = (int)n;
-    win.w0 = max((int)(blockIdx.x * kTreeThreads) - kTreeHalo, 0);
-    win.w1 = min((int)(blockIdx.x * kTreeThreads) + kTreeThreads + kTreeHalo, (int)n);
+    win.w0 = max((int)(block * kTreeThreads) - kTreeHalo, 0);
+    win.w1 = min((int)(block * kTreeThreads) + kTreeThreads + kTreeHalo, (int)n);
     for (int k = win.w0 + (int)threadIdx.x; k < win.w1; k += kTreeThreads) s_keys[k - win.w0] = codes[k];
     __syncthreads();
     // (no early return: the boxes leave through a workgroup-wide LDS transpose below)
@@ -615,7 +630,6 @@ __global__ __launch_bounds__(kTreeThreads) void tree_kernel(const uint32_t* __re
     // The boxes: computed per node, written per LINE — every thread parks its record in LDS and the workgroup writes
     // the block's records as consecutive float4 (a wave's store covers 1 KB of whole records, not 64 quarter lines).
     constexpr int kQuads = MODE == TREE_FUSED ? 4 : 2;             // float4 per record: 64-byte traversal node / 32-byte AABB
-    __shared__ float4 s_out[MODE == TREE_TOPOLOGY ? 1 : kTreeThreads * kQuads];
     if (MODE == TREE_REFERENCE) {
         const uint32_t a[1] = {(uint32_t)first}, b[1] = {valid ? (uint32_t)last : (uint32_t)first};
         float mn[1][3], mx[1][3];
@@ -640,7 +654,7 @@ __global__ __launch_bounds__(kTreeThreads) void tree_kernel(const uint32_t* __re
     }
     if (MODE != TREE_TOPOLOGY) {
         __syncthreads();
-        const uint32_t b0 = blockIdx.x * kTreeThreads;
+        const uint32_t b0 = block * kTreeThreads;
         float4* out = MODE == TREE_FUSED ? reinterpret_cast<float4*>(fused + b0) : reinterpret_cast<float4*>(bvh + b0);
         const uint32_t live = n - 1 > b0 ? min(n - 1 - b0, (uint32_t)kTreeThreads) * kQuads : 0u;   // float4s of existing nodes
 #pragma unroll
@@ -652,6 +666,39 @@ __global__ __launch_bounds__(kTreeThreads) void tree_kernel(const uint32_t* __re
             }
         }
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kTreeThreads) void tree_kernel(const uint32_t* __restrict__ codes, uint32_t n,
+                                                            lbvh_internal_node* __restrict__ internal,
+                                                            lbvh_leaf_node* __restrict__ leaf, uint32_t* __restrict__ zero_word,
+                                                            hier_t hier, lbvh_aabb* __restrict__ bvh,
+                                                            lbvh_fast_node* __restrict__ fused, uint32_t leaf_base,
+                                                            const uint32_t* __restrict__ sorted_indices)
+{
+    __shared__ uint32_t s_keys[kTreeWindow];
+    __shared__ float4 s_out[MODE == TREE_TOPOLOGY ? 1 : kTreeThreads * (MODE == TREE_FUSED ? 4 : 2)];
+    tree_body<MODE>(blockIdx.x, s_keys, s_out, codes, n, internal, leaf, zero_word, hier, bvh, fused, leaf_base, sorted_indices);
+}
+
+// lbvh_build_scene's two trees — the derived one over aligned keys, the reference's over the distributed keys — in ONE launch,
+// workgroups alternating (even: derived, odd: reference): both progress side by side as they did on two streams, without the
+// cross-stream dependencies (fork, hierarchy-ready, join: ~5 us each on this runtime) around them
+__global__ __launch_bounds__(kTreeThreads) void tree_pair_kernel(const uint32_t* __restrict__ aligned_codes,
+                                                                 const uint32_t* __restrict__ codes, uint32_t n,
+                                                                 lbvh_internal_node* __restrict__ internal,
+                                                                 lbvh_leaf_node* __restrict__ leaf, hier_t hier,
+                                                                 lbvh_aabb* __restrict__ bvh, lbvh_fast_node* __restrict__ fused,
+                                                                 uint32_t leaf_base, const uint32_t* __restrict__ sorted_indices)
+{
+    __shared__ uint32_t s_keys[kTreeWindow];
+    __shared__ float4 s_out[kTreeThreads * 4];
+    const uint32_t block = blockIdx.x >> 1;
+    if (blockIdx.x & 1u)
+        tree_body<TREE_REFERENCE>(block, s_keys, s_out, codes, n, internal, leaf, nullptr, hier, bvh, nullptr, 0u, nullptr);
+    else
+        tree_body<TREE_FUSED>(block, s_keys, s_out, aligned_codes, n, nullptr, nullptr, nullptr, hier, nullptr, fused, leaf_base,
+                              sorted_indices);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -977,22 +1024,21 @@ __device__ __forceinline__ void store_hier(const hier_t& h, uint32_t k, uint32_t
 }
 
 template <bool TERMS>
-__global__ __launch_bounds__(kAkThreads) void gather_hier_kernel(const lbvh_aabb* __restrict__ tri_aabb,
-                                                                 const uint32_t* __restrict__ sorted_indices, uint32_t n,
-                                                                 box3 scene, hier_t hier, int32_t* __restrict__ terms,
-                                                                 int32_t* __restrict__ chunk_max)
+__device__ __forceinline__ void gather_hier_body(uint32_t block, const lbvh_aabb* __restrict__ tri_aabb,
+                                                 const uint32_t* __restrict__ sorted_indices, uint32_t n, const box3& scene,
+                                                 const hier_t& hier, int32_t* __restrict__ terms, int32_t* __restrict__ chunk_max)
 {
     __shared__ int32_t s_wave[kAkThreads / LBVH_WAVE];
     __shared__ float s_six[6][kAkItems * (kAkThreads / LBVH_WAVE)];     // the 16 level-6 boxes of this workgroup, in leaf order
     const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
     int32_t mine = INT32_MIN;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {      // the NEUTRAL box of range_boxes: the unused slot behind the top level
+    if (block == 0 && threadIdx.x == 0) {      // the NEUTRAL box of range_boxes: the unused slot behind the top level
         store_corner(hier.lo + (hier.n2x2 - 1u), INFINITY, INFINITY, INFINITY);
         store_corner(hier.hi + (hier.n2x2 - 1u), -INFINITY, -INFINITY, -INFINITY);
     }
 #pragma unroll
     for (int k = 0; k < kAkItems; k++) {
-        const uint32_t i = blockIdx.x * kAkChunk + (uint32_t)k * kAkThreads + threadIdx.x;
+        const uint32_t i = block * kAkChunk + (uint32_t)k * kAkThreads + threadIdx.x;
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
         if (i < n) {
             const float4* src = reinterpret_cast<const float4*>(&tri_aabb[sorted_indices[i]]);
@@ -1032,13 +1078,13 @@ __global__ __launch_bounds__(kAkThreads) void gather_hier_kernel(const lbvh_aabb
     if (TERMS) {
         int32_t all;
         (void)block_inclusive_max(mine, s_wave, &all);                    // (barrier inside)
-        if (threadIdx.x == 0) chunk_max[blockIdx.x] = all;
+        if (threadIdx.x == 0) chunk_max[block] = all;
     } else {
         __syncthreads();
     }
     // levels 7 .. 10 from the 16 level-6 boxes (entry e covers leaves [block * 1024 + 64 e, + 64))
     if (threadIdx.x < 16u) {
-        const uint32_t e = threadIdx.x, start = blockIdx.x * kAkChunk + e * 64u;
+        const uint32_t e = threadIdx.x, start = block * kAkChunk + e * 64u;
         float mn[3], mx[3];
 #pragma unroll
         for (int d = 0; d < 3; d++) { mn[d] = s_six[d][e]; mx[d] = s_six[3 + d][e]; }
@@ -1052,6 +1098,15 @@ __global__ __launch_bounds__(kAkThreads) void gather_hier_kernel(const lbvh_aabb
             if ((e & ((1u << (lev - 6)) - 1u)) == 0 && start < n && lev <= hier.levels) store_hier(hier, lev, start >> lev, mn, mx);
         }
     }
+}
+
+template <bool TERMS>
+__global__ __launch_bounds__(kAkThreads) void gather_hier_kernel(const lbvh_aabb* __restrict__ tri_aabb,
+                                                                 const uint32_t* __restrict__ sorted_indices, uint32_t n,
+                                                                 box3 scene, hier_t hier, int32_t* __restrict__ terms,
+                                                                 int32_t* __restrict__ chunk_max)
+{
+    gather_hier_body<TERMS>(blockIdx.x, tri_aabb, sorted_indices, n, scene, hier, terms, chunk_max);
 }
 
 // hierarchy levels above 10 (blocks of 2048 leaves and more): a few hundred boxes at 1 M leaves, one workgroup.
@@ -1151,12 +1206,12 @@ __global__ __launch_bounds__(kAkThreads) void aligned_keys_scan_kernel(int32_t* 
 // alone, like this scan — one launch less on the derived lane's critical path (8.5 us + a gap).
 constexpr uint32_t kTopLdsSmall = 1024;
 template <bool SELF>
-__global__ __launch_bounds__(kAkThreads) void aligned_keys_apply_kernel(uint32_t n, const int32_t* __restrict__ chunk_excl,
-                                                                        uint32_t* keys, hier_t hier)
+__device__ __forceinline__ void aligned_keys_apply_body(uint32_t block, uint32_t n, const int32_t* __restrict__ chunk_excl,
+                                                        uint32_t* keys, const hier_t& hier)
 {
     __shared__ int32_t s_wave[kAkThreads / LBVH_WAVE];
     __shared__ int32_t s_before[kAkThreads / LBVH_WAVE];
-    if (blockIdx.x * kAkChunk >= n) {          // the extra workgroup
+    if (block * kAkChunk >= n) {          // the extra workgroup
         __shared__ float s_box[6][kTopLdsSmall];
         hier_top_levels<kAkThreads, kTopLdsSmall>(hier, n, s_box);
         return;
@@ -1164,14 +1219,14 @@ __global__ __launch_bounds__(kAkThreads) void aligned_keys_apply_kernel(uint32_t
     int32_t carry;
     if (SELF) {
         int32_t part = INT32_MIN;
-        for (uint32_t c = threadIdx.x; c < blockIdx.x; c += kAkThreads) part = max(part, chunk_excl[c]);
+        for (uint32_t c = threadIdx.x; c < block; c += kAkThreads) part = max(part, chunk_excl[c]);
         (void)block_inclusive_max(part, s_before, &carry);
     } else {
-        carry = chunk_excl[blockIdx.x];
+        carry = chunk_excl[block];
     }
 #pragma unroll
     for (int k = 0; k < kAkItems; k++) {
-        const uint32_t i = blockIdx.x * kAkChunk + (uint32_t)k * kAkThreads + threadIdx.x;
+        const uint32_t i = block * kAkChunk + (uint32_t)k * kAkThreads + threadIdx.x;
         const int32_t v = i < n ? (int32_t)keys[i] : INT32_MIN;
         int32_t all;
         const int32_t incl = block_inclusive_max(v, s_wave, &all);
@@ -1179,6 +1234,43 @@ __global__ __launch_bounds__(kAkThreads) void aligned_keys_apply_kernel(uint32_t
         carry = max(carry, all);
         __syncthreads();           // s_wave is reused by the next sub-chunk
     }
+}
+
+template <bool SELF>
+__global__ __launch_bounds__(kAkThreads) void aligned_keys_apply_kernel(uint32_t n, const int32_t* __restrict__ chunk_excl,
+                                                                        uint32_t* keys, hier_t hier)
+{
+    aligned_keys_apply_body<SELF>(blockIdx.x, n, chunk_excl, keys, hier);
+}
+
+// ---- merged launches of lbvh_build_scene (scenes whose scans fit one workgroup's self-scan: up to 2 M triangles) --------------
+// After the sort the build has two independent strands — the derived scene's (gather + hierarchy, aligned keys, derived tree) and
+// the reference's (DistributeKeys, reference tree; its boxes come from the same hierarchy).  Rounds 2 - 3 ran them on two
+// streams; every cross-stream dependency of the replayed graph cost ~5 us of idle chip (fork after the sort, "hierarchy ready",
+// join).  Here each strand's k-th kernel shares ONE launch with the other's: three launches on one stream, the same workgroups,
+// the same results.
+__global__ __launch_bounds__(256) void gather_and_reduce_kernel(const lbvh_aabb* __restrict__ tri_aabb,
+                                                                const uint32_t* __restrict__ sorted_indices, uint32_t n, box3 scene,
+                                                                hier_t hier, int32_t* __restrict__ terms, int32_t* __restrict__ chunk_max,
+                                                                uint32_t gather_blocks, const uint32_t* __restrict__ keys,
+                                                                uint32_t* __restrict__ chunk_sums, uint32_t* __restrict__ boundary)
+{
+    // the long strand first (the gather's random reads), DistributeKeys' reduction fills in behind it
+    if (blockIdx.x < gather_blocks) gather_hier_body<true>(blockIdx.x, tri_aabb, sorted_indices, n, scene, hier, terms, chunk_max);
+    else distribute_reduce_body(blockIdx.x - gather_blocks, keys, n, chunk_sums, boundary);
+}
+
+__global__ __launch_bounds__(256) void apply_pair_kernel(uint32_t n, const int32_t* __restrict__ chunk_max, uint32_t* aligned_keys,
+                                                         hier_t hier, uint32_t aligned_blocks, uint32_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ chunk_sums,
+                                                         const uint32_t* __restrict__ boundary)
+{
+    // block 0: the hierarchy's top levels (one workgroup, the longest of this launch: first), then the aligned keys, then
+    // DistributeKeys' apply pass
+    if (blockIdx.x < aligned_blocks)
+        aligned_keys_apply_body<true>(blockIdx.x == 0 ? aligned_blocks - 1u : blockIdx.x - 1u, n, chunk_max, aligned_keys, hier);
+    else
+        distribute_apply_body<true>(blockIdx.x - aligned_blocks, keys, n, chunk_sums, boundary);
 }
 
 }  // namespace
@@ -1277,6 +1369,42 @@ int lbvh_launch_tree_fused(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys
     const uint32_t blocks = (n - 1 + kTreeThreads - 1) / kTreeThreads;
     LBVH_LAUNCH(ctx, tree_kernel<TREE_FUSED>, dim3(blocks), dim3(kTreeThreads), d_keys, n, (lbvh_internal_node*)nullptr,
                 (lbvh_leaf_node*)nullptr, (uint32_t*)nullptr, h, (lbvh_aabb*)nullptr, d_fused, leaf_base, d_sorted_indices);
+    return LBVH_OK;
+}
+
+// lbvh_build_scene with LBVH_BUILD_FAST_SCENE after the sort, as three merged launches on the current stream (see
+// gather_and_reduce_kernel).  *done = false and nothing enqueued when the scene is too large for the self-scanning forms:
+// the caller runs the two-stream chain instead.
+int lbvh_launch_post_sort_merged(lbvh_context* ctx, uint32_t n, uint32_t* d_keys, const lbvh_aabb* d_triangle_aabb,
+                                 const uint32_t* d_sorted_indices, const float box_min[3], const float box_max[3],
+                                 uint32_t* d_aligned_keys, lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh,
+                                 lbvh_fast_node* d_fused, uint32_t leaf_base, bool* done)
+{
+    static_assert(kAkThreads == 256 && kDistThreads == 256 && kTreeThreads == 256, "the merged launches run 256-thread bodies");
+    *done = false;
+    const uint32_t a_chunks = (n + kAkChunk - 1) / kAkChunk;
+    const uint32_t d_chunks = (uint32_t)(((uint64_t)n + kDistChunk - 1) / kDistChunk);
+    if (a_chunks > kSelfScanChunks || d_chunks > kSelfScanChunks) return LBVH_OK;
+    hier_t h;
+    int rc = hier_plan(ctx, n, &h);
+    if (rc != LBVH_OK) return rc;
+    // the same scratch the two-stream chain uses: lane 1's for the aligned keys' chunk maxima, lane 0's for DistributeKeys
+    if ((rc = lbvh_reserve(ctx, &ctx->scan_scratch[1], &ctx->scan_scratch_bytes[1], (size_t)a_chunks * 8)) != LBVH_OK) return rc;
+    if ((rc = lbvh_reserve(ctx, &ctx->scan_scratch[0], &ctx->scan_scratch_bytes[0], (size_t)d_chunks * 8)) != LBVH_OK) return rc;
+    int32_t* chunk_max = (int32_t*)ctx->scan_scratch[1];
+    uint32_t* chunk_sums = (uint32_t*)ctx->scan_scratch[0];
+    uint32_t* boundary = chunk_sums + d_chunks;
+    box3 scene;
+    for (int k = 0; k < 3; k++) { scene.mn[k] = box_min[k]; scene.mx[k] = box_max[k]; }
+    LBVH_LAUNCH(ctx, gather_and_reduce_kernel, dim3(a_chunks + d_chunks), dim3(256), d_triangle_aabb, d_sorted_indices, n, scene, h,
+                (int32_t*)d_aligned_keys, chunk_max, a_chunks, (const uint32_t*)d_keys, chunk_sums, boundary);
+    const uint32_t a_blocks = a_chunks + (h.levels > kHierLocalLevels ? 1u : 0u);       // + the top levels' workgroup
+    LBVH_LAUNCH(ctx, apply_pair_kernel, dim3(a_blocks + d_chunks), dim3(256), n, (const int32_t*)chunk_max, d_aligned_keys, h, a_blocks,
+                d_keys, (const uint32_t*)chunk_sums, (const uint32_t*)boundary);
+    const uint32_t t_blocks = (n - 1 + kTreeThreads - 1) / kTreeThreads;
+    LBVH_LAUNCH(ctx, tree_pair_kernel, dim3(2 * t_blocks), dim3(kTreeThreads), (const uint32_t*)d_aligned_keys, (const uint32_t*)d_keys, n,
+                d_internal, d_leaf, h, d_bvh, d_fused, leaf_base, d_sorted_indices);
+    *done = true;
     return LBVH_OK;
 }
 

@@ -200,6 +200,12 @@ int lbvh_launch_animate_morton(lbvh_context* ctx, const lbvh_anim& anim, lbvh_tr
                                const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys, uint32_t* d_indices,
                                lbvh_aabb* d_aabb, uint32_t* d_zero, uint32_t zero_words, lbvh_fast_tri* d_lines,
                                lbvh_internal_node* d_reset_internal = nullptr, lbvh_leaf_node* d_reset_leaf = nullptr);
+// lbvh_build_scene (LBVH_BUILD_FAST_SCENE) after the sort as three merged launches on the current stream; *done = false: too large,
+// nothing enqueued
+int lbvh_launch_post_sort_merged(lbvh_context* ctx, uint32_t n, uint32_t* d_keys, const lbvh_aabb* d_triangle_aabb,
+                                 const uint32_t* d_sorted_indices, const float box_min[3], const float box_max[3],
+                                 uint32_t* d_aligned_keys, lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh,
+                                 lbvh_fast_node* d_fused, uint32_t leaf_base, bool* done);
 // the sort with its scratch described / already cleared by the caller
 int lbvh_sort_scratch(lbvh_context* ctx, uint32_t count, uint32_t** d_zero, uint32_t* zero_words);
 int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t count, bool scratch_cleared);

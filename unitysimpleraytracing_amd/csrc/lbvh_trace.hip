@@ -1448,6 +1448,22 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
         if ((rc = (lbvh_status)lbvh_launch_sort(ctx, d_keys, d_indices, capacity, zero != nullptr)) != LBVH_OK) return rc;
     }
     const bool fast = (flags & LBVH_BUILD_FAST_SCENE) != 0;
+    static const bool env_two_streams = getenv("LBVH_BUILD_TWO_STREAMS") != nullptr;     // measurement switch: the round 2 - 3 form
+    if (fast && !env_two_streams) {
+        // both strands of the rest of the chain — derived scene, reference arrays — in three merged launches on this stream
+        // (lbvh_build.hip "merged launches"): scenes up to 2 M triangles
+        for (int k = 0; k < 3; k++) ctx->fast_centre[k] = 0.5f * (h_box_min[k] + h_box_max[k]);      // as build_fast_scene_parts
+        if ((rc = (lbvh_status)lbvh_reserve(ctx, &ctx->fast_tree, &ctx->fast_tree_bytes, (size_t)n * 4)) != LBVH_OK) return rc;
+        bool done = false;
+        if ((rc = (lbvh_status)lbvh_launch_post_sort_merged(ctx, n, d_keys, d_aabb, d_indices, h_box_min, h_box_max,
+                                                            (uint32_t*)ctx->fast_tree, d_internal, d_leaf, d_bvh, ctx->fast_nodes,
+                                                            ctx->fast_capacity, &done)) != LBVH_OK)
+            return rc;
+        if (done) {
+            LBVH_HIP_TRY(ctx, hipGetLastError());
+            return LBVH_OK;
+        }
+    }
     if (fast) {
         // lane 1: the derived traversal scene needs only the sorted indices and the triangle AABBs; its first kernels also
         // build the range hierarchy both tree kernels take their boxes from
