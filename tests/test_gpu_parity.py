@@ -323,6 +323,35 @@ def test_cfg4_sixteen_million_triangles_on_one_gpu(ctx):
     assert (fast["t"] == ref["t"]).all()
     oh, _ = O.trace_primary(b, cam, step=(4, 4), threads=O.num_threads())
     assert (oh["t"] == ref["t"][::4, ::4][: oh.shape[0], : oh.shape[1]]).all()
+    # the one-call rebuild at this size (two streams after the sort: beyond the merged launches' limit), poisoned node arrays
+    c.bvh_internal_node.fill_u32(0x1357246, mirror=False)
+    c.bvh_leaf_node.fill_u32(0x2468135, mirror=False)
+    d.rebuild()
+    assert_build_equal(c, b)
+    d.update(cam, mode=L.TRACE_FAST)
+    assert (d.hits()["t"] == ref["t"]).all()
+    d.on_destroy()
+
+
+@pytest.mark.parametrize("n", [2_097_152, 2_097_153])
+def test_build_scene_on_both_sides_of_the_merged_launch_limit(ctx, n):
+    """lbvh_build_scene runs the chain after the sort as three merged launches while the self-scanning apply passes cover the
+    scene (2048 chunks of 1024 leaves), and as two streams beyond: the last size of the one form and the first of the other,
+    poisoned arrays, against the oracle word for word, and the traced frame of the derived scene against the reference walk."""
+    tris = scenes.random_triangles(n, seed=77, extent=118.0, edge=0.8)
+    d, c, b = build_both(ctx, tris)
+    cam = scenes.camera(240, 135, (0.0, 0.0, 255.0))
+    for rep in range(2):
+        c.bvh_internal_node.fill_u32(0x2345678 + rep, mirror=False)
+        c.bvh_leaf_node.fill_u32(0x9ABCDEF + rep, mirror=False)
+        c.bvh_data.fill_u32(0x7FC00000, mirror=False)
+        c.keys.fill_u32(0, mirror=False)
+        d.rebuild()
+        assert_build_equal(c, b)
+        d.update(cam, mode=L.TRACE_FAST)
+        fast = d.hits()
+        d.update(cam, mode=L.TRACE_REFERENCE)
+        assert (fast["t"] == d.hits()["t"]).all()
     d.on_destroy()
 
 
