@@ -333,6 +333,29 @@ def test_cfg4_sixteen_million_triangles_on_one_gpu(ctx):
     d.on_destroy()
 
 
+@pytest.mark.parametrize("n,cap", [(2, None), (3, 8), (255, None), (256, 300), (257, None), (1023, 1024), (1024, None), (1025, 2048),
+                                   (2047, None), (2048, 2049), (2049, None), (4097, 5000), (65_537, None)])
+def test_build_scene_at_chunk_and_level_borders(ctx, n, cap):
+    """The one-call rebuild (merged launches) where its pieces change shape: one / two workgroups of the 256-node tree kernel, the
+    1024-leaf chunks of the gather (level 10 of the hierarchy: the top-levels workgroup appears at 1025 leaves), the 2048-key
+    chunks of DistributeKeys, pad slots behind the tree (capacity > n) — poisoned node arrays, every word against the oracle, and
+    the traced frame against the reference walk."""
+    tris = scenes.random_triangles(n, seed=1000 + n, extent=100.0, edge=6.0)
+    d, c, b = build_both(ctx, tris, cap)
+    cam = scenes.camera(96, 64, (0.0, 0.0, 240.0))
+    for rep in range(2):
+        c.bvh_internal_node.fill_u32(0x3456789 + rep, mirror=False)
+        c.bvh_leaf_node.fill_u32(0xABCDEF0 + rep, mirror=False)
+        c.bvh_data.fill_u32(0x7FC00000, mirror=False)
+        d.rebuild()
+        assert_build_equal(c, b)
+        d.update(cam, mode=L.TRACE_FAST)
+        fast = d.hits()
+        d.update(cam, mode=L.TRACE_REFERENCE)
+        assert (fast["t"] == d.hits()["t"]).all()
+    d.on_destroy()
+
+
 @pytest.mark.parametrize("n", [2_097_152, 2_097_153])
 def test_build_scene_on_both_sides_of_the_merged_launch_limit(ctx, n):
     """lbvh_build_scene runs the chain after the sort as three merged launches while the self-scanning apply passes cover the
