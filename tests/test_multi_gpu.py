@@ -164,6 +164,64 @@ def test_ipc_mapped_frame_buffer_and_device_side_flags_between_processes(ctx):
     flags.dispose()
 
 
+_GATHER_CHILD = r"""
+import ctypes as C, sys, os
+import numpy as np
+root, rank, world, store, frames, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), sys.argv[6]
+sys.path.insert(0, root)
+import torch.distributed as dist
+from unitysimpleraytracing_amd import _native as N, layouts as L, scenes
+from unitysimpleraytracing_amd.host import Context, DataBuffer, RaytracingMeshDrawer
+from unitysimpleraytracing_amd.frame_gather import FrameGather
+dist.init_process_group("gloo", init_method="file://" + store, rank=rank, world_size=world)
+W, H = 250, 131
+tris = scenes.random_triangles(4096, seed=1)
+with Context(0) as ctx:
+    d = RaytracingMeshDrawer(ctx, tris).awake()
+    g = FrameGather(ctx, dist, rank, world, W, H, 0, staged=True, mode=mode)
+    assert g.mode == mode, g.peer_error
+    bad = 0
+    for f in range(frames):
+        cam = N.Camera.from_dict(scenes.camera(W, H, (0.0, 0.0, 250.0 - f)))       # another picture every frame
+        s = d.container.scene()
+        if rank == 0:
+            # the consumer of the previous frame, and a poison no share may be overtaken by: both only ENQUEUED, no host
+            # synchronisation between frames on any rank
+            g.frame.fill_u32(0x7FC00000, mirror=False)
+        g.trace_share(cam, s, L.TRACE_FAST)
+        if rank == 0:
+            got = g.frame.get_data().copy()
+            alone = DataBuffer(ctx, W * H, L.HIT)
+            N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(cam), 0, 0, W, H, C.byref(s), L.TRACE_FAST, alone.device, None))
+            bad += int((got.view(np.uint32) != alone.get_data().view(np.uint32)).any())
+            alone.dispose()
+    ctx.sync()
+    dist.barrier()
+    g.close()
+    d.on_destroy()
+dist.barrier()
+print("frames_wrong", bad)
+"""
+
+
+@pytest.mark.parametrize("mode", ["peer", "packed"])
+def test_frame_gather_between_processes_with_a_consumer_on_the_owner(tmp_path, mode):
+    """frame_gather.FrameGather with three PROCESSES on cuda:0 (gloo for the set-up): every frame another camera, the owner
+    poisons its buffer in front of every frame and reads the assembled frame back behind it, nobody synchronises on the
+    host between frames — the other ranks run ahead.  Every frame must equal the one-context frame word for word: a share of
+    frame f + 1 that landed before the owner had read frame f (or before its poison) would show."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    store = str(tmp_path / "rendezvous")
+    world, frames = 3, 12
+    procs = [subprocess.Popen([sys.executable, "-c", _GATHER_CHILD, ROOT, str(r), str(world), store, str(frames), mode], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    assert "frames_wrong 0" in outs[0][0], outs[0][0][-500:]
+
+
 def test_cpp_multi_gpu_drawer():
     """host/lbvh_host.hpp MultiGpuDrawer through the compiled driver: 3 logical ranks, 8 frames (two modes x static, static,
     turned, rebuilt) assembled in the owner's poisoned buffer == the frames one context traces alone."""

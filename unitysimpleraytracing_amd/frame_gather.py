@@ -10,7 +10,10 @@ behind the C ABI's "one frame from N GPUs" calls (include/lbvh.h):
            (lbvh_ipc_import after lbvh_peer_enable) and traces its share STRAIGHT INTO rank 0's memory: the trace kernel's
            stores travel over xGMI while the tiles finish, nothing is copied afterwards.  Completion: rank r enqueues
            lbvh_frame_signal(flags[r - 1] := frame number) behind its trace, rank 0 enqueues lbvh_frame_wait — a bounded
-           device-side wait — behind its own share.  No host round trip and no collective per frame.
+           device-side wait — behind its own share; the other way round, rank 0 signals "frame f has been read" in front
+           of its next share and the others wait for that before they store into the buffer again.  No host round trip and
+           no collective per frame; the ranks have to enqueue their frames within the wait's bound (LBVH_SPIN_LIMIT, seconds)
+           of each other.
   packed   every rank traces its share into a contiguous block (lbvh_trace_primary_shard_packed), the blocks reach rank 0
            by one torch.distributed gather (RCCL send / recv over xGMI), rank 0 puts them at their pixels
            (lbvh_frame_unpack).  The fallback when the GPUs cannot map each other's memory (or IPC is unavailable).
@@ -87,6 +90,8 @@ class FrameGather:
     torch.distributed, `staged` = the backend moves host memory only (gloo: ranks sharing a GPU in tests)."""
 
     SELF_TEST_WORDS = 256
+    FLAG_SLOTS = 64           # rank r's "my share of frame f is in the buffer" in slot r - 1 ...
+    CONSUMED_SLOT = 63        # ... and rank 0's "frame f has been read" in the last one
 
     def __init__(self, ctx, dist, rank, world, width, height, device_id, staged, mode="auto"):
         from .host import DataBuffer
@@ -125,7 +130,9 @@ class FrameGather:
         err = None
         if self.rank == 0:
             try:
-                self._flags = DataBuffer(ctx, 64, np.uint32, 0)
+                if self.world - 1 > self.CONSUMED_SLOT:
+                    raise N.LbvhError(-1, f"the flag array has {self.CONSUMED_SLOT} completion slots")
+                self._flags = DataBuffer(ctx, self.FLAG_SLOTS, np.uint32, 0)
                 ctx.sync()               # the zero fill has happened before anybody may signal
                 payload = [(self.device_id, ctx.ipc_export(self.frame.device), ctx.ipc_export(self._flags.device))]
             except N.LbvhError as e:
@@ -204,6 +211,13 @@ class FrameGather:
         ctx, rank, world = self.ctx, self.rank, self.world
         self.frame_no += 1
         if self.mode == "peer":
+            # frame k may be overwritten only when rank 0 has read it: whatever rank 0 enqueued on its stream since the
+            # previous call (shading, a read-back) is in front of this signal, and the others wait for it — on the device, like
+            # the completion flags — before their first store of the new frame (the `consumed` event of host.MultiGpuDrawer)
+            if rank == 0:
+                ctx.frame_signal(self._flags.device, self.CONSUMED_SLOT, self.frame_no - 1)
+            else:
+                ctx.frame_wait(C.c_void_p(self._peer_flags.value + 4 * self.CONSUMED_SLOT), 1, self.frame_no - 1)
             target = self.frame.device if rank == 0 else self._peer_frame
             N.check(ctx.handle, N.lib.lbvh_trace_primary_shard(ctx.handle, C.byref(camera), rank, world, C.byref(scene), trace_mode, target, None))
             if own_done_event is not None:
@@ -231,9 +245,10 @@ class FrameGather:
             torch.cuda.current_stream().wait_event(self._ev_traced)
             parts = list(self._gathered.view(world, -1).unbind(0)) if rank == 0 else None
             dist.gather(self._packed, parts, dst=0)
-            if rank == 0:
-                self._ev_gathered.record()
-                ctx.wait_event(C.c_void_p(self._ev_gathered.cuda_event))
+            # every rank's library stream goes behind the collective: rank 0 unpacks what it received, and on the others the
+            # NEXT frame's trace must not overwrite the packed block while it is still being sent
+            self._ev_gathered.record()
+            ctx.wait_event(C.c_void_p(self._ev_gathered.cuda_event))
         if rank == 0:
             N.check(ctx.handle, N.lib.lbvh_frame_unpack(ctx.handle, C.c_void_p(self._gathered.data_ptr()), self.stride, 0, world, world,
                                                         self.width, self.height, self.frame.device))
