@@ -386,7 +386,8 @@ lbvh_status lbvh_ipc_close(lbvh_context* ctx, void* d_ptr);
 lbvh_status lbvh_frame_signal(lbvh_context* ctx, uint32_t* d_flags, uint32_t slot, uint32_t value);
 /* Work enqueued on this context after the call starts only when d_flags[s] >= value (as signed distance: wrap-around safe)
  * for every s < n_slots — e.g. every other rank has signalled this frame.  The wait runs on the device and is bounded: if a
- * flag never arrives the next lbvh_sync / lbvh_buffer_download returns LBVH_ERR_HIP, the GPU does not hang.  n_slots <= 64. */
+ * flag never arrives the next lbvh_sync / lbvh_buffer_download returns LBVH_ERR_HIP, the GPU does not hang.  n_slots <= 64.
+ * d_flags may be another GPU's memory (polled over xGMI: the ranks that wait for the owner's "frame read" word). */
 lbvh_status lbvh_frame_wait(lbvh_context* ctx, const uint32_t* d_flags, uint32_t n_slots, uint32_t value);
 
 /* lbvh_trace_primary_shard with the share written CONTIGUOUSLY: record of lane l (pixel (l & 7, l >> 3) of the tile) of the

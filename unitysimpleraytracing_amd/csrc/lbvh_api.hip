@@ -412,8 +412,8 @@ lbvh_status lbvh_ipc_close(lbvh_context* ctx, void* d_ptr)
 // Completion flags between GPUs that share no process (bench.py: one rank per GPU).  The signalling kernel runs after the
 // stream's earlier kernels have ended (their stores have left this GPU's caches: the end-of-kernel release) and publishes
 // with a system-scope release store; flag and data take the same xGMI path to the owner's memory.  The waiting kernel polls
-// with system-scope acquire loads — its own HBM, written by the peers — and ends when every flag has reached the frame
-// number; what the stream runs after it starts with the usual kernel-start invalidate and reads the peers' records.
+// with system-scope acquire loads — its own HBM written by the peers, or the owner's word read over xGMI — and ends when every
+// flag has reached the frame number; what the stream runs after it starts with the usual kernel-start invalidate and reads the peers' records.
 __global__ void frame_signal_kernel(uint32_t* flag, uint32_t value)
 {
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
