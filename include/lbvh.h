@@ -275,14 +275,17 @@ lbvh_status lbvh_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* 
 /* ---- the whole build chain in one call ----------------------------------------------------------- */
 
 #define LBVH_BUILD_FAST_SCENE  1u   /* also build the derived traversal scene (= lbvh_build_fast_scene)        */
-#define LBVH_BUILD_RESET_NODES 2u   /* refill d_internal / d_leaf with 0xFFFFFFFF first (capacity slots)       */
+#define LBVH_BUILD_RESET_NODES 2u   /* d_internal / d_leaf come out as after a refill with 0xFFFFFFFF           *
+                                     * (capacity slots: the slots past the tree and the root's parent word are  *
+                                     * written, every other word is the tree's)                                 */
 
 /* RaytracingMeshDrawer.Awake()'s build chain (Sc/RaytracingMeshDrawer.cs:34-51) = lbvh_morton_aabb ->
  * lbvh_sort_pairs(capacity) -> lbvh_distribute_keys -> lbvh_build_tree -> lbvh_refit (+ lbvh_build_fast_scene
  * with LBVH_BUILD_FAST_SCENE), with identical results.  After the sort the reference's arrays and the derived
- * traversal scene are two independent chains of short latency-bound kernels; this call runs them concurrently
- * on the context's stream and an internal side stream and joins them before it returns control to the
- * stream, so later calls on the context see both.  For per-frame rebuilds of dynamic scenes. */
+ * traversal scene are two independent chains of short latency-bound kernels; this call runs them side by side —
+ * sharing three launches on the context's stream (up to 2 M triangles), or on the stream and an internal side
+ * stream joined before control returns to the stream — so later calls on the context see both.  For per-frame
+ * rebuilds of dynamic scenes. */
 lbvh_status lbvh_build_scene(lbvh_context* ctx, const lbvh_triangle* d_triangles, uint32_t n, uint32_t capacity,
                              const float h_box_min[3], const float h_box_max[3], uint32_t* d_keys,
                              uint32_t* d_indices, lbvh_aabb* d_aabb, lbvh_internal_node* d_internal,

@@ -1409,7 +1409,8 @@ lbvh_status lbvh_build_fast_scene(lbvh_context* ctx, const lbvh_scene* h_scene, 
 
 }  // extern "C"
 
-// RaytracingMeshDrawer.Awake()'s whole build chain, as two concurrent lanes after the sort.
+// RaytracingMeshDrawer.Awake()'s whole build chain: after the sort two independent strands — as three merged launches on one
+// stream up to 2 M triangles (lbvh_build.hip "merged launches"), as two concurrent lanes (streams) beyond.
 // morton_done: the Morton kernel (keys, indices, triangle AABBs, triangle lines, the sort's cleared scratch) has been enqueued by
 // the caller already — lbvh_animate_build_scene's fused animate + Morton kernel, whose arguments change every frame and
 // therefore stay outside the replayed graph
