@@ -478,6 +478,32 @@ def main():
                 "steps_per_packet": round(float(st2["pops"]) / (W * H / 64.0), 1)}
         kernel_ms_of(ccam)                              # history back to the timed camera
 
+        # LBVH_TRACE_FAST_EXACT (not the timed mode): the packet walk + the reference's choice wherever two triangles are hit at
+        # exactly the same t — every word of the frame equals LBVH_TRACE_REFERENCE's; what it costs, and the check itself
+        exact_mode = None
+        if mode == L.TRACE_FAST:
+            N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s), L.TRACE_REFERENCE, full.device, None))
+            ref_frame = full.get_data().view(np.uint32).copy()
+            N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s), L.TRACE_FAST, full.device, None))
+            fast_differs = int((full.get_data().view(np.uint32) != ref_frame).reshape(-1, 4).any(axis=1).sum())
+            for _ in range(3):
+                N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s), L.TRACE_FAST_EXACT, full.device, None))
+            e0, e1 = ctx.event(), ctx.event()
+            ctx.record(e0)
+            for _ in range(reps):
+                N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s), L.TRACE_FAST_EXACT, full.device, None))
+            ctx.record(e1)
+            exact_ms = ctx.elapsed_ms(e0, e1) / reps
+            exact_equal = bool((full.get_data().view(np.uint32) == ref_frame).all())
+            if not exact_equal:
+                raise SystemExit("LBVH_TRACE_FAST_EXACT frame differs from the LBVH_TRACE_REFERENCE frame")
+            exact_mode = {"mode": "LBVH_TRACE_FAST_EXACT", "trace_ms": round(exact_ms, 4), "Mrays_s": round(W * H / (exact_ms * 1e-3) / 1e6, 2),
+                          "equals_reference_mode_word_for_word": exact_equal,
+                          "pixels_where_plain_fast_mode_differs": fast_differs,
+                          "note": "the timed mode is LBVH_TRACE_FAST (same t everywhere; on exact t ties it keeps the lowest triangle "
+                                  "index, the reference the triangle its visit order meets first)"}
+            kernel_ms_of(ccam)
+
         # per-kernel breakdown of one build
         ctx.profile_begin()
         for _ in range(5):
@@ -628,6 +654,7 @@ def main():
                                                    "before every frame (what a first frame costs); moving = camera yawed 1 degree per frame")
                                  if extras else None,
             "second_camera": near,
+            "exact_mode": exact_mode,
             "build_kernels_ms": prof_build,
             "cfg5_dynamic": dynamic,
         }

@@ -16,6 +16,8 @@ public static class LbvhNative
 
     public const int ABI_VERSION = 10;             // LBVH_ABI_VERSION of the include/lbvh.h this file was written against
     public const int TRACE_REFERENCE = 0, TRACE_FAST = 1;
+    // TRACE_FAST + the reference's choice wherever two triangles are hit at exactly the same t: every record == TRACE_REFERENCE's
+    public const int TRACE_FAST_EXACT = 2;
     public const uint BUILD_FAST_SCENE = 1, BUILD_RESET_NODES = 2;      // lbvh_build_scene flags
 
     [StructLayout(LayoutKind.Sequential)]

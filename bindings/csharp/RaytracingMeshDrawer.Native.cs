@@ -31,6 +31,9 @@ public class RaytracingMeshDrawer : MonoBehaviour
     [SerializeField] private ShaderContainer _shaderContainer;      // unused by the native path; kept for the scene's wiring
     [SerializeField] private Texture _meshTexture;                  // must be a readable Texture2D
     [SerializeField] private int[] _gpuDevices;                     // HIP devices to shard the rays over; empty: device 0
+    // true: LBVH_TRACE_FAST_EXACT — every hit record is the reference kernel's, also where two triangles are hit at exactly the
+    // same t (a handful of pixels per frame; + 40 % traversal time).  false: LBVH_TRACE_FAST (same t; lowest triangle index there)
+    [SerializeField] private bool _exactTies = true;
 
     private Camera _camera;
     private MeshBufferContainer _container;                         // rank 0's (the reference's fields)
@@ -153,7 +156,8 @@ public class RaytracingMeshDrawer : MonoBehaviour
             // every GPU's share of the frame, written at its pixels of rank 0's buffer (one launch each, enqueued round-robin)
             IntPtr rc = LbvhContext.HandleOf(r);
             LbvhNative.Scene scene = _containers[r].NativeScene();
-            LbvhNative.Check(rc, LbvhNative.lbvh_trace_primary_shard(rc, ref cam, (uint)r, (uint)ranks, ref scene, LbvhNative.TRACE_FAST,
+            LbvhNative.Check(rc, LbvhNative.lbvh_trace_primary_shard(rc, ref cam, (uint)r, (uint)ranks, ref scene,
+                                                                     _exactTies ? LbvhNative.TRACE_FAST_EXACT : LbvhNative.TRACE_FAST,
                                                                      _hits.Pointer, IntPtr.Zero));
             if (r != 0) LbvhNative.Check(rc, LbvhNative.lbvh_event_record(rc, _done[r]));
         }

@@ -117,6 +117,10 @@ typedef struct lbvh_camera {
 /* Traversal flavours of lbvh_trace_primary. */
 #define LBVH_TRACE_REFERENCE 0  /* the reference's visit order, no pruning, separate node arrays */
 #define LBVH_TRACE_FAST      1  /* 8x8 packets over fused 64-B nodes, near-first, t-pruned; same min-t */
+#define LBVH_TRACE_FAST_EXACT 2 /* LBVH_TRACE_FAST, and every record equals LBVH_TRACE_REFERENCE's word for word: a ray
+                                 * that meets two triangles at EXACTLY the same t (the one case in which the fast walk's
+                                 * order-independent choice — lowest triangle index — can differ from the triangle the
+                                 * reference's visit order meets first) is traced again by the reference's own loop */
 
 /* Optional per-launch traversal statistics (sums over all rays of the launch), in the
  * reference's visit semantics for LBVH_TRACE_REFERENCE: P nodes popped, B internal boxes hit,

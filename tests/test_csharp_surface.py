@@ -21,7 +21,7 @@ REF = "/root/reference/Assets/_Scripts"
 ADDED = {
     "MeshBufferContainer": {"LbvhNative.Scene NativeScene()"},                    # the six buffers Update() binds, as one struct
     "ComputeBufferSorter<TKey,TValue>": {"bool ValidateAfterSort"},               # the reference validates always; here opt-in
-    "RaytracingMeshDrawer": {"serialized int[] _gpuDevices"},                     # BASELINE configs[2]: the GPUs to shard the rays over
+    "RaytracingMeshDrawer": {"serialized int[] _gpuDevices", "serialized bool _exactTies"},                     # BASELINE configs[2]: the GPUs to shard the rays over
 }
 DROPPED = {
     "RaytracingMeshDrawer": {"message OnDrawGizmos()"},                           # editor gizmos: SURVEY section 2, out of scope

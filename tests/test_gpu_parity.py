@@ -965,6 +965,74 @@ def test_fast_mode_image_differs_from_reference_mode_only_where_t_ties(ctx, caps
         d.on_destroy()
 
 
+def test_fast_exact_mode_equals_the_reference_mode_word_for_word(ctx, capsys):
+    """LBVH_TRACE_FAST_EXACT = the packet walk + the rays that met two triangles at exactly the same t traced again by the
+    reference's own loop: every word of every hit record equals LBVH_TRACE_REFERENCE's — at the metric's size (1 M triangles,
+    1080p, camera outside and inside the scene), on a scene with every second triangle duplicated (ties on every hit of
+    theirs: ~2 000 pixels), on a scene where EVERY triangle is duplicated (every hit ties: the list holds most of the frame),
+    with a moving camera (history reprojected), from a cold start, for shares of a frame (1 / 2 / 3 / 8 shards: cooperative
+    heavy tiles with their LDS keys) and for packed shares."""
+    dup = scenes.tiled_torus(nu=40, nv=24, grid=3)
+    half = np.concatenate([dup, dup[::2]])
+    twice = np.concatenate([dup, dup])
+    cases = [("cfg2, camera z=250", scenes.tiled_torus(), (0.0, 0.0, 250.0), 1920, 1080),
+             ("cfg2, camera inside", None, (3.0, 2.0, 20.0), 1920, 1080),
+             ("every second triangle duplicated", half, (0.0, 0.0, 140.0), 640, 360),
+             ("every triangle duplicated", twice, (0.0, 0.0, 140.0), 640, 360)]
+    d = None
+    for name, tris, pos, w, h in cases:
+        if tris is not None:
+            if d is not None:
+                d.on_destroy()
+            d = H().RaytracingMeshDrawer(ctx, tris).awake()
+        cam = scenes.camera(w, h, pos)
+        d.update(cam, mode=L.TRACE_REFERENCE)
+        ref = words(d.hits()).copy()
+        ctx.trace_forget()
+        seen = []
+        for frame in range(3):                                           # cold, then twice with the dispatch history
+            d._hits.fill_u32(0x7FC00000, mirror=False)
+            d.update(cam, mode=L.TRACE_FAST_EXACT)
+            got = words(d.hits())
+            assert (got == ref).all(), (name, frame, int((got != ref).any(axis=-1).sum()))
+        d.update(cam, mode=L.TRACE_FAST)
+        fast_differs = int((words(d.hits()) != ref).reshape(-1, 4).any(axis=1).sum())
+        seen.append(fast_differs)
+        # a camera that turns and moves: reprojected history
+        for k in range(1, 4):
+            c2 = dict(scenes.camera(w, h, (pos[0] + 0.3 * k, pos[1], pos[2] - 0.5 * k)))
+            d.update(c2, mode=L.TRACE_REFERENCE)
+            r2 = words(d.hits()).copy()
+            d.update(c2, mode=L.TRACE_FAST_EXACT)
+            assert (words(d.hits()) == r2).all(), (name, "moved", k)
+        # shares of the frame into one poisoned full-frame buffer, and packed shares
+        for shards in (1, 2, 3, 8):
+            d._hits.fill_u32(0x7FC00000, mirror=False)
+            for rep in range(2):                                         # second round: with each share's history
+                for r in range(shards):
+                    d.update_shard(cam, r, shards, mode=L.TRACE_FAST_EXACT)
+            assert (words(d.hits()) == ref).all(), (name, "shards", shards)
+        if tris is not None and len(tris) < 200_000:                   # packed shares of the tie-heavy scenes (record slot = item * 64 + lane)
+            from unitysimpleraytracing_amd import _native as N
+            ccam, s3 = N.Camera.from_dict(cam), d.container.scene()
+            stride = int(N.lib.lbvh_shard_records(w, h, 0, 3))
+            packed = H().DataBuffer(ctx, stride * 3, L.HIT)
+            frame_buf = H().DataBuffer(ctx, w * h, L.HIT)
+            for rep in range(2):
+                packed.fill_u32(0x7FC00000, mirror=False)
+                for r in range(3):
+                    at = C.c_void_p(packed.device.value + r * stride * 16)
+                    N.check(ctx.handle, N.lib.lbvh_trace_primary_shard_packed(ctx.handle, C.byref(ccam), r, 3, C.byref(s3), L.TRACE_FAST_EXACT, at, None))
+                frame_buf.fill_u32(0x7FC00000, mirror=False)
+                N.check(ctx.handle, N.lib.lbvh_frame_unpack(ctx.handle, packed.device, stride, 0, 3, 3, w, h, frame_buf.device))
+                assert (words(frame_buf.get_data().reshape(h, w)) == ref).all(), (name, "packed", rep)
+            packed.dispose()
+            frame_buf.dispose()
+        with capsys.disabled():
+            print(f"\n  [{name}] {w}x{h}: LBVH_TRACE_FAST alone differs from the reference mode on {seen[0]} pixel(s); LBVH_TRACE_FAST_EXACT on none")
+    d.on_destroy()
+
+
 def test_cfg2_full_size(ctx):
     tris = scenes.tiled_torus()                                    # 1 000 000 triangles
     d = H().RaytracingMeshDrawer(ctx, tris).awake()

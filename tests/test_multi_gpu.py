@@ -75,7 +75,7 @@ def test_packed_shares_and_unpack(ctx, shards, size):
     cam = scenes.camera(W, Ht, (0.0, 0.0, 300.0))
     ccam = N.Camera.from_dict(cam)
     s = d.container.scene()
-    for mode in (L.TRACE_FAST, L.TRACE_REFERENCE):
+    for mode in (L.TRACE_FAST, L.TRACE_REFERENCE, L.TRACE_FAST_EXACT):
         d.update(cam, mode=mode)
         full = d.hits()
         stride = int(N.lib.lbvh_shard_records(W, Ht, 0, shards))

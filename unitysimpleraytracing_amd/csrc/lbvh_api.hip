@@ -93,6 +93,7 @@ int lbvh_check_fault(lbvh_context* ctx)
     snprintf(msg, sizeof msg, "%s (fault %u): results enqueued before this call are invalid",
              code == LBVH_FAULT_RAY_STACK    ? "a per-ray traversal stack ran out of entries"
              : code == LBVH_FAULT_FRAME_WAIT ? "lbvh_frame_wait: a rank's completion flag never arrived"
+             : code == LBVH_FAULT_TIE_LIST ? "LBVH_TRACE_FAST_EXACT: more exact ties than the list holds (more than one per ray)"
                                              : "a bounded inter-workgroup wait gave up", code);
     return lbvh_set_error(ctx, LBVH_ERR_HIP, "device-side protocol fault", msg);
 }
@@ -210,6 +211,7 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
     if (ctx->fast_tree) (void)hipFree(ctx->fast_tree);
     if (ctx->hier) (void)hipFree(ctx->hier);
     if (ctx->ray_scratch) (void)hipFree(ctx->ray_scratch);
+    if (ctx->tie_list) (void)hipFree(ctx->tie_list);
     if (ctx->wide_nodes) (void)hipFree(ctx->wide_nodes);
     if (ctx->trace_frame_costs) (void)hipFree(ctx->trace_frame_costs);
     for (auto& s : ctx->prof_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }

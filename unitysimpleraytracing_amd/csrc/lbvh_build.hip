@@ -649,8 +649,9 @@ __device__ __forceinline__ void tree_body(uint32_t block, uint32_t* s_keys, floa
         if (valid && right_leaf) rref = 0x80000000u | (leaf_base + sorted_indices[split + 1]);
         s_out[threadIdx.x * 4 + 0] = make_float4(cmn[0][0], cmn[0][1], cmn[0][2], __uint_as_float(lref));
         s_out[threadIdx.x * 4 + 1] = make_float4(cmx[0][0], cmx[0][1], cmx[0][2], __uint_as_float(rref));
-        s_out[threadIdx.x * 4 + 2] = make_float4(cmn[1][0], cmn[1][1], cmn[1][2], 0.0f);
-        s_out[threadIdx.x * 4 + 3] = make_float4(cmx[1][0], cmx[1][1], cmx[1][2], 0.0f);
+        // (the two spare words: the children's leaf positions, read by LBVH_TRACE_FAST_EXACT when the child is a leaf)
+        s_out[threadIdx.x * 4 + 2] = make_float4(cmn[1][0], cmn[1][1], cmn[1][2], __uint_as_float((uint32_t)split));
+        s_out[threadIdx.x * 4 + 3] = make_float4(cmx[1][0], cmx[1][1], cmx[1][2], __uint_as_float((uint32_t)split + 1u));
     }
     if (MODE != TREE_TOPOLOGY) {
         __syncthreads();

@@ -25,6 +25,8 @@ static_assert(sizeof(lbvh_hit) == 16, "hit record must be 16 bytes");
 #define LBVH_FAULT_RAY_STACK 2u
 // lbvh_frame_wait gave up: another rank's completion flag for this frame never arrived
 #define LBVH_FAULT_FRAME_WAIT 3u
+// LBVH_TRACE_FAST_EXACT: more tied candidates than the list holds (one per ray of the launch)
+#define LBVH_FAULT_TIE_LIST 4u
 // polls before a spin gives up: each poll is a round trip to the coherence point (>= 0.5 us), so this is seconds —
 // orders of magnitude beyond any legitimate wait (a predecessor tile's run time), and never a hung GPU
 #define LBVH_SPIN_LIMIT (1u << 22)
@@ -137,6 +139,9 @@ struct lbvh_context {
     void* wide_nodes = nullptr;
     size_t wide_nodes_bytes = 0;
     bool wide_valid = false;
+    // LBVH_TRACE_FAST_EXACT: rays listed for the reference's walk (lbvh_trace.hip retrace_ties_kernel)
+    void* tie_list = nullptr;
+    size_t tie_list_bytes = 0;
     lbvh_ray_stats* ray_stats = nullptr;      // lbvh_ray_stats_target: the four-wide walkers add their counters here while set
     uint32_t ray_walker = 1;                  // lbvh_debug_ray_walker: 0 binary nodes, 1 four-wide, 2 four-wide with the few-rays kernel always
 

@@ -37,6 +37,12 @@ struct trace_args {
     uint32_t shard_index, shard_count;   // this launch traces every shard_count-th GROUP of tiles
     uint32_t line_bytes;                 // size of the node + triangle line array if it is below 4 GB, else 0
     uint32_t packed;                     // 1: records go to hits[work item * 64 + lane] (lbvh_trace_primary_shard_packed)
+    // LBVH_TRACE_FAST_EXACT (nullptr otherwise): every triangle a ray meets at exactly its best t is listed here — [0] = count,
+    // then entries {record slot, px | py << 16, leaf position, t} — and resolve_ties_* give the record to the one the
+    // REFERENCE's visit order meets first
+    uint32_t* ties;
+    uint32_t tie_capacity;
+    const uint32_t* sorted_indices;      // leaf position -> triangle
 };
 
 constexpr int kOrderClasses = 16;         // cost classes of the packet dispatch order
@@ -173,6 +179,96 @@ __global__ __launch_bounds__(64) void trace_reference_kernel(trace_args a, lbvh_
         if (STATS && best_t < LBVH_MAX_FLOAT) n_hit = 1;
     }
     if (STATS) add_stats(stats, n_pops, n_box, n_leaf, n_tri, n_hit);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LBVH_TRACE_FAST_EXACT: which of several triangles hit at exactly the same t the reference keeps
+// ---------------------------------------------------------------------------------------------
+// The reference keeps the triangle its loop meets FIRST (strict `<`, Raytracing.compute:95).  Its loop (:138-176) tests a node's
+// leaf children at once — left, then right — and pushes the internal ones, left then right, so the right subtree is popped
+// before the left one.  That is a fixed order of the leaves, whatever the ray (a box that is missed only removes leaves from
+// it): at every node, [left child if it is a leaf] [right child if a leaf] [right subtree] [left subtree].  Two leaves are
+// ordered by the first node at which their paths from the root part, so a leaf's rank is the string of two-bit digits along its
+// path — 0 / 1: the leaf itself as left / right child, 2: into the right subtree, 3: into the left one — compared from the root.
+// The reference's own stack holds 64 entries, so a path has at most 64 digits: 128 bits.  Climbing from the leaf, every digit
+// is shifted in at the top, so the root's digit ends up most significant.
+struct tie_key { unsigned long long hi, lo; };
+__device__ __forceinline__ bool key_less(const tie_key& a, const tie_key& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+
+__device__ __forceinline__ tie_key reference_visit_key(const lbvh_scene& s, uint32_t leaf_position)
+{
+    tie_key k = {0ull, 0ull};
+    auto shift_in = [&](unsigned long long digit) { k.lo = (k.lo >> 2) | (k.hi << 62); k.hi = (k.hi >> 2) | (digit << 62); };
+    const uint32_t* leaf = reinterpret_cast<const uint32_t*>(&s.leaf_nodes[leaf_position]);       // {parent, index}
+    uint32_t node = leaf[0];
+    {
+        const uint32_t* nd = reinterpret_cast<const uint32_t*>(&s.internal_nodes[node]);            // {left, ltype, right, rtype, parent, index}
+        shift_in((nd[0] == leaf_position && nd[1] == LBVH_LEAF_NODE) ? 0ull : 1ull);
+    }
+    for (int guard = 0; guard < 64 && node != 0u; guard++) {
+        const uint32_t parent = reinterpret_cast<const uint32_t*>(&s.internal_nodes[node])[4];
+        const uint32_t* nd = reinterpret_cast<const uint32_t*>(&s.internal_nodes[parent]);
+        shift_in((nd[0] == node && nd[1] == LBVH_INTERNAL_NODE) ? 3ull : 2ull);
+        node = parent;
+    }
+    return k;
+}
+
+constexpr uint32_t kTiePosition = 0x80000000u;       // a record's triangle word still holds a leaf position (resolve pending)
+
+// pass 1: every listed candidate whose t is the record's t tries to take the record (a compare-and-swap on the record's
+// triangle word, which holds the leaf position of the candidate in the lead)
+__global__ __launch_bounds__(256) void resolve_ties_lead_kernel(trace_args a, lbvh_scene s, lbvh_hit* __restrict__ hits, uint32_t* __restrict__ fault)
+{
+    const uint32_t count = a.ties[0];
+    if (count > a.tie_capacity) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(fault, LBVH_FAULT_TIE_LIST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const uint32_t slot = a.ties[4 + 4 * i], pos = a.ties[6 + 4 * i], tbits = a.ties[7 + 4 * i];
+        uint32_t* rec = reinterpret_cast<uint32_t*>(&hits[slot]);
+        if (rec[0] != tbits) continue;                       // a tie at a t that was beaten later
+        const tie_key mine = reference_visit_key(s, pos);
+        uint32_t lead = __hip_atomic_load(&rec[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (lead != (pos | kTiePosition)) {
+            const tie_key theirs = reference_visit_key(s, lead & ~kTiePosition);
+            if (!key_less(mine, theirs)) break;
+            if (__hip_atomic_compare_exchange_strong(&rec[1], &lead, pos | kTiePosition, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                break;
+        }
+    }
+}
+
+// pass 2 (a launch later: every lead is final): the candidate in the lead writes the record as the reference computes it
+__global__ __launch_bounds__(256) void resolve_ties_write_kernel(trace_args a, lbvh_scene s, lbvh_hit* __restrict__ hits)
+{
+    const uint32_t count = min(a.ties[0], a.tie_capacity);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const uint32_t slot = a.ties[4 + 4 * i], xy = a.ties[5 + 4 * i], pos = a.ties[6 + 4 * i], tbits = a.ties[7 + 4 * i];
+        uint32_t* rec = reinterpret_cast<uint32_t*>(&hits[slot]);
+        if (rec[0] != tbits || rec[1] != (pos | kTiePosition)) continue;
+        const uint32_t tri = s.sorted_indices[pos];
+        const ray_t ray = make_ray(a.cam, xy & 0xFFFFu, xy >> 16);
+        const float4* tv = reinterpret_cast<const float4*>(&s.triangles[tri]);
+        float u = 0.0f, v = 0.0f;
+        const float dist = ray_triangle(ray, tv[0], tv[1], tv[2], u, v);
+        reinterpret_cast<float4*>(hits)[slot] = make_float4(dist, __uint_as_float(tri), u, v);
+    }
+}
+
+// one candidate per lane of `mask` onto the list (called where the lanes of `mask` are active)
+__device__ __forceinline__ void list_tie(const trace_args& a, uint64_t mask, uint32_t slot, uint32_t xy, uint32_t pos, float t)
+{
+    const uint32_t lane = lane_id();
+    const int first = __builtin_ctzll(mask);
+    uint32_t base = 0;
+    if ((int)lane == first) base = atomicAdd(&a.ties[0], (uint32_t)__popcll(mask));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+    const uint32_t i = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (i < a.tie_capacity) {
+        a.ties[4 + 4 * i] = slot; a.ties[5 + 4 * i] = xy; a.ties[6 + 4 * i] = pos; a.ties[7 + 4 * i] = __float_as_uint(t);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -376,13 +472,20 @@ __device__ __forceinline__ uint32_t node_line_bytes(uint32_t lane, bool ordered,
     return (flip ? d ^ 4u : d) * 4u;
 }
 
+// EXACT (LBVH_TRACE_FAST_EXACT, one ray per lane): best_tri holds a LEAF POSITION (from the parent's line: dwords 11 / 15), every
+// candidate that loses a tie at exactly the best t is listed at once, and `tied` collects the lanes that saw one
+struct tie_sink { const trace_args* a; uint32_t slot, xy; uint64_t tied; };
+
 // SIGNS: all active rays of the packet share the sign of each direction component (and have finite non-zero
 // inverse directions): bit i of `neg` = component i is negative.  The near / far planes of both child boxes are
 // then picked on the scalar unit and the box tests lose their six min / max each (ray_box_ordered).
-template <bool STATS, int R, bool SIGNS, bool BUF>
-__device__ __forceinline__ uint32_t walk_packet(const line_source& src, packet_rays<R>& P, walk_counters& C, uint32_t neg)
+template <bool STATS, int R, bool SIGNS, bool BUF, bool EXACT = false>
+__device__ __forceinline__ uint32_t walk_packet(const line_source& src, packet_rays<R>& P, walk_counters& C, uint32_t neg,
+                                                tie_sink* sink = nullptr)
 {
+    static_assert(!EXACT || R == 1, "the exact mode walks one ray per lane");
     const uint32_t lane = lane_id();
+    bool tied = false;
     int stack = 0;            // wave-shared stack: slot k lives in lane k of this VGPR
     uint32_t sp = 0;          // scalar
     uint32_t steps = 0;
@@ -441,7 +544,12 @@ __device__ __forceinline__ uint32_t walk_packet(const line_source& src, packet_r
                     if (STATS) C.tri++;
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_fast_triangle(P.ray[r], v0, v1, v2, u, v);
-                    if (closer(dist, __float_as_uint(v0.w), P.best_t[r], P.best_tri[r])) { P.best_t[r] = dist; P.best_tri[r] = __float_as_uint(v0.w); P.best_u[r] = u; P.best_v[r] = v; }
+                    const uint32_t id = EXACT ? __float_as_uint(nd.rmin.w) : __float_as_uint(v0.w);      // EXACT: the left leaf's position
+                    if (EXACT && dist == P.best_t[r] && dist != LBVH_MAX_FLOAT) {
+                        tied = true;                                       // the candidate that does not stay in the running is listed now
+                        list_tie(*sink->a, __ballot(true), sink->slot, sink->xy, max(id, P.best_tri[r]), dist);
+                    }
+                    if (closer(dist, id, P.best_t[r], P.best_tri[r])) { P.best_t[r] = dist; P.best_tri[r] = id; P.best_u[r] = u; P.best_v[r] = v; }
                 }
                 hit_r[r] = hit_r[r] && !(tr[r] > P.best_t[r]);
                 any_r |= hit_r[r];
@@ -458,7 +566,12 @@ __device__ __forceinline__ uint32_t walk_packet(const line_source& src, packet_r
                     if (STATS) C.tri++;
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_fast_triangle(P.ray[r], v0, v1, v2, u, v);
-                    if (closer(dist, __float_as_uint(v0.w), P.best_t[r], P.best_tri[r])) { P.best_t[r] = dist; P.best_tri[r] = __float_as_uint(v0.w); P.best_u[r] = u; P.best_v[r] = v; }
+                    const uint32_t id = EXACT ? __float_as_uint(nd.rmax.w) : __float_as_uint(v0.w);      // EXACT: the right leaf's position
+                    if (EXACT && dist == P.best_t[r] && dist != LBVH_MAX_FLOAT) {
+                        tied = true;
+                        list_tie(*sink->a, __ballot(true), sink->slot, sink->xy, max(id, P.best_tri[r]), dist);
+                    }
+                    if (closer(dist, id, P.best_t[r], P.best_tri[r])) { P.best_t[r] = dist; P.best_tri[r] = id; P.best_u[r] = u; P.best_v[r] = v; }
                 }
                 hit_l[r] = hit_l[r] && !(tl[r] > P.best_t[r]);
                 any_l |= hit_l[r];
@@ -497,7 +610,10 @@ __device__ __forceinline__ uint32_t walk_packet(const line_source& src, packet_r
         } else if (mr != 0) {
             w_node = w_r;
         } else {
-            if (sp == 0) return steps;
+            if (sp == 0) {
+                if (EXACT) sink->tied = __ballot(tied);
+                return steps;
+            }
             sp--;
             w_node = fetch_line<BUF>(src, (uint32_t)__builtin_amdgcn_readlane(stack, sp & 63u), node_bytes);
         }
@@ -923,7 +1039,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
 }
 
 // one tile (work item w) walked by one wave
-template <bool STATS>
+template <bool STATS, bool EXACT = false>
 __device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_node* __restrict__ nodes,
                                            const lbvh_fast_tri* __restrict__ tris, uint32_t w, uint32_t lane,
                                            uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits, lbvh_trace_stats* stats,
@@ -945,6 +1061,21 @@ __device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_
     src.lines = nodes;
     src.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<lbvh_fast_node*>(nodes), 0, (int)a.line_bytes, 0x00020000);
     uint32_t steps;
+    tie_sink sink = {&a, 0u, 0u, 0ull};
+    if (EXACT) {
+        // the general walker with the tie bookkeeping (closer() on leaf positions: the loser of every exact tie is listed)
+        sink.slot = (uint32_t)hit_slot(a, w, lane, px0, py0);
+        sink.xy = px0 | (py0 << 16);
+        if (a.line_bytes != 0)
+            steps = ordered ? walk_packet<false, 1, true, true, true>(src, P, C, neg, &sink) : walk_packet<false, 1, false, true, true>(src, P, C, 0u, &sink);
+        else
+            steps = ordered ? walk_packet<false, 1, true, false, true>(src, P, C, neg, &sink) : walk_packet<false, 1, false, false, true>(src, P, C, 0u, &sink);
+        // a ray that saw a tie: its candidate in the lead joins the list and stays in the record as a position until the
+        // resolve kernels have run; every other ray's position becomes its triangle here
+        const bool mine = (sink.tied >> lane) & 1ull;
+        if (mine) list_tie(a, sink.tied, sink.slot, sink.xy, P.best_tri[0], P.best_t[0]);
+        if (P.act[0] && P.best_t[0] < LBVH_MAX_FLOAT) P.best_tri[0] = mine ? (P.best_tri[0] | kTiePosition) : a.sorted_indices[P.best_tri[0]];
+    } else
     if (!STATS && ordered && packet_one_origin(P))
         steps = a.line_bytes != 0 ? walk_packet_lean<true>(src, P, neg) : walk_packet_lean<false>(src, P, neg);
     else if (a.line_bytes != 0)
@@ -968,7 +1099,7 @@ __device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_
 
 // A full chip (a whole frame on one GPU): one wave per tile, 4 tiles per workgroup, the w-th tile of the class
 // lists, heaviest class first.  No cooperative tiles: with every wave slot taken they do not pay (287 -> 304 us).
-template <bool STATS>
+template <bool STATS, bool EXACT = false>
 __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
                                                            const lbvh_fast_tri* __restrict__ tris, uint32_t n_work,
                                                            const uint32_t* __restrict__ counts, const uint32_t* __restrict__ lists,
@@ -984,7 +1115,7 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
         for (; c > 0 && k >= counts[c]; c--) k -= counts[c];
         w = lists[(size_t)c * n_work + k];
     }
-    light_tile<STATS>(a, nodes, tris, w, lane, cost, hits, stats, tile_cost);
+    light_tile<STATS, EXACT>(a, nodes, tris, w, lane, cost, hits, stats, tile_cost);
 }
 
 // One launch per frame share.  Workgroups of 8 waves; the hardware dispatcher hands them out in index order:
@@ -1298,6 +1429,12 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     // (a moved camera: the plain kernel — the widened costs would make every neighbour of a heavy tile cooperative, 0.27 - 0.29 ms;
     // marking by the un-widened reprojected cost finds too few of them: 0.20 - 0.22 against 0.21 plain)
     const bool whole = n_work > kSharedMaxWork && spread == 0;
+    if (a.ties != nullptr) {
+        // LBVH_TRACE_FAST_EXACT: one tile per wave with the tie bookkeeping, in the history's order when there is one
+        const uint32_t blocks = (n_work + 3) / 4;
+        LBVH_LAUNCH(ctx, (trace_packet_kernel<false, true>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris, n_work,
+                    have_history ? counts : nullptr, lists, cost, d_hits, d_stats, d_tile_cost);
+    } else
     if (have_history && whole) {
         coop_params hp = {n_work / 4u, kHeavyClassWhole, kCoopGrain};
         const uint32_t blocks = hp.cap + (n_work + kCoopWavesWhole - 1) / kCoopWavesWhole;
@@ -1642,7 +1779,7 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
 {
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     LBVH_REQUIRE(ctx, h_camera != nullptr && h_scene != nullptr);
-    LBVH_REQUIRE(ctx, mode == LBVH_TRACE_REFERENCE || mode == LBVH_TRACE_FAST);
+    LBVH_REQUIRE(ctx, mode == LBVH_TRACE_REFERENCE || mode == LBVH_TRACE_FAST || mode == LBVH_TRACE_FAST_EXACT);
     const lbvh_camera cam = *h_camera;
     const lbvh_scene s = *h_scene;
     LBVH_REQUIRE(ctx, cam.screen_width > 0 && cam.screen_height > 0);
@@ -1659,6 +1796,9 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
     a.shard_index = shard_index; a.shard_count = shard_count;
     a.line_bytes = 0;
     a.packed = packed ? 1u : 0u;
+    a.ties = nullptr;
+    a.tie_capacity = 0;
+    a.sorted_indices = s.sorted_indices;
     a.tiles_x = (uint32_t)(x1 - x0 + 7) / 8;
     a.tiles_y = (uint32_t)(y1 - y0 + 7) / 8;
     const uint32_t n_tiles = shard_work(a.tiles_x * a.tiles_y, shard_index, shard_count);
@@ -1679,6 +1819,21 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
             const int frc = lbvh_require_fast(ctx, s, "lbvh_trace_primary (LBVH_TRACE_FAST)");
             if (frc != LBVH_OK) return frc;
         }
+        const bool exact = mode == LBVH_TRACE_FAST_EXACT;
+        if (exact) {
+            // the list of tied candidates: one entry per ray of the launch (a scene of doubled triangles lists about one per hit
+            // ray; more — three coincident triangles everywhere — is reported as LBVH_FAULT_TIE_LIST), cleared here
+            LBVH_REQUIRE(ctx, !d_stats && !d_tile_cost);
+            LBVH_REQUIRE(ctx, s.sorted_indices && s.internal_nodes && s.leaf_nodes && s.triangles);
+            LBVH_REQUIRE(ctx, x0 >= 0 && y0 >= 0 && x1 <= 65535 && y1 <= 65535);      // a listed ray's pixel is px | py << 16
+            const uint64_t rays = (uint64_t)n_tiles * 64u;
+            LBVH_REQUIRE(ctx, rays <= 0x3FFFFFFFull);
+            const int trc = lbvh_reserve(ctx, &ctx->tie_list, &ctx->tie_list_bytes, 16 + (size_t)rays * 16);
+            if (trc != LBVH_OK) return trc;
+            a.ties = (uint32_t*)ctx->tie_list;
+            a.tie_capacity = (uint32_t)rays;
+            LBVH_HIP_TRY(ctx, hipMemsetAsync(a.ties, 0, 4, ctx->cur_stream));
+        }
         // 1 ray per lane = 8 x 8-pixel packets: 0.27 ms; 1x2: 0.43, 2x1: 0.45, 3x1: 0.68, 4x1: 0.82, 2x2: 0.92 ms
         // (more rays per lane cut node fetches per ray but lengthen every step and the per-tile critical path;
         // while the tile queues still cost 0.7 ms per launch, 2x1 had looked best).  4-wide 128-byte nodes
@@ -1686,6 +1841,12 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
         // 110 us more build — re-measured after the queues were gone, still a loss.
         const int prc = launch_packets(ctx, a, d_hits, d_stats, d_tile_cost);
         if (prc != LBVH_OK) return prc;
+        if (exact) {
+            // two small launches: the lead among a record's candidates (compare-and-swap by the reference's visit order), then
+            // the record as the reference computes it.  Without ties both find an empty list.
+            LBVH_LAUNCH(ctx, resolve_ties_lead_kernel, dim3(64), dim3(256), a, s, d_hits, ctx->fault_dev);
+            LBVH_LAUNCH(ctx, resolve_ties_write_kernel, dim3(64), dim3(256), a, s, d_hits);
+        }
     }
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;

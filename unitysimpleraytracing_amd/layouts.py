@@ -44,6 +44,7 @@ MAX_FLOAT = np.float32(2139095040.0)  # (float)0x7F7FFFFF, Assets/_Shaders/Const
 
 TRACE_REFERENCE = 0
 TRACE_FAST = 1
+TRACE_FAST_EXACT = 2      # TRACE_FAST + rays that meet an exact t tie re-traced by the reference's walk: == TRACE_REFERENCE, every word
 
 # Scene box the reference hard-wires for Morton normalisation
 # (Assets/_Scripts/MeshBufferContainer.cs:9-15)
