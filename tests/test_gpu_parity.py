@@ -969,7 +969,8 @@ def test_fast_exact_mode_equals_the_reference_mode_word_for_word(ctx, capsys):
     """LBVH_TRACE_FAST_EXACT = the packet walk + the rays that met two triangles at exactly the same t traced again by the
     reference's own loop: every word of every hit record equals LBVH_TRACE_REFERENCE's — at the metric's size (1 M triangles,
     1080p, camera outside and inside the scene), on a scene with every second triangle duplicated (ties on every hit of
-    theirs: ~2 000 pixels), on a scene where EVERY triangle is duplicated (every hit ties: the list holds most of the frame),
+    theirs: ~2 000 pixels), on a scene where EVERY triangle is duplicated (every hit ties: the list holds most of the frame), on
+    one with four coincident copies of every triangle (the list runs over: the fallback through the reference's loop),
     with a moving camera (history reprojected), from a cold start, for shares of a frame (1 / 2 / 3 / 8 shards: cooperative
     heavy tiles with their LDS keys) and for packed shares."""
     dup = scenes.tiled_torus(nu=40, nv=24, grid=3)
@@ -978,7 +979,10 @@ def test_fast_exact_mode_equals_the_reference_mode_word_for_word(ctx, capsys):
     cases = [("cfg2, camera z=250", scenes.tiled_torus(), (0.0, 0.0, 250.0), 1920, 1080),
              ("cfg2, camera inside", None, (3.0, 2.0, 20.0), 1920, 1080),
              ("every second triangle duplicated", half, (0.0, 0.0, 140.0), 640, 360),
-             ("every triangle duplicated", twice, (0.0, 0.0, 140.0), 640, 360)]
+             ("every triangle duplicated", twice, (0.0, 0.0, 140.0), 640, 360),
+             # four coincident copies: three candidates drop out per hit ray, the one-per-ray list runs over -> the marked rays go
+             # through the reference's loop
+             ("every triangle four times", np.concatenate([dup[: len(dup) // 3]] * 4), (0.0, 0.0, 140.0), 320, 180)]
     d = None
     for name, tris, pos, w, h in cases:
         if tris is not None:

@@ -115,6 +115,14 @@ with Context(0) as ctx:
         d.update(cam, mode=L.TRACE_REFERENCE)
         rh = d.hits()
         assert (words(rh) == words(oh)).all(), (kind, n, w, h, "reference hits")
+        # LBVH_TRACE_FAST_EXACT: every word of the oracle's records ("dups" scenes tie on most pixels), whole frame and shards
+        for frame in range(2):
+            if shards == 1:
+                d.update(cam, mode=L.TRACE_FAST_EXACT)
+            else:
+                for r in range(shards):
+                    d.update_shard(cam, r, shards, mode=L.TRACE_FAST_EXACT)
+            assert (words(d.hits()) == words(oh)).all(), (kind, n, w, h, shards, frame, "exact mode")
         # a sub-rectangle of the frame, two frames (its own history), then the same rectangle from a turned camera
         if w >= 3 and h >= 3:
             x0, y0 = int(rng.integers(0, w - 1)), int(rng.integers(0, h - 1))
@@ -130,6 +138,8 @@ with Context(0) as ctx:
             assert (d.hits()["t"] == oh2["t"][y0:y1, x0:x1]).all(), (kind, n, w, h, "rectangle, second camera")
         d.update(cam2, mode=L.TRACE_FAST)
         assert (d.hits()["t"] == oh2["t"]).all(), (kind, n, w, h, "second camera")
+        d.update(cam2, mode=L.TRACE_FAST_EXACT)
+        assert (words(d.hits()) == words(oh2)).all(), (kind, n, w, h, "second camera, exact mode")
         d.on_destroy()
         # ---- every so often: the dynamic scene + path tracer (cfg5 extension) against its own oracle ---------------
         if cases % 8 == 0:

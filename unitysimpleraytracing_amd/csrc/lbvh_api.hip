@@ -93,7 +93,6 @@ int lbvh_check_fault(lbvh_context* ctx)
     snprintf(msg, sizeof msg, "%s (fault %u): results enqueued before this call are invalid",
              code == LBVH_FAULT_RAY_STACK    ? "a per-ray traversal stack ran out of entries"
              : code == LBVH_FAULT_FRAME_WAIT ? "lbvh_frame_wait: a rank's completion flag never arrived"
-             : code == LBVH_FAULT_TIE_LIST ? "LBVH_TRACE_FAST_EXACT: more exact ties than the list holds (more than one per ray)"
                                              : "a bounded inter-workgroup wait gave up", code);
     return lbvh_set_error(ctx, LBVH_ERR_HIP, "device-side protocol fault", msg);
 }

@@ -25,8 +25,7 @@ static_assert(sizeof(lbvh_hit) == 16, "hit record must be 16 bytes");
 #define LBVH_FAULT_RAY_STACK 2u
 // lbvh_frame_wait gave up: another rank's completion flag for this frame never arrived
 #define LBVH_FAULT_FRAME_WAIT 3u
-// LBVH_TRACE_FAST_EXACT: more tied candidates than the list holds (one per ray of the launch)
-#define LBVH_FAULT_TIE_LIST 4u
+
 // polls before a spin gives up: each poll is a round trip to the coherence point (>= 0.5 us), so this is seconds —
 // orders of magnitude beyond any legitimate wait (a predecessor tile's run time), and never a hung GPU
 #define LBVH_SPIN_LIMIT (1u << 22)

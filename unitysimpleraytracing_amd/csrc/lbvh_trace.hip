@@ -114,6 +114,56 @@ __device__ __forceinline__ void add_stats(lbvh_trace_stats* stats, uint32_t pops
 // ---------------------------------------------------------------------------------------------
 // LBVH_TRACE_REFERENCE
 // ---------------------------------------------------------------------------------------------
+// one ray through the reference's loop (Raytracing.compute:128-176): the lane's column of s_stack is its stack
+template <bool STATS>
+__device__ __forceinline__ float4 reference_ray(const lbvh_scene& s, const ray_t& ray, uint32_t (*s_stack)[LBVH_WAVE], uint32_t lane,
+                                                uint32_t& n_pops, uint32_t& n_box, uint32_t& n_leaf, uint32_t& n_tri)
+{
+    float best_t = LBVH_MAX_FLOAT;                    // :129
+    uint32_t best_tri = 0;                            // :130
+    float best_u = 0.0f, best_v = 0.0f;               // :131
+
+    uint32_t sp = 0;
+    s_stack[0][lane] = 0;                             // :135
+    sp = 1;
+    while (sp != 0) {                                 // :138
+        sp--;
+        const uint32_t index = s_stack[sp][lane];     // :141
+        if (STATS) n_pops++;
+        const float4* nb = reinterpret_cast<const float4*>(&s.bvh[index]);
+        float tmin;
+        if (!ray_box(nb[0], nb[1], ray, tmin)) continue;     // :143-146
+        if (STATS) n_box++;
+        const uint32_t* nd = reinterpret_cast<const uint32_t*>(&s.internal_nodes[index]);
+        const uint2 lc = *reinterpret_cast<const uint2*>(nd + 0);
+        const uint2 rc = *reinterpret_cast<const uint2*>(nd + 2);
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const uint2 c = side == 0 ? lc : rc;      // left then right  :148-175
+            if (c.y == LBVH_INTERNAL_NODE) {
+                if (sp < (uint32_t)kStackDepth) s_stack[sp][lane] = c.x;
+                sp++;
+            } else {
+                const uint32_t tri = s.sorted_indices[s.leaf_nodes[c.x].index];   // :158
+                if (STATS) n_leaf++;
+                const float4* tb = reinterpret_cast<const float4*>(&s.triangle_aabb[tri]);
+                float tmin2;
+                if (ray_box(tb[0], tb[1], ray, tmin2)) {                          // :91
+                    if (STATS) n_tri++;
+                    const float4* tv = reinterpret_cast<const float4*>(&s.triangles[tri]);
+                    float u = 0.0f, v = 0.0f;
+                    const float dist = ray_triangle(ray, tv[0], tv[1], tv[2], u, v);
+                    if (dist < best_t) {                                          // :95
+                        best_t = dist; best_tri = tri; best_u = u; best_v = v;
+                    }
+                }
+            }
+        }
+        if (sp > (uint32_t)kStackDepth) sp = kStackDepth;   // unreachable for unique keys
+    }
+    return make_float4(best_t, __uint_as_float(best_tri), best_u, best_v);
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(64) void trace_reference_kernel(trace_args a, lbvh_scene s,
                                                              lbvh_hit* __restrict__ hits,
@@ -128,55 +178,9 @@ __global__ __launch_bounds__(64) void trace_reference_kernel(trace_args a, lbvh_
     uint32_t n_pops = 0, n_box = 0, n_leaf = 0, n_tri = 0, n_hit = 0;
     if (active) {
         const ray_t ray = make_ray(a.cam, px, py);
-        float best_t = LBVH_MAX_FLOAT;                    // :129
-        uint32_t best_tri = 0;                            // :130
-        float best_u = 0.0f, best_v = 0.0f;               // :131
-
-        uint32_t sp = 0;
-        s_stack[0][lane] = 0;                             // :135
-        sp = 1;
-        while (sp != 0) {                                 // :138
-            sp--;
-            const uint32_t index = s_stack[sp][lane];     // :141
-            if (STATS) n_pops++;
-            const float4* nb = reinterpret_cast<const float4*>(&s.bvh[index]);
-            float tmin;
-            if (!ray_box(nb[0], nb[1], ray, tmin)) continue;     // :143-146
-            if (STATS) n_box++;
-            const uint32_t* nd = reinterpret_cast<const uint32_t*>(&s.internal_nodes[index]);
-            const uint2 lc = *reinterpret_cast<const uint2*>(nd + 0);
-            const uint2 rc = *reinterpret_cast<const uint2*>(nd + 2);
-#pragma unroll
-            for (int side = 0; side < 2; side++) {
-                const uint2 c = side == 0 ? lc : rc;      // left then right  :148-175
-                if (c.y == LBVH_INTERNAL_NODE) {
-                    if (sp < (uint32_t)kStackDepth) s_stack[sp][lane] = c.x;
-                    sp++;
-                } else {
-                    const uint32_t tri = s.sorted_indices[s.leaf_nodes[c.x].index];   // :158
-                    if (STATS) n_leaf++;
-                    const float4* tb = reinterpret_cast<const float4*>(&s.triangle_aabb[tri]);
-                    float tmin2;
-                    if (ray_box(tb[0], tb[1], ray, tmin2)) {                          // :91
-                        if (STATS) n_tri++;
-                        const float4* tv = reinterpret_cast<const float4*>(&s.triangles[tri]);
-                        float u = 0.0f, v = 0.0f;
-                        const float dist = ray_triangle(ray, tv[0], tv[1], tv[2], u, v);
-                        if (dist < best_t) {                                          // :95
-                            best_t = dist; best_tri = tri; best_u = u; best_v = v;
-                        }
-                    }
-                }
-            }
-            if (sp > (uint32_t)kStackDepth) sp = kStackDepth;   // unreachable for unique keys
-        }
-        float4 out;
-        out.x = best_t;
-        out.y = __uint_as_float(best_tri);
-        out.z = best_u;
-        out.w = best_v;
+        const float4 out = reference_ray<STATS>(s, ray, s_stack, lane, n_pops, n_box, n_leaf, n_tri);
         reinterpret_cast<float4*>(hits)[hit_slot(a, blockIdx.x, lane, px, py)] = out;
-        if (STATS && best_t < LBVH_MAX_FLOAT) n_hit = 1;
+        if (STATS && out.x < LBVH_MAX_FLOAT) n_hit = 1;
     }
     if (STATS) add_stats(stats, n_pops, n_box, n_leaf, n_tri, n_hit);
 }
@@ -218,23 +222,21 @@ constexpr uint32_t kTiePosition = 0x80000000u;       // a record's triangle word
 
 // pass 1: every listed candidate whose t is the record's t tries to take the record (a compare-and-swap on the record's
 // triangle word, which holds the leaf position of the candidate in the lead)
-__global__ __launch_bounds__(256) void resolve_ties_lead_kernel(trace_args a, lbvh_scene s, lbvh_hit* __restrict__ hits, uint32_t* __restrict__ fault)
+__global__ __launch_bounds__(256) void resolve_ties_lead_kernel(trace_args a, lbvh_scene s, lbvh_hit* __restrict__ hits)
 {
     const uint32_t count = a.ties[0];
-    if (count > a.tie_capacity) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(fault, LBVH_FAULT_TIE_LIST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
+    if (count > a.tie_capacity) return;                      // the list ran over: retrace_marked_kernel takes every ray that saw a tie
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
         const uint32_t slot = a.ties[4 + 4 * i], pos = a.ties[6 + 4 * i], tbits = a.ties[7 + 4 * i];
         uint32_t* rec = reinterpret_cast<uint32_t*>(&hits[slot]);
         if (rec[0] != tbits) continue;                       // a tie at a t that was beaten later
         const tie_key mine = reference_visit_key(s, pos);
-        uint32_t lead = __hip_atomic_load(&rec[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (system scope: the frame may be another GPU's memory — one frame from N GPUs)
+        uint32_t lead = __hip_atomic_load(&rec[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         while (lead != (pos | kTiePosition)) {
             const tie_key theirs = reference_visit_key(s, lead & ~kTiePosition);
             if (!key_less(mine, theirs)) break;
-            if (__hip_atomic_compare_exchange_strong(&rec[1], &lead, pos | kTiePosition, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            if (__hip_atomic_compare_exchange_strong(&rec[1], &lead, pos | kTiePosition, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
                 break;
         }
     }
@@ -243,7 +245,8 @@ __global__ __launch_bounds__(256) void resolve_ties_lead_kernel(trace_args a, lb
 // pass 2 (a launch later: every lead is final): the candidate in the lead writes the record as the reference computes it
 __global__ __launch_bounds__(256) void resolve_ties_write_kernel(trace_args a, lbvh_scene s, lbvh_hit* __restrict__ hits)
 {
-    const uint32_t count = min(a.ties[0], a.tie_capacity);
+    const uint32_t count = a.ties[0];
+    if (count > a.tie_capacity) return;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
         const uint32_t slot = a.ties[4 + 4 * i], xy = a.ties[5 + 4 * i], pos = a.ties[6 + 4 * i], tbits = a.ties[7 + 4 * i];
         uint32_t* rec = reinterpret_cast<uint32_t*>(&hits[slot]);
@@ -254,6 +257,25 @@ __global__ __launch_bounds__(256) void resolve_ties_write_kernel(trace_args a, l
         float u = 0.0f, v = 0.0f;
         const float dist = ray_triangle(ray, tv[0], tv[1], tv[2], u, v);
         reinterpret_cast<float4*>(hits)[slot] = make_float4(dist, __uint_as_float(tri), u, v);
+    }
+}
+
+// The list holds one candidate per ray of the launch.  A scene that ties more often than that (many coincident triangles on
+// most pixels) runs it over; then nothing of it is used: every ray that saw a tie — its record's triangle word still carries
+// kTiePosition — goes through the reference's own loop (slow, and only then: otherwise the kernel's 256 waves leave at once).
+__global__ __launch_bounds__(64) void retrace_marked_kernel(trace_args a, lbvh_scene s, uint32_t n_work, lbvh_hit* __restrict__ hits)
+{
+    __shared__ uint32_t s_stack[kStackDepth][LBVH_WAVE];
+    if (a.ties[0] <= a.tie_capacity) return;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const uint32_t tile = shard_tile(w, a.shard_index, a.shard_count);
+        uint32_t px, py;
+        if (!(tile < a.tiles_x * a.tiles_y && tile_pixel(a, tile, lane, px, py))) continue;
+        const size_t slot = hit_slot(a, w, lane, px, py);
+        if ((reinterpret_cast<const uint32_t*>(&hits[slot])[1] & kTiePosition) == 0u) continue;
+        uint32_t unused = 0;
+        reinterpret_cast<float4*>(hits)[slot] = reference_ray<false>(s, make_ray(a.cam, px, py), s_stack, lane, unused, unused, unused, unused);
     }
 }
 
@@ -1822,9 +1844,9 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
         const bool exact = mode == LBVH_TRACE_FAST_EXACT;
         if (exact) {
             // the list of tied candidates: one entry per ray of the launch (a scene of doubled triangles lists about one per hit
-            // ray; more — three coincident triangles everywhere — is reported as LBVH_FAULT_TIE_LIST), cleared here
+            // ray; when more coincide on most pixels the list runs over and retrace_marked_kernel takes those rays), cleared here
             LBVH_REQUIRE(ctx, !d_stats && !d_tile_cost);
-            LBVH_REQUIRE(ctx, s.sorted_indices && s.internal_nodes && s.leaf_nodes && s.triangles);
+            LBVH_REQUIRE(ctx, s.sorted_indices && s.triangle_aabb && s.internal_nodes && s.leaf_nodes && s.bvh && s.triangles);
             LBVH_REQUIRE(ctx, x0 >= 0 && y0 >= 0 && x1 <= 65535 && y1 <= 65535);      // a listed ray's pixel is px | py << 16
             const uint64_t rays = (uint64_t)n_tiles * 64u;
             LBVH_REQUIRE(ctx, rays <= 0x3FFFFFFFull);
@@ -1844,8 +1866,9 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
         if (exact) {
             // two small launches: the lead among a record's candidates (compare-and-swap by the reference's visit order), then
             // the record as the reference computes it.  Without ties both find an empty list.
-            LBVH_LAUNCH(ctx, resolve_ties_lead_kernel, dim3(64), dim3(256), a, s, d_hits, ctx->fault_dev);
+            LBVH_LAUNCH(ctx, resolve_ties_lead_kernel, dim3(64), dim3(256), a, s, d_hits);
             LBVH_LAUNCH(ctx, resolve_ties_write_kernel, dim3(64), dim3(256), a, s, d_hits);
+            LBVH_LAUNCH(ctx, retrace_marked_kernel, dim3(256), dim3(64), a, s, n_tiles, d_hits);      // (a list that ran over)
         }
     }
     LBVH_HIP_TRY(ctx, hipGetLastError());
