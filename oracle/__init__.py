@@ -141,9 +141,12 @@ def path_resolve(states):
 
 
 def path_trace(built, camera, bounces=4, t_min=1e-3, albedo=0.7, seed=1, threads=1):
-    """The DynamicPathTracer.render pipeline on the host (primary rays = reference traversal)."""
+    """The DynamicPathTracer.render pipeline on the host.  Every segment — the primary rays too — takes the closest hit with
+    exact ties going to the lowest triangle index (orc_trace_rays: the order-independent rule of LBVH_TRACE_FAST and of the GPU's
+    per-ray walkers), so the whole path state is comparable bit for bit; the primary rays accept any t (no t_min: Raytracing.compute
+    has no t > 0 test)."""
     st = path_begin(camera)
-    hits, _ = trace_primary(built, camera, threads=threads)
+    hits = trace_rays(built, st, -3.0e38, threads=threads)
     path_scatter(built, hits.reshape(-1), st, 0, seed, albedo)
     for b in range(1, bounces + 1):
         h = trace_rays(built, st, t_min, threads=threads)

@@ -907,7 +907,11 @@ void orc_path_begin(const lbvh_camera* cam, lbvh_path_state* states)
         }
 }
 
-/* closest hit of arbitrary rays, reference visit order over the reference arrays, accept rule + t > t_min */
+/* closest hit of arbitrary rays over the reference arrays (test infrastructure for the cfg5 extension, which has no reference
+ * counterpart: include/lbvh.h lbvh_trace_rays).  Accept rule: t > t_min, strictly nearer — and among triangles hit at EXACTLY the
+ * same t the lowest triangle index, whatever order the walk meets them in (the rule of LBVH_TRACE_FAST, which the GPU's per-ray
+ * walkers share: a result that does not depend on the visit order).  The reference's own first-met rule lives in
+ * orc_trace_primary. */
 int orc_trace_rays(const lbvh_path_state* states, size_t count, float t_min, const lbvh_scene* s, lbvh_hit* hits,
                    int threads)
 {
@@ -946,7 +950,9 @@ int orc_trace_rays(const lbvh_path_state* states, size_t count, float t_min, con
                     const lbvh_triangle* t = &s->triangles[tri];
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_triangle(ray.origin, ray.dir, t->a, t->b, t->c, &u, &v);
-                    if (dist > t_min && dist < result->t) { result->t = dist; result->tri = tri; result->u = u; result->v = v; }
+                    if (dist > t_min && (dist < result->t || (dist == result->t && tri < result->tri))) {
+                        result->t = dist; result->tri = tri; result->u = u; result->v = v;
+                    }
                 }
             }
         }

@@ -1347,10 +1347,12 @@ def test_secondary_rays_and_path_trace_bit_exact(ctx):
     img = pt.image()
     oimg, ost = O.path_trace(b, cam, bounces=4, t_min=1e-3, albedo=0.7, seed=5, threads=8)
     gst = pt.states.get_data()[: 160 * 96]
-    # exact ties between two triangles may pick different winners; everything else is bit-identical
-    same = (gst["origin"] == ost["origin"]).all(axis=1) & (gst["dir"] == ost["dir"]).all(axis=1)
-    assert same.mean() > 0.995
-    assert (img.view(np.uint16).reshape(-1, 4)[same] == oimg.view(np.uint16).reshape(-1, 4)[same]).all()
+    # every path state and every pixel, bit for bit: the oracle's segments resolve exact t ties like the GPU's walkers do (lowest
+    # triangle index: an order-independent rule), so nothing is left to "except ties"
+    for field in ("origin", "dir", "throughput", "radiance"):
+        assert (gst[field].view(np.uint32) == ost[field].view(np.uint32)).all(), field
+    assert (gst["alpha"] == ost["alpha"]).all() and (gst["alive"] == ost["alive"]).all()
+    assert (img.view(np.uint16) == oimg.view(np.uint16)).all()
     # one bounce in isolation: identical hit distances for identical rays
     st = O.path_begin(cam)
     ph, _ = O.trace_primary(b, cam, threads=8)
@@ -1363,8 +1365,7 @@ def test_secondary_rays_and_path_trace_bit_exact(ctx):
     N().check(ctx.handle, N().lib.lbvh_trace_rays(ctx.handle, sb.device, len(st), 1e-3, C.byref(s), hb.device))
     gh = hb.get_data()
     oh = O.trace_rays(b, st, 1e-3, threads=8)
-    assert (gh["t"] == oh["t"]).all()
-    assert ((gh["tri"] == oh["tri"]) | (gh["t"] == oh["t"])).all()
+    assert (words(gh) == words(oh)).all()               # t, triangle (ties: the lowest index on both sides), u, v
     pt.drawer.on_destroy()
 
 
@@ -1428,22 +1429,19 @@ def test_cfg5_full_size_frame_against_the_oracle(ctx):
     sampled = np.zeros((Ht, W), dtype=bool)
     sampled[2::4, 1::4] = True
     st["alive"][~sampled] = 0
-    ph, _ = O.trace_primary(b, cam, rect=(1, 2, W, Ht), step=(4, 4), threads=8)
-    hits = np.zeros((Ht, W), dtype=L.HIT)
-    hits["t"] = L.MAX_FLOAT
-    hits[2::4, 1::4] = ph
     flat = st.reshape(-1)
-    O.path_scatter(b, hits.reshape(-1), flat, 0, 9, 0.7)
+    hits = O.trace_rays(b, flat, -3.0e38, threads=8)               # the primary segment: any t, ties to the lowest index (as LBVH_TRACE_FAST)
+    O.path_scatter(b, hits, flat, 0, 9, 0.7)
     for k in range(1, 5):
         h = O.trace_rays(b, flat, 1e-3, threads=8)
         O.path_scatter(b, h, flat, k, 9, 0.7)
     oimg = O.path_resolve(flat).reshape(Ht, W, 4)
     g, o = gst[sampled], st[sampled]
     same = (g["origin"] == o["origin"]).all(axis=1) & (g["dir"] == o["dir"]).all(axis=1)
-    assert len(g) == 270 * 480 and same.mean() > 0.995, same.mean()
+    assert len(g) == 270 * 480 and same.all(), same.mean()
     for field in ("throughput", "radiance"):
-        assert (g[field][same].view(np.uint32) == o[field][same].view(np.uint32)).all(), field
-    assert (g["alpha"][same] == o["alpha"][same]).all() and (g["alive"][same] == o["alive"][same]).all()
+        assert (g[field].view(np.uint32) == o[field].view(np.uint32)).all(), field
+    assert (g["alpha"] == o["alpha"]).all() and (g["alive"] == o["alive"]).all()
     assert (img[sampled].view(np.uint16)[same] == oimg[sampled].view(np.uint16)[same]).all()
     assert 0.3 < float((img[..., 3] > 0).mean()) < 0.6             # the primary hit fraction of cfg2's camera
     pt.drawer.on_destroy()
@@ -1606,9 +1604,8 @@ def test_path_trace_tiny_frames(ctx, res):
         img = pt.image()
         oimg, ost = O.path_trace(b, cam, bounces=3, t_min=1e-3, albedo=0.7, seed=9, threads=4)
         gst = pt.states.get_data()[: res[0] * res[1]]
-        same = (gst["origin"] == ost["origin"]).all(axis=1) & (gst["dir"] == ost["dir"]).all(axis=1)
-        assert same.mean() > 0.98 or same.size < 64
-        assert (img.view(np.uint16).reshape(-1, 4)[same] == oimg.view(np.uint16).reshape(-1, 4)[same]).all()
+        assert (gst["origin"] == ost["origin"]).all() and (gst["dir"] == ost["dir"]).all()
+        assert (img.view(np.uint16) == oimg.view(np.uint16)).all()
     pt.drawer.on_destroy()
 
 
