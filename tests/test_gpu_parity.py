@@ -644,6 +644,8 @@ def test_trace_fast_from_inside_the_scene(ctx, pos, yaw, pitch):
         assert (fh["t"] == oh["t"]).all()
         same = fh["tri"] == oh["tri"]
         assert same.mean() > 0.999 and (fh["u"][same] == oh["u"][same]).all() and (fh["v"][same] == oh["v"][same]).all()
+        d.update(cam, mode=L.TRACE_FAST_EXACT)                     # ... and with the reference's choice on ties: every word
+        assert (words(d.hits()) == words(oh)).all()
     d.on_destroy()
 
 
@@ -751,6 +753,8 @@ def test_repeated_frames_cost_ordered_and_cooperative_tiles(ctx):
             same = got["tri"] == ref["tri"]
             assert same.mean() > 0.9999                              # exact ties may pick the other triangle
             assert (got["u"][same] == ref["u"][same]).all() and (got["v"][same] == ref["v"][same]).all()
+        d.update(cam, mode=L.TRACE_FAST_EXACT)                       # the exact mode: every word of the reference mode's frame
+        assert (words(d.hits()) == words(ref)).all()
         assert int(d.stats()["hits"]) == int((ref["t"] < L.MAX_FLOAT).sum())
         # the profiling entry point reports per-tile steps in both regimes
         s = d.container.scene()
