@@ -32,7 +32,7 @@ public class RaytracingMeshDrawer : MonoBehaviour
     [SerializeField] private Texture _meshTexture;                  // must be a readable Texture2D
     [SerializeField] private int[] _gpuDevices;                     // HIP devices to shard the rays over; empty: device 0
     // true: LBVH_TRACE_FAST_EXACT — every hit record is the reference kernel's, also where two triangles are hit at exactly the
-    // same t (a handful of pixels per frame; + 40 % traversal time).  false: LBVH_TRACE_FAST (same t; lowest triangle index there)
+    // same t (a handful of pixels per frame; + 20 % traversal time).  false: LBVH_TRACE_FAST (same t; lowest triangle index there)
     [SerializeField] private bool _exactTies = true;
 
     private Camera _camera;

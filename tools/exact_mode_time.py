@@ -1,5 +1,5 @@
 import ctypes as C, os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unitysimpleraytracing_amd import _native as N, layouts as L, scenes
 from unitysimpleraytracing_amd.host import Context, DataBuffer, RaytracingMeshDrawer
 W, H = 1920, 1080

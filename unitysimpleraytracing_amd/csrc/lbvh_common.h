@@ -141,6 +141,8 @@ struct lbvh_context {
     // LBVH_TRACE_FAST_EXACT: rays listed for the reference's walk (lbvh_trace.hip retrace_ties_kernel)
     void* tie_list = nullptr;
     size_t tie_list_bytes = 0;
+    void* tie_list_cleared = nullptr;         // the block whose two counters are in rotation
+    uint32_t tie_turn = 0;
     lbvh_ray_stats* ray_stats = nullptr;      // lbvh_ray_stats_target: the four-wide walkers add their counters here while set
     uint32_t ray_walker = 1;                  // lbvh_debug_ray_walker: 0 binary nodes, 1 four-wide, 2 four-wide with the few-rays kernel always
 

@@ -40,8 +40,9 @@ struct trace_args {
     // LBVH_TRACE_FAST_EXACT (nullptr otherwise): every triangle a ray meets at exactly its best t is listed here — [0] = count,
     // then entries {record slot, px | py << 16, leaf position, t} — and resolve_ties_* give the record to the one the
     // REFERENCE's visit order meets first
-    uint32_t* ties;
-    uint32_t tie_capacity;
+    uint32_t* ties;                      // (words 0 / 1: this frame's count / the next one's — they take turns, and a frame's last
+    uint32_t tie_capacity;               // resolve kernel clears the other one: no fill in front of the trace)
+    uint32_t tie_turn;
     const uint32_t* sorted_indices;      // leaf position -> triangle
 };
 
@@ -199,23 +200,42 @@ __global__ __launch_bounds__(64) void trace_reference_kernel(trace_args a, lbvh_
 struct tie_key { unsigned long long hi, lo; };
 __device__ __forceinline__ bool key_less(const tie_key& a, const tie_key& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
 
-__device__ __forceinline__ tie_key reference_visit_key(const lbvh_scene& s, uint32_t leaf_position)
+// (two leaves at once: a climb is a chain of dependent loads — ONE per level: a node's record holds its parent's index — and
+// two chains in flight cost what one does)
+__device__ __forceinline__ void reference_visit_keys(const lbvh_scene& s, uint32_t leaf_a, uint32_t leaf_b, tie_key& ka, tie_key& kb)
 {
-    tie_key k = {0ull, 0ull};
-    auto shift_in = [&](unsigned long long digit) { k.lo = (k.lo >> 2) | (k.hi << 62); k.hi = (k.hi >> 2) | (digit << 62); };
-    const uint32_t* leaf = reinterpret_cast<const uint32_t*>(&s.leaf_nodes[leaf_position]);       // {parent, index}
-    uint32_t node = leaf[0];
-    {
-        const uint32_t* nd = reinterpret_cast<const uint32_t*>(&s.internal_nodes[node]);            // {left, ltype, right, rtype, parent, index}
-        shift_in((nd[0] == leaf_position && nd[1] == LBVH_LEAF_NODE) ? 0ull : 1ull);
+    tie_key k[2] = {{0ull, 0ull}, {0ull, 0ull}};
+    auto shift_in = [&](int i, unsigned long long digit) { k[i].lo = (k[i].lo >> 2) | (k[i].hi << 62); k[i].hi = (k[i].hi >> 2) | (digit << 62); };
+    struct rec3 { uint32_t left, ltype, parent; };
+    auto load = [&](uint32_t node) {             // {left, ltype, right, rtype, parent, index}: the words a climb needs
+        const uint32_t* nd = reinterpret_cast<const uint32_t*>(&s.internal_nodes[node]);
+        const uint2 lt = *reinterpret_cast<const uint2*>(nd);
+        return rec3{lt.x, lt.y, nd[4]};
+    };
+    const uint32_t leaf[2] = {leaf_a, leaf_b};
+    uint32_t node[2];
+    rec3 rec[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) node[i] = reinterpret_cast<const uint32_t*>(&s.leaf_nodes[leaf[i]])[0];           // {parent, index}
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        rec[i] = load(node[i]);
+        shift_in(i, (rec[i].left == leaf[i] && rec[i].ltype == LBVH_LEAF_NODE) ? 0ull : 1ull);
     }
-    for (int guard = 0; guard < 64 && node != 0u; guard++) {
-        const uint32_t parent = reinterpret_cast<const uint32_t*>(&s.internal_nodes[node])[4];
-        const uint32_t* nd = reinterpret_cast<const uint32_t*>(&s.internal_nodes[parent]);
-        shift_in((nd[0] == node && nd[1] == LBVH_INTERNAL_NODE) ? 3ull : 2ull);
-        node = parent;
+    for (int guard = 0; guard < 64 && (node[0] != 0u || node[1] != 0u); guard++) {
+        rec3 up[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) up[i] = load(node[i] != 0u ? rec[i].parent : 0u);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            if (node[i] == 0u) continue;
+            shift_in(i, (up[i].left == node[i] && up[i].ltype == LBVH_INTERNAL_NODE) ? 3ull : 2ull);
+            node[i] = rec[i].parent;
+            rec[i] = up[i];
+        }
     }
-    return k;
+    ka = k[0];
+    kb = k[1];
 }
 
 constexpr uint32_t kTiePosition = 0x80000000u;       // a record's triangle word still holds a leaf position (resolve pending)
@@ -224,17 +244,17 @@ constexpr uint32_t kTiePosition = 0x80000000u;       // a record's triangle word
 // triangle word, which holds the leaf position of the candidate in the lead)
 __global__ __launch_bounds__(256) void resolve_ties_lead_kernel(trace_args a, lbvh_scene s, lbvh_hit* __restrict__ hits)
 {
-    const uint32_t count = a.ties[0];
-    if (count > a.tie_capacity) return;                      // the list ran over: retrace_marked_kernel takes every ray that saw a tie
+    const uint32_t count = a.ties[a.tie_turn];
+    if (count > a.tie_capacity) return;                      // the list ran over: the second kernel takes every ray that saw a tie
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
         const uint32_t slot = a.ties[4 + 4 * i], pos = a.ties[6 + 4 * i], tbits = a.ties[7 + 4 * i];
         uint32_t* rec = reinterpret_cast<uint32_t*>(&hits[slot]);
         if (rec[0] != tbits) continue;                       // a tie at a t that was beaten later
-        const tie_key mine = reference_visit_key(s, pos);
         // (system scope: the frame may be another GPU's memory — one frame from N GPUs)
         uint32_t lead = __hip_atomic_load(&rec[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         while (lead != (pos | kTiePosition)) {
-            const tie_key theirs = reference_visit_key(s, lead & ~kTiePosition);
+            tie_key mine, theirs;
+            reference_visit_keys(s, pos, lead & ~kTiePosition, mine, theirs);
             if (!key_less(mine, theirs)) break;
             if (__hip_atomic_compare_exchange_strong(&rec[1], &lead, pos | kTiePosition, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
                 break;
@@ -242,32 +262,31 @@ __global__ __launch_bounds__(256) void resolve_ties_lead_kernel(trace_args a, lb
     }
 }
 
-// pass 2 (a launch later: every lead is final): the candidate in the lead writes the record as the reference computes it
-__global__ __launch_bounds__(256) void resolve_ties_write_kernel(trace_args a, lbvh_scene s, lbvh_hit* __restrict__ hits)
-{
-    const uint32_t count = a.ties[0];
-    if (count > a.tie_capacity) return;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
-        const uint32_t slot = a.ties[4 + 4 * i], xy = a.ties[5 + 4 * i], pos = a.ties[6 + 4 * i], tbits = a.ties[7 + 4 * i];
-        uint32_t* rec = reinterpret_cast<uint32_t*>(&hits[slot]);
-        if (rec[0] != tbits || rec[1] != (pos | kTiePosition)) continue;
-        const uint32_t tri = s.sorted_indices[pos];
-        const ray_t ray = make_ray(a.cam, xy & 0xFFFFu, xy >> 16);
-        const float4* tv = reinterpret_cast<const float4*>(&s.triangles[tri]);
-        float u = 0.0f, v = 0.0f;
-        const float dist = ray_triangle(ray, tv[0], tv[1], tv[2], u, v);
-        reinterpret_cast<float4*>(hits)[slot] = make_float4(dist, __uint_as_float(tri), u, v);
-    }
-}
-
-// The list holds one candidate per ray of the launch.  A scene that ties more often than that (many coincident triangles on
-// most pixels) runs it over; then nothing of it is used: every ray that saw a tie — its record's triangle word still carries
-// kTiePosition — goes through the reference's own loop (slow, and only then: otherwise the kernel's 256 waves leave at once).
-__global__ __launch_bounds__(64) void retrace_marked_kernel(trace_args a, lbvh_scene s, uint32_t n_work, lbvh_hit* __restrict__ hits)
+// pass 2 (a launch later: every lead is final): the candidate in the lead writes the record as the reference computes it.
+// The list holds one candidate per ray of the launch; a scene that ties more often than that (three and more coincident
+// triangles on most pixels) runs it over, and then nothing of it is used: every ray that saw a tie — its record's triangle word
+// still carries kTiePosition — goes through the reference's own loop (slow, and only then).  Last of the frame's kernels: it
+// clears the NEXT frame's counter.
+__global__ __launch_bounds__(64) void resolve_ties_write_kernel(trace_args a, lbvh_scene s, uint32_t n_work, lbvh_hit* __restrict__ hits)
 {
     __shared__ uint32_t s_stack[kStackDepth][LBVH_WAVE];
-    if (a.ties[0] <= a.tie_capacity) return;
     const uint32_t lane = threadIdx.x;
+    const uint32_t count = a.ties[a.tie_turn];
+    if (blockIdx.x == 0 && lane == 0) a.ties[a.tie_turn ^ 1u] = 0u;
+    if (count <= a.tie_capacity) {
+        for (uint32_t i = blockIdx.x * LBVH_WAVE + lane; i < count; i += gridDim.x * LBVH_WAVE) {
+            const uint32_t slot = a.ties[4 + 4 * i], xy = a.ties[5 + 4 * i], pos = a.ties[6 + 4 * i], tbits = a.ties[7 + 4 * i];
+            uint32_t* rec = reinterpret_cast<uint32_t*>(&hits[slot]);
+            if (rec[0] != tbits || rec[1] != (pos | kTiePosition)) continue;
+            const uint32_t tri = s.sorted_indices[pos];
+            const ray_t ray = make_ray(a.cam, xy & 0xFFFFu, xy >> 16);
+            const float4* tv = reinterpret_cast<const float4*>(&s.triangles[tri]);
+            float u = 0.0f, v = 0.0f;
+            const float dist = ray_triangle(ray, tv[0], tv[1], tv[2], u, v);
+            reinterpret_cast<float4*>(hits)[slot] = make_float4(dist, __uint_as_float(tri), u, v);
+        }
+        return;
+    }
     for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
         const uint32_t tile = shard_tile(w, a.shard_index, a.shard_count);
         uint32_t px, py;
@@ -285,7 +304,7 @@ __device__ __forceinline__ void list_tie(const trace_args& a, uint64_t mask, uin
     const uint32_t lane = lane_id();
     const int first = __builtin_ctzll(mask);
     uint32_t base = 0;
-    if ((int)lane == first) base = atomicAdd(&a.ties[0], (uint32_t)__popcll(mask));
+    if ((int)lane == first) base = atomicAdd(&a.ties[a.tie_turn], (uint32_t)__popcll(mask));
     base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
     const uint32_t i = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     if (i < a.tie_capacity) {
@@ -723,9 +742,10 @@ __device__ __forceinline__ bool lean_triangle(const ray_t& r, const lean_tri& T,
     return !(det < 1e-8f && det > -1e-8f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f);
 }
 
-template <bool BUF>
-__device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, packet_rays<1>& P, uint32_t neg)
+template <bool BUF, bool EXACT = false>
+__device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, packet_rays<1>& P, uint32_t neg, tie_sink* sink = nullptr)
 {
+    uint64_t tied = 0;        // EXACT: lanes that met a second triangle at exactly their best t (see walk_packet)
     const uint32_t lane = lane_id();
     const ray_t r = P.ray[0];
     int stack = 0;            // wave-shared stack: slot k lives in lane k of this VGPR
@@ -757,9 +777,18 @@ __device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, pac
         // leaves first: their hits tighten best_t before anything is entered
         if (leaf_l) {
             if (ml != 0) {
-                const lean_tri T = uniform_tri(w_l, o_lane);
+                lean_tri T = uniform_tri(w_l, o_lane);
+                if (EXACT) T.index = (uint32_t)__builtin_amdgcn_readlane(w_node, 11);      // the left leaf's position
                 float t, u, v;            // every lane computes; the lanes that hit the leaf's box may keep the result
-                if (lean_triangle(r, T, t, u, v) && hit_l && closer(t, T.index, best_t, best_tri)) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
+                const bool cand = lean_triangle(r, T, t, u, v) && hit_l;
+                if (EXACT) {
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(cand) & __builtin_amdgcn_ballot_w64(t == best_t);
+                    if (m != 0) {         // (rare) the candidate that drops out of an exact tie is listed now
+                        tied |= m;
+                        if ((m >> lane) & 1ull) list_tie(*sink->a, m, sink->slot, sink->xy, max(T.index, best_tri), t);
+                    }
+                }
+                if (cand && closer(t, T.index, best_t, best_tri)) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
                 const bool still_r = !(tr > best_t);
                 hit_r = hit_r && still_r;
                 mr &= __builtin_amdgcn_ballot_w64(still_r);
@@ -768,9 +797,18 @@ __device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, pac
         }
         if (leaf_r) {
             if (mr != 0) {
-                const lean_tri T = uniform_tri(w_r, o_lane);
+                lean_tri T = uniform_tri(w_r, o_lane);
+                if (EXACT) T.index = (uint32_t)__builtin_amdgcn_readlane(w_node, 15);      // the right leaf's position
                 float t, u, v;
-                if (lean_triangle(r, T, t, u, v) && hit_r && closer(t, T.index, best_t, best_tri)) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
+                const bool cand = lean_triangle(r, T, t, u, v) && hit_r;
+                if (EXACT) {
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(cand) & __builtin_amdgcn_ballot_w64(t == best_t);
+                    if (m != 0) {
+                        tied |= m;
+                        if ((m >> lane) & 1ull) list_tie(*sink->a, m, sink->slot, sink->xy, max(T.index, best_tri), t);
+                    }
+                }
+                if (cand && closer(t, T.index, best_t, best_tri)) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
                 ml &= __builtin_amdgcn_ballot_w64(!(tl > best_t));
             }
             mr = 0;
@@ -793,6 +831,7 @@ __device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, pac
         }
     }
     P.best_t[0] = best_t; P.best_tri[0] = best_tri; P.best_u[0] = best_u; P.best_v[0] = best_v;
+    if (EXACT) sink->tied = tied;
     return steps;
 }
 
@@ -865,6 +904,7 @@ struct coop_shared {
     unsigned long long best[64];     // per ray: ordered t << 32 | line index of the triangle
     uint32_t give[32];               // subtrees on offer
     uint32_t give_n, lock, idle, steps;
+    unsigned long long ties;         // EXACT: rays that met two triangles at exactly the same t
 };
 
 __device__ __forceinline__ void coop_lock(coop_shared& S)
@@ -879,7 +919,10 @@ __device__ __forceinline__ void coop_unlock(coop_shared& S)
 }
 
 // one heavy tile (work item w) walked by the waves of this workgroup
-template <bool STATS, int WAVES>
+// EXACT (LBVH_TRACE_FAST_EXACT): the shared keys carry leaf POSITIONS (from the parent's line) instead of line indices, the
+// candidate that loses an exact tie in the atomic minimum is listed at once, and the tile's writer leaves the rays that saw a tie
+// to the resolve kernels (see walk_packet / light_tile)
+template <bool STATS, int WAVES, bool EXACT = false>
 __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, const lbvh_fast_node* __restrict__ nodes,
                                           const lbvh_fast_tri* __restrict__ tris, uint32_t n_work, uint32_t w,
                                           coop_params heavy_cap, uint32_t* __restrict__ cost, lbvh_hit* __restrict__ hits,
@@ -898,7 +941,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
     const bool ordered = packet_signs(P, neg);      // see walk_packet
     const uint32_t node_bytes = node_line_bytes(lane, ordered, neg);
     if (threadIdx.x < 64u) S.best[threadIdx.x] = (unsigned long long)ordered_key(LBVH_MAX_FLOAT) << 32;
-    if (threadIdx.x == 0) { S.give_n = 0; S.lock = 0; S.idle = n_waves - 1u; S.steps = 0; }
+    if (threadIdx.x == 0) { S.give_n = 0; S.lock = 0; S.idle = n_waves - 1u; S.steps = 0; S.ties = 0; }
     __syncthreads();
 
     volatile coop_shared& V = S;
@@ -908,6 +951,8 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
     uint32_t cur = 0;
     walk_counters C = {0, 0, 0, 0};
     uint32_t steps = 0;
+    bool tied = false;
+    const uint32_t my_slot = EXACT ? (uint32_t)hit_slot(a, w, lane, px0, py0) : 0u, my_xy = px0 | (py0 << 16);
     for (;;) {
         if (!have) {
             uint32_t got = kNone, all_idle = 0;
@@ -970,7 +1015,13 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                     const float dist = ray_fast_triangle(P.ray[0], v0, v1, v2, u, v);
                     if (dist <= best_t && dist != LBVH_MAX_FLOAT) {    // ties go to the atomic: (t, line index) orders them (see closer())
                         best_t = dist;
-                        atomicMin(&S.best[lane], ((unsigned long long)ordered_key(dist) << 32) | (lref & 0x7FFFFFFFu));
+                        const uint32_t id = EXACT ? (uint32_t)__builtin_amdgcn_readlane(w_node, 11) : (lref & 0x7FFFFFFFu);
+                        const unsigned long long key = ((unsigned long long)ordered_key(dist) << 32) | id;
+                        const unsigned long long was = atomicMin(&S.best[lane], key);
+                        if (EXACT && (uint32_t)(was >> 32) == (uint32_t)(key >> 32) && was != key) {
+                            tied = true;                           // the candidate that is not kept joins the list
+                            list_tie(a, __ballot(true), my_slot, my_xy, (uint32_t)max(was, key), dist);
+                        }
                     }
                 }
                 hit_r = hit_r && !(tr > best_t);
@@ -985,7 +1036,13 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                     const float dist = ray_fast_triangle(P.ray[0], v0, v1, v2, u, v);
                     if (dist <= best_t && dist != LBVH_MAX_FLOAT) {    // ties go to the atomic: (t, line index) orders them (see closer())
                         best_t = dist;
-                        atomicMin(&S.best[lane], ((unsigned long long)ordered_key(dist) << 32) | (rref & 0x7FFFFFFFu));
+                        const uint32_t id = EXACT ? (uint32_t)__builtin_amdgcn_readlane(w_node, 15) : (rref & 0x7FFFFFFFu);
+                        const unsigned long long key = ((unsigned long long)ordered_key(dist) << 32) | id;
+                        const unsigned long long was = atomicMin(&S.best[lane], key);
+                        if (EXACT && (uint32_t)(was >> 32) == (uint32_t)(key >> 32) && was != key) {
+                            tied = true;
+                            list_tie(a, __ballot(true), my_slot, my_xy, (uint32_t)max(was, key), dist);
+                        }
                     }
                 }
                 hit_l = hit_l && !(tl > best_t);
@@ -1033,7 +1090,11 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
         have = false;
         if (lane == 0) atomicAdd(&S.idle, 1u);
     }
-    if (lane == 0) atomicAdd(&S.steps, steps);
+    const uint64_t tied_lanes = EXACT ? __ballot(tied) : 0ull;
+    if (lane == 0) {
+        atomicAdd(&S.steps, steps);
+        if (EXACT && tied_lanes) atomicOr(&S.ties, (unsigned long long)tied_lanes);
+    }
     __syncthreads();
     uint32_t n_hit = 0;
     if (wave == 0) {
@@ -1047,12 +1108,24 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
             float4 out = make_float4(LBVH_MAX_FLOAT, __uint_as_float(0u), 0.0f, 0.0f);
             if (t < LBVH_MAX_FLOAT) {
                 // barycentrics (and the original index) from the winning triangle: the same arithmetic as in the walk
+                const lbvh_fast_node* line = EXACT ? reinterpret_cast<const lbvh_fast_node*>(tris) + a.sorted_indices[(uint32_t)key]
+                                                   : &nodes[(uint32_t)key];                                // a triangle line
                 float4 v0, v1, v2;
-                unpack_fast_triangle(reinterpret_cast<const float4*>(&nodes[(uint32_t)key]), v0, v1, v2);   // a triangle line
+                unpack_fast_triangle(reinterpret_cast<const float4*>(line), v0, v1, v2);
                 float u = 0.0f, v = 0.0f;
                 const float dist = ray_fast_triangle(P.ray[0], v0, v1, v2, u, v);
                 out = make_float4(dist, v0.w, u, v);
                 if (STATS) n_hit++;
+            }
+            if (EXACT) {
+                // a ray that saw a tie: its candidate in the lead joins the list and stays in the record as a position
+                const uint64_t tm = S.ties;
+                const bool mine = P.act[0] && ((tm >> lane) & 1ull) && t < LBVH_MAX_FLOAT;
+                const uint64_t mm = __ballot(mine);
+                if (mine) {
+                    list_tie(a, mm, my_slot, my_xy, (uint32_t)key, t);
+                    out.y = __uint_as_float((uint32_t)key | kTiePosition);
+                }
             }
             reinterpret_cast<float4*>(hits)[hit_slot(a, w, lane, px0, py0)] = out;
         }
@@ -1085,10 +1158,12 @@ __device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_
     uint32_t steps;
     tie_sink sink = {&a, 0u, 0u, 0ull};
     if (EXACT) {
-        // the general walker with the tie bookkeeping (closer() on leaf positions: the loser of every exact tie is listed)
+        // the walkers with the tie bookkeeping (closer() on leaf positions: the loser of every exact tie is listed)
         sink.slot = (uint32_t)hit_slot(a, w, lane, px0, py0);
         sink.xy = px0 | (py0 << 16);
-        if (a.line_bytes != 0)
+        if (ordered && packet_one_origin(P))
+            steps = a.line_bytes != 0 ? walk_packet_lean<true, true>(src, P, neg, &sink) : walk_packet_lean<false, true>(src, P, neg, &sink);
+        else if (a.line_bytes != 0)
             steps = ordered ? walk_packet<false, 1, true, true, true>(src, P, C, neg, &sink) : walk_packet<false, 1, false, true, true>(src, P, C, 0u, &sink);
         else
             steps = ordered ? walk_packet<false, 1, true, false, true>(src, P, C, neg, &sink) : walk_packet<false, 1, false, false, true>(src, P, C, 0u, &sink);
@@ -1145,7 +1220,7 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
 //     (workgroups beyond the actual number of heavy tiles leave at once) — at the FRONT of the grid, so they start
 //     first (as a second kernel on another stream they were starved by the light tiles' workgroups);
 //   * the rest: one tile per wave, the w-th tile of the class lists after the heavy ones, heaviest class first.
-template <bool STATS, int WAVES>
+template <bool STATS, int WAVES, bool EXACT = false>
 __global__ __launch_bounds__(WAVES * 64) void trace_shared_kernel(trace_args a, const lbvh_fast_node* __restrict__ nodes,
                                                                        const lbvh_fast_tri* __restrict__ tris, uint32_t n_work,
                                                                        const uint32_t* __restrict__ counts,
@@ -1171,11 +1246,11 @@ __global__ __launch_bounds__(WAVES * 64) void trace_shared_kernel(trace_args a, 
         w = lists[(size_t)c * n_work + k];
     }
     if (blockIdx.x < heavy_cap.cap) {
-        coop_tile<STATS, WAVES>(S, a, nodes, tris, n_work, w, heavy_cap, cost, hits, stats, tile_cost);
+        coop_tile<STATS, WAVES, EXACT>(S, a, nodes, tris, n_work, w, heavy_cap, cost, hits, stats, tile_cost);
         return;
     }
     if (w >= n_work) return;
-    light_tile<STATS>(a, nodes, tris, w, lane, cost, hits, stats, tile_cost);
+    light_tile<STATS, EXACT>(a, nodes, tris, w, lane, cost, hits, stats, tile_cost);
 }
 
 // Files every work item of the last trace under one of 16 cost classes (half-octave scale): lists[c][...] with
@@ -1451,16 +1526,14 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     // (a moved camera: the plain kernel — the widened costs would make every neighbour of a heavy tile cooperative, 0.27 - 0.29 ms;
     // marking by the un-widened reprojected cost finds too few of them: 0.20 - 0.22 against 0.21 plain)
     const bool whole = n_work > kSharedMaxWork && spread == 0;
-    if (a.ties != nullptr) {
-        // LBVH_TRACE_FAST_EXACT: one tile per wave with the tie bookkeeping, in the history's order when there is one
-        const uint32_t blocks = (n_work + 3) / 4;
-        LBVH_LAUNCH(ctx, (trace_packet_kernel<false, true>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris, n_work,
-                    have_history ? counts : nullptr, lists, cost, d_hits, d_stats, d_tile_cost);
-    } else
+    const bool exact = a.ties != nullptr;          // LBVH_TRACE_FAST_EXACT: the same three launch shapes, kernels with the tie bookkeeping
     if (have_history && whole) {
         coop_params hp = {n_work / 4u, kHeavyClassWhole, kCoopGrain};
         const uint32_t blocks = hp.cap + (n_work + kCoopWavesWhole - 1) / kCoopWavesWhole;
-        if (d_stats)
+        if (exact)
+            LBVH_LAUNCH(ctx, (trace_shared_kernel<false, kCoopWavesWhole, true>), dim3(blocks), dim3(kCoopWavesWhole * 64), a, ctx->fast_nodes,
+                        ctx->fast_tris, n_work, counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
+        else if (d_stats)
             LBVH_LAUNCH(ctx, (trace_shared_kernel<true, kCoopWavesWhole>), dim3(blocks), dim3(kCoopWavesWhole * 64), a, ctx->fast_nodes, ctx->fast_tris,
                         n_work, counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
         else
@@ -1469,7 +1542,10 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     } else if (have_history && n_work <= kSharedMaxWork && !stale_coop) {
         coop_params hp = {n_work / 4u, first_class, kCoopGrain};
         const uint32_t blocks = hp.cap + (n_work + kCoopWaves - 1) / kCoopWaves;
-        if (d_stats)
+        if (exact)
+            LBVH_LAUNCH(ctx, (trace_shared_kernel<false, kCoopWaves, true>), dim3(blocks), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris,
+                        n_work, counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
+        else if (d_stats)
             LBVH_LAUNCH(ctx, (trace_shared_kernel<true, kCoopWaves>), dim3(blocks), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris, n_work,
                         counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
         else
@@ -1477,7 +1553,10 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
                         counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
     } else {
         const uint32_t blocks = (n_work + 3) / 4;
-        if (d_stats)
+        if (exact)
+            LBVH_LAUNCH(ctx, (trace_packet_kernel<false, true>), dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris, n_work,
+                        have_history ? counts : nullptr, lists, cost, d_hits, d_stats, d_tile_cost);
+        else if (d_stats)
             LBVH_LAUNCH(ctx, trace_packet_kernel<true>, dim3(blocks), dim3(256), a, ctx->fast_nodes, ctx->fast_tris, n_work,
                         have_history ? counts : nullptr, lists, cost, d_hits, d_stats, d_tile_cost);
         else
@@ -1844,17 +1923,24 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
         const bool exact = mode == LBVH_TRACE_FAST_EXACT;
         if (exact) {
             // the list of tied candidates: one entry per ray of the launch (a scene of doubled triangles lists about one per hit
-            // ray; when more coincide on most pixels the list runs over and retrace_marked_kernel takes those rays), cleared here
+            // ray; when more coincide on most pixels the list runs over and the second resolve kernel takes those rays through the reference's loop)
             LBVH_REQUIRE(ctx, !d_stats && !d_tile_cost);
             LBVH_REQUIRE(ctx, s.sorted_indices && s.triangle_aabb && s.internal_nodes && s.leaf_nodes && s.bvh && s.triangles);
             LBVH_REQUIRE(ctx, x0 >= 0 && y0 >= 0 && x1 <= 65535 && y1 <= 65535);      // a listed ray's pixel is px | py << 16
             const uint64_t rays = (uint64_t)n_tiles * 64u;
             LBVH_REQUIRE(ctx, rays <= 0x3FFFFFFFull);
+            const size_t had = ctx->tie_list_bytes;
             const int trc = lbvh_reserve(ctx, &ctx->tie_list, &ctx->tie_list_bytes, 16 + (size_t)rays * 16);
             if (trc != LBVH_OK) return trc;
+            if (ctx->tie_list_bytes != had) ctx->tie_list_cleared = nullptr;      // a new block (possibly at the old address)
+            if (ctx->tie_list != ctx->tie_list_cleared) {          // a fresh block (or a frame that did not reach its last kernel):
+                LBVH_HIP_TRY(ctx, hipMemsetAsync(ctx->tie_list, 0, 16, ctx->cur_stream));      // both counters start at zero
+                ctx->tie_turn = 0;
+            }
+            ctx->tie_list_cleared = nullptr;                       // valid again once this frame's last kernel is enqueued
             a.ties = (uint32_t*)ctx->tie_list;
             a.tie_capacity = (uint32_t)rays;
-            LBVH_HIP_TRY(ctx, hipMemsetAsync(a.ties, 0, 4, ctx->cur_stream));
+            a.tie_turn = ctx->tie_turn;
         }
         // 1 ray per lane = 8 x 8-pixel packets: 0.27 ms; 1x2: 0.43, 2x1: 0.45, 3x1: 0.68, 4x1: 0.82, 2x2: 0.92 ms
         // (more rays per lane cut node fetches per ray but lengthen every step and the per-tile critical path;
@@ -1865,10 +1951,13 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
         if (prc != LBVH_OK) return prc;
         if (exact) {
             // two small launches: the lead among a record's candidates (compare-and-swap by the reference's visit order), then
-            // the record as the reference computes it.  Without ties both find an empty list.
+            // the record as the reference computes it (or, after a list that ran over, the marked rays through the
+            // reference's loop).  Without ties both find an empty list.
             LBVH_LAUNCH(ctx, resolve_ties_lead_kernel, dim3(64), dim3(256), a, s, d_hits);
-            LBVH_LAUNCH(ctx, resolve_ties_write_kernel, dim3(64), dim3(256), a, s, d_hits);
-            LBVH_LAUNCH(ctx, retrace_marked_kernel, dim3(256), dim3(64), a, s, n_tiles, d_hits);      // (a list that ran over)
+            LBVH_LAUNCH(ctx, resolve_ties_write_kernel, dim3(256), dim3(64), a, s, n_tiles, d_hits);
+            LBVH_HIP_TRY(ctx, hipGetLastError());
+            ctx->tie_turn ^= 1u;
+            ctx->tie_list_cleared = ctx->tie_list;
         }
     }
     LBVH_HIP_TRY(ctx, hipGetLastError());
