@@ -120,7 +120,10 @@ typedef struct lbvh_camera {
 #define LBVH_TRACE_FAST_EXACT 2 /* LBVH_TRACE_FAST, and every record equals LBVH_TRACE_REFERENCE's word for word: a ray
                                  * that meets two triangles at EXACTLY the same t (the one case in which the fast walk's
                                  * order-independent choice — lowest triangle index — can differ from the triangle the
-                                 * reference's visit order meets first) is traced again by the reference's own loop */
+                                 * reference's visit order meets first) is given to the triangle that order meets first:
+                                 * the order is read off the scene's internalNodes / leafNodes (parent words, child
+                                 * types; leaf j's `index` is j, as TreeConstructor writes it, BVH.compute:116-120).
+                                 * No d_stats with this mode. */
 
 /* Optional per-launch traversal statistics (sums over all rays of the launch), in the
  * reference's visit semantics for LBVH_TRACE_REFERENCE: P nodes popped, B internal boxes hit,
