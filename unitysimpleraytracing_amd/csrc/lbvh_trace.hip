@@ -299,9 +299,12 @@ __global__ __launch_bounds__(64) void resolve_ties_write_kernel(trace_args a, lb
 }
 
 // one candidate per lane of `mask` onto the list (called where the lanes of `mask` are active)
-__device__ __forceinline__ void list_tie(const trace_args& a, uint64_t mask, uint32_t slot, uint32_t xy, uint32_t pos, float t)
+__device__ __forceinline__ void list_tie(const trace_args& a, uint64_t mask, uint32_t w, uint32_t px, uint32_t py, uint32_t pos, float t)
 {
     const uint32_t lane = lane_id();
+    // (the record slot and the pixel are formed here, in the rare branch: the walk keeps nothing alive for them but the
+    // pixel coordinates, which its last store needs anyway)
+    const uint32_t slot = (uint32_t)hit_slot(a, w, lane, px, py), xy = px | (py << 16);
     const int first = __builtin_ctzll(mask);
     uint32_t base = 0;
     if ((int)lane == first) base = atomicAdd(&a.ties[a.tie_turn], (uint32_t)__popcll(mask));
@@ -515,7 +518,7 @@ __device__ __forceinline__ uint32_t node_line_bytes(uint32_t lane, bool ordered,
 
 // EXACT (LBVH_TRACE_FAST_EXACT, one ray per lane): best_tri holds a LEAF POSITION (from the parent's line: dwords 11 / 15), every
 // candidate that loses a tie at exactly the best t is listed at once, and `tied` collects the lanes that saw one
-struct tie_sink { const trace_args* a; uint32_t slot, xy; uint64_t tied; };
+struct tie_sink { const trace_args* a; uint32_t w, px, py; uint64_t tied; };
 
 // SIGNS: all active rays of the packet share the sign of each direction component (and have finite non-zero
 // inverse directions): bit i of `neg` = component i is negative.  The near / far planes of both child boxes are
@@ -588,7 +591,7 @@ __device__ __forceinline__ uint32_t walk_packet(const line_source& src, packet_r
                     const uint32_t id = EXACT ? __float_as_uint(nd.rmin.w) : __float_as_uint(v0.w);      // EXACT: the left leaf's position
                     if (EXACT && dist == P.best_t[r] && dist != LBVH_MAX_FLOAT) {
                         tied = true;                                       // the candidate that does not stay in the running is listed now
-                        list_tie(*sink->a, __ballot(true), sink->slot, sink->xy, max(id, P.best_tri[r]), dist);
+                        list_tie(*sink->a, __ballot(true), sink->w, sink->px, sink->py, max(id, P.best_tri[r]), dist);
                     }
                     if (closer(dist, id, P.best_t[r], P.best_tri[r])) { P.best_t[r] = dist; P.best_tri[r] = id; P.best_u[r] = u; P.best_v[r] = v; }
                 }
@@ -610,7 +613,7 @@ __device__ __forceinline__ uint32_t walk_packet(const line_source& src, packet_r
                     const uint32_t id = EXACT ? __float_as_uint(nd.rmax.w) : __float_as_uint(v0.w);      // EXACT: the right leaf's position
                     if (EXACT && dist == P.best_t[r] && dist != LBVH_MAX_FLOAT) {
                         tied = true;
-                        list_tie(*sink->a, __ballot(true), sink->slot, sink->xy, max(id, P.best_tri[r]), dist);
+                        list_tie(*sink->a, __ballot(true), sink->w, sink->px, sink->py, max(id, P.best_tri[r]), dist);
                     }
                     if (closer(dist, id, P.best_t[r], P.best_tri[r])) { P.best_t[r] = dist; P.best_tri[r] = id; P.best_u[r] = u; P.best_v[r] = v; }
                 }
@@ -785,7 +788,7 @@ __device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, pac
                     const uint64_t m = __builtin_amdgcn_ballot_w64(cand) & __builtin_amdgcn_ballot_w64(t == best_t);
                     if (m != 0) {         // (rare) the candidate that drops out of an exact tie is listed now
                         tied |= m;
-                        if ((m >> lane) & 1ull) list_tie(*sink->a, m, sink->slot, sink->xy, max(T.index, best_tri), t);
+                        if ((m >> lane) & 1ull) list_tie(*sink->a, m, sink->w, sink->px, sink->py, max(T.index, best_tri), t);
                     }
                 }
                 if (cand && closer(t, T.index, best_t, best_tri)) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
@@ -805,7 +808,7 @@ __device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, pac
                     const uint64_t m = __builtin_amdgcn_ballot_w64(cand) & __builtin_amdgcn_ballot_w64(t == best_t);
                     if (m != 0) {
                         tied |= m;
-                        if ((m >> lane) & 1ull) list_tie(*sink->a, m, sink->slot, sink->xy, max(T.index, best_tri), t);
+                        if ((m >> lane) & 1ull) list_tie(*sink->a, m, sink->w, sink->px, sink->py, max(T.index, best_tri), t);
                     }
                 }
                 if (cand && closer(t, T.index, best_t, best_tri)) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
@@ -952,7 +955,6 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
     walk_counters C = {0, 0, 0, 0};
     uint32_t steps = 0;
     bool tied = false;
-    const uint32_t my_slot = EXACT ? (uint32_t)hit_slot(a, w, lane, px0, py0) : 0u, my_xy = px0 | (py0 << 16);
     for (;;) {
         if (!have) {
             uint32_t got = kNone, all_idle = 0;
@@ -1020,7 +1022,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                         const unsigned long long was = atomicMin(&S.best[lane], key);
                         if (EXACT && (uint32_t)(was >> 32) == (uint32_t)(key >> 32) && was != key) {
                             tied = true;                           // the candidate that is not kept joins the list
-                            list_tie(a, __ballot(true), my_slot, my_xy, (uint32_t)max(was, key), dist);
+                            list_tie(a, __ballot(true), w, px0, py0, (uint32_t)max(was, key), dist);
                         }
                     }
                 }
@@ -1041,7 +1043,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                         const unsigned long long was = atomicMin(&S.best[lane], key);
                         if (EXACT && (uint32_t)(was >> 32) == (uint32_t)(key >> 32) && was != key) {
                             tied = true;
-                            list_tie(a, __ballot(true), my_slot, my_xy, (uint32_t)max(was, key), dist);
+                            list_tie(a, __ballot(true), w, px0, py0, (uint32_t)max(was, key), dist);
                         }
                     }
                 }
@@ -1123,7 +1125,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                 const bool mine = P.act[0] && ((tm >> lane) & 1ull) && t < LBVH_MAX_FLOAT;
                 const uint64_t mm = __ballot(mine);
                 if (mine) {
-                    list_tie(a, mm, my_slot, my_xy, (uint32_t)key, t);
+                    list_tie(a, mm, w, px0, py0, (uint32_t)key, t);
                     out.y = __uint_as_float((uint32_t)key | kTiePosition);
                 }
             }
@@ -1156,11 +1158,10 @@ __device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_
     src.lines = nodes;
     src.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<lbvh_fast_node*>(nodes), 0, (int)a.line_bytes, 0x00020000);
     uint32_t steps;
-    tie_sink sink = {&a, 0u, 0u, 0ull};
+    tie_sink sink = {&a, 0u, 0u, 0u, 0ull};
     if (EXACT) {
         // the walkers with the tie bookkeeping (closer() on leaf positions: the loser of every exact tie is listed)
-        sink.slot = (uint32_t)hit_slot(a, w, lane, px0, py0);
-        sink.xy = px0 | (py0 << 16);
+        sink.w = w; sink.px = px0; sink.py = py0;
         if (ordered && packet_one_origin(P))
             steps = a.line_bytes != 0 ? walk_packet_lean<true, true>(src, P, neg, &sink) : walk_packet_lean<false, true>(src, P, neg, &sink);
         else if (a.line_bytes != 0)
@@ -1170,7 +1171,7 @@ __device__ __forceinline__ void light_tile(const trace_args& a, const lbvh_fast_
         // a ray that saw a tie: its candidate in the lead joins the list and stays in the record as a position until the
         // resolve kernels have run; every other ray's position becomes its triangle here
         const bool mine = (sink.tied >> lane) & 1ull;
-        if (mine) list_tie(a, sink.tied, sink.slot, sink.xy, P.best_tri[0], P.best_t[0]);
+        if (mine) list_tie(a, sink.tied, w, px0, py0, P.best_tri[0], P.best_t[0]);
         if (P.act[0] && P.best_t[0] < LBVH_MAX_FLOAT) P.best_tri[0] = mine ? (P.best_tri[0] | kTiePosition) : a.sorted_indices[P.best_tri[0]];
     } else
     if (!STATS && ordered && packet_one_origin(P))
