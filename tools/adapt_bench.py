@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""In-flight cooperation (trace_adaptive_kernel) against the history-driven dispatch: cfg2 frame static / cold / moving, and
-one rank's share for N = 2, 4, 8 — mean ms of HIP events around the trace alone.  Variants by environment (read once per
-process by the library): LBVH_ADAPT=0 (round 3's kernels), LBVH_ADAPT_T (threshold), LBVH_ADAPT_ORDER=0 (never use the
-history), LBVH_ADAPT_WAVES."""
+"""The cfg2 frame in one table: whole frame static / cold (dispatch history dropped before every frame) / camera yawing 1 degree
+per frame, and one rank's share of the frame for N = 2, 4, 8 (static and cold) — mean (and worst) us of HIP events around the
+trace alone.  `--check`: every frame also compared with the reference mode's t.  A library variant is measured by
+LBVH_LIB=build_exp/liblbvh_<name>.so (tools/build_variant.sh), alternating with the product in one gpurun call."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
