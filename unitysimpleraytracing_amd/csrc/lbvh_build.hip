@@ -1376,6 +1376,14 @@ int lbvh_launch_tree_fused(lbvh_context* ctx, uint32_t n, const uint32_t* d_keys
 // lbvh_build_scene with LBVH_BUILD_FAST_SCENE after the sort, as three merged launches on the current stream (see
 // gather_and_reduce_kernel).  *done = false and nothing enqueued when the scene is too large for the self-scanning forms:
 // the caller runs the two-stream chain instead.
+// does a scene of n triangles take the merged launches (the self-scanning apply passes cover it)?
+bool lbvh_post_sort_merges(uint32_t n)
+{
+    const uint32_t a_chunks = (n + kAkChunk - 1) / kAkChunk;
+    const uint32_t d_chunks = (uint32_t)(((uint64_t)n + kDistChunk - 1) / kDistChunk);
+    return a_chunks <= kSelfScanChunks && d_chunks <= kSelfScanChunks;
+}
+
 int lbvh_launch_post_sort_merged(lbvh_context* ctx, uint32_t n, uint32_t* d_keys, const lbvh_aabb* d_triangle_aabb,
                                  const uint32_t* d_sorted_indices, const float box_min[3], const float box_max[3],
                                  uint32_t* d_aligned_keys, lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh,
@@ -1383,9 +1391,9 @@ int lbvh_launch_post_sort_merged(lbvh_context* ctx, uint32_t n, uint32_t* d_keys
 {
     static_assert(kAkThreads == 256 && kDistThreads == 256 && kTreeThreads == 256, "the merged launches run 256-thread bodies");
     *done = false;
+    if (!lbvh_post_sort_merges(n)) return LBVH_OK;
     const uint32_t a_chunks = (n + kAkChunk - 1) / kAkChunk;
     const uint32_t d_chunks = (uint32_t)(((uint64_t)n + kDistChunk - 1) / kDistChunk);
-    if (a_chunks > kSelfScanChunks || d_chunks > kSelfScanChunks) return LBVH_OK;
     hier_t h;
     int rc = hier_plan(ctx, n, &h);
     if (rc != LBVH_OK) return rc;

@@ -208,6 +208,7 @@ int lbvh_launch_animate_morton(lbvh_context* ctx, const lbvh_anim& anim, lbvh_tr
                                lbvh_internal_node* d_reset_internal = nullptr, lbvh_leaf_node* d_reset_leaf = nullptr);
 // lbvh_build_scene (LBVH_BUILD_FAST_SCENE) after the sort as three merged launches on the current stream; *done = false: too large,
 // nothing enqueued
+bool lbvh_post_sort_merges(uint32_t n);
 int lbvh_launch_post_sort_merged(lbvh_context* ctx, uint32_t n, uint32_t* d_keys, const lbvh_aabb* d_triangle_aabb,
                                  const uint32_t* d_sorted_indices, const float box_min[3], const float box_max[3],
                                  uint32_t* d_aligned_keys, lbvh_internal_node* d_internal, lbvh_leaf_node* d_leaf, lbvh_aabb* d_bvh,

@@ -1772,8 +1772,15 @@ static lbvh_status build_scene_impl(lbvh_context* ctx, const lbvh_anim* anim, co
     const uint64_t args_key = key;
     mix_scratch(mix);
     if (key == 0) key = 1;
-    static const bool env_no_graph = getenv("LBVH_NO_GRAPH") != nullptr;     // debugging / measurement switch
-    const bool graphs = ctx->own_stream && !ctx->prof_enabled && !ctx->build_graph_off && !env_no_graph;
+    static const bool env_no_graph = getenv("LBVH_NO_GRAPH") != nullptr;     // debugging / measurement switches
+    static const bool env_graph = getenv("LBVH_BUILD_GRAPH") != nullptr;
+    static const bool env_two_streams = getenv("LBVH_BUILD_TWO_STREAMS") != nullptr;
+    // The replayed graph pays where the chain forks onto a second stream (the derived scene beyond the merged launches' size).  On
+    // ONE stream — the merged chain's nine launches, the reference arrays alone — kernels enqueued one by one run 5 - 8 us sooner
+    // than the graph (rebuild 0.241 against 0.249 ms, reference arrays alone 0.184 against 0.190, step 0.420 against 0.428:
+    // profiles/r4/f); the host's launches are hidden behind the GPU's work.
+    const bool single_stream = (flags & LBVH_BUILD_FAST_SCENE) == 0 || (lbvh_post_sort_merges(n) && !env_two_streams);
+    const bool graphs = ctx->own_stream && !ctx->prof_enabled && !ctx->build_graph_off && !env_no_graph && (!single_stream || env_graph);
     // Host-side state of the call, the same on every path below (plain launches, capture, replay): Morton and the sort
     // rewrite keys / indices / triangle AABBs — whatever derived scene existed is stale — and with
     // LBVH_BUILD_FAST_SCENE the derived scene describes THIS scene once the work is enqueued.
