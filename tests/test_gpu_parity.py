@@ -364,7 +364,7 @@ def test_build_scene_on_both_sides_of_the_merged_launch_limit(ctx, n):
     tris = scenes.random_triangles(n, seed=77, extent=118.0, edge=0.8)
     d, c, b = build_both(ctx, tris)
     cam = scenes.camera(240, 135, (0.0, 0.0, 255.0))
-    for rep in range(2):
+    for rep in range(4):                                              # (two streams: plain, captured, replayed, replayed)
         c.bvh_internal_node.fill_u32(0x2345678 + rep, mirror=False)
         c.bvh_leaf_node.fill_u32(0x9ABCDEF + rep, mirror=False)
         c.bvh_data.fill_u32(0x7FC00000, mirror=False)
