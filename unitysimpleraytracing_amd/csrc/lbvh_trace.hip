@@ -43,6 +43,7 @@ struct trace_args {
     uint32_t* ties;                      // (words 0 / 1: this frame's count / the next one's — they take turns, and a frame's last
     uint32_t tie_capacity;               // resolve kernel clears the other one: no fill in front of the trace)
     uint32_t tie_turn;
+    uint32_t centre_first;               // 1: without history a whole frame's tiles are taken centre-out (trace_packet_kernel)
     const uint32_t* sorted_indices;      // leaf position -> triangle
 };
 
@@ -1212,6 +1213,17 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
         int c = kOrderClasses - 1;
         for (; c > 0 && k >= counts[c]; c--) k -= counts[c];
         w = lists[(size_t)c * n_work + k];
+    } else if (a.shard_count == 1u && a.centre_first && w < a.tiles_x * a.tiles_y) {      // (items past the last tile: the last group's tail)
+        // No history (a first frame, another layout): rows and columns are taken centre-out instead of top-down — what costs
+        // most is usually in the middle of the picture, and a frame is as long as its heaviest tiles started late
+        // (cfg2, first frames: 274 - 284 -> 259 - 261 us on the same box).  A hint like the history's: any order gives the same records.
+        auto centre_out = [](uint32_t k, uint32_t n) {
+            const uint32_t mid = n / 2u;
+            if (n & 1u) return (k & 1u) ? mid + (k + 1u) / 2u : mid - k / 2u;
+            return (k & 1u) ? mid + (k - 1u) / 2u : mid - 1u - k / 2u;
+        };
+        const uint32_t ty = w / a.tiles_x, tx = w - ty * a.tiles_x;
+        w = centre_out(ty, a.tiles_y) * a.tiles_x + centre_out(tx, a.tiles_x);
     }
     light_tile<STATS, EXACT>(a, nodes, tris, w, lane, cost, hits, stats, tile_cost);
 }
@@ -1418,6 +1430,8 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     }
     const uint32_t n_work = shard_work(a.tiles_x * a.tiles_y, a.shard_index, a.shard_count);
     if (n_work == 0) return LBVH_OK;
+    static const bool env_row_major = getenv("LBVH_COLD_ROW_MAJOR") != nullptr;      // measurement switch
+    a.centre_first = env_row_major ? 0u : 1u;
     // [class counts | cost of each work item in the last trace | 16 class lists]: valid for one frame layout
     const size_t cost_bytes = (((size_t)n_work * 4) + 255) & ~(size_t)255;
     void* before = ctx->trace_queues;
