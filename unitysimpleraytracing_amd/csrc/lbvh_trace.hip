@@ -1224,6 +1224,15 @@ __global__ __launch_bounds__(256) void trace_packet_kernel(trace_args a, const l
         };
         const uint32_t ty = w / a.tiles_x, tx = w - ty * a.tiles_x;
         w = centre_out(ty, a.tiles_y) * a.tiles_x + centre_out(tx, a.tiles_x);
+    } else if (a.centre_first && a.shard_count > 1u) {
+        // a share of a frame: its groups of 8 tiles (they lie in row-major order over the picture) from the middle one outwards
+        auto centre_out = [](uint32_t k, uint32_t n) {
+            const uint32_t mid = n / 2u;
+            if (n & 1u) return (k & 1u) ? mid + (k + 1u) / 2u : mid - k / 2u;
+            return (k & 1u) ? mid + (k - 1u) / 2u : mid - 1u - k / 2u;
+        };
+        const uint32_t groups = n_work / kShardGroup;          // (n_work is a whole number of groups)
+        w = centre_out(w / kShardGroup, groups) * kShardGroup + w % kShardGroup;
     }
     light_tile<STATS, EXACT>(a, nodes, tris, w, lane, cost, hits, stats, tile_cost);
 }
