@@ -174,3 +174,32 @@ def test_bench_starts_its_own_ranks_for_gpus_n():
     assert r.returncode != 0
     assert "no HIP device" in r.stderr and r.stdout.strip() == ""           # no JSON line from a run that did not run
     assert r.stderr.count("lbvh_create") >= 1
+
+
+def test_centre_out_tile_order_is_a_permutation():
+    """Frames without dispatch history take rows and columns (a share: its groups of 8 tiles) from the middle outwards
+    (csrc/lbvh_trace.hip trace_packet_kernel, centre_out): the arithmetic, restated, is a bijection for every size — every tile
+    of a whole frame and every work item of a share is traced exactly once, the slots past the last tile stay where they are."""
+    def centre_out(k, n):
+        mid = n // 2
+        if n & 1:
+            return mid + (k + 1) // 2 if k & 1 else mid - k // 2
+        return mid + (k - 1) // 2 if k & 1 else mid - 1 - k // 2
+
+    for n in list(range(1, 70)) + [135, 240, 1023, 1024]:
+        assert sorted(centre_out(k, n) for k in range(n)) == list(range(n))
+        assert centre_out(0, n) in (n // 2, n // 2 - 1 + (n & 1))           # starts in the middle
+    for tiles_x, tiles_y in ((240, 135), (1, 1), (7, 3), (32, 17)):
+        n_tiles = tiles_x * tiles_y
+        n_work = (n_tiles + 7) // 8 * 8                                      # whole frame: work item = tile, the last group's tail beyond
+        out = []
+        for w in range(n_work):
+            if w < n_tiles:
+                ty, tx = divmod(w, tiles_x)
+                out.append(centre_out(ty, tiles_y) * tiles_x + centre_out(tx, tiles_x))
+            else:
+                out.append(w)
+        assert sorted(out) == list(range(n_work))
+    for groups in (1, 2, 5, 506, 1013):                                      # a share: groups of 8 work items
+        out = [centre_out(w // 8, groups) * 8 + w % 8 for w in range(groups * 8)]
+        assert sorted(out) == list(range(groups * 8))
