@@ -251,6 +251,9 @@ def main():
             import torch
             torch.cuda.set_device(device_id)
         gather = FrameGather(ctx, dist, rank, world, W, H, device_id, staged=(args.backend == "gloo"), mode=args.gather)
+        if rank == 0:           # which transport `--gather auto` settled on, and why not the other (stderr: stdout is the JSON line)
+            print(f"[bench] frame gather: asked for {args.gather!r}, using {gather.mode!r}"
+                  + (f" (peer-mapped frame buffer unavailable: {gather.peer_error})" if gather.peer_error else ""), file=sys.stderr, flush=True)
 
     def trace_share(camera=None, stats=None):
         # this rank's share of the frame (every world-th group of 8 adjacent 8x8-pixel tiles), one launch, into this
@@ -266,7 +269,8 @@ def main():
         if gather is None:
             trace_share()
         else:                       # the share + its way into rank 0's frame (+ on rank 0: the wait for everybody's)
-            gather.trace_share(ccam, drawer.container.scene(), mode, own_done_event=ev[2] if ev else None)
+            gather.trace_share(ccam, drawer.container.scene(), mode, own_done_event=ev[2] if ev else None,
+                               own_start_event=ev[3] if ev else None)
         if ev:
             ctx.record(ev[1])       # end of the step = start of the next one's rebuild
 
@@ -276,7 +280,7 @@ def main():
 
     # two event records per step (each costs the stream a few microseconds): a step's rebuild starts where the
     # previous step's trace ended
-    events = [(ctx.event(), ctx.event()) + ((ctx.event(),) if gather is not None else ()) for _ in range(args.steps)]
+    events = [(ctx.event(), ctx.event()) + ((ctx.event(), ctx.event()) if gather is not None else ()) for _ in range(args.steps)]
     ev_start = ctx.event()
     barrier()
     ctx.sync()
@@ -295,7 +299,8 @@ def main():
     build_ms_max = reduce_max(build_ms)
     trace_ms_max = reduce_max(trace_ms)
     # N > 1: trace_ms contains the records' way to rank 0 (on rank 0: the wait for every rank's share); the traversal alone:
-    own_trace_ms_max = reduce_max(float(np.mean([ctx.elapsed_ms(e[0], e[2]) for e in events]))) if gather is not None else trace_ms_max
+    # (from behind the wait for rank 0's "frame read" word to the end of this rank's own kernel: no cross-rank skew in it)
+    own_trace_ms_max = reduce_max(float(np.mean([ctx.elapsed_ms(e[3], e[2]) for e in events]))) if gather is not None else trace_ms_max
 
     # ---- N > 1: the assembled frame, word for word (untimed) ------------------------------------------
     frame_check = None

@@ -14,7 +14,7 @@ public static class LbvhNative
 {
     const string Lib = "lbvh";   // liblbvh.so on Linux
 
-    public const int ABI_VERSION = 10;             // LBVH_ABI_VERSION of the include/lbvh.h this file was written against
+    public const int ABI_VERSION = 11;             // LBVH_ABI_VERSION of the include/lbvh.h this file was written against
     public const int TRACE_REFERENCE = 0, TRACE_FAST = 1;
     // TRACE_FAST + the reference's choice wherever two triangles are hit at exactly the same t: every record == TRACE_REFERENCE's
     public const int TRACE_FAST_EXACT = 2;
@@ -89,11 +89,6 @@ public static class LbvhNative
     // multi-GPU frames: this context's per-tile costs into a full-frame array / the merged array of all ranks back
     [DllImport(Lib)] public static extern int lbvh_trace_costs_export(IntPtr ctx, IntPtr dFrameCosts, uint tilesX, uint tilesY);
     [DllImport(Lib)] public static extern int lbvh_trace_costs_import(IntPtr ctx, IntPtr dFrameCosts, uint tilesX, uint tilesY);
-    [DllImport(Lib)] public static extern int lbvh_debug_ray_stack_split(IntPtr ctx, uint ldsEntries);
-    [DllImport(Lib)] public static extern int lbvh_debug_ray_walker(IntPtr ctx, uint walker);
-    [DllImport(Lib)] public static extern int lbvh_debug_ray_stack_limit(IntPtr ctx, uint deepEntries);
-    // measurement: the four-wide per-ray walkers add {rays, node lines fetched, triangles tested} (3 x ulong) while set
-    [DllImport(Lib)] public static extern int lbvh_ray_stats_target(IntPtr ctx, IntPtr dStats);
 
     // one frame from N GPUs (BASELINE configs[2]): peer-mapped frame buffer, ordering between contexts of this process
     // (sync events) or between processes (IPC handle of the buffer + completion flags waited for on the device), and
@@ -104,6 +99,8 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern int lbvh_ipc_export(IntPtr ctx, IntPtr dPtr, [Out] byte[] handle64);
     [DllImport(Lib)] public static extern int lbvh_ipc_import(IntPtr ctx, byte[] handle64, out IntPtr dPtr);
     [DllImport(Lib)] public static extern int lbvh_ipc_close(IntPtr ctx, IntPtr dPtr);
+    // completion flags a running kernel may poll while another GPU / process stores into them: uncached device memory
+    [DllImport(Lib)] public static extern int lbvh_flags_alloc(IntPtr ctx, UIntPtr nWords, out IntPtr dFlags);
     [DllImport(Lib)] public static extern int lbvh_frame_signal(IntPtr ctx, IntPtr dFlags, uint slot, uint value);
     [DllImport(Lib)] public static extern int lbvh_frame_wait(IntPtr ctx, IntPtr dFlags, uint nSlots, uint value);
     [DllImport(Lib)] public static extern int lbvh_trace_primary_shard_packed(IntPtr ctx, ref Camera camera, uint shardIndex, uint shardCount,
@@ -111,23 +108,13 @@ public static class LbvhNative
     [DllImport(Lib)] public static extern ulong lbvh_shard_records(int width, int height, uint shardIndex, uint shardCount);
     [DllImport(Lib)] public static extern int lbvh_frame_unpack(IntPtr ctx, IntPtr dPacked, ulong shareStride, uint firstShard, uint nShards,
         uint shardCount, int width, int height, IntPtr dFrameHits);
-    // measurement helper: shader clock held under a vector-ALU-bound load, MHz
-    [DllImport(Lib)] public static extern int lbvh_clock_probe(IntPtr ctx, out float shaderMhz);
     // a context whose work is ordered by a stream the caller owns (hipStream_t), e.g. an interop stream
     [DllImport(Lib)] public static extern int lbvh_create_on_stream(int deviceId, IntPtr hipStream, out IntPtr ctx);
-    // one LBVH_TRACE_FAST frame that also records the node fetches of every 8x8-pixel tile
-    [DllImport(Lib)] public static extern int lbvh_trace_tile_costs(IntPtr ctx, ref Camera camera, ref Scene scene, IntPtr dHits,
-        IntPtr dStats, IntPtr dTileSteps);
-    // HIP events on the context's stream, per-kernel timing rows, the float4 copy the sort's roofline is quoted against
+    // HIP events on the context's stream
     [DllImport(Lib)] public static extern int lbvh_event_create(IntPtr ctx, out IntPtr ev);
     [DllImport(Lib)] public static extern int lbvh_event_destroy(IntPtr ctx, IntPtr ev);
     [DllImport(Lib)] public static extern int lbvh_event_record(IntPtr ctx, IntPtr ev);
     [DllImport(Lib)] public static extern int lbvh_event_elapsed_ms(IntPtr ctx, IntPtr start, IntPtr stop, out float ms);
-    [DllImport(Lib)] public static extern int lbvh_profile_begin(IntPtr ctx);
-    [DllImport(Lib)] public static extern int lbvh_profile_end(IntPtr ctx, [Out] ProfileRow[] rows, int maxRows, out int nRows);
-    [DllImport(Lib)] public static extern int lbvh_copy_bandwidth_probe(IntPtr ctx, IntPtr dDst, IntPtr dSrc, UIntPtr bytes);
-    // host-side model of the sort's tile hand-out order (no GPU involved)
-    [DllImport(Lib)] public static extern uint lbvh_debug_sort_ticket_tile(uint k, uint x, uint group, uint queues);
 
     // dynamic scene + secondary rays (BASELINE configs[4]; extension, no reference counterpart)
     [DllImport(Lib)] public static extern int lbvh_animate(IntPtr ctx, IntPtr dRestTriangles, uint n, IntPtr dBodyIds, IntPtr dBodyCentres,

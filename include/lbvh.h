@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LBVH_ABI_VERSION 10
+#define LBVH_ABI_VERSION 11
 
 /* ---- status codes ------------------------------------------------------------------------- */
 typedef int32_t lbvh_status;
@@ -209,13 +209,6 @@ lbvh_status lbvh_morton_aabb(lbvh_context* ctx, const lbvh_triangle* d_triangles
 lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values,
                             uint32_t count);
 
-/* Host-side view of the sort's tile hand-out order (pure function, no GPU): the tile that the k-th ticket of queue x
- * stands for.  A pass kernel takes its tile from atomic tickets; on the full 8-XCD device there are 8 queues (one per
- * XCD, `group` consecutive tiles each in turn: neighbouring tiles meet in one L2), on anything else a single queue
- * (tile = ticket).  Exposed so the order invariant the decoupled look-back relies on — every tile below a handed-out
- * tile has been handed out or is the next ticket of some queue — can be model-checked without a GPU. */
-uint32_t lbvh_debug_sort_ticket_tile(uint32_t k, uint32_t x, uint32_t group, uint32_t queues);
-
 /* ---- cfg4: building blocks of the multi-GPU (key-range sharded) sort, SURVEY 8(e) ------------- *
  * The reference has no multi-GPU path; these are the local kernels of the sharded sort that
  * unitysimpleraytracing_amd/sharded_sort.py drives (one process per GPU): every rank sorts its own
@@ -376,8 +369,9 @@ lbvh_status lbvh_trace_primary_shard(lbvh_context* ctx, const lbvh_camera* h_cam
 lbvh_status lbvh_peer_enable(lbvh_context* ctx, int32_t peer_device);
 
 /* An event for ORDERING work between contexts (lbvh_event_create's are for timing: they skip the system-scope release
- * that makes a GPU's stores visible to another one).  Recorded with lbvh_event_record, destroyed with lbvh_event_destroy;
- * lbvh_event_elapsed_ms does not take it. */
+ * that makes a GPU's stores visible to another one).  Created with hipEventDisableTiming | hipEventReleaseToSystem: its record
+ * IS a system-scope release whatever the runtime's default for plain events is.  Recorded with lbvh_event_record, destroyed
+ * with lbvh_event_destroy; lbvh_event_elapsed_ms does not take it. */
 lbvh_status lbvh_sync_event_create(lbvh_context* ctx, void** out_event);
 /* The context's stream waits (on the device, the host does not block) for `event` — an event of lbvh_sync_event_create
  * recorded with lbvh_event_record on ANY context of this process, e.g. the end of another GPU's share of the frame. */
@@ -391,12 +385,22 @@ lbvh_status lbvh_ipc_export(lbvh_context* ctx, void* d_ptr, uint8_t h_handle[LBV
 lbvh_status lbvh_ipc_import(lbvh_context* ctx, const uint8_t h_handle[LBVH_IPC_HANDLE_BYTES], void** out_d_ptr);
 lbvh_status lbvh_ipc_close(lbvh_context* ctx, void* d_ptr);
 
+/* Memory for the completion flags below: n_words zeroed 32-bit words that a RUNNING kernel may poll while another GPU or
+ * process stores into them.  Ordinary device memory (lbvh_buffer_alloc: coarse-grained) only promises visibility of another
+ * device's stores at kernel boundaries, so a flag polled inside a kernel could be served stale from this GPU's L2 for as long
+ * as the kernel runs; these words are allocated uncached (hipExtMallocWithFlags, hipDeviceMallocUncached — what RCCL uses for
+ * its own flags): every load and store goes to the memory itself.  Exported / imported / freed like any other buffer
+ * (lbvh_ipc_export, lbvh_ipc_import, lbvh_buffer_free). */
+lbvh_status lbvh_flags_alloc(lbvh_context* ctx, size_t n_words, uint32_t** out_d_flags);
 /* d_flags[slot] := value once everything enqueued on this context so far has finished and its stores are visible system
- * wide (a release store at system scope; d_flags may be another GPU's memory).  Values of one slot must grow (frame numbers). */
+ * wide (a release store at system scope; d_flags may be another GPU's memory: words of lbvh_flags_alloc).  Values of one slot
+ * must grow (frame numbers). */
 lbvh_status lbvh_frame_signal(lbvh_context* ctx, uint32_t* d_flags, uint32_t slot, uint32_t value);
 /* Work enqueued on this context after the call starts only when d_flags[s] >= value (as signed distance: wrap-around safe)
- * for every s < n_slots — e.g. every other rank has signalled this frame.  The wait runs on the device and is bounded: if a
- * flag never arrives the next lbvh_sync / lbvh_buffer_download returns LBVH_ERR_HIP, the GPU does not hang.  n_slots <= 64.
+ * for every s < n_slots — e.g. every other rank has signalled this frame.  The wait runs on the device and is bounded by WALL
+ * CLOCK (20 s of the GPU's constant 100 MHz counter — a rank may still be starting up when the wait is enqueued; a poll count
+ * would make the bound depend on how fast the polls come back): if a flag has not arrived by then the next lbvh_sync /
+ * lbvh_buffer_download returns LBVH_ERR_HIP, the GPU does not hang.  n_slots <= 64.
  * d_flags may be another GPU's memory (polled over xGMI: the ranks that wait for the owner's "frame read" word). */
 lbvh_status lbvh_frame_wait(lbvh_context* ctx, const uint32_t* d_flags, uint32_t n_slots, uint32_t value);
 
@@ -481,35 +485,6 @@ typedef struct lbvh_path_state {
 lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, float t_min,
                             const lbvh_scene* h_scene, lbvh_hit* d_hits);
 
-/* Test hook: how many of a ray's stack entries live in LDS (1..16, default 16) before the walker of lbvh_trace_rays /
- * lbvh_path_bounce spills to its device-memory slab.  Results do not depend on it; tests lower it so the deep part
- * of the stack is exercised by ordinary scenes. */
-lbvh_status lbvh_debug_ray_stack_split(lbvh_context* ctx, uint32_t lds_entries);
-
-/* Measurement aid (cfg5's roofline): while d_stats is non-NULL, every launch of the four-wide per-ray walk (lbvh_trace_rays,
- * lbvh_path_bounce, lbvh_path_first_bounce) ADDS what it did to it: rays walked, 128-byte four-wide node lines fetched (one per
- * ray-step), triangle lines fetched and tested.  Zero it yourself; NULL switches the counting off (the default: the counting
- * kernels are separate instantiations, the product's carry none of it). */
-typedef struct lbvh_ray_stats {
-    uint64_t rays;
-    uint64_t node_fetches;
-    uint64_t triangle_tests;
-} lbvh_ray_stats;
-lbvh_status lbvh_ray_stats_target(lbvh_context* ctx, lbvh_ray_stats* d_stats);
-
-/* Test hook: how many entries of the device-memory part of a ray's stack the walkers may use (0 = all of it: 48 for the
- * binary walk, 112 for the four-wide one — more than any tree of this library can ask for).  A stack that runs out does not
- * drop the entry silently: the launch sets the context's fault word and the next lbvh_sync / lbvh_buffer_download returns
- * LBVH_ERR_HIP ("a per-ray traversal stack ran out of entries").  Tests lower the limit to see exactly that. */
-lbvh_status lbvh_debug_ray_stack_limit(lbvh_context* ctx, uint32_t deep_entries);
-
-/* Test hook: which walk lbvh_trace_rays / lbvh_path_bounce run — 1 (default): four-wide nodes (each binary node with its
- * largest children opened, made on first use after a rebuild; from bounce 1 on lbvh_path_bounce takes the kernel that keeps
- * a step's two fetches in flight at once: few live rays, the launch is the chain of its longest), 2: that kernel for every
- * launch, 0: the binary nodes the packet walk uses.  Hit records do not depend on it (ties go to the lower triangle index
- * on all three). */
-lbvh_status lbvh_debug_ray_walker(lbvh_context* ctx, uint32_t walker);
-
 /* Camera rays into path states (origin/dir as Raytracing.compute:108-126, throughput 1, radiance 0, alive). */
 lbvh_status lbvh_path_begin(lbvh_context* ctx, const lbvh_camera* h_camera, lbvh_path_state* d_states);
 
@@ -561,11 +536,6 @@ lbvh_status lbvh_trace_forget(lbvh_context* ctx);
 lbvh_status lbvh_trace_costs_export(lbvh_context* ctx, uint32_t* d_frame_costs, uint32_t tiles_x, uint32_t tiles_y);
 lbvh_status lbvh_trace_costs_import(lbvh_context* ctx, const uint32_t* d_frame_costs, uint32_t tiles_x, uint32_t tiles_y);
 
-/* Profiling aid: one LBVH_TRACE_FAST frame that also records, per 8x8-pixel tile (row-major,
- * ceil(W/8) x ceil(H/8) entries), the number of node fetches its packet needed. */
-lbvh_status lbvh_trace_tile_costs(lbvh_context* ctx, const lbvh_camera* h_camera, const lbvh_scene* h_scene,
-                                  lbvh_hit* d_hits, lbvh_trace_stats* d_stats, uint32_t* d_tile_steps);
-
 /* ---- measurement helpers (HIP events on the context's stream) --------------------------------- */
 
 lbvh_status lbvh_event_create(lbvh_context* ctx, void** out_event);
@@ -573,31 +543,6 @@ lbvh_status lbvh_event_destroy(lbvh_context* ctx, void* event);
 lbvh_status lbvh_event_record(lbvh_context* ctx, void* event);
 /* Waits for `stop`, then returns the elapsed milliseconds between the two recorded events. */
 lbvh_status lbvh_event_elapsed_ms(lbvh_context* ctx, void* start, void* stop, float* out_ms);
-
-/* Per-kernel timing: between lbvh_profile_begin and lbvh_profile_end every kernel the library
- * launches on this context is bracketed by its own pair of HIP events (on the context's stream).
- * lbvh_profile_end waits for the stream and returns one row per kernel name: launches and the
- * summed device time.  Off by default: it adds two event records per launch, so it is never on
- * inside a throughput measurement. */
-typedef struct lbvh_profile_row {
-    char     name[48];
-    uint32_t launches;
-    float    total_ms;
-} lbvh_profile_row;
-lbvh_status lbvh_profile_begin(lbvh_context* ctx);
-lbvh_status lbvh_profile_end(lbvh_context* ctx, lbvh_profile_row* h_rows, int32_t max_rows,
-                             int32_t* out_rows);
-
-/* The shader clock the chip holds under a vector-ALU-bound load (MHz): every CU runs dependent fp32 work for a few
- * hundred microseconds while each wave reads the shader-cycle counter (s_memtime) and the constant 100 MHz counter
- * (s_memrealtime) before and after; the median ratio is returned.  Blocking.  Issue-rate figures (instructions per
- * cycle x this clock) use it instead of assuming the 2.4 GHz maximum. */
-lbvh_status lbvh_clock_probe(lbvh_context* ctx, float* out_shader_mhz);
-
-/* Streaming device-to-device copy of `bytes` (float4 per lane) on the context's stream: the
- * box's own HBM copy rate is the measured roofline denominator quoted beside the 8 TB/s spec. */
-lbvh_status lbvh_copy_bandwidth_probe(lbvh_context* ctx, void* d_dst, const void* d_src,
-                                      size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,5 @@
-"""The C-ABI library loads on a CPU-only box and exports every symbol include/lbvh.h declares.
-No compute calls here."""
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/lbvh.h (the drop-in boundary) and
+include/lbvh_debug.h (test hooks and measurement aids) declare.  No compute calls here."""
 import ctypes as C
 import os
 import re
@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "lbvh.h")).read()
+def declared_functions(header="lbvh.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(lbvh_[a-z0-9_]+)\s*\(", text)))
 
@@ -25,10 +25,28 @@ def test_header_declares_the_expected_surface():
 
 def test_library_exports_every_declared_symbol():
     from unitysimpleraytracing_amd import _native as N
-    for name in declared_functions():
+    for name in declared_functions() + declared_functions("lbvh_debug.h"):
         assert hasattr(N.lib, name), f"liblbvh.so does not export {name}"
     assert set(N.SIGNATURES) == set(declared_functions())
-    assert N.lib.lbvh_abi_version() == N.ABI_VERSION == 10
+    assert set(N.DEBUG_SIGNATURES) == set(declared_functions("lbvh_debug.h"))
+    assert N.lib.lbvh_abi_version() == N.ABI_VERSION == 11
+
+
+def test_the_boundary_header_holds_no_test_hooks():
+    """what a Unity maintainer reads (include/lbvh.h, LbvhNative.cs) is the product's calls; hooks, probes and
+    per-kernel profiling live in lbvh_debug.h / LbvhNativeDebug.cs, and the library reads no environment variable."""
+    names = declared_functions()
+    assert not [f for f in names if "debug" in f or "probe" in f or "profile" in f or f in ("lbvh_ray_stats_target", "lbvh_trace_tile_costs")]
+    assert set(names).isdisjoint(declared_functions("lbvh_debug.h"))
+    src = os.path.join(ROOT, "unitysimpleraytracing_amd", "csrc")
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(src, f)).read(), f
+    # none of the re-hosted reference classes needs the debug table
+    cs = os.path.join(ROOT, "bindings", "csharp")
+    for f in os.listdir(cs):
+        if f.endswith(".Native.cs") or f in ("NativeBuffer.cs", "LbvhContext.cs"):
+            assert "LbvhNativeDebug" not in open(os.path.join(cs, f)).read(), f
 
 
 def test_struct_layouts_match_the_reference():
@@ -142,14 +160,15 @@ def test_csharp_binding_declares_every_entry_point_with_the_headers_arity():
     has a [DllImport] of the same name and parameter count, nothing else is imported, and each name is exported."""
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "lbvh.h")).read(), flags=re.S)
-    protos = re.findall(r"\b(?:lbvh_status|int32_t|uint32_t|uint64_t|const char\*)\s+(lbvh_\w+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S)
-    c = {name: (0 if args.strip() in ("", "void") else len(args.split(","))) for name, args in protos}
-    cs = re.sub(r"//.*", "", open(os.path.join(root, "bindings", "csharp", "LbvhNative.cs")).read())
-    imports = re.findall(r"\[DllImport\(Lib\)\]\s*public static extern \w+\s+(lbvh_\w+)\s*\(([^;]*?)\)\s*;", cs, flags=re.S)
-    d = {name: (0 if not args.strip() else len(args.split(","))) for name, args in imports}
-    assert len(c) >= 40 and set(c) == set(d), (sorted(set(c) - set(d)), sorted(set(d) - set(c)))
-    assert not [(k, c[k], d[k]) for k in c if c[k] != d[k]]
     from unitysimpleraytracing_amd import _native as N
-    for name in d:
-        assert hasattr(N.lib, name), name
+    for header, binding, least in (("lbvh.h", "LbvhNative.cs", 40), ("lbvh_debug.h", "LbvhNativeDebug.cs", 8)):
+        hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", header)).read(), flags=re.S)
+        protos = re.findall(r"\b(?:lbvh_status|int32_t|uint32_t|uint64_t|const char\*)\s+(lbvh_\w+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S)
+        c = {name: (0 if args.strip() in ("", "void") else len(args.split(","))) for name, args in protos}
+        cs = re.sub(r"//.*", "", open(os.path.join(root, "bindings", "csharp", binding)).read())
+        imports = re.findall(r"\[DllImport\(Lib\)\]\s*public static extern \w+\s+(lbvh_\w+)\s*\(([^;]*?)\)\s*;", cs, flags=re.S)
+        d = {name: (0 if not args.strip() else len(args.split(","))) for name, args in imports}
+        assert len(c) >= least and set(c) == set(d), (sorted(set(c) - set(d)), sorted(set(d) - set(c)))
+        assert not [(k, c[k], d[k]) for k in c if c[k] != d[k]]
+        for name in d:
+            assert hasattr(N.lib, name), name

@@ -88,14 +88,11 @@ def test_sort_stability_and_skew(ctx, kind, count):
 
 def test_sort_single_ticket_queue_mode():
     """contexts that are not the full 8-XCD device behind an unmasked stream take tiles in plain ticket order
-    (one queue).  LBVH_SORT_QUEUES=1 forces that mode on this box: same results, sizes beyond the point where the
-    8-queue form could have stranded tiles (> 9 M keys)."""
-    os.environ["LBVH_SORT_QUEUES"] = "1"
+    (one queue).  lbvh_debug_switch(LBVH_DEBUG_SORT_QUEUES, 1) forces that mode on this box: same results, sizes beyond the
+    point where the 8-queue form could have stranded tiles (> 9 M keys)."""
+    c1 = H().Context(0)
     try:
-        c1 = H().Context(0)
-    finally:
-        del os.environ["LBVH_SORT_QUEUES"]
-    try:
+        c1.debug_switch(N().DEBUG_SWITCH_SORT_QUEUES, 1)
         for count, kind in ((100003, "random"), (1 << 21, "morton_pads"), (12_000_001, "random")):
             keys, vals = sort_inputs(count, count % 97, kind)
             k, v = gpu_sort(c1, keys, vals)

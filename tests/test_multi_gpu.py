@@ -30,17 +30,20 @@ def _yawed(cam, deg):
 def test_one_process_n_contexts_assemble_the_frame_on_the_owner(ranks):
     """host.MultiGpuDrawer (twin of lbvh_host.hpp's): every context traces its share straight into the owner's frame
     buffer, the owner's stream waits for the others' events on the device.  Frames: two from one camera (the second is
-    dispatched by the first one's costs), a turned camera, a rebuilt scene — both modes — each into a poisoned buffer and
-    equal, word for word, to the frame one context traces alone; t equal to the oracle's."""
+    dispatched by the first one's costs), a turned camera, a rebuilt scene — all three modes — each into a poisoned buffer and
+    equal, word for word, to the frame one context traces alone; t equal to the oracle's.  Every second triangle is a copy of
+    its neighbour, so LBVH_TRACE_FAST_EXACT resolves ties on every rank against the owner's frame and must return the
+    reference mode's records."""
     from unitysimpleraytracing_amd import host as Hh
     tris = scenes.tiled_torus(nu=24, nv=16, grid=2)
+    tris[1::2] = tris[0::2][: len(tris[1::2])]
     W, Ht = 250, 131
     multi = Hh.MultiGpuDrawer([0] * ranks, tris).awake()
     one_ctx = Hh.Context(0)
     single = Hh.RaytracingMeshDrawer(one_ctx, tris).awake()
     b = O.Built(tris, capacity=single.container.capacity, threads=8)
     cam0 = scenes.camera(W, Ht, (0.0, 0.0, 120.0))
-    for mode in (L.TRACE_FAST, L.TRACE_REFERENCE):
+    for mode in (L.TRACE_FAST, L.TRACE_REFERENCE, L.TRACE_FAST_EXACT):
         for f in range(4):
             cam = cam0 if f < 2 else _yawed(cam0, 3.0 * f)
             if f == 3:
@@ -53,6 +56,9 @@ def test_one_process_n_contexts_assemble_the_frame_on_the_owner(ranks):
             single.update(cam, mode=mode)
             want = single.hits()
             assert (got.view(np.uint32) == want.view(np.uint32)).all(), (ranks, mode, f)
+            if mode == L.TRACE_FAST_EXACT:
+                single.update(cam, mode=L.TRACE_REFERENCE)
+                assert (got.view(np.uint32) == single.hits().view(np.uint32)).all(), (ranks, f)
             if f in (0, 2):
                 oh, _ = O.trace_primary(b, cam, threads=8)
                 assert (got["t"].view(np.uint32) == oh["t"].view(np.uint32)).all()
@@ -139,29 +145,57 @@ def test_ipc_mapped_frame_buffer_and_device_side_flags_between_processes(ctx):
     """The one-process-per-GPU transport (frame_gather 'peer'): the owner exports its frame buffer and flag words, two other
     PROCESSES map them, store into them and signal frame numbers; the owner's lbvh_frame_wait (on the device) lets its
     download through only when both have signalled the last frame — which then holds both processes' last patterns."""
+    from unitysimpleraytracing_amd import _native as N
     from unitysimpleraytracing_amd import host as Hh
     frames = 5
     frame = Hh.DataBuffer(ctx, 2 * 4096, np.uint32, 0)
-    flags = Hh.DataBuffer(ctx, 64, np.uint32, 0)
+    flags = ctx.flags_alloc(64)                    # zeroed uncached words (ordinary device memory promises a running kernel nothing)
     ctx.sync()
-    hf, hg = ctx.ipc_export(frame.device).hex(), ctx.ipc_export(flags.device).hex()
+    hf, hg = ctx.ipc_export(frame.device).hex(), ctx.ipc_export(flags).hex()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = [subprocess.Popen([sys.executable, "-c", _CHILD, ROOT, hf, hg, str(slot), str(frames)], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.PIPE, text=True) for slot in range(2)]
-    ctx.frame_wait(flags.device, 2, frames)        # enqueued at once: the children have not even started
+    # enqueued at once: the children have not even started — the wait's bound is wall clock (20 s), not a poll count (ADVICE r4)
+    ctx.frame_wait(flags, 2, frames)
     got = frame.get_data().copy()                  # behind the wait on the stream
     for p in procs:
         out, err = p.communicate(timeout=300)
         assert p.returncode == 0 and "child ok" in out, err[-2000:]
     for slot in range(2):
         assert (got[slot * 4096:(slot + 1) * 4096] == (slot << 16) + frames).all()
-    assert (flags.get_data()[:2] == frames).all()
+    words = np.zeros(64, dtype=np.uint32)
+    N.check(ctx.handle, N.lib.lbvh_buffer_download(ctx.handle, words.ctypes.data_as(C.c_void_p), flags, words.nbytes))
+    assert (words[:2] == frames).all() and (words[2:] == 0).all()
     # a flag that is already there: the wait returns at once; wrap-around-safe comparison
-    ctx.frame_wait(flags.device, 2, frames - 2)
+    ctx.frame_wait(flags, 2, frames - 2)
     ctx.sync()
     frame.dispose()
-    flags.dispose()
+    ctx.flags_free(flags)
+
+
+def test_frame_wait_gives_up_by_wall_clock_and_says_so(ctx):
+    """A flag that never arrives: the device-side wait ends after its wall-clock bound (lowered to 50 ms through the debug
+    switch; 20 s in the product), the next sync reports LBVH_ERR_HIP once, and the context goes on working."""
+    import time
+    from unitysimpleraytracing_amd import _native as N
+    flags = ctx.flags_alloc(4)
+    ctx.debug_switch(N.DEBUG_SWITCH_FRAME_WAIT_MS, 50)
+    try:
+        t0 = time.perf_counter()
+        ctx.frame_wait(flags, 1, 7)
+        with pytest.raises(N.LbvhError) as e:
+            ctx.sync()
+        waited = time.perf_counter() - t0
+        assert "flag" in str(e.value) or "frame" in str(e.value), str(e.value)
+        assert 0.04 < waited < 5.0, waited
+        ctx.sync()                                 # reported once
+        ctx.frame_signal(flags, 0, 7)
+        ctx.frame_wait(flags, 1, 7)                # now it is there
+        ctx.sync()
+    finally:
+        ctx.debug_switch(N.DEBUG_SWITCH_FRAME_WAIT_MS, 0)
+        ctx.flags_free(flags)
 
 
 _GATHER_CHILD = r"""
@@ -223,15 +257,17 @@ def test_frame_gather_between_processes_with_a_consumer_on_the_owner(tmp_path, m
 
 
 def test_cpp_multi_gpu_drawer():
-    """host/lbvh_host.hpp MultiGpuDrawer through the compiled driver: 3 logical ranks, 8 frames (two modes x static, static,
-    turned, rebuilt) assembled in the owner's poisoned buffer == the frames one context traces alone."""
+    """host/lbvh_host.hpp MultiGpuDrawer through the compiled driver: 1 / 3 / 8 logical ranks, 12 frames (three modes — fast,
+    reference, fast-exact — x static, static, turned, rebuilt) assembled in the owner's poisoned buffer == the frames one context
+    traces alone (the exact mode's also == the reference mode's); once more on a scene of doubled triangles, where the exact
+    mode's tie resolution runs on every rank against the owner's frame."""
     exe = os.path.join(ROOT, "unitysimpleraytracing_amd", "host", "lbvh_driver")
     assert os.path.exists(exe), "build it with __graft_entry__.build()"
-    for ranks in (1, 3, 8):
-        r = subprocess.run([exe, "multi", str(ranks), "4096", "250", "131"], capture_output=True, text=True)
+    for ranks, extra in ((1, []), (3, []), (8, []), (3, ["doubled"]), (8, ["doubled"])):
+        r = subprocess.run([exe, "multi", str(ranks), "4096", "250", "131"] + extra, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-500:]
         res = json.loads(r.stdout)
-        assert res["frames"] == 8 and res["frames_equal"] == 8 and res["ranks"] == ranks and res["hits"] > 0
+        assert res["frames"] == 12 and res["frames_equal"] == 12 and res["ranks"] == ranks and res["hits"] > 0
 
 
 @pytest.mark.parametrize("transport", ["peer", "packed"])

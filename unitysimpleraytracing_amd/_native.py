@@ -1,4 +1,4 @@
-"""ctypes binding of liblbvh.so (include/lbvh.h).  No fallback: a missing or stale library is an
+"""ctypes binding of liblbvh.so (include/lbvh.h; DEBUG_SIGNATURES: the test hooks and measurement aids of include/lbvh_debug.h).  No fallback: a missing or stale library is an
 ImportError, a failing call is an LbvhError — the product path never computes on the CPU."""
 import ctypes as C
 import os
@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LBVH_LIB: an alternative build of the same library (tools/build_variant.sh: A/B measurements of kernel variants)
 LIB_PATH = os.environ.get("LBVH_LIB") or os.path.join(_HERE, "liblbvh.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -80,7 +80,6 @@ SIGNATURES = {
                                   _I32, _P, _P]),
     "lbvh_trace_primary_shard": (_I32, [_P, C.POINTER(Camera), _U32, _U32, C.POINTER(Scene), _I32, _P, _P]),
     "lbvh_build_scene": (_I32, [_P, _P, _U32, _U32, _F3, _F3, _P, _P, _P, _P, _P, _P, _U32]),
-    "lbvh_debug_sort_ticket_tile": (_U32, [_U32, _U32, _U32, _U32]),
     "lbvh_key_histogram": (_I32, [_P, _P, _U32, _P, _U32, _U32, _U32, _P]),
     "lbvh_lower_bound": (_I32, [_P, _P, _U32, _P, _U32, _P]),
     "lbvh_trace_costs_export": (_I32, [_P, _P, _U32, _U32]),
@@ -96,35 +95,43 @@ SIGNATURES = {
     "lbvh_path_first_bounce": (_I32, [_P, C.POINTER(Camera), C.POINTER(Scene), _P, _P, _U32, C.c_float, C.c_float]),
     "lbvh_path_resolve": (_I32, [_P, _P, _SZ, _P]),
     "lbvh_trace_forget": (_I32, [_P]),
-    "lbvh_debug_ray_stack_split": (_I32, [_P, _U32]),
-    "lbvh_debug_ray_walker": (_I32, [_P, _U32]),
-    "lbvh_debug_ray_stack_limit": (_I32, [_P, _U32]),
-    "lbvh_ray_stats_target": (_I32, [_P, _P]),
     "lbvh_peer_enable": (_I32, [_P, _I32]),
     "lbvh_sync_event_create": (_I32, [_P, C.POINTER(_P)]),
     "lbvh_event_wait": (_I32, [_P, _P]),
     "lbvh_ipc_export": (_I32, [_P, _P, C.POINTER(C.c_uint8)]),
     "lbvh_ipc_import": (_I32, [_P, C.POINTER(C.c_uint8), C.POINTER(_P)]),
     "lbvh_ipc_close": (_I32, [_P, _P]),
+    "lbvh_flags_alloc": (_I32, [_P, _SZ, C.POINTER(_P)]),
     "lbvh_frame_signal": (_I32, [_P, _P, _U32, _U32]),
     "lbvh_frame_wait": (_I32, [_P, _P, _U32, _U32]),
     "lbvh_trace_primary_shard_packed": (_I32, [_P, C.POINTER(Camera), _U32, _U32, C.POINTER(Scene), _I32, _P, _P]),
     "lbvh_shard_records": (C.c_uint64, [_I32, _I32, _U32, _U32]),
     "lbvh_frame_unpack": (_I32, [_P, _P, C.c_uint64, _U32, _U32, _U32, _I32, _I32, _P]),
-    "lbvh_clock_probe": (_I32, [_P, C.POINTER(C.c_float)]),
-    "lbvh_trace_tile_costs": (_I32, [_P, C.POINTER(Camera), C.POINTER(Scene), _P, _P, _P]),
     "lbvh_shade": (_I32, [_P, _P, _SZ, _P, _P, _I32, _I32, _P]),
     "lbvh_compose": (_I32, [_P, _P, _P, _SZ, _P]),
     "lbvh_event_create": (_I32, [_P, C.POINTER(_P)]),
     "lbvh_event_destroy": (_I32, [_P, _P]),
     "lbvh_event_record": (_I32, [_P, _P]),
     "lbvh_event_elapsed_ms": (_I32, [_P, _P, _P, C.POINTER(C.c_float)]),
+}
+
+# include/lbvh_debug.h: not part of the drop-in boundary
+DEBUG_SWITCH_SORT_QUEUES, DEBUG_SWITCH_COLD_ORDER, DEBUG_SWITCH_BUILD_FORM, DEBUG_SWITCH_FRAME_WAIT_MS, DEBUG_SWITCH_SORT_FORM = range(5)
+DEBUG_SIGNATURES = {
+    "lbvh_debug_switch": (_I32, [_P, _U32, _U32]),
+    "lbvh_debug_sort_ticket_tile": (_U32, [_U32, _U32, _U32, _U32]),
+    "lbvh_debug_ray_stack_split": (_I32, [_P, _U32]),
+    "lbvh_debug_ray_walker": (_I32, [_P, _U32]),
+    "lbvh_debug_ray_stack_limit": (_I32, [_P, _U32]),
+    "lbvh_ray_stats_target": (_I32, [_P, _P]),
+    "lbvh_clock_probe": (_I32, [_P, C.POINTER(C.c_float)]),
+    "lbvh_trace_tile_costs": (_I32, [_P, C.POINTER(Camera), C.POINTER(Scene), _P, _P, _P]),
     "lbvh_profile_begin": (_I32, [_P]),
     "lbvh_profile_end": (_I32, [_P, C.POINTER(ProfileRow), _I32, C.POINTER(_I32)]),
     "lbvh_copy_bandwidth_probe": (_I32, [_P, _P, _P, _SZ]),
 }
 
-for _name, (_res, _args) in SIGNATURES.items():
+for _name, (_res, _args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
     _fn = getattr(lib, _name)          # AttributeError here = library/header mismatch
     _fn.restype = _res
     _fn.argtypes = _args

@@ -164,8 +164,7 @@ static lbvh_status create_impl(int32_t device_id, void* stream, bool own, lbvh_c
             full = false;           // a caller's stream whose mask cannot be read: assume nothing
         }
         (void)hipGetLastError();
-        ctx->sort_queues = full ? 8u : 1u;
-        if (getenv("LBVH_SORT_QUEUES")) ctx->sort_queues = atoi(getenv("LBVH_SORT_QUEUES")) == 8 ? 8u : 1u;   // tests: force a mode
+        ctx->sort_queues = ctx->sort_queues_detected = full ? 8u : 1u;      // (tests force a mode: lbvh_debug_switch)
     }
     if (hipHostMalloc((void**)&ctx->fault_host, 256, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&ctx->fault_dev, ctx->fault_host, 0) != hipSuccess) {
@@ -359,9 +358,11 @@ lbvh_status lbvh_sync_event_create(lbvh_context* ctx, void** out_event)
     LBVH_REQUIRE(ctx, out_event != nullptr);
     // an ORDERING event: its record is a system-scope release (what the timing events of lbvh_event_create leave out), so
     // whoever waits for it — another GPU's stream included — sees every store enqueued before it
+    // hipEventReleaseToSystem spelled out: whether a plain event's record releases to system scope is a runtime default
+    // (HIP_EVENT_SYS_RELEASE), and the documented contract must not depend on it
     hipEvent_t ev;
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    LBVH_HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventReleaseToSystem));
     *out_event = (void*)ev;
     return LBVH_OK;
 }
@@ -420,16 +421,71 @@ __global__ void frame_signal_kernel(uint32_t* flag, uint32_t value)
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ __launch_bounds__(64) void frame_wait_kernel(const uint32_t* flags, uint32_t n_slots, uint32_t value, uint32_t* fault)
+// The bound is WALL CLOCK (s_memrealtime: the constant 100 MHz counter), not a poll count: the waiting side may be enqueued
+// long before the signalling process has even initialised its GPU, and how fast polls come back depends on where the
+// flag lives (own HBM, or the owner's over xGMI).
+__global__ __launch_bounds__(64) void frame_wait_kernel(const uint32_t* flags, uint32_t n_slots, uint32_t value, uint32_t* fault,
+                                                        unsigned long long timeout_ticks)
 {
     const uint32_t lane = threadIdx.x;
     bool here = lane >= n_slots;
-    for (uint32_t spin = 0; spin < LBVH_SPIN_LIMIT; spin++) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
         if (!here) here = (int32_t)(__hip_atomic_load(flags + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) >= 0;
         if (__builtin_amdgcn_ballot_w64(!here) == 0) return;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) break;
         __builtin_amdgcn_s_sleep(16);
     }
     if (lane == 0) __hip_atomic_store(fault, LBVH_FAULT_FRAME_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+lbvh_status lbvh_flags_alloc(lbvh_context* ctx, size_t n_words, uint32_t** out_d_flags)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, out_d_flags != nullptr && n_words > 0);
+    *out_d_flags = nullptr;
+    LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void* p = nullptr;
+    // uncached: a kernel that polls these words while another GPU / process stores into them must read the memory, not a
+    // line its own L2 may keep for as long as the kernel runs (coarse-grained hipMalloc memory promises nothing before the
+    // kernel's end) — ADVICE r4.  256-byte granules so that no two flag arrays ever share a line.
+    const size_t bytes = (n_words * 4 + 255) & ~(size_t)255;
+    LBVH_HIP_TRY(ctx, hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached));
+    const hipError_t e = hipMemsetAsync(p, 0, bytes, ctx->stream);
+    if (e != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipFree(p);
+        return lbvh_set_error(ctx, LBVH_ERR_HIP, "lbvh_flags_alloc", "clearing the flag words failed");
+    }
+    *out_d_flags = (uint32_t*)p;
+    return LBVH_OK;
+}
+
+lbvh_status lbvh_debug_switch(lbvh_context* ctx, uint32_t which, uint32_t value)
+{
+    if (!ctx) return LBVH_ERR_INVALID_ARG;
+    LBVH_REQUIRE(ctx, which < LBVH_DEBUG_SWITCHES);
+    switch (which) {
+    case LBVH_DEBUG_SORT_QUEUES:
+        LBVH_REQUIRE(ctx, value == 0 || value == 1 || value == 8);
+        ctx->sort_queues = value ? value : ctx->sort_queues_detected;
+        break;
+    case LBVH_DEBUG_COLD_ORDER: LBVH_REQUIRE(ctx, value <= 1); break;
+    case LBVH_DEBUG_BUILD_FORM:
+        LBVH_REQUIRE(ctx, value <= 4);
+        // a captured graph belongs to the form it was captured under
+        if (value != ctx->debug_switch[which] && ctx->build_graph) {
+            LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipGraphExecDestroy(ctx->build_graph);
+            ctx->build_graph = nullptr;
+            ctx->build_graph_key = 0;
+        }
+        ctx->build_graph_off = false;
+        break;
+    case LBVH_DEBUG_SORT_FORM: LBVH_REQUIRE(ctx, value <= 1); break;
+    default: break;
+    }
+    ctx->debug_switch[which] = value;
+    return LBVH_OK;
 }
 
 lbvh_status lbvh_frame_signal(lbvh_context* ctx, uint32_t* d_flags, uint32_t slot, uint32_t value)
@@ -449,7 +505,8 @@ lbvh_status lbvh_frame_wait(lbvh_context* ctx, const uint32_t* d_flags, uint32_t
     if (n_slots == 0) return LBVH_OK;
     LBVH_REQUIRE(ctx, d_flags != nullptr && ((uintptr_t)d_flags & 3) == 0);
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    LBVH_LAUNCH(ctx, frame_wait_kernel, dim3(1), dim3(64), d_flags, n_slots, value, ctx->fault_dev);
+    const uint32_t ms = ctx->debug_switch[LBVH_DEBUG_FRAME_WAIT_MS] ? ctx->debug_switch[LBVH_DEBUG_FRAME_WAIT_MS] : 20000u;
+    LBVH_LAUNCH(ctx, frame_wait_kernel, dim3(1), dim3(64), d_flags, n_slots, value, ctx->fault_dev, (unsigned long long)ms * 100000ull);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }

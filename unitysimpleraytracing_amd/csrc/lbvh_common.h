@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/lbvh.h"
+#include "../../include/lbvh_debug.h"
 
 static_assert(sizeof(lbvh_aabb) == 32, "AABB must be 32 bytes (Sc/MeshBufferContainer.cs:103)");
 static_assert(sizeof(lbvh_triangle) == 128, "Triangle must be 128 bytes (Sc/MeshBufferContainer.cs:98)");
@@ -105,6 +106,9 @@ struct lbvh_context {
     // sort: 8 per-XCD ticket queues only on the layout they were designed for (all 256 CUs of an SPX device behind an
     // unmasked stream: workgroups dealt round-robin over the XCDs); anything else takes tiles in ticket order
     uint32_t sort_queues = 1;
+    uint32_t sort_queues_detected = 1;      // what lbvh_create found (lbvh_debug_switch(LBVH_DEBUG_SORT_QUEUES, 0) goes back to it)
+    // lbvh_debug_switch (include/lbvh_debug.h): all 0 in the product
+    uint32_t debug_switch[LBVH_DEBUG_SWITCHES] = {};
     // device-side protocol faults (a bounded spin gave up): one mapped host word, checked by lbvh_sync / download
     uint32_t* fault_host = nullptr;
     uint32_t* fault_dev = nullptr;

@@ -1439,8 +1439,7 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     }
     const uint32_t n_work = shard_work(a.tiles_x * a.tiles_y, a.shard_index, a.shard_count);
     if (n_work == 0) return LBVH_OK;
-    static const bool env_row_major = getenv("LBVH_COLD_ROW_MAJOR") != nullptr;      // measurement switch
-    a.centre_first = env_row_major ? 0u : 1u;
+    a.centre_first = ctx->debug_switch[LBVH_DEBUG_COLD_ORDER] ? 0u : 1u;      // (measurement switch: include/lbvh_debug.h)
     // [class counts | cost of each work item in the last trace | 16 class lists]: valid for one frame layout
     const size_t cost_bytes = (((size_t)n_work * 4) + 255) & ~(size_t)255;
     void* before = ctx->trace_queues;
@@ -1711,7 +1710,7 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
         if ((rc = (lbvh_status)lbvh_launch_sort(ctx, d_keys, d_indices, capacity, zero != nullptr)) != LBVH_OK) return rc;
     }
     const bool fast = (flags & LBVH_BUILD_FAST_SCENE) != 0;
-    static const bool env_two_streams = getenv("LBVH_BUILD_TWO_STREAMS") != nullptr;     // measurement switch: the round 2 - 3 form
+    const bool env_two_streams = ctx->debug_switch[LBVH_DEBUG_BUILD_FORM] >= 3;     // measurement switch: the round 2 - 3 form
     if (fast && !env_two_streams) {
         // both strands of the rest of the chain — derived scene, reference arrays — in three merged launches on this stream
         // (lbvh_build.hip "merged launches"): scenes up to 2 M triangles
@@ -1795,9 +1794,9 @@ static lbvh_status build_scene_impl(lbvh_context* ctx, const lbvh_anim* anim, co
     const uint64_t args_key = key;
     mix_scratch(mix);
     if (key == 0) key = 1;
-    static const bool env_no_graph = getenv("LBVH_NO_GRAPH") != nullptr;     // debugging / measurement switches
-    static const bool env_graph = getenv("LBVH_BUILD_GRAPH") != nullptr;
-    static const bool env_two_streams = getenv("LBVH_BUILD_TWO_STREAMS") != nullptr;
+    // debugging / measurement switches (lbvh_debug_switch LBVH_DEBUG_BUILD_FORM: 1 plain always, 2 graph always, 3 two streams plain, 4 two streams as a graph)
+    const uint32_t form = ctx->debug_switch[LBVH_DEBUG_BUILD_FORM];
+    const bool env_no_graph = form == 1 || form == 3, env_graph = form == 2 || form == 4, env_two_streams = form >= 3;
     // The replayed graph pays where the chain forks onto a second stream (the derived scene beyond the merged launches' size).  On
     // ONE stream — the merged chain's nine launches, the reference arrays alone — kernels enqueued one by one run 5 - 8 us sooner
     // than the graph (rebuild 0.241 against 0.249 ms, reference arrays alone 0.184 against 0.190, step 0.420 against 0.428:

@@ -12,8 +12,10 @@ behind the C ABI's "one frame from N GPUs" calls (include/lbvh.h):
            lbvh_frame_signal(flags[r - 1] := frame number) behind its trace, rank 0 enqueues lbvh_frame_wait — a bounded
            device-side wait — behind its own share; the other way round, rank 0 signals "frame f has been read" in front
            of its next share and the others wait for that before they store into the buffer again.  No host round trip and
-           no collective per frame; the ranks have to enqueue their frames within the wait's bound (LBVH_SPIN_LIMIT, seconds)
-           of each other.
+           no collective per frame; the ranks have to enqueue their frames within the wait's bound (20 s of wall clock) of
+           each other.  The flag words are uncached device memory (lbvh_flags_alloc): a kernel that polls them while another
+           GPU stores into them must not be served from its own L2.  UNVERIFIED ON MORE THAN ONE PHYSICAL GPU
+           until a multi-GPU run exists (every test and stand-in shares one GPU); `auto` keeps the self-test and the fallback.
   packed   every rank traces its share into a contiguous block (lbvh_trace_primary_shard_packed), the blocks reach rank 0
            by one torch.distributed gather (RCCL send / recv over xGMI), rank 0 puts them at their pixels
            (lbvh_frame_unpack).  The fallback when the GPUs cannot map each other's memory (or IPC is unavailable).
@@ -132,9 +134,8 @@ class FrameGather:
             try:
                 if self.world - 1 > self.CONSUMED_SLOT:
                     raise N.LbvhError(-1, f"the flag array has {self.CONSUMED_SLOT} completion slots")
-                self._flags = DataBuffer(ctx, self.FLAG_SLOTS, np.uint32, 0)
-                ctx.sync()               # the zero fill has happened before anybody may signal
-                payload = [(self.device_id, ctx.ipc_export(self.frame.device), ctx.ipc_export(self._flags.device))]
+                self._flags = ctx.flags_alloc(self.FLAG_SLOTS)      # zeroed, uncached (returns after the fill has happened)
+                payload = [(self.device_id, ctx.ipc_export(self.frame.device), ctx.ipc_export(self._flags))]
             except N.LbvhError as e:
                 err = str(e)
         dist.broadcast_object_list(payload, src=0)
@@ -160,7 +161,7 @@ class FrameGather:
                     ctx.frame_signal(self._peer_flags, self.rank - 1, 1)
                     ctx.sync()
                 else:
-                    ctx.frame_wait(self._flags.device, self.world - 1, 1)
+                    ctx.frame_wait(self._flags, self.world - 1, 1)
                     got = np.zeros(self.world * words, dtype=np.uint32)
                     N.check(ctx.handle, N.lib.lbvh_buffer_download(ctx.handle, got.ctypes.data_as(C.c_void_p), self.frame.device, got.nbytes))
                     for r in range(1, self.world):
@@ -185,7 +186,7 @@ class FrameGather:
                     pass
                 setattr(self, p, None)
         if getattr(self, "_flags", None) is not None:
-            self._flags.dispose()
+            self.ctx.flags_free(self._flags)
             self._flags = None
 
     # ---- packed shares + one gather ---------------------------------------------------------------------------------
@@ -203,11 +204,12 @@ class FrameGather:
         torch.cuda.synchronize()
 
     # ---- per frame --------------------------------------------------------------------------------------------------
-    def trace_share(self, camera, scene, trace_mode, own_done_event=None):
+    def trace_share(self, camera, scene, trace_mode, own_done_event=None, own_start_event=None):
         """Enqueue this rank's share of the frame and its way to rank 0.  On rank 0 the context's stream is, afterwards,
-        behind the WHOLE frame (every rank's records are in self.frame for whatever is enqueued next).  own_done_event: a
-        timing event recorded right behind this rank's own traversal (before any waiting / moving), for the `without the
-        gather` figure."""
+        behind the WHOLE frame (every rank's records are in self.frame for whatever is enqueued next).  own_start_event /
+        own_done_event: timing events recorded right in front of / behind this rank's own traversal — behind the wait for
+        rank 0's "frame read" word and before any waiting / moving of records — for the `without the gather` figure (the
+        span between them holds no cross-rank skew: ADVICE r4)."""
         ctx, rank, world = self.ctx, self.rank, self.world
         self.frame_no += 1
         if self.mode == "peer":
@@ -215,19 +217,23 @@ class FrameGather:
             # previous call (shading, a read-back) is in front of this signal, and the others wait for it — on the device, like
             # the completion flags — before their first store of the new frame (the `consumed` event of host.MultiGpuDrawer)
             if rank == 0:
-                ctx.frame_signal(self._flags.device, self.CONSUMED_SLOT, self.frame_no - 1)
+                ctx.frame_signal(self._flags, self.CONSUMED_SLOT, self.frame_no - 1)
             else:
                 ctx.frame_wait(C.c_void_p(self._peer_flags.value + 4 * self.CONSUMED_SLOT), 1, self.frame_no - 1)
+            if own_start_event is not None:
+                ctx.record(own_start_event)
             target = self.frame.device if rank == 0 else self._peer_frame
             N.check(ctx.handle, N.lib.lbvh_trace_primary_shard(ctx.handle, C.byref(camera), rank, world, C.byref(scene), trace_mode, target, None))
             if own_done_event is not None:
                 ctx.record(own_done_event)
             if rank == 0:
-                ctx.frame_wait(self._flags.device, world - 1, self.frame_no)
+                ctx.frame_wait(self._flags, world - 1, self.frame_no)
             else:
                 ctx.frame_signal(self._peer_flags, rank - 1, self.frame_no)
             return
         torch, dist = self.torch, self.dist
+        if own_start_event is not None:
+            ctx.record(own_start_event)
         N.check(ctx.handle, N.lib.lbvh_trace_primary_shard_packed(ctx.handle, C.byref(camera), rank, world, C.byref(scene), trace_mode,
                                                                   C.c_void_p(self._packed.data_ptr()), None))
         if own_done_event is not None:

@@ -121,6 +121,20 @@ class Context:
     def ipc_close(self, device_ptr):
         N.check(self.handle, N.lib.lbvh_ipc_close(self.handle, device_ptr))
 
+    def flags_alloc(self, n_words):
+        """n_words zeroed completion flags a running kernel may poll while another GPU / process stores into them (uncached
+        device memory, lbvh_flags_alloc); free with flags_free"""
+        p = C.c_void_p()
+        N.check(self.handle, N.lib.lbvh_flags_alloc(self.handle, int(n_words), C.byref(p)))
+        return p
+
+    def flags_free(self, flags_ptr):
+        N.check(self.handle, N.lib.lbvh_buffer_free(self.handle, flags_ptr))
+
+    def debug_switch(self, which, value):
+        """include/lbvh_debug.h: test / measurement switches of this context (all 0 in the product)"""
+        N.check(self.handle, N.lib.lbvh_debug_switch(self.handle, int(which), int(value)))
+
     def frame_signal(self, flags_ptr, slot, value):
         """flags[slot] := value (system-scope release) once everything enqueued so far has finished"""
         N.check(self.handle, N.lib.lbvh_frame_signal(self.handle, flags_ptr, slot, value))

@@ -23,11 +23,13 @@ static uint64_t splitmix64(uint64_t& s)
 }
 static float uniform(uint64_t& s, float lo, float hi) { return lo + (hi - lo) * (float)((splitmix64(s) >> 40) * (1.0 / 16777216.0)); }
 
-static std::vector<lbvh_triangle> random_mesh(uint32_t n)
+// doubled: every second triangle is a copy of the one before it — every hit on one is an exact t tie with the other
+static std::vector<lbvh_triangle> random_mesh(uint32_t n, bool doubled = false)
 {
     std::vector<lbvh_triangle> mesh(n);
     uint64_t seed = 1;
     for (auto& t : mesh) {
+        if (doubled && ((&t - mesh.data()) & 1)) { t = *(&t - 1); continue; }
         std::memset(&t, 0, sizeof t);
         for (int k = 0; k < 3; k++) {
             const float c = uniform(seed, -100.0f, 100.0f);
@@ -59,7 +61,10 @@ static int multi_main(int argc, char** argv)
     const int ranks = argc > 2 ? atoi(argv[2]) : 2;
     const uint32_t n = argc > 3 ? (uint32_t)atoi(argv[3]) : 4096;
     const int w = argc > 4 ? atoi(argv[4]) : 256, h = argc > 5 ? atoi(argv[5]) : 256;
-    const std::vector<lbvh_triangle> mesh = random_mesh(n);
+    // "doubled": a scene full of exact t ties — LBVH_TRACE_FAST_EXACT's tie resolution then runs on EVERY rank against the owner's
+    // frame (system-scope loads and compare-and-swaps on peer memory): ADVICE r4
+    const bool doubled = argc > 6 && std::strcmp(argv[6], "doubled") == 0;
+    const std::vector<lbvh_triangle> mesh = random_mesh(n, doubled);
     try {
         const int n_dev = lbvh::Context::device_count();
         if (n_dev <= 0) { std::fprintf(stderr, "no HIP device visible\n"); return 1; }
@@ -72,7 +77,7 @@ static int multi_main(int argc, char** argv)
         single.Awake();
         int frames = 0, equal = 0;
         size_t hits = 0;
-        for (int mode : {LBVH_TRACE_FAST, LBVH_TRACE_REFERENCE})
+        for (int mode : {LBVH_TRACE_FAST, LBVH_TRACE_REFERENCE, LBVH_TRACE_FAST_EXACT})
             for (int f = 0; f < 4; f++) {
                 // two frames from one camera (the second is dispatched by the first one's costs), then a turned one, then a
                 // rebuilt scene
@@ -87,6 +92,12 @@ static int multi_main(int argc, char** argv)
                                               (size_t)w * h * sizeof(lbvh_hit)) == 0;
                 frames++;
                 equal += same ? 1 : 0;
+                if (mode == LBVH_TRACE_FAST_EXACT) {      // ... and the exact mode's frame is the reference mode's, word for word
+                    single.Update(cam, LBVH_TRACE_REFERENCE);
+                    single.Hits().GetData();
+                    if (std::memcmp(multi.Hits().LocalBuffer().data(), single.Hits().LocalBuffer().data(), (size_t)w * h * sizeof(lbvh_hit)) != 0)
+                        equal--;
+                }
                 if (mode == LBVH_TRACE_REFERENCE && f == 0)
                     for (size_t i = 0; i < (size_t)w * h; i++) hits += multi.Hits().LocalBuffer()[i].t < LBVH_MAX_FLOAT ? 1 : 0;
             }
