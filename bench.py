@@ -564,8 +564,13 @@ def main():
         # against 8 TB/s — small, because the walk prunes (the reference algorithm's bytes priced at this duration would be
         # several times the peak: `reference_equivalent_GBs`) and because the scene it walks is cache-resident.  The busiest unit
         # of the kernel is the vector pipe, carried beside it under its own name (`valu_issue`); DESIGN 13.3 for what binds a step.
-        roofline = {"roofline_version": 3,        # 3 (round 3 on): frac = HBM fraction of the kernel's own bytes; valu_issue against the 2-cycle rate
-                    "kernel": kname, "kernel_ms": round(trace_kernel_ms, 4), "bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS,
+        # roofline_version 4 (round 5): `bound` says what DESIGN 13.3 measured — a step is a ~90-instruction
+        # dependent chain across the vector pipe (busy 0.9), the scalar unit and the memory system: "issue+latency" — while
+        # achieved / peak / frac stay the HBM figures SURVEY 8(d) asks for (`roofline_of`); the counters that matter are also
+        # flat scalars (traffic_bytes, valu_pipe_busy_frac, ...) beside the nested objects
+        roofline = {"roofline_version": 4,
+                    "kernel": kname, "kernel_ms": round(trace_kernel_ms, 4), "bound": "issue+latency", "roofline_of": "hbm",
+                    "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": hbm["frac"],
                     "algorithmic_bytes": round(bytes_per_ray * W * H), "bytes_per_ray": hbm["bytes_per_ray"],
                     "bytes_per_ray_basis": hbm["bytes_per_ray_basis"], "measured_copy_GBs": hbm["measured_copy_GBs"],
@@ -596,6 +601,16 @@ def main():
         else:
             roofline["valu_issue"] = None
         roofline["traffic"] = traffic
+        # the same as flat scalars (a parser that keeps one level of the object keeps these)
+        roofline["traffic_bytes"] = traffic["bytes"] if traffic else None
+        roofline["traffic_fetch_bytes"] = traffic["fetch_bytes_x2"] if traffic else None
+        roofline["traffic_write_bytes"] = traffic["write_bytes"] if traffic else None
+        roofline["traffic_over_algorithmic"] = round(traffic["bytes"] / (bytes_per_ray * W * H), 3) if traffic else None
+        vi = roofline["valu_issue"]
+        for k_flat, k_src in (("valu_pipe_busy_frac", "pipe_busy_frac"), ("valu_issue_frac", "frac"), ("valu_per_step", "valu_per_step"),
+                              ("salu_per_step", "salu_per_step"), ("steps_per_frame", "steps"), ("cycles_per_valu", "cycles_per_valu"),
+                              ("salu_issue_frac", "salu_issue_frac"), ("lane_utilisation", "lane_utilisation")):
+            roofline[k_flat] = vi[k_src] if vi else None
         # what the kernel replaces: the reference algorithm's per-ray walk, priced at this kernel's duration (a speed-up
         # figure, not a roofline fraction)
         roofline["reference_equivalent_GBs"] = round(ref_bytes(rs) * W * H / (trace_kernel_ms * 1e-3) / 1e9, 1)
@@ -624,6 +639,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall_ms, 4),
             "build_ms": round(build_ms_max, 4), "trace_ms": round(trace_ms_max, 4),
+            # `value` is the best of three cases (every timed frame is dispatched from the identical previous frame's per-tile
+            # costs): the same share as a FIRST frame and under a camera turning 1 degree per frame, first-class beside it
+            "value_cold": round(W * H / (extras["trace_cold_ms"] * 1e-3) / 1e6, 2) if extras else None,
+            "value_moving": round(W * H / (extras["trace_moving_ms"] * 1e-3) / 1e6, 2) if extras else None,
+            "value_static_scene": round(W * H / (extras["trace_static_scene_ms"] * 1e-3) / 1e6, 2) if extras else None,
+            "trace_cold_ms": extras.get("trace_cold_ms"), "trace_moving_ms": extras.get("trace_moving_ms"),
+            "trace_static_scene_ms": extras.get("trace_static_scene_ms"),
             "build_reference_stages_ms": round(ref_build_ms, 4),
             "build_reference_stages_Mtri_s": round(n_tris / (ref_build_ms * 1e-3) / 1e6, 2),
             "value_without_gather": round(W * H / (own_trace_ms_max * 1e-3) / 1e6, 2),
@@ -774,11 +796,15 @@ def cpu_leg(tris, cam):
     nb1, s1 = build_rate(1, 3.0)
     nbt, st = build_rate(threads, 3.0)
     r1, step1, n1, dt1 = trace_rate(1, 6.0)
-    rt, stept, nt, dtt = trace_rate(threads, 6.0)
-    return {"value": round(rt, 4), "unit": "Mrays/s", "build_Mtri_s": round(len(tris) / st / 1e6, 4), "cores": threads, "kind": "port",
+    # the trace leg is embarrassingly parallel (8x8 ray tiles handed out dynamically, no barriers): every core the process may
+    # use, not the count that suits the barrier-heavy build
+    rt, stept, nt, dtt = trace_rate(allowed, 6.0)
+    return {"value": round(rt, 4), "unit": "Mrays/s", "build_Mtri_s": round(len(tris) / st / 1e6, 4), "cores": allowed, "kind": "port",
+            "nproc": os.cpu_count(), "cores_allowed": allowed, "trace_cores": allowed, "build_cores": threads,
             "scalar": {"value": round(r1, 4), "unit": "Mrays/s", "build_Mtri_s": round(len(tris) / s1 / 1e6, 4), "cores": 1},
-            "sample": f"OpenMP x{threads}: best of {nbt} warm 1M-triangle rebuilds ({st:.4f} s) + the 1080p frame sampled every {stept} "
-                      f"pixel(s) in x and y ({nt} rays, {dtt:.2f} s); scalar: best of {nb1} rebuilds ({s1:.3f} s) + every {step1} "
+            "sample": f"the box shows {os.cpu_count()} hardware threads, this process may use {allowed}; OpenMP: best of {nbt} warm 1M-triangle "
+                      f"rebuilds on {threads} threads (the count that builds fastest: {st:.4f} s) + the 1080p frame on {allowed} threads sampled "
+                      f"every {stept} pixel(s) in x and y ({nt} rays, {dtt:.2f} s); scalar: best of {nb1} rebuilds ({s1:.3f} s) + every {step1} "
                       f"pixel(s) ({n1} rays, {dt1:.2f} s); reference visit order (no pruning), 8x8 ray tiles handed out dynamically"}
 
 
