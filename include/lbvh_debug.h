@@ -22,7 +22,8 @@ extern "C" {
  *                               triangles, a replayed two-stream graph above), 1 plain launches always, 2 a replayed graph
  *                               always, 3 the two-stream form (plain), 4 the two-stream form as a graph
  *   LBVH_DEBUG_FRAME_WAIT_MS    wall-clock bound of lbvh_frame_wait's device-side wait in milliseconds (0: the default, 20 s)
- *   LBVH_DEBUG_SORT_FORM        1: lbvh_sort_pairs always runs the four 8-bit LSD passes (0: the two-level form where it applies) */
+ *   LBVH_DEBUG_SORT_FORM        1: the sort always runs the four 8-bit LSD passes, 2: the two-level form wherever the size allows
+ *                               (0: chosen per call from the last sort's largest bucket) */
 enum {
     LBVH_DEBUG_SORT_QUEUES = 0,
     LBVH_DEBUG_COLD_ORDER = 1,

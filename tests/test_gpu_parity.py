@@ -102,6 +102,108 @@ def test_sort_single_ticket_queue_mode():
         c1.close()
 
 
+# ---- round 5: the two-level form (one MSD pass + one bucket-local kernel) for 2^15 <= count < 2^21 --------------------------------
+
+@pytest.fixture
+def sort_form(ctx):
+    """forces the sort's form on the shared context for one test (lbvh_debug_switch LBVH_DEBUG_SORT_FORM) and restores the default"""
+    def force(form):
+        ctx.debug_switch(N().DEBUG_SWITCH_SORT_FORM, form)
+    yield force
+    ctx.debug_switch(N().DEBUG_SWITCH_SORT_FORM, 0)
+
+
+@pytest.mark.parametrize("count", [1 << 15, (1 << 15) + 1, 40000, 65536 + 63, 100003, 262144, 524288 - 1, 1000448, 1500001, (1 << 21) - 1])
+def test_sort_two_level_random_sizes(ctx, sort_form, count):
+    """Both forms on the same input, each forced: the unique stable sort either way (oracle), for sizes across the form's range —
+    buckets of ~128 .. ~8 192 pairs (uniform 32-bit keys: the bucket digit is the top byte)."""
+    keys, vals = sort_inputs(count, count, "random")
+    ok, ov = O.sort_pairs(keys, vals)
+    for form in (2, 1):
+        sort_form(form)
+        gk, gv = gpu_sort(ctx, keys, vals)
+        assert (gk == ok).all() and (gv == ov).all(), form
+
+
+@pytest.mark.parametrize("kind", ["morton_pads", "all_equal", "few_digits", "reversed", "one_bucket_low_bits", "two_hot_buckets"])
+@pytest.mark.parametrize("count", [40000, 131072, 300001])
+def test_sort_two_level_skewed_buckets(ctx, sort_form, kind, count):
+    """The two-level form forced on inputs whose buckets do NOT fit one workgroup's registers (everything in one bucket, a few
+    hot buckets, duplicates only): the bucket kernel's chunk-by-chunk path through global memory — three passes, and four in the
+    last bucket (0xDEADBEEF, the pads) with its copy back.  Stable: the values are a permutation, equal keys keep their order."""
+    if kind == "one_bucket_low_bits":
+        rng = np.random.default_rng(5)
+        keys = (0x42000000 | rng.integers(0, 1 << 24, size=count, dtype=np.uint64)).astype(np.uint32)
+        keys[: count // 3] = keys[count // 3: 2 * (count // 3)]      # duplicates too
+        vals = rng.permutation(count).astype(np.uint32)
+    elif kind == "two_hot_buckets":
+        rng = np.random.default_rng(6)
+        keys = rng.integers(0, 1 << 32, size=count, dtype=np.uint64).astype(np.uint32)
+        hot = rng.random(count)
+        keys[hot < 0.45] = (0x07000000 | (keys[hot < 0.45] & 0x00FFFFFF))
+        keys[hot > 0.60] = (0xFF000000 | (keys[hot > 0.60] & 0x00FFFFFF))
+        vals = rng.permutation(count).astype(np.uint32)
+    else:
+        keys, vals = sort_inputs(count, 17, kind)
+    ok, ov = O.sort_pairs(keys, vals)
+    sort_form(2)
+    gk, gv = gpu_sort(ctx, keys, vals)
+    assert (gk == ok).all() and (gv == ov).all()
+
+
+def test_sort_form_follows_the_last_sorts_largest_bucket():
+    """The default (no switch): a context's first sort takes the four passes and leaves its largest bucket behind; after a
+    uniform input the next sort is two-level, after a skewed one it is four passes again — seen in the per-kernel profile.  Every
+    result is the oracle's whatever the form."""
+    c = H().Context(0)
+    try:
+        def kernels(keys, vals):
+            kb, vb = up(c, keys, np.uint32), up(c, vals, np.uint32)
+            c.profile_begin()
+            N().check(c.handle, N().lib.lbvh_sort_pairs(c.handle, kb.device, vb.device, len(keys)))
+            prof = c.profile_end()
+            k, v = kb.get_data()[: len(keys)].copy(), vb.get_data()[: len(keys)].copy()
+            kb.dispose(); vb.dispose()
+            ok, ov = O.sort_pairs(keys, vals)
+            assert (k == ok).all() and (v == ov).all()
+            return prof
+        uniform = sort_inputs(300001, 1, "random")
+        skewed = sort_inputs(300001, 2, "all_equal")
+        forms = []
+        for keys, vals in (uniform, uniform, skewed, skewed, uniform, uniform):
+            prof = kernels(keys, vals)
+            forms.append("two" if any("sort_bucket_kernel" in k for k in prof) else "four")
+        # first: nothing known -> four; then uniform -> two; the skewed input is still sorted two-level ONCE (slow path), then four
+        assert forms == ["four", "two", "two", "four", "four", "two"], forms
+    finally:
+        c.close()
+
+
+def test_rebuild_with_the_two_level_sort_is_bit_exact(ctx, sort_form):
+    """lbvh_build_scene with the sort's form forced either way (the build's bucket digit is bits 22..29: Morton codes below 2^30,
+    the pads and nothing else in the last bucket): keys, indices and every node word identical to the oracle on the tiled-torus
+    scene (1/8 size), a scene with every triangle twice and a scene inside ONE Morton cell (one bucket: the slow path)."""
+    scenes_ = {"torus": scenes.tiled_torus(nu=40, nv=25), "doubled": None, "one_cell": None}
+    t = scenes.tiled_torus(nu=24, nv=16, grid=3)
+    t[1::2] = t[0::2][: len(t[1::2])]
+    scenes_["doubled"] = t
+    small = scenes.random_triangles(60000, seed=9, extent=0.1, edge=0.01)
+    scenes_["one_cell"] = small
+    for name, tris in scenes_.items():
+        b = None
+        for form in (2, 1, 2):
+            sort_form(form)
+            d = H().RaytracingMeshDrawer(ctx, tris).awake()
+            d.rebuild()
+            c = d.container
+            c.get_all_gpu_data()
+            if b is None:
+                b = O.Built(tris, capacity=c.capacity, threads=8)
+            assert (c.keys.local == b.keys).all() and (c.triangle_index.local == b.indices).all(), (name, form)
+            assert (words(c.bvh_internal_node.local) == words(b.internal)).all() and (words(c.bvh_leaf_node.local) == words(b.leaf)).all(), (name, form)
+            d.on_destroy()
+
+
 def test_sort_count_zero_and_repeat(ctx):
     kb, vb = up(ctx, np.zeros(4, np.uint32)), up(ctx, np.zeros(4, np.uint32))
     N().check(ctx.handle, N().lib.lbvh_sort_pairs(ctx.handle, kb.device, vb.device, 0))

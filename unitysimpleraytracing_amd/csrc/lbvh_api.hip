@@ -174,6 +174,8 @@ static lbvh_status create_impl(int32_t device_id, void* stream, bool own, lbvh_c
         return lbvh_set_error(nullptr, LBVH_ERR_OUT_OF_MEMORY, "lbvh_create", "no mapped host memory for the fault word");
     }
     memset(ctx->fault_host, 0, 256);
+    // words 16 .. 19: the largest bucket of the last sort (lbvh_sort.hip, the two-level form's hint); nothing known yet
+    for (int i = 16; i < 20; i++) ctx->fault_host[i] = 0xFFFFFFFFu;
     *out_ctx = ctx;
     return LBVH_OK;
 }
@@ -481,7 +483,7 @@ lbvh_status lbvh_debug_switch(lbvh_context* ctx, uint32_t which, uint32_t value)
         }
         ctx->build_graph_off = false;
         break;
-    case LBVH_DEBUG_SORT_FORM: LBVH_REQUIRE(ctx, value <= 1); break;
+    case LBVH_DEBUG_SORT_FORM: LBVH_REQUIRE(ctx, value <= 2); break;
     default: break;
     }
     ctx->debug_switch[which] = value;

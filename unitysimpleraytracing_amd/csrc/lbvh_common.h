@@ -219,7 +219,9 @@ int lbvh_launch_post_sort_merged(lbvh_context* ctx, uint32_t n, uint32_t* d_keys
                                  lbvh_fast_node* d_fused, uint32_t leaf_base, bool* done);
 // the sort with its scratch described / already cleared by the caller
 int lbvh_sort_scratch(lbvh_context* ctx, uint32_t count, uint32_t** d_zero, uint32_t* zero_words);
-int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t count, bool scratch_cleared);
+// key_bits: keys below 2^key_bits are the common case (30 for Morton codes; anything above still sorts correctly): where the
+// two-level form (lbvh_sort.hip) takes its bucket digit from
+int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t count, bool scratch_cleared, uint32_t key_bits = 32u);
 // the frontier counter lbvh_launch_refit(n) will use on the current lane (sizes the scratch)
 int lbvh_refit_counter(lbvh_context* ctx, uint32_t n, uint32_t** d_counter);
 // the stand-alone refit (lbvh_refit): d_sorted_indices may be nullptr (boxes already in leaf order)

@@ -34,7 +34,20 @@
 // reaches memory as two masked partial writes; on one XCD the halves merge in its L2.  So tickets are
 // per XCD and hand out kGroup CONSECUTIVE tiles to each XCD in turn (measured on the access pattern
 // alone, tools/ubench/tilecopy.hip: 2.9 -> 4.0 TB/s for unaligned 128-B runs).
+// Round 5 — the TWO-LEVEL form for latency-bound sizes (2^15 <= count < 2^21: the 1 M-triangle rebuild).  There a pass is not
+// bandwidth but the latency of ~250 dependent tiles (ticket, rank, two-level look-back, scatter: 15 us each, 62 us for four).
+// Two-level: ONE global onesweep pass on the most significant digit (stable partition into 256 buckets; digit =
+// min(key >> msd_shift, 255), msd_shift = key_bits - 8 from the caller's hint: 22 for Morton codes < 2^30, so that 0xFFFFFFFF
+// pads and anything else >= 2^30 land in the last bucket), then ONE kernel in which a workgroup sorts its whole bucket by the
+// remaining low bits — 3 stable 8-bit LSD passes (4 over the full key for the last bucket) with the pairs in registers and the
+// exchanges through LDS, no look-back, no global traffic between the passes.  Two launches and one look-back chain instead of
+// five and four.  The result is the same unique stable sort.  A bucket beyond one workgroup's registers (16 384 pairs) is
+// sorted by its workgroup chunk by chunk through global memory: correct for any input, slow — so the form is chosen per call
+// from the LAST sort's largest bucket (mapped host words the first pass kernel leaves behind; a hint one sort stale, like the
+// traversal's dispatch history: either form gives the same words).
 #include "lbvh_common.h"
+
+#include <algorithm>
 
 namespace {
 
@@ -48,14 +61,21 @@ constexpr uint32_t kValueMask = (1u << 30) - 1u;
 constexpr int kLook = 2;                   // group words inspected per look-back step
 constexpr int kLbGroup = 8;                // tiles per look-back group
 
+// the most significant digit of the two-level form: everything at or above 255 << msd_shift shares the last bucket
+__device__ __forceinline__ uint32_t msd_digit(uint32_t k, uint32_t msd_shift) { return min(k >> msd_shift, (uint32_t)kRadix - 1u); }
+
 // ---- all four digit histograms in one read of the keys ------------------------------------------
+// HIST_FOUR: ghist[p][256] for the four LSD passes; HIST_MSD: ghist[4][256] = the bucket sizes of the two-level form (with
+// HIST_FOUR too: the four-pass form keeps the statistic the next call's choice is made from)
+enum { HIST_FOUR = 1, HIST_MSD = 2 };
+template <int MODE>
 __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t* __restrict__ keys,
-                                                                  uint32_t count, uint32_t* __restrict__ ghist)
+                                                                  uint32_t count, uint32_t* __restrict__ ghist, uint32_t msd_shift)
 {
-    __shared__ uint32_t s_hist[kPasses][kRadix];
+    __shared__ uint32_t s_hist[kPasses + 1][kRadix];
     const uint32_t t = threadIdx.x;
 #pragma unroll
-    for (int p = 0; p < kPasses; p++) s_hist[p][t] = 0;
+    for (int p = 0; p < kPasses + 1; p++) s_hist[p][t] = 0;
     __syncthreads();
     // grid-stride over 16-B vectors (4 keys per lane per load), 2 loads in flight per thread
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -77,21 +97,34 @@ __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t
         const uint32_t nactive = (uint32_t)__popcll(active);
         if (__all(k == k0)) {
             if (first) {
+                if (MODE & HIST_FOUR) {
 #pragma unroll
-                for (int p = 0; p < kPasses; p++) atomicAdd(&s_hist[p][(k0 >> (8 * p)) & 255u], nactive);
+                    for (int p = 0; p < kPasses; p++) atomicAdd(&s_hist[p][(k0 >> (8 * p)) & 255u], nactive);
+                }
+                if (MODE & HIST_MSD) atomicAdd(&s_hist[kPasses][msd_digit(k0, msd_shift)], nactive);
             }
             return;
         }
-        atomicAdd(&s_hist[0][k & 255u], 1u);
-        atomicAdd(&s_hist[1][(k >> 8) & 255u], 1u);
+        if (MODE & HIST_FOUR) {
+            atomicAdd(&s_hist[0][k & 255u], 1u);
+            atomicAdd(&s_hist[1][(k >> 8) & 255u], 1u);
 #pragma unroll
-        for (int p = 2; p < kPasses; p++) {
-            const uint32_t d = (k >> (8 * p)) & 255u;
-            const uint32_t d0 = (k0 >> (8 * p)) & 255u;
+            for (int p = 2; p < kPasses; p++) {
+                const uint32_t d = (k >> (8 * p)) & 255u;
+                const uint32_t d0 = (k0 >> (8 * p)) & 255u;
+                if (__all(d == d0)) {
+                    if (first) atomicAdd(&s_hist[p][d0], nactive);
+                } else {
+                    atomicAdd(&s_hist[p][d], 1u);
+                }
+            }
+        }
+        if (MODE & HIST_MSD) {
+            const uint32_t d = msd_digit(k, msd_shift), d0 = msd_digit(k0, msd_shift);
             if (__all(d == d0)) {
-                if (first) atomicAdd(&s_hist[p][d0], nactive);
+                if (first) atomicAdd(&s_hist[kPasses][d0], nactive);
             } else {
-                atomicAdd(&s_hist[p][d], 1u);
+                atomicAdd(&s_hist[kPasses][d], 1u);
             }
         }
     };
@@ -114,13 +147,17 @@ __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t
         const uint32_t idx = t < 4u ? t : tail0 + (t - 4u);
         if (t < 4u ? t < head : idx < count) {
             const uint32_t k = keys[idx];
+            if (MODE & HIST_FOUR) {
 #pragma unroll
-            for (int p = 0; p < kPasses; p++) atomicAdd(&s_hist[p][(k >> (8 * p)) & 255u], 1u);
+                for (int p = 0; p < kPasses; p++) atomicAdd(&s_hist[p][(k >> (8 * p)) & 255u], 1u);
+            }
+            if (MODE & HIST_MSD) atomicAdd(&s_hist[kPasses][msd_digit(k, msd_shift)], 1u);
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < kPasses; p++) {
+    for (int p = 0; p < kPasses + 1; p++) {
+        if (p < kPasses ? !(MODE & HIST_FOUR) : !(MODE & HIST_MSD)) continue;
         const uint32_t c = s_hist[p][t];
         if (c) atomicAdd(&ghist[p * kRadix + t], c);
     }
@@ -134,11 +171,14 @@ __host__ __device__ __forceinline__ uint32_t ticket_tile(uint32_t k, uint32_t x,
 }
 
 // ---- one pass: rank + look-back + scatter ----------------------------------------------------------
-template <int THREADS, int ITEMS, bool STREAM>
+// MSD: the two-level form's one global pass — digit = msd_digit(key, shift) instead of a byte of the key
+template <int THREADS, int ITEMS, bool STREAM, bool MSD = false>
 __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t count, uint32_t shift,
     const uint32_t* __restrict__ ghist,   // [256] digit totals of this pass
+    const uint32_t* __restrict__ msd_hist,// (nullable) [256] bucket sizes of the two-level form: tile 0 leaves their maximum ...
+    uint32_t* bucket_stat,                // ... in these four mapped host words (the NEXT sort's choice of form)
     uint32_t* status,                     // [tiles][256] tile words of this pass (zeroed per sort)
     uint32_t* gstatus,                    // [ceil(tiles / kLbGroup)][256] group words of this pass (zeroed per sort)
     uint32_t* tickets,                    // [8] per-XCD tile tickets of this pass (zeroed per sort)
@@ -184,6 +224,13 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     const uint32_t tile = s_tile;
     const uint32_t base = tile * (uint32_t)TILE;
     const uint32_t nvalid = min((uint32_t)TILE, count - base);
+    auto digit_of = [shift](uint32_t k) { return MSD ? msd_digit(k, shift) : (k >> shift) & (uint32_t)(kRadix - 1); };
+    if (msd_hist && tile == 0 && w < (uint32_t)DWAVES) {       // the largest bucket of this input (a hint for the next call)
+        uint32_t m = msd_hist[t];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+        if (lane == 0) __hip_atomic_store(bucket_stat + w, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // 4 words: the host takes their maximum
+    }
 
     // exclusive scan of the pass's digit totals = first output index of each digit (every tile
     // recomputes it from 1 KB of L2-resident counters: cheaper than a launch)
@@ -231,7 +278,7 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         const unsigned long long lane_bit = 1ull << lane;
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
-            const uint32_t d = (key[i] >> shift) & (kRadix - 1);
+            const uint32_t d = digit_of(key[i]);
             u32x4* cell = cells + d;
             __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(cell), lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const u32x4 c = *reinterpret_cast<volatile u32x4*>(cell);
@@ -334,7 +381,7 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     // Keys and values go through the SAME LDS buffer one after the other: half the LDS per tile.
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
-        const uint32_t d = (key[i] >> shift) & (kRadix - 1);
+        const uint32_t d = digit_of(key[i]);
         const uint32_t r = (i & 1) ? rank2[i / 2] >> 16 : rank2[i / 2] & 0xFFFFu;
         const uint32_t lpos = (uint32_t)s_wcnt[w][d] + r;            // local position in the digit-sorted tile
         if (i & 1) rank2[i / 2] = (rank2[i / 2] & 0xFFFFu) | (lpos << 16); else rank2[i / 2] = (rank2[i / 2] & 0xFFFF0000u) | lpos;
@@ -395,7 +442,7 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     for (int j = 0; j < ITEMS; j++) {
         const uint32_t pos = (uint32_t)j * THREADS + t;
         const uint32_t k = s_xchg[pos];
-        const uint32_t d = (k >> shift) & (kRadix - 1);
+        const uint32_t d = digit_of(k);
         if (j & 3) dig4[j / 4] |= d << (8 * (j & 3)); else dig4[j / 4] = d;
         const uint32_t dst = s_gofs[d] + pos;
         if (pos < nvalid) __builtin_amdgcn_raw_buffer_store_b32(k, keys_rsrc, dst * 4u, 0, 0);
@@ -417,12 +464,12 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
 template <int THREADS, int ITEMS, bool STREAM>
 void launch_passes(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t* alt_keys, uint32_t* alt_vals,
                    uint32_t count, uint32_t tiles, uint32_t* ghist, uint32_t* status, uint32_t* gstatus, uint32_t groups,
-                   uint32_t* tickets, uint32_t group)
+                   uint32_t* tickets, uint32_t group, const uint32_t* msd_hist = nullptr, uint32_t* bucket_stat = nullptr)
 {
     uint32_t *ks = d_keys, *vs = d_values, *kd = alt_keys, *vd = alt_vals;
     for (uint32_t p = 0; p < (uint32_t)kPasses; p++) {   // ComputeBufferSorter.cs:102
         LBVH_LAUNCH(ctx, (sort_onesweep_kernel<THREADS, ITEMS, STREAM>), dim3(tiles), dim3(THREADS), ks, vs, kd, vd, count,
-                    8u * p, ghist + p * kRadix, status + (size_t)p * tiles * kRadix,
+                    8u * p, ghist + p * kRadix, p == 0 ? msd_hist : nullptr, bucket_stat, status + (size_t)p * tiles * kRadix,
                     gstatus + (size_t)p * groups * kRadix, tickets + 8u * p, tiles, group, ctx->sort_queues, ctx->fault_dev);
         uint32_t* tmp;
         tmp = ks; ks = kd; kd = tmp;
@@ -450,8 +497,9 @@ static int sort_prepare(lbvh_context* ctx, uint32_t count, sort_plan* pl)
     const uint32_t tile = (uint32_t)threads * (uint32_t)items;
     const uint32_t tiles = (uint32_t)(((uint64_t)count + tile - 1) / tile);
     const size_t pair_bytes = (((size_t)count * 4) + 255) & ~(size_t)255;
-    // [ghist 4x256 | tickets (4 passes x 8 XCDs, padded to 256 B) | tile words 4 x tiles x 256 | group words] is zeroed per sort
-    const size_t head_bytes = (size_t)kPasses * kRadix * 4 + 256;
+    // [ghist 4x256 + the two-level form's bucket sizes 256 | tickets (4 passes x 8 XCDs, padded to 256 B) | tile words 4 x tiles x 256 |
+    // group words] is zeroed per sort
+    const size_t head_bytes = (size_t)(kPasses + 1) * kRadix * 4 + 256;
     const uint32_t groups = (tiles + (uint32_t)kLbGroup - 1u) / (uint32_t)kLbGroup;
     const size_t status_bytes = (size_t)kPasses * ((size_t)tiles + groups) * kRadix * 4;
     int rc = lbvh_reserve(ctx, &ctx->sort_scratch, &ctx->sort_scratch_bytes, 2 * pair_bytes + head_bytes + status_bytes);
@@ -463,7 +511,7 @@ static int sort_prepare(lbvh_context* ctx, uint32_t count, sort_plan* pl)
     pl->alt_keys = (uint32_t*)p;
     pl->alt_vals = (uint32_t*)(p + pair_bytes);
     pl->ghist = (uint32_t*)(p + 2 * pair_bytes);
-    pl->tickets = pl->ghist + kPasses * kRadix;
+    pl->tickets = pl->ghist + (kPasses + 1) * kRadix;
     pl->status = (uint32_t*)(p + 2 * pair_bytes + head_bytes);
     pl->gstatus = pl->status + (size_t)kPasses * tiles * kRadix;
     pl->zero_bytes = head_bytes + status_bytes;
@@ -484,7 +532,12 @@ int lbvh_sort_scratch(lbvh_context* ctx, uint32_t count, uint32_t** d_zero, uint
     return LBVH_OK;
 }
 
-int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t count, bool scratch_cleared)
+// sizes at which a pass is latency, not bandwidth (below: too few pairs to matter; above: 16 K-key tiles, bandwidth-bound passes —
+// there an MSD-first form was measured to gain nothing: profiles/r4/b_bucket_local_sort_passes.txt)
+static inline bool two_level_size(uint32_t count) { return count >= (1u << 15) && count < (1u << 21); }
+constexpr int kBucketThreads = 1024, kBucketItems = 16;        // a bucket of up to 16 384 pairs lives in one workgroup's registers
+
+int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t count, bool scratch_cleared, uint32_t key_bits)
 {
     if (count < 2) return LBVH_OK;
     sort_plan pl;
@@ -502,15 +555,45 @@ int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, ui
     // 1024 global atomics each block ends with do not pile up on the same counters
     uint32_t hblocks = (count + 8191u) / 8192u;
     if (hblocks > 256u * 8u) hblocks = 256u * 8u;
-    LBVH_LAUNCH(ctx, sort_histogram_kernel, dim3(hblocks), dim3(kThreads), d_keys, count, ghist);
     // consecutive tiles per XCD: 16 when every XCD still gets several groups, fewer for small sorts
     const uint32_t group = tiles >= 1024u ? 16u : tiles >= 128u ? 8u : 1u;
+    // The form.  Two-level where a pass is latency (two_level_size) and the LAST sort of this context had no bucket beyond one
+    // workgroup's registers — the first pass kernel of either form leaves the largest bucket of ITS input in four mapped host
+    // words; read here without any synchronisation: a hint, one sort stale (a first sort, or one after a skewed input, takes the
+    // four passes; a skewed input after a uniform one is sorted correctly by the bucket kernel's slow path, once).
+    // lbvh_debug_switch(LBVH_DEBUG_SORT_FORM): 1 four passes always, 2 two-level wherever the size allows.
+    const uint32_t msd_shift = (key_bits >= 8u && key_bits <= 32u ? key_bits : 32u) - 8u;
+    uint32_t* msd_hist = ghist + kPasses * kRadix;
+    uint32_t* stat_dev = ctx->fault_dev + 16;                   // words 16 .. 19 of the mapped block (word 0: the fault word)
+    bool two_level = false;
+    if (two_level_size(count)) {
+        const volatile uint32_t* st = ctx->fault_host + 16;
+        const uint32_t largest = std::max(std::max(st[0], st[1]), std::max(st[2], st[3]));
+        const uint32_t form = ctx->debug_switch[LBVH_DEBUG_SORT_FORM];
+        two_level = form == 2u || (form == 0u && largest <= (uint32_t)(kBucketThreads * kBucketItems));
+    }
+    if (two_level) {
+        LBVH_LAUNCH(ctx, sort_histogram_kernel<HIST_MSD>, dim3(hblocks), dim3(kThreads), d_keys, count, ghist, msd_shift);
+        LBVH_LAUNCH(ctx, (sort_onesweep_kernel<512, 8, false, true>), dim3(tiles), dim3(512), d_keys, d_values, alt_keys, alt_vals, count,
+                    msd_shift, msd_hist, msd_hist, stat_dev, status, gstatus, tickets, tiles, group, ctx->sort_queues, ctx->fault_dev);
+        LBVH_LAUNCH(ctx, (sort_bucket_kernel<kBucketThreads, kBucketItems>), dim3(kRadix), dim3(kBucketThreads), alt_keys, alt_vals, d_keys,
+                    d_values, msd_shift, msd_hist);
+        LBVH_HIP_TRY(ctx, hipGetLastError());
+        return LBVH_OK;       // the buckets are back in d_keys / d_values
+    }
+    const bool stat = two_level_size(count);
+    if (stat)
+        LBVH_LAUNCH(ctx, sort_histogram_kernel<HIST_FOUR | HIST_MSD>, dim3(hblocks), dim3(kThreads), d_keys, count, ghist, msd_shift);
+    else
+        LBVH_LAUNCH(ctx, sort_histogram_kernel<HIST_FOUR>, dim3(hblocks), dim3(kThreads), d_keys, count, ghist, msd_shift);
+    const uint32_t* stat_hist = stat ? msd_hist : nullptr;
     if (items == 16 && count >= (1u << 23))
         launch_passes<512, 16, true>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     else if (items == 16)
         launch_passes<512, 16, false>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     else
-        launch_passes<512, 8, false>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
+        launch_passes<512, 8, false>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group,
+                                     stat_hist, stat_dev);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;   // 4 passes: the result is back in d_keys / d_values
 }
@@ -525,7 +608,7 @@ extern "C" lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     lbvh_note_write(ctx, d_keys, (size_t)count * 4);
     lbvh_note_write(ctx, d_values, (size_t)count * 4);
-    return (lbvh_status)lbvh_launch_sort(ctx, d_keys, d_values, count, false);
+    return (lbvh_status)lbvh_launch_sort(ctx, d_keys, d_values, count, false, 32u);
 }
 
 

@@ -1707,7 +1707,8 @@ static lbvh_status build_scene_enqueue(lbvh_context* ctx, const lbvh_triangle* d
         if (!morton_done)
             lbvh_launch_morton(ctx, d_triangles, n, capacity, h_box_min, h_box_max, d_keys, d_indices, d_aabb, zero, zero_words, lines,
                                reset ? d_internal : nullptr, reset ? d_leaf : nullptr);
-        if ((rc = (lbvh_status)lbvh_launch_sort(ctx, d_keys, d_indices, capacity, zero != nullptr)) != LBVH_OK) return rc;
+        // (Morton codes are below 2^30: MeshBufferContainer.cs:41-50; the 0xFFFFFFFF pads are not, and sort last all the same)
+        if ((rc = (lbvh_status)lbvh_launch_sort(ctx, d_keys, d_indices, capacity, zero != nullptr, 30u)) != LBVH_OK) return rc;
     }
     const bool fast = (flags & LBVH_BUILD_FAST_SCENE) != 0;
     const bool env_two_streams = ctx->debug_switch[LBVH_DEBUG_BUILD_FORM] >= 3;     // measurement switch: the round 2 - 3 form
