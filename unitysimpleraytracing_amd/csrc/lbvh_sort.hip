@@ -461,6 +461,222 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     }
 }
 
+// ---- the two-level form's second kernel: one workgroup sorts one bucket ---------------------------------------------------------
+// A tile of up to THREADS x ITEMS pairs held in registers, wave-striped over the first `aw` waves of the workgroup: wave w < aw
+// owns slots [w 64 it, (w + 1) 64 it), item i = 64 consecutive slots, so (wave, item, lane) order is array order; the other waves
+// hold nothing (a small bucket spread over all sixteen waves pays sixteen waves' worth of rank cells to clear and to scan: the
+// kernel's floor was 17 us for 512-pair buckets that way).  bucket_rank ranks the tile by the byte at `pshift` exactly as a pass
+// kernel does (per-wave peer-mask cells in LDS) and returns each item's position in the digit-sorted tile (two per register);
+// thread t < 256 also gets digit t's count.  Slots past the tile's last pair carry 0xFFFFFFFF: largest digit, last in array
+// order, so they rank behind every real pair in every pass.
+template <int THREADS, int ITEMS>
+__device__ __forceinline__ void bucket_rank(const uint32_t (&key)[ITEMS], uint32_t aw, uint32_t my_it, uint32_t pshift, uint32_t* s_xchg,
+                                            uint16_t (*s_wcnt)[kRadix], uint32_t* s_dstart, uint32_t* s_wsum, uint32_t (&lpos2)[ITEMS / 2],
+                                            uint32_t& digit_total)
+{
+    constexpr int DWAVES = kRadix / LBVH_WAVE;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t t = threadIdx.x, w = t >> 6, lane = lane_id();
+    for (uint32_t i = t; i < aw * (uint32_t)kRadix; i += THREADS) reinterpret_cast<uint4*>(s_xchg)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    {
+        u32x4* cells = reinterpret_cast<u32x4*>(s_xchg) + w * kRadix;
+        const unsigned long long lane_bit = 1ull << lane;
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            if ((uint32_t)i >= my_it) continue;                 // uniform over the wave
+            const uint32_t d = (key[i] >> pshift) & (kRadix - 1);
+            u32x4* cell = cells + d;
+            __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(cell), lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u32x4 c = *reinterpret_cast<volatile u32x4*>(cell);
+            const uint64_t peers = ((uint64_t)c.y << 32) | c.x;
+            const uint32_t r = mbcnt64(peers);
+            const uint32_t old = c.z;
+            if (r == 0) *cell = u32x4{0u, 0u, old + (uint32_t)__popcll(peers), 0u};
+            if (i & 1) lpos2[i / 2] |= (old + r) << 16; else lpos2[i / 2] = old + r;
+            asm volatile("" : "+v"(lpos2[i / 2]));
+        }
+    }
+    __syncthreads();
+    // digit t: its count, and where each wave's run of it starts inside the digit (ONE serial walk over the active waves)
+    uint32_t ltotal = 0;
+    if (t < (uint32_t)kRadix) {
+        for (uint32_t i = 0; i < aw; i++) {
+            const uint32_t c = s_xchg[(i * kRadix + t) * 4 + 2];
+            s_wcnt[i][t] = (uint16_t)ltotal;
+            ltotal += c;
+        }
+    }
+    const uint32_t incl = wave_inclusive_sum(ltotal);
+    if (lane == 63 && w < (uint32_t)DWAVES) s_wsum[w] = incl;
+    __syncthreads();
+    digit_total = ltotal;
+    if (t < (uint32_t)kRadix) {
+        uint32_t wave_prefix = 0;
+#pragma unroll
+        for (int i = 0; i < DWAVES; i++) wave_prefix += (uint32_t)i < w ? s_wsum[i] : 0u;
+        s_dstart[t] = incl - ltotal + wave_prefix;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        if ((uint32_t)i >= my_it) continue;
+        const uint32_t d = (key[i] >> pshift) & (kRadix - 1);
+        const uint32_t r = (i & 1) ? lpos2[i / 2] >> 16 : lpos2[i / 2] & 0xFFFFu;
+        const uint32_t lpos = s_dstart[d] + (uint32_t)s_wcnt[w][d] + r;
+        if (i & 1) lpos2[i / 2] = (lpos2[i / 2] & 0xFFFFu) | (lpos << 16); else lpos2[i / 2] = (lpos2[i / 2] & 0xFFFF0000u) | lpos;
+    }
+    // (the callers' next barrier separates these reads of the cells / s_wcnt / s_dstart from whatever overwrites them)
+}
+
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restrict__ keys_in, uint32_t* __restrict__ vals_in,
+                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                              uint32_t msd_shift, const uint32_t* __restrict__ msd_hist)
+{
+    constexpr int TILE = THREADS * ITEMS;
+    constexpr int WAVES = THREADS / LBVH_WAVE, DWAVES = kRadix / LBVH_WAVE;
+    // (key, value) pairs change places through LDS as 8-byte words: one write, one barrier, one read per pass; the rank cells
+    // (16 B per active wave and digit) live in the same buffer between the exchanges
+    constexpr int XCHG_WORDS = 2 * TILE > WAVES * kRadix * 4 ? 2 * TILE : WAVES * kRadix * 4;
+    static_assert(TILE <= 65536, "local positions are kept in 16 bits");
+    __shared__ __attribute__((aligned(16))) uint32_t s_xchg[XCHG_WORDS];
+    __shared__ uint16_t s_wcnt[WAVES][kRadix];
+    __shared__ uint32_t s_dstart[kRadix];
+    __shared__ uint32_t s_wsum[DWAVES + 1];
+    __shared__ uint32_t s_base[kRadix];          // big buckets: next output index of each digit, relative to the bucket
+    __shared__ uint32_t s_start, s_size;
+    uint2* s_pair = reinterpret_cast<uint2*>(s_xchg);
+    const uint32_t t = threadIdx.x, w = t >> 6, lane = lane_id();
+    const uint32_t b = blockIdx.x;
+    {   // where bucket b starts: exclusive scan of the 256 bucket sizes (1 KB of L2-resident counters, cheaper than a launch)
+        const uint32_t total = t < (uint32_t)kRadix ? msd_hist[t] : 0u;
+        const uint32_t incl = wave_inclusive_sum(total);
+        if (lane == 63 && w < (uint32_t)DWAVES) s_wsum[w] = incl;
+        __syncthreads();
+        if (t == b) {
+            uint32_t wave_prefix = 0;
+            for (uint32_t i = 0; i < w; i++) wave_prefix += s_wsum[i];
+            s_start = incl - total + wave_prefix;
+            s_size = total;
+        }
+        __syncthreads();
+    }
+    const uint32_t start = s_start, size = s_size;
+    if (size == 0) return;
+    // the remaining bits below the bucket digit; the last bucket holds everything from 255 << msd_shift up: the whole key
+    const uint32_t passes = b == (uint32_t)kRadix - 1u ? 4u : (msd_shift + 7u) / 8u;
+    uint32_t key[ITEMS], lpos2[ITEMS / 2];
+    uint32_t digit_total;
+
+    if (size <= (uint32_t)TILE) {
+        // ---- the whole bucket in this workgroup's registers -------------------------------------------------------------------
+        // 512 pairs per active wave (8 items) until all sixteen waves are in use, then more items per wave
+        uint32_t val[ITEMS];
+        const uint32_t aw = min((size + 511u) / 512u, (uint32_t)WAVES);
+        const uint32_t it = (size + aw * LBVH_WAVE - 1u) / (aw * LBVH_WAVE);          // 1 .. ITEMS
+        const uint32_t my_it = w < aw ? it : 0u;
+        const uint32_t stripe = it * LBVH_WAVE;
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            if ((uint32_t)i >= my_it) continue;
+            const uint32_t idx = w * stripe + (uint32_t)i * LBVH_WAVE + lane;
+            key[i] = idx < size ? keys_in[start + idx] : 0xFFFFFFFFu;
+            val[i] = idx < size ? vals_in[start + idx] : 0u;
+        }
+        for (uint32_t p = 0; p < passes; p++) {
+            bucket_rank<THREADS, ITEMS>(key, aw, my_it, 8u * p, s_xchg, s_wcnt, s_dstart, s_wsum, lpos2, digit_total);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                if ((uint32_t)i >= my_it) continue;
+                s_pair[(i & 1) ? lpos2[i / 2] >> 16 : lpos2[i / 2] & 0xFFFFu] = make_uint2(key[i], val[i]);
+            }
+            __syncthreads();
+            if (p + 1 == passes) {
+                for (uint32_t pos = t; pos < size; pos += THREADS) {
+                    const uint2 kv = s_pair[pos];
+                    keys_out[start + pos] = kv.x;
+                    vals_out[start + pos] = kv.y;
+                }
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                if ((uint32_t)i >= my_it) continue;
+                const uint2 kv = s_pair[w * stripe + (uint32_t)i * LBVH_WAVE + lane];
+                key[i] = kv.x;
+                val[i] = kv.y;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- a bucket beyond the registers of one workgroup: LSD passes through global memory, chunk by chunk -----------------------
+    // Correct for any input and slow (one workgroup moves the whole bucket `passes` times): the form is only chosen when the
+    // last sort had no such bucket.  Ping-pong between the two buffers' [start, start + size) regions.
+    uint32_t *src_k = keys_in, *src_v = vals_in, *dst_k = keys_out, *dst_v = vals_out;
+    for (uint32_t p = 0; p < passes; p++) {
+        const uint32_t pshift = 8u * p;
+        if (t < (uint32_t)kRadix) s_base[t] = 0;
+        __syncthreads();
+        for (uint32_t idx = t; idx < size; idx += THREADS) atomicAdd(&s_base[(src_k[start + idx] >> pshift) & (kRadix - 1)], 1u);
+        __syncthreads();
+        {   // exclusive scan of the digit counts in place
+            const uint32_t total = t < (uint32_t)kRadix ? s_base[t] : 0u;
+            const uint32_t incl = wave_inclusive_sum(total);
+            if (lane == 63 && w < (uint32_t)DWAVES) s_wsum[w] = incl;
+            __syncthreads();
+            if (t < (uint32_t)kRadix) {
+                uint32_t wave_prefix = 0;
+#pragma unroll
+                for (int i = 0; i < DWAVES; i++) wave_prefix += (uint32_t)i < w ? s_wsum[i] : 0u;
+                s_base[t] = incl - total + wave_prefix;
+            }
+            __syncthreads();
+        }
+        for (uint32_t c0 = 0; c0 < size; c0 += (uint32_t)TILE) {
+            const uint32_t nvalid = min((uint32_t)TILE, size - c0);
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const uint32_t idx = w * (uint32_t)(LBVH_WAVE * ITEMS) + (uint32_t)i * LBVH_WAVE + lane;
+                key[i] = idx < nvalid ? src_k[start + c0 + idx] : 0xFFFFFFFFu;
+            }
+            bucket_rank<THREADS, ITEMS>(key, (uint32_t)WAVES, (uint32_t)ITEMS, pshift, s_xchg, s_wcnt, s_dstart, s_wsum, lpos2, digit_total);
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const uint32_t idx = w * (uint32_t)(LBVH_WAVE * ITEMS) + (uint32_t)i * LBVH_WAVE + lane;
+                const uint32_t d = (key[i] >> pshift) & (kRadix - 1);
+                const uint32_t lpos = (i & 1) ? lpos2[i / 2] >> 16 : lpos2[i / 2] & 0xFFFFu;
+                if (idx < nvalid) {
+                    const uint32_t dst = start + s_base[d] + (lpos - s_dstart[d]);        // its rank among the chunk's pairs of digit d
+                    dst_k[dst] = key[i];
+                    dst_v[dst] = src_v[start + c0 + idx];
+                }
+            }
+            __syncthreads();
+            if (t < (uint32_t)kRadix) {
+                // (the chunk's padding slots were counted under digit 255: they are not pairs)
+                s_base[t] += digit_total - (t == (uint32_t)kRadix - 1u ? (uint32_t)TILE - nvalid : 0u);
+            }
+            __syncthreads();
+        }
+        // what this workgroup wrote is what it reads next: through the coherence point (rare path: the fence's cost is not an issue)
+        __threadfence();
+        __syncthreads();
+        uint32_t* tmp;
+        tmp = src_k; src_k = dst_k; dst_k = tmp;
+        tmp = src_v; src_v = dst_v; dst_v = tmp;
+    }
+    if (src_k != keys_out) {          // an even number of passes (the last bucket's four) ends in the other buffer
+        for (uint32_t idx = t; idx < size; idx += THREADS) {
+            keys_out[start + idx] = src_k[start + idx];
+            vals_out[start + idx] = src_v[start + idx];
+        }
+    }
+}
+
 template <int THREADS, int ITEMS, bool STREAM>
 void launch_passes(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t* alt_keys, uint32_t* alt_vals,
                    uint32_t count, uint32_t tiles, uint32_t* ghist, uint32_t* status, uint32_t* gstatus, uint32_t groups,
