@@ -577,12 +577,17 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
         const uint32_t it = (size + aw * LBVH_WAVE - 1u) / (aw * LBVH_WAVE);          // 1 .. ITEMS
         const uint32_t my_it = w < aw ? it : 0u;
         const uint32_t stripe = it * LBVH_WAVE;
+        // (buffer loads: a 32-bit byte offset per load instead of a 64-bit address — thirty-two loads in flight inside the
+        // register budget; lanes past the bucket's end read 0 and become the largest key)
+        const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(keys_in + start, 0, (int)(size * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(vals_in + start, 0, (int)(size * 4u), 0x00020000);
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
             if ((uint32_t)i >= my_it) continue;
             const uint32_t idx = w * stripe + (uint32_t)i * LBVH_WAVE + lane;
-            key[i] = idx < size ? keys_in[start + idx] : 0xFFFFFFFFu;
-            val[i] = idx < size ? vals_in[start + idx] : 0u;
+            const uint32_t k = __builtin_amdgcn_raw_buffer_load_b32(k_rsrc, idx * 4u, 0, 0);
+            key[i] = idx < size ? k : 0xFFFFFFFFu;
+            val[i] = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, idx * 4u, 0, 0);
         }
         for (uint32_t p = 0; p < passes; p++) {
             bucket_rank<THREADS, ITEMS>(key, aw, my_it, 8u * p, s_xchg, s_wcnt, s_dstart, s_wsum, lpos2, digit_total);
@@ -616,6 +621,9 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
     // ---- a bucket beyond the registers of one workgroup: LSD passes through global memory, chunk by chunk -----------------------
     // Correct for any input and slow (one workgroup moves the whole bucket `passes` times): the form is only chosen when the
     // last sort had no such bucket.  Ping-pong between the two buffers' [start, start + size) regions.
+    // (8 pairs per thread and chunk here: this path must not cost the other one registers)
+    constexpr int SI = ITEMS < 8 ? ITEMS : 8, STILE = THREADS * SI;
+    uint32_t skey[SI], slpos2[SI / 2];
     uint32_t *src_k = keys_in, *src_v = vals_in, *dst_k = keys_out, *dst_v = vals_out;
     for (uint32_t p = 0; p < passes; p++) {
         const uint32_t pshift = 8u * p;
@@ -636,29 +644,29 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
             }
             __syncthreads();
         }
-        for (uint32_t c0 = 0; c0 < size; c0 += (uint32_t)TILE) {
-            const uint32_t nvalid = min((uint32_t)TILE, size - c0);
+        for (uint32_t c0 = 0; c0 < size; c0 += (uint32_t)STILE) {
+            const uint32_t nvalid = min((uint32_t)STILE, size - c0);
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) {
-                const uint32_t idx = w * (uint32_t)(LBVH_WAVE * ITEMS) + (uint32_t)i * LBVH_WAVE + lane;
-                key[i] = idx < nvalid ? src_k[start + c0 + idx] : 0xFFFFFFFFu;
+            for (int i = 0; i < SI; i++) {
+                const uint32_t idx = w * (uint32_t)(LBVH_WAVE * SI) + (uint32_t)i * LBVH_WAVE + lane;
+                skey[i] = idx < nvalid ? src_k[start + c0 + idx] : 0xFFFFFFFFu;
             }
-            bucket_rank<THREADS, ITEMS>(key, (uint32_t)WAVES, (uint32_t)ITEMS, pshift, s_xchg, s_wcnt, s_dstart, s_wsum, lpos2, digit_total);
+            bucket_rank<THREADS, SI>(skey, (uint32_t)WAVES, (uint32_t)SI, pshift, s_xchg, s_wcnt, s_dstart, s_wsum, slpos2, digit_total);
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) {
-                const uint32_t idx = w * (uint32_t)(LBVH_WAVE * ITEMS) + (uint32_t)i * LBVH_WAVE + lane;
-                const uint32_t d = (key[i] >> pshift) & (kRadix - 1);
-                const uint32_t lpos = (i & 1) ? lpos2[i / 2] >> 16 : lpos2[i / 2] & 0xFFFFu;
+            for (int i = 0; i < SI; i++) {
+                const uint32_t idx = w * (uint32_t)(LBVH_WAVE * SI) + (uint32_t)i * LBVH_WAVE + lane;
+                const uint32_t d = (skey[i] >> pshift) & (kRadix - 1);
+                const uint32_t lpos = (i & 1) ? slpos2[i / 2] >> 16 : slpos2[i / 2] & 0xFFFFu;
                 if (idx < nvalid) {
                     const uint32_t dst = start + s_base[d] + (lpos - s_dstart[d]);        // its rank among the chunk's pairs of digit d
-                    dst_k[dst] = key[i];
+                    dst_k[dst] = skey[i];
                     dst_v[dst] = src_v[start + c0 + idx];
                 }
             }
             __syncthreads();
             if (t < (uint32_t)kRadix) {
                 // (the chunk's padding slots were counted under digit 255: they are not pairs)
-                s_base[t] += digit_total - (t == (uint32_t)kRadix - 1u ? (uint32_t)TILE - nvalid : 0u);
+                s_base[t] += digit_total - (t == (uint32_t)kRadix - 1u ? (uint32_t)STILE - nvalid : 0u);
             }
             __syncthreads();
         }
