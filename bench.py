@@ -167,6 +167,21 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist_mod
+        # The set-up must fail LOUDLY and at once, not inside a collective: count the devices before anything initialises one
+        # (torch.cuda.device_count() does not create a HIP context) and say what to run instead
+        visible = torch.cuda.device_count()
+        if args.backend == "nccl" and (device_id < 0 or device_id >= visible):      # (gloo: lbvh_create itself says "no HIP device")
+            raise SystemExit(f"[bench] rank {rank}/{world}: needs HIP device {device_id}, this process sees {visible} "
+                             f"(--backend {args.backend}); one rank per GPU: --gpus N <= the node's GPUs, or every rank on one GPU: "
+                             "--backend gloo --device 0")
+        if args.backend == "nccl" and args.device is not None and world > 1:
+            raise SystemExit("[bench] --backend nccl (RCCL) needs one GPU per rank: --device puts every rank on the same one; "
+                             "use --backend gloo --device D for the N-rank code path on one GPU")
+        if rank == 0:
+            print(f"[bench] {world} ranks, backend {args.backend}, rank r on HIP device "
+                  f"{'r' if args.device is None else args.device} of {visible} visible, rendezvous "
+                  f"{'file store (self-launched)' if os.environ.get('LBVH_BENCH_RENDEZVOUS_FILE') else 'MASTER_ADDR:PORT (torchrun)'}",
+                  file=sys.stderr, flush=True)
         # stdout carries ONE JSON line: whatever the communication libraries print while they connect goes to stderr
         sys.stdout.flush()
         saved_stdout = os.dup(1)

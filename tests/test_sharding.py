@@ -176,6 +176,43 @@ def test_bench_starts_its_own_ranks_for_gpus_n():
     assert r.stderr.count("lbvh_create") >= 1
 
 
+def _bench(args, extra_env=None, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_rccl_launch_fails_cleanly_without_gpus():
+    """the launch shape the driver uses on an 8-GPU node — `--gpus N`, backend nccl (= RCCL), one rank per
+    GPU, `device_id=` given to init_process_group — has only ever run with gloo here.  Without GPUs it must end at once with
+    a status and one sentence per rank that names the missing device (counted BEFORE anything initialises HIP), not with a
+    traceback from inside torch or a hang in a rendezvous; and never with a JSON line."""
+    try:
+        import torch
+        if torch.cuda.device_count() > 0:
+            pytest.skip("a GPU is visible: the ranks would run the real benchmark")
+    except ImportError:
+        pytest.skip("no torch")
+    import time
+    t0 = time.time()
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])                  # self-launched ranks, file:// rendezvous
+    assert r.returncode != 0 and r.stdout.strip() == "" and "Traceback" not in r.stderr
+    assert r.stderr.count("needs HIP device") == 2 and "rank 1/2: needs HIP device 1" in r.stderr
+    # the driver's shape: torchrun's environment, one process = one rank
+    env = {"RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29544"}
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], env)
+    assert r.returncode != 0 and "rank 1/2: needs HIP device 1" in r.stderr and "Traceback" not in r.stderr
+    # arguments that cannot mean anything
+    r = _bench(["--gpus", "4", "--steps", "1"], dict(env, RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and "Traceback" not in r.stderr
+    r = _bench(["--gpus", "2", "--backend", "nccl", "--device", "0", "--steps", "1"], env)
+    assert r.returncode != 0 and ("one GPU per rank" in r.stderr or "needs HIP device" in r.stderr) and "Traceback" not in r.stderr
+    assert time.time() - t0 < 120
+
+
 def test_centre_out_tile_order_is_a_permutation():
     """Frames without dispatch history take rows and columns (a share: its groups of 8 tiles) from the middle outwards
     (csrc/lbvh_trace.hip trace_packet_kernel, centre_out): the arithmetic, restated, is a bijection for every size — every tile

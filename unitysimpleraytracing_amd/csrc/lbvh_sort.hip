@@ -537,7 +537,7 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
     constexpr int TILE = THREADS * ITEMS;
     constexpr int WAVES = THREADS / LBVH_WAVE, DWAVES = kRadix / LBVH_WAVE;
     // (key, value) pairs change places through LDS as 8-byte words: one write, one barrier, one read per pass; the rank cells
-    // (16 B per active wave and digit) live in the same buffer between the exchanges
+    // (a 64-bit peer mask and a 32-bit count per active wave and digit) live in the same buffer between the exchanges
     constexpr int XCHG_WORDS = 2 * TILE > WAVES * kRadix * 4 ? 2 * TILE : WAVES * kRadix * 4;
     static_assert(TILE <= 65536, "local positions are kept in 16 bits");
     __shared__ __attribute__((aligned(16))) uint32_t s_xchg[XCHG_WORDS];
