@@ -471,30 +471,65 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
 // order, so they rank behind every real pair in every pass.
 template <int THREADS, int ITEMS>
 __device__ __forceinline__ void bucket_rank(const uint32_t (&key)[ITEMS], uint32_t aw, uint32_t my_it, uint32_t pshift, uint32_t* s_xchg,
-                                            uint16_t (*s_wcnt)[kRadix], uint32_t* s_dstart, uint32_t* s_wsum, uint32_t (&lpos2)[ITEMS / 2],
-                                            uint32_t& digit_total)
+                                            uint32_t* s_cnt, uint16_t (*s_wcnt)[kRadix], uint32_t* s_dstart, uint32_t* s_wsum,
+                                            uint32_t (&lpos2)[ITEMS / 2], uint32_t& digit_total)
 {
-    constexpr int DWAVES = kRadix / LBVH_WAVE;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int DWAVES = kRadix / LBVH_WAVE, WAVES = THREADS / LBVH_WAVE;
+    constexpr int G = ITEMS < 4 ? ITEMS : 4;                     // items of a wave ranked at once
     const uint32_t t = threadIdx.x, w = t >> 6, lane = lane_id();
-    for (uint32_t i = t; i < aw * (uint32_t)kRadix; i += THREADS) reinterpret_cast<uint4*>(s_xchg)[i] = make_uint4(0u, 0u, 0u, 0u);
+    // Ranking, four items of a wave in flight.  The pass kernels' form (OR my lane bit into the cell of (wave, digit), read the
+    // cell back, the lowest peer updates its count) is a chain of three dependent LDS round trips PER ITEM, and with one
+    // workgroup of sixteen lock-stepped waves per CU nothing hides it: the kernel measured 0.6 us per item and pass.  Here a
+    // group of four items goes through the chain together: four banks of 64-bit peer masks [bank][wave][digit] take the four
+    // ORs, then the four reads; the lowest peer of each (item, digit) clears its mask for the next group and adds the group's
+    // size to the count of (wave, digit) with a RETURNING add — LDS executes a wave's instructions in order, so the adds of
+    // successive items see each other — and hands the old count to its peers by a lane permute.  One chain of four round trips
+    // per four items instead of three per item.
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(s_xchg);           // [G][WAVES][256]
+    for (uint32_t i = t; i < aw * (uint32_t)kRadix; i += THREADS) {
+#pragma unroll
+        for (int j = 0; j < G; j++) masks[(uint32_t)j * (WAVES * kRadix) + i] = 0ull;
+        s_cnt[i] = 0u;
+    }
     __syncthreads();
     {
-        u32x4* cells = reinterpret_cast<u32x4*>(s_xchg) + w * kRadix;
+        unsigned long long* wmask = masks + w * kRadix;
+        uint32_t* wcount = s_cnt + w * kRadix;
         const unsigned long long lane_bit = 1ull << lane;
 #pragma unroll
-        for (int i = 0; i < ITEMS; i++) {
-            if ((uint32_t)i >= my_it) continue;                 // uniform over the wave
-            const uint32_t d = (key[i] >> pshift) & (kRadix - 1);
-            u32x4* cell = cells + d;
-            __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(cell), lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const u32x4 c = *reinterpret_cast<volatile u32x4*>(cell);
-            const uint64_t peers = ((uint64_t)c.y << 32) | c.x;
-            const uint32_t r = mbcnt64(peers);
-            const uint32_t old = c.z;
-            if (r == 0) *cell = u32x4{0u, 0u, old + (uint32_t)__popcll(peers), 0u};
-            if (i & 1) lpos2[i / 2] |= (old + r) << 16; else lpos2[i / 2] = old + r;
-            asm volatile("" : "+v"(lpos2[i / 2]));
+        for (int g = 0; g < ITEMS; g += G) {
+            if ((uint32_t)g >= my_it) continue;                 // uniform over the wave
+            uint32_t d[G];
+            uint64_t peers[G];
+            uint32_t old[G];
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                if ((uint32_t)(g + j) >= my_it) continue;
+                d[j] = (key[g + j] >> pshift) & (kRadix - 1);
+                __hip_atomic_fetch_or(wmask + j * (WAVES * kRadix) + d[j], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                if ((uint32_t)(g + j) >= my_it) continue;
+                peers[j] = *reinterpret_cast<volatile unsigned long long*>(wmask + j * (WAVES * kRadix) + d[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                if ((uint32_t)(g + j) >= my_it) continue;
+                old[j] = 0;
+                if (mbcnt64(peers[j]) == 0) {                   // the lowest lane of this (item, digit)
+                    wmask[j * (WAVES * kRadix) + d[j]] = 0ull;
+                    old[j] = __hip_atomic_fetch_add(wcount + d[j], (uint32_t)__popcll(peers[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                if ((uint32_t)(g + j) >= my_it) continue;
+                const int i = g + j;
+                const uint32_t first = (uint32_t)__shfl((int)old[j], __builtin_ctzll(peers[j]));      // same-digit pairs of earlier items
+                const uint32_t r = first + mbcnt64(peers[j]);
+                if (i & 1) lpos2[i / 2] |= r << 16; else lpos2[i / 2] = r;
+            }
         }
     }
     __syncthreads();
@@ -502,7 +537,7 @@ __device__ __forceinline__ void bucket_rank(const uint32_t (&key)[ITEMS], uint32
     uint32_t ltotal = 0;
     if (t < (uint32_t)kRadix) {
         for (uint32_t i = 0; i < aw; i++) {
-            const uint32_t c = s_xchg[(i * kRadix + t) * 4 + 2];
+            const uint32_t c = s_cnt[i * kRadix + t];
             s_wcnt[i][t] = (uint16_t)ltotal;
             ltotal += c;
         }
@@ -536,11 +571,12 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
 {
     constexpr int TILE = THREADS * ITEMS;
     constexpr int WAVES = THREADS / LBVH_WAVE, DWAVES = kRadix / LBVH_WAVE;
-    // (key, value) pairs change places through LDS as 8-byte words: one write, one barrier, one read per pass; the rank cells
-    // (a 64-bit peer mask and a 32-bit count per active wave and digit) live in the same buffer between the exchanges
-    constexpr int XCHG_WORDS = 2 * TILE > WAVES * kRadix * 4 ? 2 * TILE : WAVES * kRadix * 4;
+    // (key, value) pairs change places through LDS as 8-byte words: one write, one barrier, one read per pass; the four banks of
+    // peer masks (bucket_rank) live in the same buffer between the exchanges
+    constexpr int XCHG_WORDS = 2 * TILE > WAVES * kRadix * 8 ? 2 * TILE : WAVES * kRadix * 8;
     static_assert(TILE <= 65536, "local positions are kept in 16 bits");
     __shared__ __attribute__((aligned(16))) uint32_t s_xchg[XCHG_WORDS];
+    __shared__ uint32_t s_cnt[WAVES][kRadix];    // pairs of (wave, digit) ranked so far in this pass
     __shared__ uint16_t s_wcnt[WAVES][kRadix];
     __shared__ uint32_t s_dstart[kRadix];
     __shared__ uint32_t s_wsum[DWAVES + 1];
@@ -590,7 +626,7 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
             val[i] = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, idx * 4u, 0, 0);
         }
         for (uint32_t p = 0; p < passes; p++) {
-            bucket_rank<THREADS, ITEMS>(key, aw, my_it, 8u * p, s_xchg, s_wcnt, s_dstart, s_wsum, lpos2, digit_total);
+            bucket_rank<THREADS, ITEMS>(key, aw, my_it, 8u * p, s_xchg, &s_cnt[0][0], s_wcnt, s_dstart, s_wsum, lpos2, digit_total);
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < ITEMS; i++) {
@@ -651,7 +687,7 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
                 const uint32_t idx = w * (uint32_t)(LBVH_WAVE * SI) + (uint32_t)i * LBVH_WAVE + lane;
                 skey[i] = idx < nvalid ? src_k[start + c0 + idx] : 0xFFFFFFFFu;
             }
-            bucket_rank<THREADS, SI>(skey, (uint32_t)WAVES, (uint32_t)SI, pshift, s_xchg, s_wcnt, s_dstart, s_wsum, slpos2, digit_total);
+            bucket_rank<THREADS, SI>(skey, (uint32_t)WAVES, (uint32_t)SI, pshift, s_xchg, &s_cnt[0][0], s_wcnt, s_dstart, s_wsum, slpos2, digit_total);
 #pragma unroll
             for (int i = 0; i < SI; i++) {
                 const uint32_t idx = w * (uint32_t)(LBVH_WAVE * SI) + (uint32_t)i * LBVH_WAVE + lane;
