@@ -461,6 +461,17 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     }
 }
 
+#ifndef LBVH_RANK_GROUP
+#define LBVH_RANK_GROUP 1          // items of a wave ranked at once by the bucket kernel (bucket_rank; 1 / 2 / 4 measured equal)
+#endif
+#ifdef LBVH_BUCKET_TIMING
+// measurement variant (tools/build_variant.sh timing -DLBVH_BUCKET_TIMING): s_memtime at the phase borders of every bucket
+__device__ unsigned long long g_bucket_timing[kRadix][40];
+#define LBVH_BT(slot) do { if (threadIdx.x == 0) g_bucket_timing[blockIdx.x][slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LBVH_BT(slot) do { } while (0)
+#endif
+
 // ---- the two-level form's second kernel: one workgroup sorts one bucket ---------------------------------------------------------
 // A tile of up to THREADS x ITEMS pairs held in registers, wave-striped over the first `aw` waves of the workgroup: wave w < aw
 // owns slots [w 64 it, (w + 1) 64 it), item i = 64 consecutive slots, so (wave, item, lane) order is array order; the other waves
@@ -475,16 +486,15 @@ __device__ __forceinline__ void bucket_rank(const uint32_t (&key)[ITEMS], uint32
                                             uint32_t (&lpos2)[ITEMS / 2], uint32_t& digit_total)
 {
     constexpr int DWAVES = kRadix / LBVH_WAVE, WAVES = THREADS / LBVH_WAVE;
-    constexpr int G = ITEMS < 4 ? ITEMS : 4;                     // items of a wave ranked at once
+    constexpr int G = ITEMS < LBVH_RANK_GROUP ? ITEMS : LBVH_RANK_GROUP;      // items of a wave ranked at once
     const uint32_t t = threadIdx.x, w = t >> 6, lane = lane_id();
-    // Ranking, four items of a wave in flight.  The pass kernels' form (OR my lane bit into the cell of (wave, digit), read the
-    // cell back, the lowest peer updates its count) is a chain of three dependent LDS round trips PER ITEM, and with one
-    // workgroup of sixteen lock-stepped waves per CU nothing hides it: the kernel measured 0.6 us per item and pass.  Here a
-    // group of four items goes through the chain together: four banks of 64-bit peer masks [bank][wave][digit] take the four
-    // ORs, then the four reads; the lowest peer of each (item, digit) clears its mask for the next group and adds the group's
-    // size to the count of (wave, digit) with a RETURNING add — LDS executes a wave's instructions in order, so the adds of
-    // successive items see each other — and hands the old count to its peers by a lane permute.  One chain of four round trips
-    // per four items instead of three per item.
+    // Ranking: the pass kernels' form with the cell split in two arrays — OR my lane bit into the 64-bit peer mask of (wave,
+    // digit), read it back (LDS executes a wave's instructions in order: the read sees all 64 ORs); the lowest peer clears the
+    // mask and adds the group's size to the count of (wave, digit) with a RETURNING add, and hands the old count to its peers by
+    // a lane permute.  G items may go through that chain together (G banks of masks).  Measured (profiles/r5/b_*): the kernel is
+    // bound by the LDS instruction rate of its ONE workgroup per CU — ~940 cycles per item and pass for sixteen waves' ORs, reads,
+    // adds and permutes — not by the chain's latency: G = 1 / 2 / 4 run the 12 K-pair bucket in 37.0 / 38.2 / 39.9 us, the
+    // 16-byte-cell form of the pass kernels in 38.5.
     unsigned long long* masks = reinterpret_cast<unsigned long long*>(s_xchg);           // [G][WAVES][256]
     for (uint32_t i = t; i < aw * (uint32_t)kRadix; i += THREADS) {
 #pragma unroll
@@ -492,6 +502,7 @@ __device__ __forceinline__ void bucket_rank(const uint32_t (&key)[ITEMS], uint32
         s_cnt[i] = 0u;
     }
     __syncthreads();
+    LBVH_BT(32);
     {
         unsigned long long* wmask = masks + w * kRadix;
         uint32_t* wcount = s_cnt + w * kRadix;
@@ -533,6 +544,7 @@ __device__ __forceinline__ void bucket_rank(const uint32_t (&key)[ITEMS], uint32
         }
     }
     __syncthreads();
+    LBVH_BT(33);
     // digit t: its count, and where each wave's run of it starts inside the digit (ONE serial walk over the active waves)
     uint32_t ltotal = 0;
     if (t < (uint32_t)kRadix) {
@@ -553,6 +565,7 @@ __device__ __forceinline__ void bucket_rank(const uint32_t (&key)[ITEMS], uint32
         s_dstart[t] = incl - ltotal + wave_prefix;
     }
     __syncthreads();
+    LBVH_BT(34);
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         if ((uint32_t)i >= my_it) continue;
@@ -564,6 +577,7 @@ __device__ __forceinline__ void bucket_rank(const uint32_t (&key)[ITEMS], uint32
     // (the callers' next barrier separates these reads of the cells / s_wcnt / s_dstart from whatever overwrites them)
 }
 
+
 template <int THREADS, int ITEMS>
 __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restrict__ keys_in, uint32_t* __restrict__ vals_in,
                                                               uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
@@ -573,7 +587,7 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
     constexpr int WAVES = THREADS / LBVH_WAVE, DWAVES = kRadix / LBVH_WAVE;
     // (key, value) pairs change places through LDS as 8-byte words: one write, one barrier, one read per pass; the four banks of
     // peer masks (bucket_rank) live in the same buffer between the exchanges
-    constexpr int XCHG_WORDS = 2 * TILE > WAVES * kRadix * 8 ? 2 * TILE : WAVES * kRadix * 8;
+    constexpr int XCHG_WORDS = 2 * TILE > WAVES * kRadix * 2 * LBVH_RANK_GROUP ? 2 * TILE : WAVES * kRadix * 2 * LBVH_RANK_GROUP;
     static_assert(TILE <= 65536, "local positions are kept in 16 bits");
     __shared__ __attribute__((aligned(16))) uint32_t s_xchg[XCHG_WORDS];
     __shared__ uint32_t s_cnt[WAVES][kRadix];    // pairs of (wave, digit) ranked so far in this pass
@@ -585,6 +599,7 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
     uint2* s_pair = reinterpret_cast<uint2*>(s_xchg);
     const uint32_t t = threadIdx.x, w = t >> 6, lane = lane_id();
     const uint32_t b = blockIdx.x;
+    LBVH_BT(0);
     {   // where bucket b starts: exclusive scan of the 256 bucket sizes (1 KB of L2-resident counters, cheaper than a launch)
         const uint32_t total = t < (uint32_t)kRadix ? msd_hist[t] : 0u;
         const uint32_t incl = wave_inclusive_sum(total);
@@ -599,6 +614,10 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
         __syncthreads();
     }
     const uint32_t start = s_start, size = s_size;
+    LBVH_BT(1);
+#ifdef LBVH_BUCKET_TIMING
+    if (threadIdx.x == 0) g_bucket_timing[blockIdx.x][39] = size;
+#endif
     if (size == 0) return;
     // the remaining bits below the bucket digit; the last bucket holds everything from 255 << msd_shift up: the whole key
     const uint32_t passes = b == (uint32_t)kRadix - 1u ? 4u : (msd_shift + 7u) / 8u;
@@ -625,21 +644,26 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
             key[i] = idx < size ? k : 0xFFFFFFFFu;
             val[i] = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, idx * 4u, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LBVH_BT(2);
         for (uint32_t p = 0; p < passes; p++) {
             bucket_rank<THREADS, ITEMS>(key, aw, my_it, 8u * p, s_xchg, &s_cnt[0][0], s_wcnt, s_dstart, s_wsum, lpos2, digit_total);
             __syncthreads();
+            LBVH_BT(3 + 4 * p);
 #pragma unroll
             for (int i = 0; i < ITEMS; i++) {
                 if ((uint32_t)i >= my_it) continue;
                 s_pair[(i & 1) ? lpos2[i / 2] >> 16 : lpos2[i / 2] & 0xFFFFu] = make_uint2(key[i], val[i]);
             }
             __syncthreads();
+            LBVH_BT(4 + 4 * p);
             if (p + 1 == passes) {
                 for (uint32_t pos = t; pos < size; pos += THREADS) {
                     const uint2 kv = s_pair[pos];
                     keys_out[start + pos] = kv.x;
                     vals_out[start + pos] = kv.y;
                 }
+                LBVH_BT(30);
                 return;
             }
 #pragma unroll
@@ -650,6 +674,7 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
                 val[i] = kv.y;
             }
             __syncthreads();
+            LBVH_BT(5 + 4 * p);
         }
         return;
     }
@@ -839,6 +864,19 @@ int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, ui
         LBVH_LAUNCH(ctx, (sort_bucket_kernel<kBucketThreads, kBucketItems>), dim3(kRadix), dim3(kBucketThreads), alt_keys, alt_vals, d_keys,
                     d_values, msd_shift, msd_hist);
         LBVH_HIP_TRY(ctx, hipGetLastError());
+#ifdef LBVH_BUCKET_TIMING
+        {
+            static unsigned long long h[kRadix][40];
+            (void)hipStreamSynchronize(ctx->cur_stream);
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bucket_timing), sizeof h);
+            int big = 0;
+            for (int b2 = 0; b2 < kRadix; b2++) if (h[b2][39] > h[big][39] && h[b2][39] <= 16384) big = b2;
+            fprintf(stderr, "[bucket timing] largest bucket %d (%llu pairs), s_memtime ticks since the kernel's first instruction:", big, h[big][39]);
+            const int slots[] = {1, 2, 3, 4, 5, 7, 8, 9, 11, 12, 30, 32, 33, 34};
+            for (int q : slots) fprintf(stderr, " [%d] %lld", q, (long long)(h[big][q] - h[big][0]));
+            fprintf(stderr, "\n");
+        }
+#endif
         return LBVH_OK;       // the buckets are back in d_keys / d_values
     }
     const bool stat = two_level_size(count);
