@@ -23,18 +23,14 @@ extern "C" {
  *                               always, 3 the two-stream form (plain), 4 the two-stream form as a graph
  *   LBVH_DEBUG_FRAME_WAIT_MS    wall-clock bound of lbvh_frame_wait's device-side wait in milliseconds (0: the default, 20 s)
  *   LBVH_DEBUG_SORT_FORM        1: the sort always runs the four 8-bit LSD passes, 2: the two-level form wherever the size allows
- *                               (0: chosen per call from the last sort's largest bucket)
- *   LBVH_DEBUG_RAY_SORT         experiment (round 5): lbvh_path_bounce sorts its live rays before the walk — 1: by direction octant, then
- *                               Morton code of the origin; 2: by Morton code of the origin, then octant.  Reads the live count back (one
- *                               host synchronisation per bounce); records are identical to the unsorted walk's */
+ *                               (0: chosen per call from the last sort's largest bucket) */
 enum {
     LBVH_DEBUG_SORT_QUEUES = 0,
     LBVH_DEBUG_COLD_ORDER = 1,
     LBVH_DEBUG_BUILD_FORM = 2,
     LBVH_DEBUG_FRAME_WAIT_MS = 3,
     LBVH_DEBUG_SORT_FORM = 4,
-    LBVH_DEBUG_RAY_SORT = 5,
-    LBVH_DEBUG_SWITCHES = 6
+    LBVH_DEBUG_SWITCHES = 5
 };
 lbvh_status lbvh_debug_switch(lbvh_context* ctx, uint32_t which, uint32_t value);
 

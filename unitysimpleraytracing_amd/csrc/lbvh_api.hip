@@ -211,7 +211,6 @@ lbvh_status lbvh_destroy(lbvh_context* ctx)
     if (ctx->fast_tree) (void)hipFree(ctx->fast_tree);
     if (ctx->hier) (void)hipFree(ctx->hier);
     if (ctx->ray_scratch) (void)hipFree(ctx->ray_scratch);
-    if (ctx->ray_sort_keys) (void)hipFree(ctx->ray_sort_keys);
     if (ctx->tie_list) (void)hipFree(ctx->tie_list);
     if (ctx->wide_nodes) (void)hipFree(ctx->wide_nodes);
     if (ctx->trace_frame_costs) (void)hipFree(ctx->trace_frame_costs);
@@ -485,7 +484,6 @@ lbvh_status lbvh_debug_switch(lbvh_context* ctx, uint32_t which, uint32_t value)
         ctx->build_graph_off = false;
         break;
     case LBVH_DEBUG_SORT_FORM: LBVH_REQUIRE(ctx, value <= 2); break;
-    case LBVH_DEBUG_RAY_SORT: LBVH_REQUIRE(ctx, value <= 2); break;
     default: break;
     }
     ctx->debug_switch[which] = value;

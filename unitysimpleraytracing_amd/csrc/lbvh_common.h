@@ -135,8 +135,6 @@ struct lbvh_context {
 
     // lbvh_trace_rays: live-ray list
     void* ray_scratch = nullptr;
-    void* ray_sort_keys = nullptr;            // LBVH_DEBUG_RAY_SORT (experiment): sort keys of the live rays
-    size_t ray_sort_keys_bytes = 0;
     uint32_t ray_stack_lds = 16;              // lbvh_debug_ray_stack_split
     uint32_t ray_stack_deep = 0xFFFFFFFFu;    // lbvh_debug_ray_stack_limit: entries of the device-memory part the walkers may use
     size_t ray_scratch_bytes = 0;

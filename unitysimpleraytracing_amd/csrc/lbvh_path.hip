@@ -65,7 +65,9 @@ constexpr int kWideStackDeep = 112;
 
 // Live rays only: alive_rays_kernel writes the miss record of every dead ray and compacts the indices of the live
 // ones (after the first bounce more than half of a frame's paths have left the scene).  (Sorting the live rays by direction octant + Morton code of the origin on top of this was
-// measured: the sort costs 0.15 ms per bounce and the walk does not get faster.)
+// measured: the sort costs 0.15 ms per bounce and the walk does not get faster.  Measured again in round 5 on the four-wide
+// walkers with counters, profiles/r5/c_ray_sort_between_bounces.txt: HBM-side fetch -17 %, L2 misses -15 %, walk time 1.206 ->
+// 1.201 ms — the walk waits for its rays' dependent line fetches at full occupancy, not for bandwidth.)
 __global__ __launch_bounds__(256) void alive_rays_kernel(const lbvh_path_state* __restrict__ states, size_t count,
                                                          uint32_t* __restrict__ n_alive, uint32_t* __restrict__ list,
                                                          lbvh_hit* __restrict__ hits)
@@ -706,32 +708,6 @@ __global__ __launch_bounds__(256) void path_resolve_kernel(const lbvh_path_state
     reinterpret_cast<ushort4*>(out)[i] = o;
 }
 
-// EXPERIMENT (round 5; lbvh_debug_switch LBVH_DEBUG_RAY_SORT): a sort key per live ray — Morton code of the
-// origin in the reference's scene box and the direction's octant — so that the walk can take the live rays in an order that keeps
-// neighbours in the tree together.  form 1: octant major (3 bits), origin Morton code 9 bits per axis below it; form 2: origin
-// Morton code (10 bits per axis) major, octant below it.
-__device__ __forceinline__ uint32_t expand10(uint32_t v)
-{
-    v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u;
-    return v;
-}
-__global__ __launch_bounds__(256) void ray_sort_keys_kernel(const lbvh_path_state* __restrict__ states, const uint32_t* __restrict__ list,
-                                                            uint32_t n_live, uint32_t form, uint32_t* __restrict__ keys)
-{
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k >= n_live) return;
-    const float4* st = reinterpret_cast<const float4*>(&states[list[k]]);
-    const float4 o = st[0], d = st[1];
-    const float q[3] = {(o.x + 125.0f) * (1024.0f / 250.0f), (o.y + 125.0f) * (1024.0f / 250.0f), (o.z + 125.0f) * (1024.0f / 250.0f)};
-    uint32_t c[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) c[a] = (uint32_t)fminf(fmaxf(q[a], 0.0f), 1023.0f);
-    const uint32_t morton = expand10(c[0]) * 4u + expand10(c[1]) * 2u + expand10(c[2]);
-    const uint32_t octant = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
-    keys[k] = form == 1u ? (octant << 27) | (morton >> 3) : (morton << 2) | (octant >> 1);      // (form 2 keeps two of the three sign bits: 32 bits)
-}
-
 }  // namespace
 
 static_assert(sizeof(lbvh_path_state) == 64, "path state must be 64 bytes");
@@ -900,22 +876,6 @@ static lbvh_status path_bounce_impl(lbvh_context* ctx, const lbvh_scene* h_scene
     else
         LBVH_LAUNCH(ctx, (path_scatter_kernel<true, false>), scatter_grid, dim3(256), h_scene->triangles, d_hits, count, bounce, seed, albedo,
                     d_states, n_alive, list, lbvh_camera{});
-    if (ctx->debug_switch[LBVH_DEBUG_RAY_SORT] != 0u) {
-        // EXPERIMENT: the live rays sorted by (octant, origin) before the walk.  The live count is read back (a host
-        // synchronisation per bounce: this form is for measuring the WALK, not the frame); the list holds path indices and the
-        // states stay where they are, so every record is the unsorted walk's.
-        uint32_t n_live = 0;
-        LBVH_HIP_TRY(ctx, hipMemcpyAsync(&n_live, n_alive, 4, hipMemcpyDeviceToHost, ctx->cur_stream));
-        LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->cur_stream));
-        if (n_live > 1u) {
-            rc = lbvh_reserve(ctx, &ctx->ray_sort_keys, &ctx->ray_sort_keys_bytes, (size_t)count * 4);
-            if (rc != LBVH_OK) return rc;
-            LBVH_LAUNCH(ctx, ray_sort_keys_kernel, dim3((n_live + 255u) / 256u), dim3(256), d_states, list, n_live,
-                        ctx->debug_switch[LBVH_DEBUG_RAY_SORT], (uint32_t*)ctx->ray_sort_keys);
-            rc = lbvh_launch_sort(ctx, (uint32_t*)ctx->ray_sort_keys, list, n_live, false, 32u);
-            if (rc != LBVH_OK) return rc;
-        }
-    }
     return launch_ray_walk(ctx, d_states, n_alive, list, t_min, d_hits, count, bounce >= 1u);
 }
 
