@@ -438,6 +438,36 @@ def main():
         weak = {"Mrays_s": round(world * W * H / (ms_w * 1e-3) / 1e6, 2), "ms_per_frame_per_gpu": round(ms_w, 4),
                 "workload": "every GPU traces the whole 1080p frame, %d frames in flight" % world}
         whole.dispose()
+    # untimed extra: the same scene at 3840x2160 — every rank its share of ONE 4K frame, history-driven like the
+    # timed frames.  At 8.3 M rays a 1/8 share is a whole 1080p frame's worth of work: this curve separates the latency floor of a
+    # share (launch, filing, the heaviest tile's chain: what bounds the 1080p shares) from throughput.  Never the headline.
+    frame_4k = None
+    if mode == L.TRACE_FAST and not cfg4:
+        W4, H4 = 3840, 2160
+        cam4 = N.Camera.from_dict(scenes.camera(W4, H4, CAMERA_POS))
+        hits4 = DataBuffer(ctx, W4 * H4, L.HIT)
+        s4 = drawer.container.scene()
+
+        def share_4k():
+            N.check(ctx.handle, N.lib.lbvh_trace_primary_shard(ctx.handle, C.byref(cam4), rank, world, C.byref(s4), mode, hits4.device, None))
+        for _ in range(3):
+            share_4k()
+        e0, e1 = ctx.event(), ctx.event()
+        ctx.sync()
+        barrier()
+        total = 0.0
+        for _ in range(reps):
+            ctx.record(e0)
+            share_4k()
+            ctx.record(e1)
+            total += ctx.elapsed_ms(e0, e1)
+        ctx.destroy_event(e0); ctx.destroy_event(e1)
+        ms4 = reduce_max(total / reps)
+        frame_4k = {"Mrays_s": round(W4 * H4 / (ms4 * 1e-3) / 1e6, 2), "share_ms": round(ms4, 4), "rays": W4 * H4,
+                    "workload": "the cfg2 scene at 3840x2160: every rank its share of one frame (static camera, HIP events around the "
+                                "share's launch, max over ranks; no gather, no rebuild) — an extra beside the 1080p metric"}
+        hits4.dispose()
+        trace_share(); ctx.sync()                      # the 1080p layout's history back for what follows
     sharded_sort_check = None
     if sorter is not None and rank == 0:
         # the timed steps left the sharded sort's result in the container: compare it with the one-GPU sort
@@ -704,6 +734,9 @@ def main():
             out["sharded_sort_matches_single_gpu"] = sharded_sort_check
         if weak is not None:
             out["weak_scaling_extra"] = weak
+        if frame_4k is not None:
+            out["frame_4k"] = frame_4k
+            out["value_4k"] = frame_4k["Mrays_s"]
     for e in events + [(ev_start,)]:
         for x in e:
             ctx.destroy_event(x)
