@@ -1551,7 +1551,13 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     const bool whole = n_work > kSharedMaxWork && spread == 0;
     const bool exact = a.ties != nullptr;          // LBVH_TRACE_FAST_EXACT: the same three launch shapes, kernels with the tie bookkeeping
     if (have_history && whole) {
-        coop_params hp = {n_work / 4u, kHeavyClassWhole, kCoopGrain};
+        // at most 1/64 of the frame's tiles (the heaviest: the lists are heaviest first) — cfg2 has 190 tiles of 256 steps or
+        // more among 32 400, but on a scene whose EVERY tile is that heavy (cfg4: 16 M triangles, sub-pixel) a quarter of the frame
+        // walked cooperatively cost +50 % steps on all of it: 1.43 ms against 1.01 for the plain kernel (profiles/r5/d_*)
+        #ifndef LBVH_WHOLE_COOP_DIV
+#define LBVH_WHOLE_COOP_DIV 64u
+#endif
+        coop_params hp = {std::max(64u, n_work / LBVH_WHOLE_COOP_DIV), kHeavyClassWhole, kCoopGrain};
         const uint32_t blocks = hp.cap + (n_work + kCoopWavesWhole - 1) / kCoopWavesWhole;
         if (exact)
             LBVH_LAUNCH(ctx, (trace_shared_kernel<false, kCoopWavesWhole, true>), dim3(blocks), dim3(kCoopWavesWhole * 64), a, ctx->fast_nodes,
