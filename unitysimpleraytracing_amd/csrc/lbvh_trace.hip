@@ -1549,8 +1549,9 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
     // (a moved camera: the plain kernel — the widened costs would make every neighbour of a heavy tile cooperative, 0.27 - 0.29 ms;
     // marking by the un-widened reprojected cost finds too few of them: 0.20 - 0.22 against 0.21 plain)
     // (round 5: with the cooperative set capped at 1/64 of the tiles, cooperative whole frames under a MOVED camera measure the
-    // same as the plain kernel — yaw 1 degree 0.207 / 0.208 ms, strafe 0.208 / 0.197 — the penalty of a moving camera is the
-    // prediction of which tiles are heavy, not the lack of cooperation)
+    // same as the plain kernel — yaw 1 degree 0.207 / 0.208 ms, strafe 0.208 / 0.197 — and with a larger set (1/32, 1/16, 1/8 of
+    // the tiles, enough to hold every neighbour of a heavy tile that the widened costs mark) worse: 0.215 / 0.238 / 0.272 ms.
+    // The penalty of a moving camera is the prediction of WHICH tiles are heavy, not the lack of cooperation)
     const bool whole = n_work > kSharedMaxWork && spread == 0;
     const bool exact = a.ties != nullptr;          // LBVH_TRACE_FAST_EXACT: the same three launch shapes, kernels with the tie bookkeeping
     if (have_history && whole) {
