@@ -515,11 +515,15 @@ __device__ __forceinline__ void range_boxes(const hier_t& h, const uint32_t a[NQ
     }
 }
 
+// hierarchy levels resolved per round of a range query: one range (the reference's boxes) / two ranges (the derived tree's child
+// boxes).  Round 5: 3 / 1 instead of round 2's 4 / 2 — fewer block indices and corners alive at once: 72 -> 60 - 62 registers, 7 -> 8
+// waves per SIMD, tree_pair_kernel 86.4 -> 81.8 us at 1 M triangles (4 / 1, 2 / 1, 1 / 1 within 0.5 us; 4 / 3: 89, 4 / 4: 94),
+// the 16 M-triangle build unchanged
 #ifndef LBVH_RQ_LV1
-#define LBVH_RQ_LV1 4
+#define LBVH_RQ_LV1 3
 #endif
 #ifndef LBVH_RQ_LV2
-#define LBVH_RQ_LV2 2
+#define LBVH_RQ_LV2 1
 #endif
 enum { TREE_TOPOLOGY = 0, TREE_REFERENCE = 1, TREE_FUSED = 2 };
 // TREE_TOPOLOGY   lbvh_build_tree: the reference's node arrays only
