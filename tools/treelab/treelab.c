@@ -361,11 +361,14 @@ static inline int tri_test(const ray_t* r, uint32_t orig, float* t_out)
 }
 
 // walk_packet_lean's control flow for one 8x8 tile; returns the steps, fills best_t / best_leaf of the 64 lanes
+static int g_cull = 0;               // 1: a popped node whose wave-minimum entry distance exceeds every active lane's best t is dropped unfetched
+static uint64_t g_culled = 0;
 static uint32_t* g_cnt;              // leaves under each node (evaluate fills it)
 static uint64_t g_hist[40][2];       // packet steps by log2(leaves under the node): [..][0] all, [..][1] steps that entered nothing and tested no leaf
 static uint32_t walk_tile(const tree_t* t, const ray_t* rays, const int* act, float* best_t, uint32_t* best_leaf, uint32_t* leaf_tests)
 {
     uint32_t stack[256], sp = 0, steps = 0, node = 0;
+    float stack_t[256];
     for (int l = 0; l < 64; l++) { best_t[l] = act[l] ? MAXF : -INFINITY; best_leaf[l] = 0xFFFFFFFFu; }
     for (;;) {
         const node_t* nd = &t->nd[node];
@@ -423,13 +426,34 @@ static uint32_t walk_tile(const tree_t* t, const ray_t* rays, const int* act, fl
             const int by_votes = __builtin_popcountll(both & le) - __builtin_popcountll(both & ~le);
             const int by_lanes = __builtin_popcountll(ml) - __builtin_popcountll(mr);
             const int l_near = (by_votes != 0 ? by_votes : by_lanes) >= 0;
+            {   // entry distance of the far child: the minimum over the lanes that want it
+                const uint64_t mf = l_near ? mr : ml;
+                float m = INFINITY;
+                for (int l = 0; l < 64; l++) if ((mf >> l) & 1) m = fminf(m, l_near ? tr[l] : tl[l]);
+                stack_t[sp] = m;
+            }
             stack[sp++] = l_near ? nd->r : nd->l;
             node = l_near ? nd->l : nd->r;
         } else if (ml) node = nd->l;
         else if (mr) node = nd->r;
         else {
-            if (!sp) break;
-            node = stack[--sp];
+            int done = 0;
+            for (;;) {
+                if (!sp) { done = 1; break; }
+                --sp;
+                if (g_cull) {
+                    float worst = -INFINITY;            // the largest best t of the active lanes
+                    for (int l = 0; l < 64; l++) if (act[l]) worst = fmaxf(worst, best_t[l]);
+                    if (stack_t[sp] > worst) {
+#pragma omp atomic
+                        g_culled++;
+                        continue;
+                    }
+                }
+                node = stack[sp];
+                break;
+            }
+            if (done) break;
         }
     }
     return steps;
@@ -510,6 +534,7 @@ static void evaluate(const char* name, const tree_t* t, double build_s)
             total += steps[tile]; leaf_tests += lt;
             for (int l = 0; l < 64; l++) if (act[l] && bt[l] < MAXF) { hits++; tsum += bt[l]; }
         }
+        if (g_cull) { printf(" [culled at pop: %llu]", (unsigned long long)g_culled); g_culled = 0; }
         qsort(steps, tiles, 4, cmp_u32);
         uint32_t heavy = 0;
         for (uint32_t i = 0; i < tiles; i++) heavy += steps[i] >= 256;
@@ -588,6 +613,7 @@ int main(int argc, char** argv)
     for (int a = 2; a < argc; a++) {
         const char* w = argv[a];
         if (!strcmp(w, "hist")) g_show_hist = 1;
+        else if (!strcmp(w, "cull")) g_cull = 1;
         else if (!strcmp(w, "radix")) run_range("radix(aligned keys) [product]", akeys, SPLIT_RADIX, SPLIT_RADIX, 0);
         else if (!strcmp(w, "sweep")) run_range("sweep SAH in sorted order, all levels", akeys, SPLIT_SWEEP, SPLIT_SWEEP, 0);
         else if (!strcmp(w, "median")) run_range("median split in sorted order", akeys, SPLIT_MEDIAN, SPLIT_MEDIAN, 0);
