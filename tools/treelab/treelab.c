@@ -361,6 +361,9 @@ static inline int tri_test(const ray_t* r, uint32_t orig, float* t_out)
 }
 
 // walk_packet_lean's control flow for one 8x8 tile; returns the steps, fills best_t / best_leaf of the 64 lanes
+static int g_tw = 8, g_th = 8;        // tile shape (g_tw x g_th = 64 lanes)
+static int g_near_rule = 0;          // 0: majority vote (the product); 1: the child whose minimum entry distance is smaller
+static int g_predict = 0;
 static int g_cull = 0;               // 1: a popped node whose wave-minimum entry distance exceeds every active lane's best t is dropped unfetched
 static uint64_t g_culled = 0;
 static uint32_t* g_cnt;              // leaves under each node (evaluate fills it)
@@ -425,7 +428,12 @@ static uint32_t walk_tile(const tree_t* t, const ray_t* rays, const int* act, fl
             for (int l = 0; l < 64; l++) if (tl[l] <= tr[l]) le |= 1ull << l;
             const int by_votes = __builtin_popcountll(both & le) - __builtin_popcountll(both & ~le);
             const int by_lanes = __builtin_popcountll(ml) - __builtin_popcountll(mr);
-            const int l_near = (by_votes != 0 ? by_votes : by_lanes) >= 0;
+            int l_near = (by_votes != 0 ? by_votes : by_lanes) >= 0;
+            if (g_near_rule == 1) {
+                float ml_min = INFINITY, mr_min = INFINITY;
+                for (int l = 0; l < 64; l++) { if ((ml >> l) & 1) ml_min = fminf(ml_min, tl[l]); if ((mr >> l) & 1) mr_min = fminf(mr_min, tr[l]); }
+                l_near = ml_min <= mr_min;
+            }
             {   // entry distance of the far child: the minimum over the lanes that want it
                 const uint64_t mf = l_near ? mr : ml;
                 float m = INFINITY;
@@ -518,14 +526,14 @@ static void evaluate(const char* name, const tree_t* t, double build_s)
     const float cams[2] = {250.0f, 160.0f};
     for (int ci = 0; ci < 2; ci++) {
         camera_t c = {1920, 1080, tanf(30.0f * (float)M_PI / 180.0f), 0.3f, {0.0f, 0.0f, cams[ci]}};
-        const uint32_t tx = (c.w + 7) / 8, ty = (c.h + 7) / 8, tiles = tx * ty;
+        const uint32_t tx = (c.w + g_tw - 1) / g_tw, ty = (c.h + g_th - 1) / g_th, tiles = tx * ty;
         uint32_t* steps = malloc(tiles * 4);
         uint64_t total = 0, leaf_tests = 0, hits = 0; double tsum = 0.0;
 #pragma omp parallel for schedule(dynamic, 16) reduction(+ : total, leaf_tests, hits, tsum)
         for (uint32_t tile = 0; tile < tiles; tile++) {
             ray_t rays[64]; int act[64]; float bt[64]; uint32_t bl[64];
             for (int l = 0; l < 64; l++) {
-                const uint32_t px = (tile % tx) * 8 + (l & 7), py = (tile / tx) * 8 + (l >> 3);
+                const uint32_t px = (tile % tx) * g_tw + (l % g_tw), py = (tile / tx) * g_th + (l / g_tw);
                 act[l] = px < (uint32_t)c.w && py < (uint32_t)c.h;
                 rays[l] = camera_ray(&c, px < (uint32_t)c.w ? px : c.w - 1, py < (uint32_t)c.h ? py : c.h - 1);
             }
@@ -535,6 +543,45 @@ static void evaluate(const char* name, const tree_t* t, double build_s)
             for (int l = 0; l < 64; l++) if (act[l] && bt[l] < MAXF) { hits++; tsum += bt[l]; }
         }
         if (g_cull) { printf(" [culled at pop: %llu]", (unsigned long long)g_culled); g_culled = 0; }
+        if (g_predict) {
+            // how well do a few single rays per tile predict which tiles are heavy?  predictor = node visits of the per-ray walk
+            // for the tile's centre ray / the largest over a 2x2 / 4x4 grid of its rays; recall of the tiles of >= 256 packet steps
+            // among the 506 (1/64 of the frame) the predictor ranks highest, and among twice / four times as many
+            const int grids[3] = {1, 2, 4};
+            for (int gi = 0; gi < 3; gi++) {
+                const int gdim = grids[gi];
+                uint32_t* pred = malloc(tiles * 4);
+#pragma omp parallel for schedule(dynamic, 16)
+                for (uint32_t tile = 0; tile < tiles; tile++) {
+                    uint32_t m = 0;
+                    for (int a = 0; a < gdim; a++)
+                        for (int b = 0; b < gdim; b++) {
+                            uint32_t px = (tile % tx) * g_tw + (uint32_t)((2 * a + 1) * g_tw / (2 * gdim)), py = (tile / tx) * g_th + (uint32_t)((2 * b + 1) * g_th / (2 * gdim));
+                            if (px >= (uint32_t)c.w) px = c.w - 1;
+                            if (py >= (uint32_t)c.h) py = c.h - 1;
+                            ray_t r = camera_ray(&c, px, py);
+                            float bt; uint32_t bl;
+                            const uint32_t v = walk_ray(t, &r, 0.0f, &bt, &bl);
+                            if (v > m) m = v;
+                        }
+                    pred[tile] = m;
+                }
+                uint32_t* sorted = malloc(tiles * 4);
+                memcpy(sorted, pred, tiles * 4);
+                qsort(sorted, tiles, 4, cmp_u32);
+                uint32_t heavy = 0;
+                for (uint32_t i = 0; i < tiles; i++) heavy += steps[i] >= 256;
+                printf("\n   predictor %dx%d rays per tile: heavy tiles %u;", gdim, gdim, heavy);
+                for (int mult = 1; mult <= 4; mult *= 2) {
+                    const uint32_t K = (tiles / 64) * mult, thr = sorted[tiles - K];
+                    uint32_t found = 0, picked = 0;
+                    for (uint32_t i = 0; i < tiles; i++) if (pred[i] >= thr) { picked++; found += steps[i] >= 256; }
+                    printf(" top %u (picked %u): recall %.2f;", K, picked, (double)found / heavy);
+                }
+                free(pred); free(sorted);
+            }
+            printf("\n");
+        }
         qsort(steps, tiles, 4, cmp_u32);
         uint32_t heavy = 0;
         for (uint32_t i = 0; i < tiles; i++) heavy += steps[i] >= 256;
@@ -614,6 +661,9 @@ int main(int argc, char** argv)
         const char* w = argv[a];
         if (!strcmp(w, "hist")) g_show_hist = 1;
         else if (!strcmp(w, "cull")) g_cull = 1;
+        else if (!strcmp(w, "predict")) g_predict = 1;
+        else if (!strncmp(w, "tile", 4)) { sscanf(w + 4, "%dx%d", &g_tw, &g_th); printf("tile %dx%d\n", g_tw, g_th); }
+        else if (!strncmp(w, "near", 4)) { g_near_rule = atoi(w + 4); printf("near rule %d\n", g_near_rule); }
         else if (!strcmp(w, "radix")) run_range("radix(aligned keys) [product]", akeys, SPLIT_RADIX, SPLIT_RADIX, 0);
         else if (!strcmp(w, "sweep")) run_range("sweep SAH in sorted order, all levels", akeys, SPLIT_SWEEP, SPLIT_SWEEP, 0);
         else if (!strcmp(w, "median")) run_range("median split in sorted order", akeys, SPLIT_MEDIAN, SPLIT_MEDIAN, 0);
