@@ -363,6 +363,7 @@ static inline int tri_test(const ray_t* r, uint32_t orig, float* t_out)
 // walk_packet_lean's control flow for one 8x8 tile; returns the steps, fills best_t / best_leaf of the 64 lanes
 static int g_tw = 8, g_th = 8;        // tile shape (g_tw x g_th = 64 lanes)
 static int g_near_rule = 0;          // 0: majority vote (the product); 1: the child whose minimum entry distance is smaller
+static int g_pop_nearest = 0;        // 1: a pop takes the waiting entry with the smallest entry distance, not the newest
 static int g_predict = 0;
 static int g_cull = 0;               // 1: a popped node whose wave-minimum entry distance exceeds every active lane's best t is dropped unfetched
 static uint64_t g_culled = 0;
@@ -448,6 +449,13 @@ static uint32_t walk_tile(const tree_t* t, const ray_t* rays, const int* act, fl
             int done = 0;
             for (;;) {
                 if (!sp) { done = 1; break; }
+                if (g_pop_nearest) {                   // bring the nearest waiting entry to the top
+                    uint32_t at = sp - 1;
+                    for (uint32_t k = 0; k + 1 < sp; k++) if (stack_t[k] < stack_t[at]) at = k;
+                    const uint32_t tn = stack[at]; const float tt = stack_t[at];
+                    stack[at] = stack[sp - 1]; stack_t[at] = stack_t[sp - 1];
+                    stack[sp - 1] = tn; stack_t[sp - 1] = tt;
+                }
                 --sp;
                 if (g_cull) {
                     float worst = -INFINITY;            // the largest best t of the active lanes
@@ -662,6 +670,7 @@ int main(int argc, char** argv)
         if (!strcmp(w, "hist")) g_show_hist = 1;
         else if (!strcmp(w, "cull")) g_cull = 1;
         else if (!strcmp(w, "predict")) g_predict = 1;
+        else if (!strcmp(w, "popnearest")) g_pop_nearest = 1;
         else if (!strncmp(w, "tile", 4)) { sscanf(w + 4, "%dx%d", &g_tw, &g_th); printf("tile %dx%d\n", g_tw, g_th); }
         else if (!strncmp(w, "near", 4)) { g_near_rule = atoi(w + 4); printf("near rule %d\n", g_near_rule); }
         else if (!strcmp(w, "radix")) run_range("radix(aligned keys) [product]", akeys, SPLIT_RADIX, SPLIT_RADIX, 0);
