@@ -365,6 +365,8 @@ static int g_tw = 8, g_th = 8;        // tile shape (g_tw x g_th = 64 lanes)
 static int g_near_rule = 0;          // 0: majority vote (the product); 1: the child whose minimum entry distance is smaller
 static int g_pop_nearest = 0;        // 1: a pop takes the waiting entry with the smallest entry distance, not the newest
 static int g_predict = 0;
+static __thread uint32_t tl_step_cap = 0;       // if set: walk_tile stops after this many steps
+static __thread uint32_t* tl_lane_work = NULL;   // if set: [64] steps in which the lane wanted a child or tested a leaf
 static int g_cull = 0;               // 1: a popped node whose wave-minimum entry distance exceeds every active lane's best t is dropped unfetched
 static uint64_t g_culled = 0;
 static uint32_t* g_cnt;              // leaves under each node (evaluate fills it)
@@ -376,6 +378,7 @@ static uint32_t walk_tile(const tree_t* t, const ray_t* rays, const int* act, fl
     for (int l = 0; l < 64; l++) { best_t[l] = act[l] ? MAXF : -INFINITY; best_leaf[l] = 0xFFFFFFFFu; }
     for (;;) {
         const node_t* nd = &t->nd[node];
+        if (tl_step_cap && steps >= tl_step_cap) break;
         steps++;
         const int lg = 31 - __builtin_clz(g_cnt[node]);
         int useful = 0;
@@ -389,6 +392,7 @@ static uint32_t walk_tile(const tree_t* t, const ray_t* rays, const int* act, fl
         if (nd->l & LEAF) {
             if (ml) {
                 (*leaf_tests)++; useful = 1;
+                if (tl_lane_work) for (int l = 0; l < 64; l++) if ((ml >> l) & 1) tl_lane_work[l]++;
                 const uint32_t pos = nd->l & ~LEAF;
                 for (int l = 0; l < 64; l++) {
                     float tt;
@@ -404,6 +408,7 @@ static uint32_t walk_tile(const tree_t* t, const ray_t* rays, const int* act, fl
         if (nd->r & LEAF) {
             if (mr) {
                 (*leaf_tests)++; useful = 1;
+                if (tl_lane_work) for (int l = 0; l < 64; l++) if ((mr >> l) & 1) tl_lane_work[l]++;
                 const uint32_t pos = nd->r & ~LEAF;
                 for (int l = 0; l < 64; l++) {
                     float tt;
@@ -417,6 +422,7 @@ static uint32_t walk_tile(const tree_t* t, const ray_t* rays, const int* act, fl
             mr = 0;
         }
         if (ml || mr) useful = 1;
+        if (tl_lane_work) for (int l = 0; l < 64; l++) if (((ml | mr) >> l) & 1) tl_lane_work[l]++;
 #pragma omp atomic
         g_hist[lg][0]++;
         if (!useful) {
@@ -589,6 +595,52 @@ static void evaluate(const char* name, const tree_t* t, double build_s)
                 free(pred); free(sorted);
             }
             printf("\n");
+            // the same from COARSE PACKETS: 64 rays = 4 x 4 tiles x (2 x 2 rays per tile), walked as one packet (the product's walk);
+            // a tile's predictor = the largest per-lane work count of its 4 rays.  What the pre-pass costs: its steps and its longest packet
+            if (g_tw == 8 && g_th == 8)
+            for (uint32_t cap = 0; cap <= 192; cap = cap ? cap * 2 : 48) {
+                const uint32_t cx = (tx + 3) / 4, cy = (ty + 3) / 4, coarse = cx * cy;
+                uint32_t* pred = calloc(tiles, 4);
+                uint64_t csteps = 0; uint32_t cmax = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : csteps) reduction(max : cmax)
+                for (uint32_t cp = 0; cp < coarse; cp++) {
+                    ray_t rays[64]; int act[64]; float bt[64]; uint32_t bl[64]; uint32_t work[64] = {0};
+                    uint32_t tile_of[64];
+                    for (int l = 0; l < 64; l++) {
+                        // lane l: tile (l & 3, (l >> 2) & 3) of the block, ray (l >> 4) & 1, (l >> 5) & 1 of its 2 x 2
+                        const uint32_t bx = (cp % cx) * 4 + (l & 3), by = (cp / cx) * 4 + ((l >> 2) & 3);
+                        const uint32_t px = bx * 8 + 2 + 4 * ((l >> 4) & 1), py = by * 8 + 2 + 4 * ((l >> 5) & 1);
+                        act[l] = bx < tx && by < ty && px < (uint32_t)c.w && py < (uint32_t)c.h;
+                        tile_of[l] = act[l] ? by * tx + bx : 0xFFFFFFFFu;
+                        rays[l] = camera_ray(&c, px < (uint32_t)c.w ? px : c.w - 1, py < (uint32_t)c.h ? py : c.h - 1);
+                    }
+                    uint32_t lt = 0;
+                    tl_lane_work = work;
+                    tl_step_cap = cap;
+                    const uint32_t st = walk_tile(t, rays, act, bt, bl, &lt);
+                    tl_lane_work = NULL;
+                    tl_step_cap = 0;
+                    csteps += st; if (st > cmax) cmax = st;
+                    for (int l = 0; l < 64; l++) if (tile_of[l] != 0xFFFFFFFFu) {
+#pragma omp critical
+                        if (work[l] > pred[tile_of[l]]) pred[tile_of[l]] = work[l];
+                    }
+                }
+                uint32_t* sorted = malloc(tiles * 4);
+                memcpy(sorted, pred, tiles * 4);
+                qsort(sorted, tiles, 4, cmp_u32);
+                uint32_t heavy = 0;
+                for (uint32_t i = 0; i < tiles; i++) heavy += steps[i] >= 256;
+                printf("   coarse pre-pass (step cap %u): %u packets, %llu steps (%.1f per packet, longest %u);", cap, coarse, (unsigned long long)csteps, (double)csteps / coarse, cmax);
+                for (int mult = 1; mult <= 4; mult *= 2) {
+                    const uint32_t K = (tiles / 64) * mult, thr = sorted[tiles - K];
+                    uint32_t found = 0, picked = 0;
+                    for (uint32_t i = 0; i < tiles; i++) if (pred[i] >= thr) { picked++; found += steps[i] >= 256; }
+                    printf(" top %u (picked %u): recall %.2f;", K, picked, (double)found / heavy);
+                }
+                printf("\n");
+                free(pred); free(sorted);
+            }
         }
         qsort(steps, tiles, 4, cmp_u32);
         uint32_t heavy = 0;
