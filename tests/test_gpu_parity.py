@@ -1742,6 +1742,51 @@ def test_path_first_bounce_equals_begin_plus_bounce_zero(ctx):
     pt.drawer.on_destroy()
 
 
+def test_path_bounces_from_the_live_list_equal_bounces_over_every_pixel(ctx):
+    """Round 5: lbvh_path_bounce b >= 1 (and the frame's last lbvh_path_scatter) look only at the paths the bounce before listed as
+    live, if they continue that very frame.  Same frame three ways — (a) as the host classes issue it (lists used), (b) with the
+    path states sent through the host between the calls (an outside write: the list is dropped, every pixel is scanned), (c) with
+    a foreign lbvh_trace_rays in between (takes the list buffer) — states, hit records and image word for word the same."""
+    tris, body, centres = scenes.tiled_torus(nu=24, nv=16, grid=2, with_bodies=True)
+    pt = H().DynamicPathTracer(ctx, tris, body, centres, t_min=1e-3, albedo=0.7, seed=33)
+    w, h = 211, 123
+    count = w * h
+    s = pt.drawer.container.scene()
+    hd, lib = ctx.handle, N().lib
+    ccam = N().Camera.from_dict(scenes.camera(w, h, (2.0, 1.0, 95.0)))
+    results = []
+    for variant in ("lists", "states rewritten", "foreign rays"):
+        states = H().DataBuffer(ctx, count, L.PATH_STATE)
+        hits = H().DataBuffer(ctx, count, L.HIT)
+        image = H().DataBuffer(ctx, count, np.uint64)
+        other_states = H().DataBuffer(ctx, 64, L.PATH_STATE)
+        other_hits = H().DataBuffer(ctx, 64, L.HIT)
+        other_states.fill_u32(0, mirror=False)
+
+        def disturb():
+            if variant == "states rewritten":
+                st = states.get_data().copy()
+                states.local[:] = st
+                states.sync()                                                      # lbvh_buffer_upload: an outside write
+            elif variant == "foreign rays":
+                N().check(hd, lib.lbvh_trace_rays(hd, other_states.device, 64, 1e-3, C.byref(s), other_hits.device))
+        N().check(hd, lib.lbvh_trace_primary(hd, C.byref(ccam), 0, 0, w, h, C.byref(s), L.TRACE_FAST, hits.device, None))
+        N().check(hd, lib.lbvh_path_first_bounce(hd, C.byref(ccam), C.byref(s), states.device, hits.device, 33, 0.7, 1e-3))
+        for b in range(1, 4):
+            disturb()
+            N().check(hd, lib.lbvh_path_bounce(hd, C.byref(s), states.device, hits.device, count, b, 33, 0.7, 1e-3))
+        disturb()
+        N().check(hd, lib.lbvh_path_scatter(hd, C.byref(s), hits.device, count, 4, 33, 0.7, states.device))
+        N().check(hd, lib.lbvh_path_resolve(hd, states.device, count, image.device))
+        results.append((states.get_data().copy(), hits.get_data().copy(), image.get_data().copy()))
+        for bfr in (states, hits, image, other_states, other_hits):
+            bfr.dispose()
+    for r in results[1:]:
+        assert (words(r[0]) == words(results[0][0])).all() and (words(r[1]) == words(results[0][1])).all() and (r[2] == results[0][2]).all()
+    assert results[0][0]["radiance"].sum() > 0
+    pt.drawer.on_destroy()
+
+
 def test_path_bounce_zero_treats_prefilled_hit_records_as_misses(ctx):
     """a hit buffer pre-filled with 0xFFFFFFFF words (what lbvh_driver.cpp does) and only partly traced holds
     {t >= MAX_FLOAT, triangle = 0xFFFFFFFF} records that are the CALLER's, not marks of paths that ended earlier: at

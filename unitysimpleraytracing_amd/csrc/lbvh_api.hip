@@ -51,6 +51,10 @@ static bool ranges_overlap(const void* a, size_t a_bytes, const void* b, size_t 
 
 void lbvh_note_write(lbvh_context* ctx, const void* p, size_t bytes)
 {
+    // path states / hit records written from outside: the live-path list of the last bounce no longer describes them
+    if (ctx->ray_list.valid && (ranges_overlap(p, bytes, ctx->ray_list.states, ctx->ray_list.count * sizeof(lbvh_path_state)) ||
+                                ranges_overlap(p, bytes, ctx->ray_list.hits, ctx->ray_list.count * sizeof(lbvh_hit))))
+        ctx->ray_list.valid = false;
     if (!ctx->fast_valid) return;
     const size_t n = ctx->fast_src.n;
     if (ranges_overlap(p, bytes, ctx->fast_src.triangles, n * sizeof(lbvh_triangle)) ||
@@ -254,6 +258,7 @@ lbvh_status lbvh_buffer_free(lbvh_context* ctx, void* d_ptr)
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     if (!d_ptr) return LBVH_OK;
     LBVH_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (d_ptr == ctx->ray_list.states || d_ptr == ctx->ray_list.hits) ctx->ray_list.valid = false;
     // a freed scene buffer can no longer back the derived scene (its address may be handed out again)
     if (ctx->fast_valid && (d_ptr == ctx->fast_src.triangles || d_ptr == ctx->fast_src.sorted_indices ||
                             d_ptr == ctx->fast_src.triangle_aabb)) {

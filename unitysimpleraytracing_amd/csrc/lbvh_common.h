@@ -137,6 +137,9 @@ struct lbvh_context {
 
     // lbvh_trace_rays: live-ray list
     void* ray_scratch = nullptr;
+    // the live-path list the last lbvh_path_bounce left behind (lbvh_path.hip): the next bounce of the same frame starts from it
+    // instead of scanning every pixel; dropped by anything that writes the states / hit records in between (lbvh_note_write)
+    struct { const void *states, *hits; size_t count; uint32_t bounce, turn; bool valid; } ray_list = {nullptr, nullptr, 0, 0, 0, false};
     uint32_t ray_stack_lds = 16;              // lbvh_debug_ray_stack_split
     uint32_t ray_stack_deep = 0xFFFFFFFFu;    // lbvh_debug_ray_stack_limit: entries of the device-memory part the walkers may use
     size_t ray_scratch_bytes = 0;

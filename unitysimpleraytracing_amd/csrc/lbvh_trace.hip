@@ -1927,6 +1927,7 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
     LBVH_REQUIRE(ctx, cam.screen_width > 0 && cam.screen_height > 0);
     LBVH_REQUIRE(ctx, x0 >= 0 && y0 >= 0 && x1 >= x0 && y1 >= y0);
     LBVH_REQUIRE(ctx, x1 <= cam.screen_width && y1 <= cam.screen_height);
+    if (d_hits == ctx->ray_list.hits) ctx->ray_list.valid = false;        // new primary hits in the path tracer's records: a new frame
     LBVH_REQUIRE(ctx, s.n >= 2);
     if (x1 == x0 || y1 == y0) return LBVH_OK;
     LBVH_REQUIRE(ctx, d_hits != nullptr && ((uintptr_t)d_hits & 15) == 0);
