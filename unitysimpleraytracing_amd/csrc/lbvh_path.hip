@@ -597,10 +597,15 @@ __device__ __forceinline__ bool scatter_path(const lbvh_triangle* __restrict__ t
 // with one path per thread the 8 100 workgroups of a 1080p frame queued on that one counter for most of the kernel's
 // 67 - 91 us (the bounces' own work shrinks with the live paths, the kernel's time did not).
 constexpr int kScatterItems = 8;
+constexpr int kScatterItemsList = 2;       // ... when the paths come from a live list (see path_scatter_kernel)
 // DOMAIN (round 5): the paths to look at are the `*n_domain` entries of `domain` — the list of live paths the previous bounce
-// left behind — instead of all `count` pixels (domain == nullptr): a bounce's scatter then costs what its live paths cost, not
-// a pass over 2 M hit records of which most are dead (1080p: 38 us per bounce whatever the bounce -> 20 / 10 / 6 us).
-template <bool LIST, bool FIRST = false>
+// left behind — instead of all `count` pixels (domain == nullptr): from the second bounce on a scatter then costs what its live
+// paths cost, not a pass over 2 M hit records of which most are dead (1080p: 35 / 33 / 33 us for bounces 2, 3 and the frame's last
+// scatter -> 27 / 18 / 14 us).
+// ITEMS paths per thread, one after the other (each item's ballot closes its chain of dependent loads): 8 for a pass over every
+// pixel — few workgroups, one list reservation each —, 2 when the domain is a list of live paths: there the kernel is the latency
+// of a thread's items in sequence (8 items: 32 us however few paths are live), not the reservation
+template <bool LIST, bool FIRST = false, int ITEMS = kScatterItems>
 __global__ __launch_bounds__(256) void path_scatter_kernel(const lbvh_triangle* __restrict__ triangles,
                                                            const lbvh_hit* hits, size_t count, uint32_t bounce,
                                                            uint32_t seed, float albedo, lbvh_path_state* __restrict__ states,
@@ -608,18 +613,18 @@ __global__ __launch_bounds__(256) void path_scatter_kernel(const lbvh_triangle* 
                                                            const uint32_t* __restrict__ domain, const uint32_t* __restrict__ n_domain)
 {
     __shared__ uint32_t s_n, s_base;
-    const size_t i0 = (size_t)blockIdx.x * (256 * kScatterItems) + threadIdx.x;
+    const size_t i0 = (size_t)blockIdx.x * (256 * ITEMS) + threadIdx.x;
     const size_t total = domain ? (size_t)*n_domain : count;
-    if ((size_t)blockIdx.x * (256 * kScatterItems) >= total) return;          // (uniform) nothing of the domain falls to this workgroup
+    if ((size_t)blockIdx.x * (256 * ITEMS) >= total) return;          // (uniform) nothing of the domain falls to this workgroup
     if (LIST) {
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
     }
-    uint32_t ofs[kScatterItems];                      // position inside this wave's run, or ~0u: the path ended
-    uint32_t idx[kScatterItems];                      // the path (pixel) index of item k
+    uint32_t ofs[ITEMS];                      // position inside this wave's run, or ~0u: the path ended
+    uint32_t idx[ITEMS];                      // the path (pixel) index of item k
     uint32_t wave_n = 0;
 #pragma unroll
-    for (int k = 0; k < kScatterItems; k++) {
+    for (int k = 0; k < ITEMS; k++) {
         const size_t at = i0 + (size_t)k * 256;
         const size_t i = at < total ? (domain ? (size_t)domain[at] : at) : 0;
         idx[k] = (uint32_t)i;
@@ -638,7 +643,7 @@ __global__ __launch_bounds__(256) void path_scatter_kernel(const lbvh_triangle* 
         if (threadIdx.x == 0 && s_n) s_base = __hip_atomic_fetch_add(n_alive, s_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kScatterItems; k++)
+        for (int k = 0; k < ITEMS; k++)
             if (ofs[k] != 0xFFFFFFFFu) list[s_base + wave_base + ofs[k]] = idx[k];
     }
 }
@@ -863,12 +868,16 @@ lbvh_status lbvh_path_scatter(lbvh_context* ctx, const lbvh_scene* h_scene, cons
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
     // the live paths of the bounce before, if this call continues that very frame (same buffers, next bounce): only they can
     // have anything to scatter
-    const bool from_list = ctx->ray_list.valid && ctx->ray_list.states == (const void*)d_states && ctx->ray_list.hits == (const void*)d_hits &&
+    const bool from_list = bounce >= 2u && ctx->ray_list.valid && ctx->ray_list.states == (const void*)d_states && ctx->ray_list.hits == (const void*)d_hits &&
                            ctx->ray_list.count == count && ctx->ray_list.bounce + 1u == bounce && ctx->ray_scratch != nullptr;
     ctx->ray_list.valid = false;                      // the states change without a new list being made
-    LBVH_LAUNCH(ctx, path_scatter_kernel<false>, dim3((unsigned)((count + 256 * kScatterItems - 1) / (256 * kScatterItems))), dim3(256), h_scene->triangles, d_hits, count,
-                bounce, seed, albedo, d_states, nullptr, nullptr, lbvh_camera{},
-                from_list ? ray_list(ctx, count, ctx->ray_list.turn) : nullptr, from_list ? ray_counter(ctx, ctx->ray_list.turn) : nullptr);
+    if (from_list)
+        LBVH_LAUNCH(ctx, (path_scatter_kernel<false, false, kScatterItemsList>), dim3((unsigned)((count + 256 * kScatterItemsList - 1) / (256 * kScatterItemsList))),
+                    dim3(256), h_scene->triangles, d_hits, count, bounce, seed, albedo, d_states, nullptr, nullptr, lbvh_camera{},
+                    ray_list(ctx, count, ctx->ray_list.turn), ray_counter(ctx, ctx->ray_list.turn));
+    else
+        LBVH_LAUNCH(ctx, path_scatter_kernel<false>, dim3((unsigned)((count + 256 * kScatterItems - 1) / (256 * kScatterItems))), dim3(256), h_scene->triangles,
+                    d_hits, count, bounce, seed, albedo, d_states, nullptr, nullptr, lbvh_camera{}, nullptr, nullptr);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;
 }
@@ -894,7 +903,9 @@ static lbvh_status path_bounce_impl(lbvh_context* ctx, const lbvh_scene* h_scene
     if (ctx->ray_scratch != before) ctx->ray_list.valid = false;
     // the paths to look at: the list the bounce before left behind, if this call continues that very frame (same buffers, next
     // bounce, nothing written into them since: lbvh_note_write); otherwise every pixel.  The new list goes into the other buffer.
-    const bool from_list = !h_first_camera && ctx->ray_list.valid && ctx->ray_list.states == (const void*)d_states &&
+    // (from the second bounce on: at bounce 1 two fifths of a frame's paths are still alive and the two forms cost the same, 53 - 56 us
+    // at 1080p; bounces 2, 3 and the last scatter 35 / 33 / 33 -> 27 - 31 / 18 - 20 / 14 - 16 us; 4 paths per thread instead of 2: 33 / 21 / 20)
+    const bool from_list = !h_first_camera && bounce >= 2u && ctx->ray_list.valid && ctx->ray_list.states == (const void*)d_states &&
                            ctx->ray_list.hits == (const void*)d_hits && ctx->ray_list.count == count && ctx->ray_list.bounce + 1u == bounce;
     const uint32_t prev = ctx->ray_list.turn, turn = from_list ? prev ^ 1u : 0u;
     uint32_t* n_alive = ray_counter(ctx, turn);
@@ -904,10 +915,13 @@ static lbvh_status path_bounce_impl(lbvh_context* ctx, const lbvh_scene* h_scene
     if (h_first_camera)
         LBVH_LAUNCH(ctx, (path_scatter_kernel<true, true>), scatter_grid, dim3(256), h_scene->triangles, d_hits, count, 0u, seed, albedo, d_states,
                     n_alive, list, *h_first_camera, nullptr, nullptr);
+    else if (from_list)
+        LBVH_LAUNCH(ctx, (path_scatter_kernel<true, false, kScatterItemsList>), dim3((unsigned)((count + 256 * kScatterItemsList - 1) / (256 * kScatterItemsList))),
+                    dim3(256), h_scene->triangles, d_hits, count, bounce, seed, albedo, d_states, n_alive, list, lbvh_camera{}, ray_list(ctx, count, prev),
+                    ray_counter(ctx, prev));
     else
         LBVH_LAUNCH(ctx, (path_scatter_kernel<true, false>), scatter_grid, dim3(256), h_scene->triangles, d_hits, count, bounce, seed, albedo,
-                    d_states, n_alive, list, lbvh_camera{}, from_list ? ray_list(ctx, count, prev) : nullptr,
-                    from_list ? ray_counter(ctx, prev) : nullptr);
+                    d_states, n_alive, list, lbvh_camera{}, nullptr, nullptr);
     ctx->ray_list.valid = true;
     ctx->ray_list.states = d_states; ctx->ray_list.hits = d_hits; ctx->ray_list.count = count;
     ctx->ray_list.bounce = h_first_camera ? 0u : bounce;
