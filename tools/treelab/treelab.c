@@ -364,6 +364,7 @@ static inline int tri_test(const ray_t* r, uint32_t orig, float* t_out)
 static int g_tw = 8, g_th = 8;        // tile shape (g_tw x g_th = 64 lanes)
 static int g_near_rule = 0;          // 0: majority vote (the product); 1: the child whose minimum entry distance is smaller
 static int g_pop_nearest = 0;        // 1: a pop takes the waiting entry with the smallest entry distance, not the newest
+static int g_steal = 0;
 static int g_predict = 0;
 static __thread uint32_t tl_step_cap = 0;       // if set: walk_tile stops after this many steps
 static __thread uint32_t* tl_lane_work = NULL;   // if set: [64] steps in which the lane wanted a child or tested a leaf
@@ -518,6 +519,80 @@ static uint32_t walk_ray(const tree_t* t, const ray_t* r, float t_min, float* be
     return visits;
 }
 
+
+// ---- wave-level work stealing for the per-ray walk (cfg5's later bounces) -----------------------------------------------
+// 64 rays, one per lane, stepped in lockstep (a step = one node visit per active lane, the latency of one dependent fetch).
+// Without stealing the wave takes as many steps as its longest ray.  With it, a lane whose ray is finished takes the OLDEST waiting
+// entry (the bottom of the stack: the farthest subtree) of the lane with the most waiting entries and walks it for that ray,
+// starting from the owner's best t at that moment; results are merged per ray (min t; ties to the lower triangle).
+typedef struct { int active; uint32_t ray, node, sb, sp; float best; uint32_t best_leaf; uint32_t stack[128]; } lane_t;
+
+static inline void lane_step(const tree_t* t, const ray_t* r, float t_min, lane_t* L)
+{
+    const node_t* nd = &t->nd[L->node];
+    float tl, tr;
+    int hl = slab(&nd->lb, r, &tl) && !(tl > L->best), hr = slab(&nd->rb, r, &tr) && !(tr > L->best);
+    if ((nd->l & LEAF) && hl) {
+        float tt;
+        const uint32_t pos = nd->l & ~LEAF;
+        if (tri_test(r, sidx[pos], &tt) && tt > t_min && (tt < L->best || (tt == L->best && sidx[pos] < sidx[L->best_leaf]))) { L->best = tt; L->best_leaf = pos; }
+        hr = hr && !(tr > L->best);
+    }
+    if ((nd->r & LEAF) && hr) {
+        float tt;
+        const uint32_t pos = nd->r & ~LEAF;
+        if (tri_test(r, sidx[pos], &tt) && tt > t_min && (tt < L->best || (tt == L->best && sidx[pos] < sidx[L->best_leaf]))) { L->best = tt; L->best_leaf = pos; }
+        hl = hl && !(tl > L->best);
+    }
+    if (nd->l & LEAF) hl = 0;
+    if (nd->r & LEAF) hr = 0;
+    if (hl && hr) {
+        const int l_near = tl <= tr;
+        L->stack[L->sp++] = l_near ? nd->r : nd->l;
+        L->node = l_near ? nd->l : nd->r;
+    } else if (hl) L->node = nd->l;
+    else if (hr) L->node = nd->r;
+    else if (L->sp > L->sb) L->node = L->stack[--L->sp];
+    else L->active = 0;
+}
+
+// returns the wave's steps; `steals_per_step` = 0: no stealing.  best[] / leaf[]: the rays' merged results
+static uint32_t wave_walk(const tree_t* t, const ray_t* rays, int n_rays, float t_min, int steals_per_step, float* best, uint32_t* leaf, uint64_t* visits)
+{
+    lane_t L[64];
+    for (int l = 0; l < 64; l++) {
+        L[l].active = l < n_rays; L[l].ray = (uint32_t)l; L[l].node = 0; L[l].sb = L[l].sp = 0; L[l].best = MAXF; L[l].best_leaf = 0;
+        if (l < n_rays) { best[l] = MAXF; leaf[l] = 0xFFFFFFFFu; }
+    }
+    uint32_t steps = 0;
+    for (;;) {
+        int any = 0;
+        for (int l = 0; l < 64; l++) any |= L[l].active;
+        if (!any) break;
+        steps++;
+        for (int l = 0; l < 64; l++) {
+            if (!L[l].active) continue;
+            (*visits)++;
+            lane_step(t, &rays[L[l].ray], t_min, &L[l]);
+            if (!L[l].active) {          // merge into the ray's result
+                const uint32_t r = L[l].ray;
+                if (L[l].best < best[r] || (L[l].best == best[r] && L[l].best < MAXF && sidx[L[l].best_leaf] < sidx[leaf[r]])) { best[r] = L[l].best; leaf[r] = L[l].best_leaf; }
+            }
+        }
+        for (int s = 0; s < steals_per_step; s++) {
+            int thief = -1, donor = -1; uint32_t depth = 0;
+            for (int l = 0; l < 64; l++) {
+                if (!L[l].active) { if (thief < 0) thief = l; }
+                else if (L[l].sp - L[l].sb > depth) { depth = L[l].sp - L[l].sb; donor = l; }
+            }
+            if (thief < 0 || donor < 0 || depth < 1) break;
+            L[thief].active = 1; L[thief].ray = L[donor].ray; L[thief].node = L[donor].stack[L[donor].sb++];
+            L[thief].sb = L[thief].sp = 0; L[thief].best = L[donor].best; L[thief].best_leaf = L[donor].best_leaf;
+        }
+    }
+    return steps;
+}
+
 static int cmp_u32(const void* a, const void* b) { return *(const uint32_t*)a < *(const uint32_t*)b ? -1 : *(const uint32_t*)a > *(const uint32_t*)b; }
 
 static uint32_t pcg(uint32_t* s) { *s = *s * 747796405u + 2891336453u; uint32_t w = ((*s >> ((*s >> 28) + 4)) ^ *s) * 277803737u; return (w >> 22) ^ w; }
@@ -660,6 +735,8 @@ static void evaluate(const char* name, const tree_t* t, double build_s)
     {
         camera_t c = {1920, 1080, tanf(30.0f * (float)M_PI / 180.0f), 0.3f, {0.0f, 0.0f, 250.0f}};
         uint64_t pv = 0, bv = 0, rays = 0, b2 = 0;
+        uint32_t* vis = calloc((size_t)(c.w / 4) * (c.h / 4), 4);      // node visits of every bounce-1 ray (0: the path had ended)
+        ray_t* brays = malloc((size_t)(c.w / 4) * (c.h / 4) * sizeof(ray_t));   // the bounce-1 rays themselves (for the wave simulation)
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : pv, bv, rays, b2)
         for (int py = 0; py < c.h; py += 4)
             for (int px = 0; px < c.w; px += 4) {
@@ -683,11 +760,57 @@ static void evaluate(const char* name, const tree_t* t, double build_s)
                     if (!(len > 1e-6f)) break;
                     ray_t q;
                     for (int k = 0; k < 3; k++) { q.o[k] = r.o[k] + r.d[k] * bt; q.d[k] = d[k] / len; q.inv[k] = 1.0f / q.d[k]; }
-                    const uint32_t vis = walk_ray(t, &q, 1e-3f, &bt, &bl);
-                    if (bounce == 0) { bv += vis; rays++; } else b2 += vis;
+                    const uint32_t visits_ = walk_ray(t, &q, 1e-3f, &bt, &bl);
+                    if (bounce == 0) { bv += visits_; rays++; vis[(size_t)(py / 4) * (c.w / 4) + px / 4] = visits_; brays[(size_t)(py / 4) * (c.w / 4) + px / 4] = q; } else b2 += visits_;
                     r = q;
                 }
             }
+        {
+            const size_t nv = (size_t)(c.w / 4) * (c.h / 4);
+            // a wave of 64 consecutive live rays takes as long as its longest ray: mean of the per-wave maxima against the mean ray
+            uint64_t wave_max_sum = 0, waves = 0; uint32_t in_wave = 0, wmax = 0, gmax = 0;
+            for (size_t i = 0; i < nv; i++) {
+                if (!vis[i]) continue;
+                if (vis[i] > wmax) wmax = vis[i];
+                if (vis[i] > gmax) gmax = vis[i];
+                if (++in_wave == 64) { wave_max_sum += wmax; waves++; in_wave = 0; wmax = 0; }
+            }
+            if (g_steal) {
+                // the live bounce-1 rays in pixel order, 64 (or 32: half-filled waves, as the later bounces' launches) per wave
+                ray_t* live_rays = malloc(nv * sizeof(ray_t));
+                size_t nl = 0;
+                for (size_t i = 0; i < nv; i++) if (vis[i]) live_rays[nl++] = brays[i];
+                for (int per_wave = 64; per_wave >= 32; per_wave /= 2) {
+                    for (int sps = 0; sps <= 4; sps = sps ? sps * 2 : 1) {
+                        uint64_t steps_sum = 0, visits = 0, worst = 0, mismatch = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : steps_sum, visits, mismatch) reduction(max : worst)
+                        for (size_t w0 = 0; w0 < nl; w0 += (size_t)per_wave) {
+                            const int cnt = (int)(nl - w0 < (size_t)per_wave ? nl - w0 : (size_t)per_wave);
+                            float best[64]; uint32_t leaf[64]; uint64_t v = 0;
+                            const uint32_t st = wave_walk(t, live_rays + w0, cnt, 1e-3f, sps, best, leaf, &v);
+                            steps_sum += st; visits += v; if (st > worst) worst = st;
+                            for (int l = 0; l < cnt; l++) {
+                                float bt; uint32_t bl;
+                                walk_ray(t, &live_rays[w0 + l], 1e-3f, &bt, &bl);
+                                if (bt != best[l]) mismatch++;
+                            }
+                        }
+                        printf("\n   waves of %d rays, %d steal(s) per step: longest wave %llu steps, mean %.1f, node visits %llu, results differing from the lone walk: %llu",
+                               per_wave, sps, (unsigned long long)worst, (double)steps_sum / (double)((nl + per_wave - 1) / per_wave), (unsigned long long)visits,
+                               (unsigned long long)mismatch);
+                    }
+                }
+                printf("\n");
+                free(live_rays);
+            }
+            free(brays);
+            qsort(vis, nv, 4, cmp_u32);
+            size_t first = 0; while (first < nv && !vis[first]) first++;
+            const size_t live = nv - first;
+            printf(" [bounce-1 visits: p50 %u p90 %u p99 %u max %u; mean of per-wave (64 rays) maxima %.1f]", vis[first + live / 2], vis[first + live * 9 / 10],
+                   vis[first + live * 99 / 100], gmax, waves ? (double)wave_max_sum / waves : 0.0);
+            free(vis);
+        }
         printf(" per-ray: primary %.1f bounce1 %.1f (x%llu) bounce2 sum %llu\n", (double)pv / (c.w / 4 * (c.h / 4)), (double)bv / (double)rays,
                (unsigned long long)rays, (unsigned long long)b2);
     }
@@ -722,6 +845,7 @@ int main(int argc, char** argv)
         if (!strcmp(w, "hist")) g_show_hist = 1;
         else if (!strcmp(w, "cull")) g_cull = 1;
         else if (!strcmp(w, "predict")) g_predict = 1;
+        else if (!strcmp(w, "steal")) g_steal = 1;
         else if (!strcmp(w, "popnearest")) g_pop_nearest = 1;
         else if (!strncmp(w, "tile", 4)) { sscanf(w + 4, "%dx%d", &g_tw, &g_th); printf("tile %dx%d\n", g_tw, g_th); }
         else if (!strncmp(w, "near", 4)) { g_near_rule = atoi(w + 4); printf("near rule %d\n", g_near_rule); }
