@@ -65,10 +65,9 @@ lbvh_status lbvh_debug_ray_stack_limit(lbvh_context* ctx, uint32_t deep_entries)
 
 /* Test hook: which walk lbvh_trace_rays / lbvh_path_bounce run — 1 (default): four-wide nodes (each binary node with its
  * largest children opened, made on first use after a rebuild; from bounce 1 on lbvh_path_bounce takes the kernel that keeps
- * a step's two fetches in flight at once and lets idle lanes take work from the deepest stacks of their wave: few live rays,
- * the launch is the chain of its longest), 2: that kernel for every launch, 3: the later bounces without the work stealing
- * (rounds 3 - 4), 0: the binary nodes the packet walk uses.  Hit records do not depend on it (ties go to the lower triangle
- * index on all of them). */
+ * a step's two fetches in flight at once: few live rays, the launch is the chain of its longest), 2: that kernel for every
+ * launch, 0: the binary nodes the packet walk uses.  Hit records do not depend on it (ties go to the lower triangle index
+ * on all three). */
 lbvh_status lbvh_debug_ray_walker(lbvh_context* ctx, uint32_t walker);
 
 /* Profiling aid: one LBVH_TRACE_FAST frame that also records, per 8x8-pixel tile (row-major,

@@ -1666,7 +1666,7 @@ def test_secondary_rays_four_wide_walk_equals_binary_walk(ctx, scene):
     hb = H().DataBuffer(ctx, len(st), L.HIT)
     s = c.scene()
     n_ = N()
-    assert n_.lib.lbvh_debug_ray_walker(ctx.handle, 4) == -1
+    assert n_.lib.lbvh_debug_ray_walker(ctx.handle, 3) == -1
     frames = {}
     try:
         for wide, split in ((0, 16), (1, 16), (1, 1), (1, 3), (2, 16), (2, 2)):

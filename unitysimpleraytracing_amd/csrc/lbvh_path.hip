@@ -567,209 +567,6 @@ __global__ __launch_bounds__(64) void trace_rays_wide_chain_kernel(const lbvh_pa
     if (STATS) add_ray_stats(stats, n_rays, n_steps, n_tris);
 }
 
-#define LBVH_RLF(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
-constexpr int kStealsPerStep = 2;          // idle lanes that may take work in one step of a wave (tools/treelab `steal`: 1 / 2 / 4 -> longest wave 122 / 97 / 82 steps)
-
-// trace_rays_wide_chain_kernel with WORK STEALING inside the wave (round 5).  The later bounces of a frame have
-// fewer live rays than the chip has lanes: every lane gets at most one ray, nothing is left to refill from, and the launch takes
-// as long as its LONGEST ray (node visits per bounce ray: median 45, 99th percentile 124, longest 234 — the launch is five times
-// its mean ray).  Here a lane whose ray is finished takes the OLDEST waiting entry (the bottom of the stack: the farthest subtree)
-// of the lane with the most waiting entries and walks it for that ray, starting from the owner's best hit at that moment; what
-// each walker finds is merged per ray in LDS — a 64-bit minimum on (t, triangle), so ties go to the lower index as everywhere —
-// and whoever finishes a ray's last walk writes its record.  A stale best hit only prunes less, never more: the record is the
-// lone walk's (tools/treelab `steal`: 0 of 54 188 rays differ; longest wave of 32 rays 234 -> 97 steps with two steals per step,
-// + 39 % node visits on lanes that had nothing to do).
-template <bool STATS>
-__global__ __launch_bounds__(64) void trace_rays_wide_steal_kernel(const lbvh_path_state* __restrict__ states, const uint32_t* __restrict__ n_alive,
-                                                             const uint32_t* __restrict__ list, float t_min,
-                                                             const lbvh_wide_node* __restrict__ wide,
-                                                             const lbvh_fast_node* __restrict__ lines, lbvh_hit* __restrict__ hits,
-                                                             uint32_t* __restrict__ deep,     // [gridDim.x][kWideStackDeep][64]
-                                                             uint32_t lds_depth,              // <= kWideStackLds
-                                                             uint32_t deep_cap,               // <= kWideStackDeep
-                                                             uint32_t* __restrict__ fault, lbvh_ray_stats* stats)
-{
-    __shared__ uint32_t s_stack[kWideStackLds][LBVH_WAVE];
-    __shared__ unsigned long long s_key[LBVH_WAVE];     // per ray slot (= the lane that loaded the ray): best (t bits << 32 | triangle) of all its walkers
-    __shared__ float2 s_uv[LBVH_WAVE];                  // ... and that hit's u, v
-    __shared__ uint32_t s_pending[LBVH_WAVE];           // walkers of the slot's ray still under way
-    __shared__ uint32_t s_index[LBVH_WAVE];             // the ray's path index (where its record goes)
-    uint32_t* wave_deep = deep + (size_t)blockIdx.x * (kWideStackDeep * LBVH_WAVE);
-    uint32_t* my_deep = wave_deep + threadIdx.x;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t total = *n_alive;
-    const uint32_t run = max((total + gridDim.x - 1) / gridDim.x, 32u);
-    uint32_t next = blockIdx.x * run;
-    if (next >= total) return;
-    const uint32_t end = min(next + run, total);
-    uint32_t n_rays = 0, n_steps = 0, n_tris = 0;
-
-    bool active = false, have = false;      // have: the registers below hold this lane's node
-    uint32_t i = 0;                          // (lbvh_trace_rays: count <= 2^32 - 1)
-    ray_t ray = {};
-    float best_t = LBVH_MAX_FLOAT, best_u = 0.0f, best_v = 0.0f;
-    uint32_t best_tri = 0, sp = 0, sb = 0, node = 0;      // sb: the stack's bottom (entries [sb, sp) wait; thieves take from the bottom)
-    uint32_t slot = lane;                                 // the ray slot this lane walks for (its own, or the lane it took work from)
-    float4 lox = {}, loy = {}, loz = {}, hix = {}, hiy = {}, hiz = {};
-    uint4 ref = {};
-    auto push = [&](uint32_t r) {
-        if (sp < lds_depth) { s_stack[sp][lane] = r; sp++; }
-        else if (sp < lds_depth + deep_cap) { my_deep[(sp - lds_depth) * LBVH_WAVE] = r; sp++; }
-        // a dropped entry would be a silently wrong hit: report it.  Cannot happen on this library's trees (a radix
-        // tree over unique 32-bit keys is <= 32 levels deep, 3 waiting siblings per level); lbvh_debug_ray_stack_limit provokes it
-        else __hip_atomic_store(fault, LBVH_FAULT_RAY_STACK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    };
-    // A step: box tests on the node fetched during the previous step, the next node chosen (against the best hit so far),
-    // then the first leaf's triangle line AND the next node requested together, the triangle tests while both are on their
-    // way.  The two fetches of a step overlap instead of following each other; what a leaf hit would have pruned from the
-    // choice is met by the next step's box tests (its children then fail `entry <= best`).
-    for (;;) {
-        const uint64_t idle = __ballot(!active);
-        if (idle != 0 && next < end) {
-            if (!active) {
-                const uint32_t k = next + mbcnt64(idle);
-                if (k < end) {
-                    i = list[k];
-                    const float4* st = reinterpret_cast<const float4*>(&states[i]);
-                    const float4 o = st[0], d = st[1];
-                    ray.ox = o.x; ray.oy = o.y; ray.oz = o.z;
-                    ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
-                    ray.ix = 1.0f / d.x; ray.iy = 1.0f / d.y; ray.iz = 1.0f / d.z;
-                    best_t = LBVH_MAX_FLOAT; best_tri = 0; best_u = 0.0f; best_v = 0.0f;
-                    sp = 0; sb = 0; node = 0; slot = lane;
-                    s_key[lane] = ((unsigned long long)__float_as_uint(LBVH_MAX_FLOAT) << 32);      // a miss: t = MAX_FLOAT, triangle 0
-                    s_uv[lane] = make_float2(0.0f, 0.0f);
-                    s_pending[lane] = 1u;
-                    s_index[lane] = i;
-                    active = true; have = false;
-                    if (STATS) n_rays++;
-                }
-            }
-            next += (uint32_t)__popcll(idle);
-        }
-        if (next >= end) {
-            // nothing left to refill from: idle lanes take work from the deepest stacks (wave-uniform control flow)
-#pragma unroll 1
-            for (int s = 0; s < kStealsPerStep; s++) {
-                const uint64_t free_lanes = __ballot(!active);
-                if (free_lanes == 0) break;
-                uint32_t cand = active ? (((sp - sb) << 6) | lane) : 0u;          // most waiting entries; the lane number makes it unique
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) cand = max(cand, (uint32_t)__shfl_xor((int)cand, d));
-                if ((cand >> 6) == 0u) break;
-                const int donor = (int)(cand & 63u), thief = __builtin_ctzll(free_lanes);
-                const uint32_t donor_sb = (uint32_t)__builtin_amdgcn_readlane((int)sb, donor);
-                const uint32_t entry = donor_sb < lds_depth ? s_stack[donor_sb][donor] : wave_deep[(donor_sb - lds_depth) * LBVH_WAVE + donor];
-                // the donor's ray and best hit so far, for the thief (readlane with a uniform lane number)
-                const float rox = LBVH_RLF(ray.ox, donor), roy = LBVH_RLF(ray.oy, donor), roz = LBVH_RLF(ray.oz, donor);
-                const float rdx = LBVH_RLF(ray.dx, donor), rdy = LBVH_RLF(ray.dy, donor), rdz = LBVH_RLF(ray.dz, donor);
-                const float rix = LBVH_RLF(ray.ix, donor), riy = LBVH_RLF(ray.iy, donor), riz = LBVH_RLF(ray.iz, donor);
-                const float dbt = LBVH_RLF(best_t, donor), dbu = LBVH_RLF(best_u, donor), dbv = LBVH_RLF(best_v, donor);
-                const uint32_t dtri = (uint32_t)__builtin_amdgcn_readlane((int)best_tri, donor);
-                const uint32_t dslot = (uint32_t)__builtin_amdgcn_readlane((int)slot, donor);
-                if ((int)lane == donor) sb++;
-                if ((int)lane == thief) {
-                    ray.ox = rox; ray.oy = roy; ray.oz = roz; ray.dx = rdx; ray.dy = rdy; ray.dz = rdz; ray.ix = rix; ray.iy = riy; ray.iz = riz;
-                    best_t = dbt; best_u = dbu; best_v = dbv; best_tri = dtri;
-                    slot = dslot; node = entry; sp = 0; sb = 0;
-                    active = true; have = false;
-                    atomicAdd(&s_pending[dslot], 1u);
-                }
-            }
-        }
-        if (!__any(active)) break;
-        uint32_t leaves = 0u;
-        uint4 leaf_ref = {};
-        bool fetch = active, done = false;
-        if (active && have) {
-            float t0, t1, t2, t3;
-            const bool h0 = wide_box(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ray, t0) && !(t0 > best_t) && ref.x != kWideEmpty;
-            const bool h1 = wide_box(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ray, t1) && !(t1 > best_t) && ref.y != kWideEmpty;
-            const bool h2 = wide_box(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ray, t2) && !(t2 > best_t) && ref.z != kWideEmpty;
-            const bool h3 = wide_box(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ray, t3) && !(t3 > best_t) && ref.w != kWideEmpty;
-            leaves = (h0 && (ref.x >> 31) ? 1u : 0u) | (h1 && (ref.y >> 31) ? 2u : 0u) | (h2 && (ref.z >> 31) ? 4u : 0u) |
-                     (h3 && (ref.w >> 31) ? 8u : 0u);
-            leaf_ref = ref;
-            // nodes to enter, ordered by entry distance: the order key is the distance's bit pattern (non-negative floats
-            // order like integers) with the slot number in its two lowest bits
-            constexpr uint32_t none = 0xFFFFFFFFu;
-            uint32_t k0 = h0 && !(ref.x >> 31) ? ((__float_as_uint(fmaxf(t0, 0.0f)) & ~3u) | 0u) : none;
-            uint32_t k1 = h1 && !(ref.y >> 31) ? ((__float_as_uint(fmaxf(t1, 0.0f)) & ~3u) | 1u) : none;
-            uint32_t k2 = h2 && !(ref.z >> 31) ? ((__float_as_uint(fmaxf(t2, 0.0f)) & ~3u) | 2u) : none;
-            uint32_t k3 = h3 && !(ref.w >> 31) ? ((__float_as_uint(fmaxf(t3, 0.0f)) & ~3u) | 3u) : none;
-            {   // five compare-exchanges
-                uint32_t a, b;
-                a = min(k0, k1); b = max(k0, k1); k0 = a; k1 = b;
-                a = min(k2, k3); b = max(k2, k3); k2 = a; k3 = b;
-                a = min(k0, k2); b = max(k0, k2); k0 = a; k2 = b;
-                a = min(k1, k3); b = max(k1, k3); k1 = a; k3 = b;
-                a = min(k1, k2); b = max(k1, k2); k1 = a; k2 = b;
-            }
-            if (k0 != none) {
-                if (k3 != none) push(pick4(ref, k3 & 3u));       // farthest first: the nearest waiting sibling is popped first
-                if (k2 != none) push(pick4(ref, k2 & 3u));
-                if (k1 != none) push(pick4(ref, k1 & 3u));
-                node = pick4(ref, k0 & 3u);
-            } else if (sp != sb) {
-                sp--;
-                node = sp < lds_depth ? s_stack[sp][lane] : my_deep[(sp - lds_depth) * LBVH_WAVE];
-            } else {
-                fetch = false;
-                done = true;              // after this step's leaves
-            }
-        }
-        // the first leaf's line, then the next node: requested back to back
-        // (a triangle line: {v0, index} | e2.x in dword 7 | {e1, e2.y} | e2.z in dword 15)
-        float4 q0 = {}, q1 = {}, q2 = {}, q3 = {};
-        if (leaves != 0u) {
-            const float4* line = reinterpret_cast<const float4*>(&lines[pick4(leaf_ref, (uint32_t)__builtin_ctz(leaves)) & 0x7FFFFFFFu]);
-            q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3];
-        }
-        if (fetch) {
-            if (STATS) n_steps++;
-            const float4* w = reinterpret_cast<const float4*>(&wide[node]);
-            lox = w[0]; loy = w[1]; loz = w[2]; hix = w[3]; hiy = w[4]; hiz = w[5];
-            ref = reinterpret_cast<const uint4*>(w)[6];
-            have = true;
-        }
-        while (leaves != 0u) {
-            leaves &= leaves - 1u;
-            if (STATS) n_tris++;
-            float u = 0.0f, v = 0.0f;
-            const float dist = ray_triangle_edges(ray, q0, q2.x, q2.y, q2.z, q1.w, q2.w, q3.w, u, v);
-            const uint32_t tri = __float_as_uint(q0.w);
-            // ties go to the lower triangle index, whatever order the leaves are met in (as in the packet walk)
-            if (dist > t_min && (dist < best_t || (dist == best_t && tri < best_tri))) { best_t = dist; best_tri = tri; best_u = u; best_v = v; }
-            if (leaves != 0u) {
-                const float4* line = reinterpret_cast<const float4*>(&lines[pick4(leaf_ref, (uint32_t)__builtin_ctz(leaves)) & 0x7FFFFFFFu]);
-                q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3];
-            }
-        }
-        // this walk is over: its best hit joins the ray's, and the ray's last walk to end writes the record (all lanes that end in
-        // this step run these instructions together: every minimum is taken before any lane looks who holds it)
-        unsigned long long mine = 0ull;
-        if (done) {
-            mine = ((unsigned long long)__float_as_uint(best_t) << 32) | best_tri;
-            atomicMin(&s_key[slot], mine);
-        }
-        if (done && s_key[slot] == mine && best_t < LBVH_MAX_FLOAT) s_uv[slot] = make_float2(best_u, best_v);
-        if (done) {
-            if (atomicSub(&s_pending[slot], 1u) == 1u) {
-                const unsigned long long k = s_key[slot];
-                const float2 uv = s_uv[slot];
-                float4 out;
-                out.x = __uint_as_float((uint32_t)(k >> 32));
-                out.y = __uint_as_float((uint32_t)k);
-                out.z = uv.x;
-                out.w = uv.y;
-                reinterpret_cast<float4*>(hits)[s_index[slot]] = out;
-            }
-            active = false;
-        }
-    }
-    if (STATS) add_ray_stats(stats, n_rays, n_steps, n_tris);
-}
-
 // ---- bounce ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t pcg_hash(uint32_t v)
 {
@@ -955,15 +752,10 @@ static lbvh_status launch_ray_walk(lbvh_context* ctx, const lbvh_path_state* d_s
         const uint32_t lds = std::min<uint32_t>(ctx->ray_stack_lds, kWideStackLds), deep_cap = std::min<uint32_t>(ctx->ray_stack_deep, kWideStackDeep);
         lbvh_ray_stats* st = ctx->ray_stats;
         const lbvh_wide_node* wn = (const lbvh_wide_node*)ctx->wide_nodes;
-        if (ctx->ray_walker == 3u && few_rays) {          // measurement: the later bounces without work stealing (round 3 - 4's kernel)
+        if (few_rays || ctx->ray_walker == 2u) {
             if (st) LBVH_LAUNCH(ctx, trace_rays_wide_chain_kernel<true>, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, wn, ctx->fast_nodes,
                                 d_hits, deep_stacks(ctx, count), lds, deep_cap, ctx->fault_dev, st);
             else LBVH_LAUNCH(ctx, trace_rays_wide_chain_kernel<false>, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, wn, ctx->fast_nodes,
-                             d_hits, deep_stacks(ctx, count), lds, deep_cap, ctx->fault_dev, st);
-        } else if (few_rays || ctx->ray_walker == 2u) {
-            if (st) LBVH_LAUNCH(ctx, trace_rays_wide_steal_kernel<true>, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, wn, ctx->fast_nodes,
-                                d_hits, deep_stacks(ctx, count), lds, deep_cap, ctx->fault_dev, st);
-            else LBVH_LAUNCH(ctx, trace_rays_wide_steal_kernel<false>, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, wn, ctx->fast_nodes,
                              d_hits, deep_stacks(ctx, count), lds, deep_cap, ctx->fault_dev, st);
         } else {
             if (st) LBVH_LAUNCH(ctx, trace_rays_wide_kernel<true>, dim3(ray_waves), dim3(LBVH_WAVE), d_states, n_alive, list, t_min, wn, ctx->fast_nodes,
@@ -1039,7 +831,7 @@ lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, 
 lbvh_status lbvh_debug_ray_walker(lbvh_context* ctx, uint32_t walker)
 {
     if (!ctx) return LBVH_ERR_INVALID_ARG;
-    LBVH_REQUIRE(ctx, walker <= 3u);
+    LBVH_REQUIRE(ctx, walker <= 2u);
     ctx->ray_walker = walker;
     return LBVH_OK;
 }
