@@ -520,7 +520,7 @@ static uint32_t walk_ray(const tree_t* t, const ray_t* r, float t_min, float* be
 }
 
 
-// ---- wave-level work stealing for the per-ray walk (cfg5's later bounces) -----------------------------------------------
+// ---- wave-level work stealing for the per-ray walk (cfg5's later bounces; DESIGN 14.6, profiles/r5/e_work_stealing_per_ray_walk.txt) -----------------------------------------------
 // 64 rays, one per lane, stepped in lockstep (a step = one node visit per active lane, the latency of one dependent fetch).
 // Without stealing the wave takes as many steps as its longest ray.  With it, a lane whose ray is finished takes the OLDEST waiting
 // entry (the bottom of the stack: the farthest subtree) of the lane with the most waiting entries and walks it for that ray,
