@@ -1742,6 +1742,36 @@ def test_path_first_bounce_equals_begin_plus_bounce_zero(ctx):
     pt.drawer.on_destroy()
 
 
+def test_light_whole_frames_take_the_eight_wave_cooperative_shape(ctx):
+    """Round 5: a whole frame whose previous frames were LIGHT (the scene far away: few tiles hold all of it) walks its heavy
+    tiles with workgroups of 8 waves instead of 4 — chosen from a work estimate two frames stale.  Six frames of a 250 k-triangle
+    scene at 1080p from far away, each into a poisoned buffer: every frame's t equals the reference mode's bit for bit and the
+    exact mode's records equal it word for word (the shape changes under way: first frames 4 waves or none, later ones 8), and
+    the same camera close by (a busy frame: back to 4 waves) likewise."""
+    tris = scenes.tiled_torus(nu=40, nv=25)
+    d, c, b = build_both(ctx, tris)
+    d.rebuild(fast=True)
+    W, Ht = 1920, 1080
+    s = c.scene()
+    hb = H().DataBuffer(ctx, W * Ht, L.HIT)
+    for pos in ((3.0, 2.0, 800.0), (3.0, 2.0, 250.0), (3.0, 2.0, 900.0)):
+        cam = N().Camera.from_dict(scenes.camera(W, Ht, pos))
+        hb.fill_u32(0x7FC00000, mirror=False)
+        N().check(ctx.handle, N().lib.lbvh_trace_primary(ctx.handle, C.byref(cam), 0, 0, W, Ht, C.byref(s), L.TRACE_REFERENCE, hb.device, None))
+        ref = hb.get_data().copy()
+        for mode in (L.TRACE_FAST, L.TRACE_FAST_EXACT):
+            for f in range(6):
+                hb.fill_u32(0x7FC00000, mirror=False)
+                N().check(ctx.handle, N().lib.lbvh_trace_primary(ctx.handle, C.byref(cam), 0, 0, W, Ht, C.byref(s), mode, hb.device, None))
+                got = hb.get_data()
+                assert (got["t"].view(np.uint32) == ref["t"].view(np.uint32)).all(), (pos, mode, f)
+                if mode == L.TRACE_FAST_EXACT:
+                    assert (words(got) == words(ref)).all(), (pos, f)
+        assert (ref["t"] < 1e30).sum() > 1000
+    hb.dispose()
+    d.on_destroy()
+
+
 def test_path_bounces_from_the_live_list_equal_bounces_over_every_pixel(ctx):
     """Round 5: lbvh_path_bounce b >= 1 (and the frame's last lbvh_path_scatter) look only at the paths the bounce before listed as
     live, if they continue that very frame.  Same frame three ways — (a) as the host classes issue it (lists used), (b) with the

@@ -880,6 +880,7 @@ constexpr uint32_t kCoopGrain = 32;        // steps of the last trace per cooper
 constexpr uint32_t kCoopMaxWork = 12288;   // tiles per launch up to which every heavy class is walked cooperatively
 constexpr uint32_t kSharedMaxWork = 24576; // ... and up to which the very heaviest are (beyond: one wave per tile only)
 constexpr uint32_t kHeavyClassFull = 9;    // above that: only classes >= this (>= 192 steps; half frame: 152 us against 184 / 160 / 193 with 8 / 10 / 11)
+constexpr uint32_t kLightFrameSteps = 640000; // whole frames whose estimated steps (class lower bounds: an underestimate) stay below this walk their heavy tiles with kCoopWaves
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kMovedCoopMaxWork = 6144;  // ... when the camera has moved since the costs were recorded (launch_packets)
 
@@ -1322,14 +1323,25 @@ __device__ __forceinline__ uint32_t item_of_tile(const tile_grid& g, uint32_t ti
 __global__ __launch_bounds__(1024) void file_tiles_kernel(const uint32_t* __restrict__ cost, uint32_t n_work,
                                                           uint32_t* __restrict__ counts, uint32_t* __restrict__ lists,
                                                           uint32_t* __restrict__ next_counts, tile_grid grid,
-                                                          const uint32_t* __restrict__ frame)
+                                                          const uint32_t* __restrict__ frame, uint32_t* work_estimate)
 {
     __shared__ uint32_t s_count[kOrderClasses], s_base[kOrderClasses];
     const uint32_t t = threadIdx.x, lane = lane_id();
     const uint32_t i = blockIdx.x * 1024u + t;
     // the class counters take turns: this launch clears the set the NEXT filing will count into (the trace that
-    // read it has finished), so no fill kernel sits between the rebuild and the trace
-    if (blockIdx.x == 0 && t < (uint32_t)kOrderClasses) next_counts[t] = 0;
+    // read it has finished), so no fill kernel sits between the rebuild and the trace.  On the way out that set tells how much
+    // work the frame before last was: tiles per class x the class's lower bound, left in a mapped host word for launch_packets
+    // (a hint two frames stale: which cooperative workgroup shape a whole frame takes)
+    if (blockIdx.x == 0 && t < (uint32_t)kOrderClasses) {
+        const uint32_t tiles_in_class = next_counts[t];
+        // lower bounds of the classes of order_class: < 12, then 12, 16, 24, 32, 48, ... (two per octave)
+        const uint32_t low = t == 0u ? 4u : ((t & 1u) ? 12u << ((t - 1u) / 2u) : 16u << (t / 2u - 1u));
+        uint32_t steps = tiles_in_class * low;
+#pragma unroll
+        for (int d = 1; d < kOrderClasses; d <<= 1) steps += (uint32_t)__shfl_xor((int)steps, d, kOrderClasses);
+        if (t == 0 && work_estimate) __hip_atomic_store(work_estimate, steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        next_counts[t] = 0;
+    }
     if (t < (uint32_t)kOrderClasses) s_count[t] = 0;
     __syncthreads();
     uint32_t cls = 0xFFFFFFFFu;
@@ -1523,7 +1535,8 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
         // the whole previous frame's costs, if the caller has merged the ranks' (multi-GPU frames under a moving camera)
         const uint32_t* frame = ctx->trace_frame_valid && ctx->trace_frame_tiles_x == a.tiles_x && ctx->trace_frame_tiles_y == a.tiles_y &&
                                         spread != 0 ? ctx->trace_frame_costs : nullptr;
-        LBVH_LAUNCH(ctx, file_tiles_kernel, dim3((n_work + 1023) / 1024), dim3(1024), cost, n_work, counts, lists, next_counts, grid, frame);
+        LBVH_LAUNCH(ctx, file_tiles_kernel, dim3((n_work + 1023) / 1024), dim3(1024), cost, n_work, counts, lists, next_counts, grid, frame,
+                    ctx->fault_dev + 24);
         ctx->trace_counts_turn ^= 1u;
     }
     // an imported cost map is a hint for the ONE frame that follows it, used or not (an unused map — static camera,
@@ -1562,8 +1575,25 @@ int launch_packets(lbvh_context* ctx, trace_args a, lbvh_hit* d_hits, lbvh_trace
 #define LBVH_WHOLE_COOP_DIV 64u
 #endif
         coop_params hp = {std::max(64u, n_work / LBVH_WHOLE_COOP_DIV), kHeavyClassWhole, kCoopGrain};
-        const uint32_t blocks = hp.cap + (n_work + kCoopWavesWhole - 1) / kCoopWavesWhole;
-        if (exact)
+        // A LIGHT whole frame (the scene far away: few tiles hold all of it, each thousands of steps) leaves most of the chip idle
+        // behind its heaviest tiles' chains: there the workgroups of 8 waves that shares of a frame use are the better shape —
+        // cfg2 from z = 800 (448 k steps, 2 % of the rays hit): 265 -> 200 us; from z = 400 (815 k): 178 -> 172; with every wave
+        // slot taken (z = 250, 160, 0: 1.6 - 2.2 M steps) they cost 5 - 8 %; 16 waves: 248 us at z = 800.  The frame before last's work estimate (mapped host
+        // word, left by file_tiles_kernel) decides; nothing known: the 4-wave shape.
+        const uint32_t work_estimate = *(const volatile uint32_t*)(ctx->fault_host + 24);
+        const bool light = work_estimate < kLightFrameSteps;
+        const uint32_t blocks = hp.cap + (light ? (n_work + kCoopWaves - 1) / kCoopWaves : (n_work + kCoopWavesWhole - 1) / kCoopWavesWhole);
+        if (light) {
+            if (exact)
+                LBVH_LAUNCH(ctx, (trace_shared_kernel<false, kCoopWaves, true>), dim3(blocks), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris,
+                            n_work, counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
+            else if (d_stats)
+                LBVH_LAUNCH(ctx, (trace_shared_kernel<true, kCoopWaves>), dim3(blocks), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris, n_work,
+                            counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
+            else
+                LBVH_LAUNCH(ctx, (trace_shared_kernel<false, kCoopWaves>), dim3(blocks), dim3(kCoopWaves * 64), a, ctx->fast_nodes, ctx->fast_tris, n_work,
+                            counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
+        } else if (exact)
             LBVH_LAUNCH(ctx, (trace_shared_kernel<false, kCoopWavesWhole, true>), dim3(blocks), dim3(kCoopWavesWhole * 64), a, ctx->fast_nodes,
                         ctx->fast_tris, n_work, counts, lists, hp, cost, d_hits, d_stats, d_tile_cost);
         else if (d_stats)
