@@ -179,6 +179,34 @@ def test_sort_form_follows_the_last_sorts_largest_bucket():
         c.close()
 
 
+def test_sort_pairs_of_morton_codes_with_pads_finds_the_second_bucket_digit():
+    """lbvh_sort_pairs has no key_bits hint.  Morton codes below 2^30 plus 0xFFFFFFFF pads (the reference's own call sequence,
+    ComputeBufferSorter.Sort on the padded key buffer) fill only 64 top-byte buckets of 16 k and more: the four-pass sort measures
+    a second candidate digit (bits 22 .. 29) as well, and the next sort is two-level on that one.  Results are the oracle's."""
+    c = H().Context(0)
+    try:
+        rng = np.random.default_rng(5)
+        n = 1 << 20
+        keys = rng.integers(0, 1 << 30, n, dtype=np.uint32)
+        keys[n - 1000:] = 0xFFFFFFFF
+        keys[::4097] = (255 << 22) | 5          # company for the pads in the last bucket
+        vals = rng.permutation(n).astype(np.uint32)
+        ok, ov = O.sort_pairs(keys, vals)
+        forms = []
+        for _ in range(3):
+            kb, vb = up(c, keys, np.uint32), up(c, vals, np.uint32)
+            c.profile_begin()
+            N().check(c.handle, N().lib.lbvh_sort_pairs(c.handle, kb.device, vb.device, n))
+            prof = c.profile_end()
+            k, v = kb.get_data()[:n].copy(), vb.get_data()[:n].copy()
+            kb.dispose(); vb.dispose()
+            assert (k == ok).all() and (v == ov).all()
+            forms.append("two" if any("sort_bucket_kernel" in q for q in prof) else "four")
+        assert forms == ["four", "two", "two"], forms
+    finally:
+        c.close()
+
+
 def test_rebuild_with_the_two_level_sort_is_bit_exact(ctx, sort_form):
     """lbvh_build_scene with the sort's form forced either way (the build's bucket digit is bits 22..29: Morton codes below 2^30,
     the pads and nothing else in the last bucket): keys, indices and every node word identical to the oracle on the tiled-torus

@@ -65,17 +65,19 @@ constexpr int kLbGroup = 8;                // tiles per look-back group
 __device__ __forceinline__ uint32_t msd_digit(uint32_t k, uint32_t msd_shift) { return min(k >> msd_shift, (uint32_t)kRadix - 1u); }
 
 // ---- all four digit histograms in one read of the keys ------------------------------------------
-// HIST_FOUR: ghist[p][256] for the four LSD passes; HIST_MSD: ghist[4][256] = the bucket sizes of the two-level form (with
-// HIST_FOUR too: the four-pass form keeps the statistic the next call's choice is made from)
-enum { HIST_FOUR = 1, HIST_MSD = 2 };
+// HIST_FOUR: ghist[p][256] for the four LSD passes; HIST_MSD: ghist[4][256] = the bucket sizes of the two-level form for the bucket
+// digit at msd_shift; HIST_MSD2: ghist[5][256] = the same for a second candidate digit at msd_shift2 (the four-pass form keeps
+// the statistics of BOTH candidates the next call's choice is made from)
+enum { HIST_FOUR = 1, HIST_MSD = 2, HIST_MSD2 = 4 };
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t* __restrict__ keys,
-                                                                  uint32_t count, uint32_t* __restrict__ ghist, uint32_t msd_shift)
+                                                                  uint32_t count, uint32_t* __restrict__ ghist, uint32_t msd_shift,
+                                                                  uint32_t msd_shift2)
 {
-    __shared__ uint32_t s_hist[kPasses + 1][kRadix];
+    __shared__ uint32_t s_hist[kPasses + 2][kRadix];
     const uint32_t t = threadIdx.x;
 #pragma unroll
-    for (int p = 0; p < kPasses + 1; p++) s_hist[p][t] = 0;
+    for (int p = 0; p < kPasses + 2; p++) s_hist[p][t] = 0;
     __syncthreads();
     // grid-stride over 16-B vectors (4 keys per lane per load), 2 loads in flight per thread
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t
                     for (int p = 0; p < kPasses; p++) atomicAdd(&s_hist[p][(k0 >> (8 * p)) & 255u], nactive);
                 }
                 if (MODE & HIST_MSD) atomicAdd(&s_hist[kPasses][msd_digit(k0, msd_shift)], nactive);
+                if (MODE & HIST_MSD2) atomicAdd(&s_hist[kPasses + 1][msd_digit(k0, msd_shift2)], nactive);
             }
             return;
         }
@@ -125,6 +128,14 @@ __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t
                 if (first) atomicAdd(&s_hist[kPasses][d0], nactive);
             } else {
                 atomicAdd(&s_hist[kPasses][d], 1u);
+            }
+        }
+        if (MODE & HIST_MSD2) {
+            const uint32_t d = msd_digit(k, msd_shift2), d0 = msd_digit(k0, msd_shift2);
+            if (__all(d == d0)) {
+                if (first) atomicAdd(&s_hist[kPasses + 1][d0], nactive);
+            } else {
+                atomicAdd(&s_hist[kPasses + 1][d], 1u);
             }
         }
     };
@@ -152,12 +163,13 @@ __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t
                 for (int p = 0; p < kPasses; p++) atomicAdd(&s_hist[p][(k >> (8 * p)) & 255u], 1u);
             }
             if (MODE & HIST_MSD) atomicAdd(&s_hist[kPasses][msd_digit(k, msd_shift)], 1u);
+            if (MODE & HIST_MSD2) atomicAdd(&s_hist[kPasses + 1][msd_digit(k, msd_shift2)], 1u);
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < kPasses + 1; p++) {
-        if (p < kPasses ? !(MODE & HIST_FOUR) : !(MODE & HIST_MSD)) continue;
+    for (int p = 0; p < kPasses + 2; p++) {
+        if (p < kPasses ? !(MODE & HIST_FOUR) : (p == kPasses ? !(MODE & HIST_MSD) : !(MODE & HIST_MSD2))) continue;
         const uint32_t c = s_hist[p][t];
         if (c) atomicAdd(&ghist[p * kRadix + t], c);
     }
@@ -177,8 +189,10 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t count, uint32_t shift,
     const uint32_t* __restrict__ ghist,   // [256] digit totals of this pass
-    const uint32_t* __restrict__ msd_hist,// (nullable) [256] bucket sizes of the two-level form: tile 0 leaves their maximum ...
-    uint32_t* bucket_stat,                // ... in these four mapped host words (the NEXT sort's choice of form)
+    const uint32_t* __restrict__ msd_hist,// (nullable) [256] (+ [256] for a second candidate digit if stat_shifts names one) bucket sizes of the two-level
+                                          // form: tile 0 leaves their maxima ...
+    uint32_t* bucket_stat,                // ... in these 4 (+ 4) mapped host words, each (digit shift << 24 | largest bucket): the NEXT sort's choice of form
+    uint32_t stat_shifts,                 // the candidates' digit shifts: first | second << 8 (second 0xFF: none)
     uint32_t* status,                     // [tiles][256] tile words of this pass (zeroed per sort)
     uint32_t* gstatus,                    // [ceil(tiles / kLbGroup)][256] group words of this pass (zeroed per sort)
     uint32_t* tickets,                    // [8] per-XCD tile tickets of this pass (zeroed per sort)
@@ -226,10 +240,16 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     const uint32_t nvalid = min((uint32_t)TILE, count - base);
     auto digit_of = [shift](uint32_t k) { return MSD ? msd_digit(k, shift) : (k >> shift) & (uint32_t)(kRadix - 1); };
     if (msd_hist && tile == 0 && w < (uint32_t)DWAVES) {       // the largest bucket of this input (a hint for the next call)
-        uint32_t m = msd_hist[t];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
-        if (lane == 0) __hip_atomic_store(bucket_stat + w, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // 4 words: the host takes their maximum
+        for (int c = 0; c < 2; c++) {
+            const uint32_t sh = (stat_shifts >> (8 * c)) & 0xFFu;
+            if (sh == 0xFFu) continue;
+            uint32_t m = msd_hist[c * kRadix + t];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+            // 4 words per candidate (one per wave of digits): the host takes their maximum and reads the shift they belong to
+            if (lane == 0) __hip_atomic_store(bucket_stat + 4 * c + w, (sh << 24) | min(m, 0xFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 
     // exclusive scan of the pass's digit totals = first output index of each digit (every tile
@@ -749,12 +769,13 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
 template <int THREADS, int ITEMS, bool STREAM>
 void launch_passes(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t* alt_keys, uint32_t* alt_vals,
                    uint32_t count, uint32_t tiles, uint32_t* ghist, uint32_t* status, uint32_t* gstatus, uint32_t groups,
-                   uint32_t* tickets, uint32_t group, const uint32_t* msd_hist = nullptr, uint32_t* bucket_stat = nullptr)
+                   uint32_t* tickets, uint32_t group, const uint32_t* msd_hist = nullptr, uint32_t* bucket_stat = nullptr,
+                   uint32_t stat_shifts = 0xFFFFu)
 {
     uint32_t *ks = d_keys, *vs = d_values, *kd = alt_keys, *vd = alt_vals;
     for (uint32_t p = 0; p < (uint32_t)kPasses; p++) {   // ComputeBufferSorter.cs:102
         LBVH_LAUNCH(ctx, (sort_onesweep_kernel<THREADS, ITEMS, STREAM>), dim3(tiles), dim3(THREADS), ks, vs, kd, vd, count,
-                    8u * p, ghist + p * kRadix, p == 0 ? msd_hist : nullptr, bucket_stat, status + (size_t)p * tiles * kRadix,
+                    8u * p, ghist + p * kRadix, p == 0 ? msd_hist : nullptr, bucket_stat, stat_shifts, status + (size_t)p * tiles * kRadix,
                     gstatus + (size_t)p * groups * kRadix, tickets + 8u * p, tiles, group, ctx->sort_queues, ctx->fault_dev);
         uint32_t* tmp;
         tmp = ks; ks = kd; kd = tmp;
@@ -784,7 +805,7 @@ static int sort_prepare(lbvh_context* ctx, uint32_t count, sort_plan* pl)
     const size_t pair_bytes = (((size_t)count * 4) + 255) & ~(size_t)255;
     // [ghist 4x256 + the two-level form's bucket sizes 256 | tickets (4 passes x 8 XCDs, padded to 256 B) | tile words 4 x tiles x 256 |
     // group words] is zeroed per sort
-    const size_t head_bytes = (size_t)(kPasses + 1) * kRadix * 4 + 256;
+    const size_t head_bytes = (size_t)(kPasses + 2) * kRadix * 4 + 256;
     const uint32_t groups = (tiles + (uint32_t)kLbGroup - 1u) / (uint32_t)kLbGroup;
     const size_t status_bytes = (size_t)kPasses * ((size_t)tiles + groups) * kRadix * 4;
     int rc = lbvh_reserve(ctx, &ctx->sort_scratch, &ctx->sort_scratch_bytes, 2 * pair_bytes + head_bytes + status_bytes);
@@ -796,7 +817,7 @@ static int sort_prepare(lbvh_context* ctx, uint32_t count, sort_plan* pl)
     pl->alt_keys = (uint32_t*)p;
     pl->alt_vals = (uint32_t*)(p + pair_bytes);
     pl->ghist = (uint32_t*)(p + 2 * pair_bytes);
-    pl->tickets = pl->ghist + (kPasses + 1) * kRadix;
+    pl->tickets = pl->ghist + (kPasses + 2) * kRadix;
     pl->status = (uint32_t*)(p + 2 * pair_bytes + head_bytes);
     pl->gstatus = pl->status + (size_t)kPasses * tiles * kRadix;
     pl->zero_bytes = head_bytes + status_bytes;
@@ -843,24 +864,48 @@ int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, ui
     // consecutive tiles per XCD: 16 when every XCD still gets several groups, fewer for small sorts
     const uint32_t group = tiles >= 1024u ? 16u : tiles >= 128u ? 8u : 1u;
     // The form.  Two-level where a pass is latency (two_level_size) and the LAST sort of this context had no bucket beyond one
-    // workgroup's registers — the first pass kernel of either form leaves the largest bucket of ITS input in four mapped host
-    // words; read here without any synchronisation: a hint, one sort stale (a first sort, or one after a skewed input, takes the
-    // four passes; a skewed input after a uniform one is sorted correctly by the bucket kernel's slow path, once).
-    // lbvh_debug_switch(LBVH_DEBUG_SORT_FORM): 1 four passes always, 2 two-level wherever the size allows.
-    const uint32_t msd_shift = (key_bits >= 8u && key_bits <= 32u ? key_bits : 32u) - 8u;
+    // workgroup's registers for the bucket digit in question — the first pass kernel of either form leaves the largest bucket of ITS
+    // input in mapped host words, each tagged with the digit's shift; read here without any synchronisation: a hint, one sort
+    // stale (a first sort, or one after a skewed input, takes the four passes; a skewed input after a uniform one is sorted
+    // correctly by the bucket kernel's slow path, once).  Candidates for the bucket digit: the 8 bits below the caller's key_bits
+    // (the rebuild: 30 -> bits 22 .. 29), for arbitrary keys the top byte and, second choice, bits 22 .. 29 (Morton codes with
+    // 0xFFFFFFFF pads sorted through lbvh_sort_pairs, the reference's own call sequence: the top byte would give 64 buckets of 16 k).
+    // The four-pass form measures both candidates; the two-level form the one it uses.
+    // lbvh_debug_switch(LBVH_DEBUG_SORT_FORM): 1 four passes always, 2 two-level (first candidate) wherever the size allows.
+    const bool hinted = key_bits >= 8u && key_bits < 32u;
+    const uint32_t cand[2] = {hinted ? key_bits - 8u : 24u, hinted ? 0xFFu : 22u};
     uint32_t* msd_hist = ghist + kPasses * kRadix;
-    uint32_t* stat_dev = ctx->fault_dev + 16;                   // words 16 .. 19 of the mapped block (word 0: the fault word)
+    uint32_t* stat_dev = ctx->fault_dev + 16;                   // words 16 .. 23 of the mapped block (word 0: the fault word)
     bool two_level = false;
+    uint32_t msd_shift = cand[0];
     if (two_level_size(count)) {
         const volatile uint32_t* st = ctx->fault_host + 16;
-        const uint32_t largest = std::max(std::max(st[0], st[1]), std::max(st[2], st[3]));
+        // the largest bucket last seen for bucket digit `shift`, or "unknown"
+        auto largest_for = [&](uint32_t shift) -> uint32_t {
+            for (int c = 0; c < 2; c++) {
+                uint32_t m = 0;
+                bool ok = true;
+                for (int w = 0; w < 4; w++) {
+                    const uint32_t v = st[4 * c + w];
+                    ok = ok && (v >> 24) == shift && v != 0xFFFFFFFFu;
+                    m = std::max(m, v & 0xFFFFFFu);
+                }
+                if (ok) return m;
+            }
+            return 0xFFFFFFFFu;
+        };
         const uint32_t form = ctx->debug_switch[LBVH_DEBUG_SORT_FORM];
-        two_level = form == 2u || (form == 0u && largest <= (uint32_t)(kBucketThreads * kBucketItems));
+        if (form == 2u) {
+            two_level = true;
+        } else if (form == 0u) {
+            for (int c = 0; c < 2 && !two_level; c++)
+                if (cand[c] != 0xFFu && largest_for(cand[c]) <= (uint32_t)(kBucketThreads * kBucketItems)) { two_level = true; msd_shift = cand[c]; }
+        }
     }
     if (two_level) {
-        LBVH_LAUNCH(ctx, sort_histogram_kernel<HIST_MSD>, dim3(hblocks), dim3(kThreads), d_keys, count, ghist, msd_shift);
+        LBVH_LAUNCH(ctx, sort_histogram_kernel<HIST_MSD>, dim3(hblocks), dim3(kThreads), d_keys, count, ghist, msd_shift, 0u);
         LBVH_LAUNCH(ctx, (sort_onesweep_kernel<512, 8, false, true>), dim3(tiles), dim3(512), d_keys, d_values, alt_keys, alt_vals, count,
-                    msd_shift, msd_hist, msd_hist, stat_dev, status, gstatus, tickets, tiles, group, ctx->sort_queues, ctx->fault_dev);
+                    msd_shift, msd_hist, msd_hist, stat_dev, msd_shift | 0xFF00u, status, gstatus, tickets, tiles, group, ctx->sort_queues, ctx->fault_dev);
         LBVH_LAUNCH(ctx, (sort_bucket_kernel<kBucketThreads, kBucketItems>), dim3(kRadix), dim3(kBucketThreads), alt_keys, alt_vals, d_keys,
                     d_values, msd_shift, msd_hist);
         LBVH_HIP_TRY(ctx, hipGetLastError());
@@ -880,18 +925,21 @@ int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, ui
         return LBVH_OK;       // the buckets are back in d_keys / d_values
     }
     const bool stat = two_level_size(count);
-    if (stat)
-        LBVH_LAUNCH(ctx, sort_histogram_kernel<HIST_FOUR | HIST_MSD>, dim3(hblocks), dim3(kThreads), d_keys, count, ghist, msd_shift);
+    if (stat && cand[1] != 0xFFu)
+        LBVH_LAUNCH(ctx, (sort_histogram_kernel<HIST_FOUR | HIST_MSD | HIST_MSD2>), dim3(hblocks), dim3(kThreads), d_keys, count, ghist, cand[0], cand[1]);
+    else if (stat)
+        LBVH_LAUNCH(ctx, (sort_histogram_kernel<HIST_FOUR | HIST_MSD>), dim3(hblocks), dim3(kThreads), d_keys, count, ghist, cand[0], 0u);
     else
-        LBVH_LAUNCH(ctx, sort_histogram_kernel<HIST_FOUR>, dim3(hblocks), dim3(kThreads), d_keys, count, ghist, msd_shift);
+        LBVH_LAUNCH(ctx, sort_histogram_kernel<HIST_FOUR>, dim3(hblocks), dim3(kThreads), d_keys, count, ghist, 0u, 0u);
     const uint32_t* stat_hist = stat ? msd_hist : nullptr;
+    const uint32_t stat_shifts = cand[0] | (cand[1] << 8);
     if (items == 16 && count >= (1u << 23))
         launch_passes<512, 16, true>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     else if (items == 16)
         launch_passes<512, 16, false>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     else
         launch_passes<512, 8, false>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group,
-                                     stat_hist, stat_dev);
+                                     stat_hist, stat_dev, stat_shifts);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;   // 4 passes: the result is back in d_keys / d_values
 }
