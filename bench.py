@@ -74,6 +74,7 @@ def parse():
     # key-range sharded sort (RCCL digit-histogram all-reduce + one all-to-all) when launched on more than one rank
     ap.add_argument("--workload", choices=["cfg2", "cfg4"], default="cfg2")
     ap.add_argument("--no-dynamic", action="store_true", help="skip the untimed cfg5 (dynamic scene + 4 bounces) extra")
+    ap.add_argument("--no-in-flight", action="store_true", help="skip the untimed steps-in-flight extra (2 / 3 contexts on one GPU)")
     # test hooks: run the N-rank path on fewer GPUs (ranks share --device, gloo instead of RCCL)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--device", type=int, default=None)
@@ -468,6 +469,48 @@ def main():
                                 "share's launch, max over ranks; no gather, no rebuild) — an extra beside the 1080p metric"}
         hits4.dispose()
         trace_share(); ctx.sync()                      # the 1080p layout's history back for what follows
+    # untimed extra, one GPU only: STEPS IN FLIGHT.  The timed step is one rebuild followed by its own trace on one stream — a
+    # latency-bound half and a vector-issue-bound half that never overlap.  An application that renders a stream of frames can
+    # keep two or three steps in flight on one GPU: contexts (own scene buffers, scratch, stream) taking the steps in turn, every
+    # step still a full rebuild followed by the trace of THAT rebuild's scene, nothing reused across steps.  Wall clock over
+    # args.steps steps, best of 3.  Reported beside `value`, never instead of it; needs no library change.
+    in_flight = None
+    if dist is None and mode == L.TRACE_FAST and not cfg4 and not args.no_in_flight:
+        more = [Context(device_id) for _ in range(2)]
+        more_drawers = [RaytracingMeshDrawer(c, tris).awake(fast=True) for c in more]
+        more_hits = [DataBuffer(c, W * H, L.HIT) for c in more]
+        lanes = [(ctx, drawer, hit_buf)] + list(zip(more, more_drawers, more_hits))
+
+        def lane_step(lane):
+            c, d, h = lane
+            d.rebuild(fast=True)
+            s_l = d.container.scene()
+            N.check(c.handle, N.lib.lbvh_trace_primary(c.handle, C.byref(ccam), 0, 0, W, H, C.byref(s_l), mode, h.device, None))
+        in_flight = {"workload": "cfg2 steps (full rebuild + 1080p frame of that rebuild) taken in turn by 1 / 2 / 3 contexts on one GPU; "
+                                 "wall clock per step, best of 3 x %d steps" % args.steps}
+        for n_l in (1, 2, 3):
+            for k in range(3 * n_l):
+                lane_step(lanes[k % n_l])
+            for c, _, _ in lanes:
+                c.sync()
+            best = float("inf")
+            for _ in range(3):
+                t0f = time.perf_counter()
+                for k in range(args.steps):
+                    lane_step(lanes[k % n_l])
+                for c, _, _ in lanes[:n_l]:
+                    c.sync()
+                best = min(best, (time.perf_counter() - t0f) * 1e3 / args.steps)
+            in_flight["ms_per_step_%d" % n_l] = round(best, 4)
+        same = all(int((h.get_data()["t"] < 2.0e9).sum()) == int((hit_buf.get_data()["t"] < 2.0e9).sum()) for h in more_hits)
+        in_flight["frames_equal"] = bool(same and all((h.get_data() == hit_buf.get_data()).all() for h in more_hits))
+        for h in more_hits:
+            h.dispose()
+        for d in more_drawers:
+            d.on_destroy()
+        for c in more:
+            c.close()
+        trace_share(); ctx.sync()
     sharded_sort_check = None
     if sorter is not None and rank == 0:
         # the timed steps left the sharded sort's result in the container: compare it with the one-GPU sort
@@ -737,6 +780,8 @@ def main():
         if frame_4k is not None:
             out["frame_4k"] = frame_4k
             out["value_4k"] = frame_4k["Mrays_s"]
+        if in_flight is not None:
+            out["steps_in_flight"] = in_flight
     for e in events + [(ev_start,)]:
         for x in e:
             ctx.destroy_event(x)

@@ -6,7 +6,9 @@ oracle; trace a random camera (inside / outside the scene, random resolution inc
 two or three frames so cost-ordered / cooperative / reprojected dispatch all run) in fast and reference mode against the
 oracle's frame.  Also sorts random (key, value) arrays of random size and digit structure, and every eighth case
 animates and path-traces a small dynamic scene (1 .. 4 bounces) against the extension's own oracle.  Prints one line per case and a
-summary; exits non-zero on the first mismatch.   usage: python tools/fuzz_parity.py [seconds] [seed]"""
+summary; exits non-zero on the first mismatch.   usage: python tools/fuzz_parity.py [seconds] [seed] [first_case]
+Every random draw of a case is made up front (draw_case), so `first_case` K replays the generator through cases 1 .. K-1 without
+running them and starts at case K: the way back to a failure that a long soak found (its message names the case's number)."""
 import ctypes as C, math, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,21 +18,28 @@ from unitysimpleraytracing_amd.host import Context, DataBuffer, RaytracingMeshDr
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) & 0xFFFFFF
+first_case = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 rng = np.random.default_rng(seed0)
-print("seed", seed0, "budget", budget, "s", flush=True)
+print("seed", seed0, "budget", budget, "s", "first case", first_case, flush=True)
 
 
 def words(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-def make_scene(kind, n):
-    if kind == "soup":
-        return scenes.random_triangles(n, seed=int(rng.integers(1 << 30)))
+def draw_scene(kind, n):
+    """The random draws of a scene (NOT the scene: a skipped case costs nothing but its draws)."""
     if kind == "torus":
-        nu = int(rng.integers(6, 40)); nv = int(rng.integers(4, 24)); g = int(rng.integers(1, 4))
-        return scenes.tiled_torus(nu=nu, nv=nv, grid=g, seed=int(rng.integers(1 << 30)))
-    t = scenes.random_triangles(n, seed=int(rng.integers(1 << 30)))
+        return dict(nu=int(rng.integers(6, 40)), nv=int(rng.integers(4, 24)), grid=int(rng.integers(1, 4)), seed=int(rng.integers(1 << 30)))
+    return dict(seed=int(rng.integers(1 << 30)))
+
+
+def make_scene(kind, n, p):
+    if kind == "soup":
+        return scenes.random_triangles(n, seed=p["seed"])
+    if kind == "torus":
+        return scenes.tiled_torus(nu=p["nu"], nv=p["nv"], grid=p["grid"], seed=p["seed"])
+    t = scenes.random_triangles(n, seed=p["seed"])
     if kind == "dups":               # every triangle several times over + a cluster in one cell
         k = max(n // 4, 1)
         t[k:2 * k] = t[:k][: len(t[k:2 * k])]
@@ -61,104 +70,137 @@ def random_camera(w, h):
     return cam
 
 
-cases = 0
-t_end = time.time() + budget
-with Context(0) as ctx:
-    while time.time() < t_end:
-        cases += 1
-        # ---- a sort ------------------------------------------------------------------------------------------------
-        count = int(rng.choice([rng.integers(1, 5000), rng.integers(5000, 400000), rng.integers(400000, 3000000)]))
-        shift = int(rng.integers(0, 25))
-        keys = (rng.integers(0, 1 << 32, size=count, dtype=np.uint64) >> np.uint64(shift) << np.uint64(rng.integers(0, shift + 1))).astype(np.uint32)
-        if rng.random() < 0.3:
+def draw_case(case, skipped):
+    """Every random draw of case `case`, in a fixed order (the generator's stream IS the case list: do not reorder)."""
+    q = {}
+    count = int(rng.choice([rng.integers(1, 5000), rng.integers(5000, 400000), rng.integers(400000, 3000000)]))
+    shift = int(rng.integers(0, 25))
+    keys = (rng.integers(0, 1 << 32, size=count, dtype=np.uint64) >> np.uint64(shift) << np.uint64(rng.integers(0, shift + 1)))
+    pads = rng.random() < 0.3
+    vals = rng.permutation(count)
+    if not skipped:
+        keys = keys.astype(np.uint32)
+        if pads:
             keys[count - count // 5:] = 0xFFFFFFFF
-        vals = rng.permutation(count).astype(np.uint32)
-        kb = DataBuffer(ctx, count, np.uint32); vb = DataBuffer(ctx, count, np.uint32)
-        kb.local[:] = keys; vb.local[:] = vals; kb.sync(); vb.sync()
-        N.check(ctx.handle, N.lib.lbvh_sort_pairs(ctx.handle, kb.device, vb.device, count))
-        ok, ov = O.sort_pairs(keys, vals)
-        assert (kb.get_data() == ok).all() and (vb.get_data() == ov).all(), ("sort", count, shift)
-        kb.dispose(); vb.dispose()
-        # ---- a scene -----------------------------------------------------------------------------------------------
-        kind = str(rng.choice(["soup", "torus", "dups", "one_cell", "slivers", "outside"]))
-        n = int(rng.choice([rng.integers(2, 70), rng.integers(70, 3000), rng.integers(3000, 120000)]))
-        tris = make_scene(kind, n)
-        n = len(tris)
-        d = RaytracingMeshDrawer(ctx, tris).awake(fast=True)
-        c = d.container
-        b = O.Built(tris, capacity=c.capacity, threads=8)
-        for how in ("awake", "rebuild", "rebuild"):                      # staged chain, then lbvh_build_scene (plain, then graph)
-            if how == "rebuild":
-                c.bvh_internal_node.fill_u32(0, mirror=False); c.bvh_data.fill_u32(0x7FC00000, mirror=False)
-                d.rebuild(fast=True)
-            bad_leaf, bad_inner = c.get_all_gpu_data()
-            assert len(bad_leaf) == 0 and len(bad_inner) == 0, (kind, n, how)
-            assert (c.keys.local == b.keys).all() and (c.triangle_index.local == b.indices).all(), (kind, n, how, "keys")
-            assert (words(c.bvh_internal_node.local)[: 6 * (n - 1)] == words(b.internal)[: 6 * (n - 1)]).all(), (kind, n, how, "internal")
-            assert (words(c.bvh_leaf_node.local)[: 2 * n] == words(b.leaf)[: 2 * n]).all(), (kind, n, how, "leaf")
-            assert (c.bvh_data.local["min"][: n - 1] == b.bvh["min"][: n - 1]).all() and (c.bvh_data.local["max"][: n - 1] == b.bvh["max"][: n - 1]).all(), (kind, n, how, "boxes")
-        w, h = int(rng.integers(1, 260)), int(rng.integers(1, 140))
-        cam = random_camera(w, h)
-        oh, _ = O.trace_primary(b, cam, threads=8)
-        shards = int(rng.choice([1, 1, 2, 3, 8]))
-        for frame in range(3):
-            cam_f = cam
-            d._hits = None if frame == 0 else d._hits
-            if shards == 1:
-                d.update(cam_f, mode=L.TRACE_FAST)
-                fh = d.hits()
-            else:
-                for r in range(shards):
-                    d.update_shard(cam_f, r, shards, mode=L.TRACE_FAST)
-                fh = d.hits()
-            assert (fh["t"] == oh["t"]).all(), (kind, n, w, h, shards, frame, "fast t")
-        d.update(cam, mode=L.TRACE_REFERENCE)
-        rh = d.hits()
-        assert (words(rh) == words(oh)).all(), (kind, n, w, h, "reference hits")
-        # LBVH_TRACE_FAST_EXACT: every word of the oracle's records ("dups" scenes tie on most pixels), whole frame and shards
+        q["keys"], q["vals"] = keys, vals.astype(np.uint32)
+    q["count"], q["shift"] = count, shift
+    q["kind"] = str(rng.choice(["soup", "torus", "dups", "one_cell", "slivers", "outside"]))
+    q["n"] = int(rng.choice([rng.integers(2, 70), rng.integers(70, 3000), rng.integers(3000, 120000)]))
+    q["scene"] = draw_scene(q["kind"], q["n"])
+    w, h = int(rng.integers(1, 260)), int(rng.integers(1, 140))
+    q["w"], q["h"] = w, h
+    q["cam"] = random_camera(w, h)
+    q["shards"] = int(rng.choice([1, 1, 2, 3, 8]))
+    if w >= 3 and h >= 3:
+        x0, y0 = int(rng.integers(0, w - 1)), int(rng.integers(0, h - 1))
+        x1, y1 = int(rng.integers(x0 + 1, w + 1)), int(rng.integers(y0 + 1, h + 1))
+        q["rect"] = (x0, y0, x1, y1)
+    q["cam2"] = random_camera(w, h)
+    if case % 8 == 0:
+        nu, nv, g = int(rng.integers(6, 28)), int(rng.integers(4, 18)), int(rng.integers(1, 4))
+        sseed = int(rng.integers(1 << 30))
+        sd, bounces, angle = int(rng.integers(1 << 20)), int(rng.integers(1, 5)), float(rng.uniform(0.0, 0.3))
+        pw, ph = int(rng.integers(1, 140)), int(rng.integers(1, 90))
+        q["path"] = dict(nu=nu, nv=nv, grid=g, seed=sseed, sd=sd, bounces=bounces, angle=angle, pw=pw, ph=ph, z=float(rng.uniform(60, 200)))
+    return q
+
+
+def run_case(ctx, case, q):
+    # ---- a sort ------------------------------------------------------------------------------------------------
+    count, shift, keys, vals = q["count"], q["shift"], q["keys"], q["vals"]
+    kb = DataBuffer(ctx, count, np.uint32); vb = DataBuffer(ctx, count, np.uint32)
+    kb.local[:] = keys; vb.local[:] = vals; kb.sync(); vb.sync()
+    N.check(ctx.handle, N.lib.lbvh_sort_pairs(ctx.handle, kb.device, vb.device, count))
+    ok, ov = O.sort_pairs(keys, vals)
+    assert (kb.get_data() == ok).all() and (vb.get_data() == ov).all(), (case, "sort", count, shift)
+    kb.dispose(); vb.dispose()
+    # ---- a scene -----------------------------------------------------------------------------------------------
+    kind, w, h, cam, shards = q["kind"], q["w"], q["h"], q["cam"], q["shards"]
+    tris = make_scene(kind, q["n"], q["scene"])
+    n = len(tris)
+    d = RaytracingMeshDrawer(ctx, tris).awake(fast=True)
+    c = d.container
+    b = O.Built(tris, capacity=c.capacity, threads=8)
+    for how in ("awake", "rebuild", "rebuild"):                      # staged chain, then lbvh_build_scene (plain, then graph)
+        if how == "rebuild":
+            c.bvh_internal_node.fill_u32(0, mirror=False); c.bvh_data.fill_u32(0x7FC00000, mirror=False)
+            d.rebuild(fast=True)
+        bad_leaf, bad_inner = c.get_all_gpu_data()
+        assert len(bad_leaf) == 0 and len(bad_inner) == 0, (case, kind, n, how)
+        assert (c.keys.local == b.keys).all() and (c.triangle_index.local == b.indices).all(), (case, kind, n, how, "keys")
+        assert (words(c.bvh_internal_node.local)[: 6 * (n - 1)] == words(b.internal)[: 6 * (n - 1)]).all(), (case, kind, n, how, "internal")
+        assert (words(c.bvh_leaf_node.local)[: 2 * n] == words(b.leaf)[: 2 * n]).all(), (case, kind, n, how, "leaf")
+        assert (c.bvh_data.local["min"][: n - 1] == b.bvh["min"][: n - 1]).all() and (c.bvh_data.local["max"][: n - 1] == b.bvh["max"][: n - 1]).all(), (case, kind, n, how, "boxes")
+    oh, _ = O.trace_primary(b, cam, threads=8)
+    for frame in range(3):
+        d._hits = None if frame == 0 else d._hits
+        if shards == 1:
+            d.update(cam, mode=L.TRACE_FAST)
+            fh = d.hits()
+        else:
+            for r in range(shards):
+                d.update_shard(cam, r, shards, mode=L.TRACE_FAST)
+            fh = d.hits()
+        assert (fh["t"] == oh["t"]).all(), (case, kind, n, w, h, shards, frame, "fast t")
+    d.update(cam, mode=L.TRACE_REFERENCE)
+    rh = d.hits()
+    assert (words(rh) == words(oh)).all(), (case, kind, n, w, h, "reference hits")
+    # LBVH_TRACE_FAST_EXACT: every word of the oracle's records ("dups" scenes tie on most pixels), whole frame and shards
+    for frame in range(2):
+        if shards == 1:
+            d.update(cam, mode=L.TRACE_FAST_EXACT)
+        else:
+            for r in range(shards):
+                d.update_shard(cam, r, shards, mode=L.TRACE_FAST_EXACT)
+        assert (words(d.hits()) == words(oh)).all(), (case, kind, n, w, h, shards, frame, "exact mode")
+    # a sub-rectangle of the frame, two frames (its own history), then the same rectangle from a turned camera
+    if "rect" in q:
+        x0, y0, x1, y1 = q["rect"]
         for frame in range(2):
-            if shards == 1:
-                d.update(cam, mode=L.TRACE_FAST_EXACT)
-            else:
-                for r in range(shards):
-                    d.update_shard(cam, r, shards, mode=L.TRACE_FAST_EXACT)
-            assert (words(d.hits()) == words(oh)).all(), (kind, n, w, h, shards, frame, "exact mode")
-        # a sub-rectangle of the frame, two frames (its own history), then the same rectangle from a turned camera
-        if w >= 3 and h >= 3:
-            x0, y0 = int(rng.integers(0, w - 1)), int(rng.integers(0, h - 1))
-            x1, y1 = int(rng.integers(x0 + 1, w + 1)), int(rng.integers(y0 + 1, h + 1))
-            for frame in range(2):
-                d.update(cam, rect=(x0, y0, x1, y1), mode=L.TRACE_FAST)
-                assert (d.hits()["t"] == oh["t"][y0:y1, x0:x1]).all(), (kind, n, w, h, (x0, y0, x1, y1), frame, "rectangle")
-        # a second camera: the history of the first one is reprojected
-        cam2 = random_camera(w, h)
-        oh2, _ = O.trace_primary(b, cam2, threads=8)
-        if w >= 3 and h >= 3:
-            d.update(cam2, rect=(x0, y0, x1, y1), mode=L.TRACE_FAST)
-            assert (d.hits()["t"] == oh2["t"][y0:y1, x0:x1]).all(), (kind, n, w, h, "rectangle, second camera")
-        d.update(cam2, mode=L.TRACE_FAST)
-        assert (d.hits()["t"] == oh2["t"]).all(), (kind, n, w, h, "second camera")
-        d.update(cam2, mode=L.TRACE_FAST_EXACT)
-        assert (words(d.hits()) == words(oh2)).all(), (kind, n, w, h, "second camera, exact mode")
-        d.on_destroy()
-        # ---- every so often: the dynamic scene + path tracer (cfg5 extension) against its own oracle ---------------
-        if cases % 8 == 0:
-            from unitysimpleraytracing_amd.host import DynamicPathTracer
-            nu, nv, g = int(rng.integers(6, 28)), int(rng.integers(4, 18)), int(rng.integers(1, 4))
-            ptris, body, centres = scenes.tiled_torus(nu=nu, nv=nv, grid=g, seed=int(rng.integers(1 << 30)), with_bodies=True)
-            sd, bounces, angle = int(rng.integers(1 << 20)), int(rng.integers(1, 5)), float(rng.uniform(0.0, 0.3))
-            pt = DynamicPathTracer(ctx, ptris, body, centres, t_min=1e-3, albedo=0.7, seed=sd)
-            pt.animate(angle)
-            pb = O.Built(O.animate(ptris, body, centres, angle), capacity=pt.drawer.container.capacity, threads=8)
-            pw, ph = int(rng.integers(1, 140)), int(rng.integers(1, 90))
-            pcam = scenes.camera(pw, ph, (0.0, 0.0, float(rng.uniform(60, 200))))
-            pt.render(pcam, bounces=bounces)
-            img = pt.image()
-            oimg, ost = O.path_trace(pb, pcam, bounces=bounces, t_min=1e-3, albedo=0.7, seed=sd, threads=8)
-            gst = pt.states.get_data()[: pw * ph]
-            # every path state and pixel: both sides resolve exact t ties to the lowest triangle index
-            assert (gst["origin"] == ost["origin"]).all() and (gst["dir"] == ost["dir"]).all(), ("path", len(ptris), pw, ph, bounces)
-            assert (img.view(np.uint16) == oimg.view(np.uint16)).all(), ("path image", len(ptris), pw, ph, bounces)
-            pt.drawer.on_destroy()
-        print(f"case {cases}: sort {count} >> {shift}; {kind} n={n} {w}x{h} shards {shards}: ok", flush=True)
-print("cases", cases, "all equal")
+            d.update(cam, rect=(x0, y0, x1, y1), mode=L.TRACE_FAST)
+            assert (d.hits()["t"] == oh["t"][y0:y1, x0:x1]).all(), (case, kind, n, w, h, (x0, y0, x1, y1), frame, "rectangle")
+    # a second camera: the history of the first one is reprojected
+    cam2 = q["cam2"]
+    oh2, _ = O.trace_primary(b, cam2, threads=8)
+    if "rect" in q:
+        d.update(cam2, rect=(x0, y0, x1, y1), mode=L.TRACE_FAST)
+        assert (d.hits()["t"] == oh2["t"][y0:y1, x0:x1]).all(), (case, kind, n, w, h, "rectangle, second camera")
+    d.update(cam2, mode=L.TRACE_FAST)
+    assert (d.hits()["t"] == oh2["t"]).all(), (case, kind, n, w, h, "second camera")
+    d.update(cam2, mode=L.TRACE_FAST_EXACT)
+    assert (words(d.hits()) == words(oh2)).all(), (case, kind, n, w, h, "second camera, exact mode")
+    d.on_destroy()
+    # ---- every eighth case: the dynamic scene + path tracer (cfg5 extension) against its own oracle ------------------
+    if "path" in q:
+        from unitysimpleraytracing_amd.host import DynamicPathTracer
+        pp = q["path"]
+        ptris, body, centres = scenes.tiled_torus(nu=pp["nu"], nv=pp["nv"], grid=pp["grid"], seed=pp["seed"], with_bodies=True)
+        sd, bounces, angle, pw, ph = pp["sd"], pp["bounces"], pp["angle"], pp["pw"], pp["ph"]
+        pt = DynamicPathTracer(ctx, ptris, body, centres, t_min=1e-3, albedo=0.7, seed=sd)
+        pt.animate(angle)
+        pb = O.Built(O.animate(ptris, body, centres, angle), capacity=pt.drawer.container.capacity, threads=8)
+        pcam = scenes.camera(pw, ph, (0.0, 0.0, pp["z"]))
+        pt.render(pcam, bounces=bounces)
+        img = pt.image()
+        oimg, ost = O.path_trace(pb, pcam, bounces=bounces, t_min=1e-3, albedo=0.7, seed=sd, threads=8)
+        gst = pt.states.get_data()[: pw * ph]
+        # every path state and pixel: both sides resolve exact t ties to the lowest triangle index
+        assert (gst["origin"] == ost["origin"]).all() and (gst["dir"] == ost["dir"]).all(), (case, "path", len(ptris), pw, ph, bounces)
+        assert (img.view(np.uint16) == oimg.view(np.uint16)).all(), (case, "path image", len(ptris), pw, ph, bounces)
+        pt.drawer.on_destroy()
+    print(f"case {case}: sort {count} >> {shift}; {kind} n={n} {w}x{h} shards {shards}: ok", flush=True)
+
+
+if __name__ == "__main__":
+    case = 0
+    while case + 1 < first_case:                      # replay the generator up to the first case asked for
+        case += 1
+        draw_case(case, skipped=True)
+    ran = 0
+    t_end = time.time() + budget
+    with Context(0) as ctx:
+        while time.time() < t_end:
+            case += 1
+            run_case(ctx, case, draw_case(case, skipped=False))
+            ran += 1
+    print("cases", ran, "all equal", f"(cases {first_case} .. {case} of seed {seed0})")
