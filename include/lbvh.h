@@ -116,7 +116,7 @@ typedef struct lbvh_camera {
 
 /* Traversal flavours of lbvh_trace_primary. */
 #define LBVH_TRACE_REFERENCE 0  /* the reference's visit order, no pruning, separate node arrays */
-#define LBVH_TRACE_FAST      1  /* 8x8 packets over fused 64-B nodes, near-first, t-pruned; same min-t */
+#define LBVH_TRACE_FAST      1  /* 8x8 packets over fused 64-B nodes, near-first, t-pruned; same min-t (see the note below) */
 #define LBVH_TRACE_FAST_EXACT 2 /* LBVH_TRACE_FAST, and every record equals LBVH_TRACE_REFERENCE's word for word: a ray
                                  * that meets two triangles at EXACTLY the same t (the one case in which the fast walk's
                                  * order-independent choice — lowest triangle index — can differ from the triangle the
@@ -124,6 +124,19 @@ typedef struct lbvh_camera {
                                  * the order is read off the scene's internalNodes / leafNodes (parent words, child
                                  * types; leaf j's `index` is j, as TreeConstructor writes it, BVH.compute:116-120).
                                  * No d_stats with this mode. */
+/* Where both fast modes differ from LBVH_TRACE_REFERENCE — by a rule, not by chance (tests/test_grazing_ray.py).
+ * The reference prunes nothing, so its record is the minimum COMPUTED t over every triangle whose box the ray's line passes —
+ * including, for a ray within ~0.01 degree of a triangle's plane, a t that is noise of the fp32 triangle test
+ * (Raytracing.compute:37-73: det ~ 1e-4, the dot products cancel) and lies IN FRONT OF the distance at which the ray enters that
+ * triangle's own padded box.  A walk that skips boxes entered beyond its best hit would report such a record or not depending
+ * on the order in which it meets the leaves (packet shape, shard count, dispatch history).  The fast modes therefore do not
+ * count a computed t that is smaller than the slab test's entry distance of the triangle's own box: their record is the
+ * nearest hit that is not in front of its own box, the same whatever the order (and whatever the number of GPUs), and equal
+ * to the reference's wherever the reference's winner is not such a t.  The CPU oracle carries the rule as an option
+ * (orc_trace_primary_rule) and the fast modes are tested equal to THAT frame bit for bit; an application that wants the
+ * reference's artefacts too has LBVH_TRACE_REFERENCE.  Frequency: one pixel in the order of 10^9 randomised rays
+ * (tools/fuzz_parity.py), none of the 2 073 600 of the benchmark's frame.  The secondary-ray calls (lbvh_trace_rays, the path
+ * tracer) use the same rule. */
 
 /* Optional per-launch traversal statistics (sums over all rays of the launch), in the
  * reference's visit semantics for LBVH_TRACE_REFERENCE: P nodes popped, B internal boxes hit,
@@ -481,7 +494,8 @@ typedef struct lbvh_path_state {
  * the reference's binary walk has 64, Raytracing.compute:113; the first 16 in LDS, deeper ones in device memory).
  * Accept rule = the reference's (own-AABB slab test, Moeller-Trumbore, t < best) plus t > t_min, which secondary
  * rays need to leave their surface and the reference lacks (Raytracing.compute:70); two triangles hit at the same t:
- * the lower triangle index, whatever order the walk meets them in (as LBVH_TRACE_FAST). */
+ * the lower triangle index, whatever order the walk meets them in; a computed t in front of its own triangle's box
+ * does not count (both as LBVH_TRACE_FAST: see the note at the traversal flavours). */
 lbvh_status lbvh_trace_rays(lbvh_context* ctx, const lbvh_path_state* d_states, size_t count, float t_min,
                             const lbvh_scene* h_scene, lbvh_hit* d_hits);
 

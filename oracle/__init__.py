@@ -58,6 +58,9 @@ _lib.orc_make_ray.restype = None
 _lib.orc_trace_primary.argtypes = [C.POINTER(_Camera), _I32, _I32, _I32, _I32, _I32, _I32,
                                    C.POINTER(_Scene), _P, _P, _I32]
 _lib.orc_trace_primary.restype = _I32
+_lib.orc_trace_primary_rule.argtypes = [C.POINTER(_Camera), _I32, _I32, _I32, _I32, _I32, _I32,
+                                        C.POINTER(_Scene), _P, _P, _I32, _I32]
+_lib.orc_trace_primary_rule.restype = _I32
 _lib.orc_build_all.argtypes = [_P, _U32, _U32, _F3, _F3, _P, _P, _P, _P, _P, _P, _I32]
 _lib.orc_build_all.restype = _I32
 
@@ -256,6 +259,49 @@ def make_ray(camera, px, py):
     return o, d, i
 
 
+def box_entry(bmin, bmax, origin, inv_dir):
+    """tmin of RayBoxIntersection (Raytracing.compute:75-87) in strict fp32, operation by operation: the distance at which the
+    slab test says the ray enters the box."""
+    f = np.float32
+    o, i = np.asarray(origin, dtype=f), np.asarray(inv_dir, dtype=f)
+    with np.errstate(all="ignore"):
+        t1 = (np.asarray(bmin, dtype=f) - o) * i
+        t2 = (np.asarray(bmax, dtype=f) - o) * i
+        return f(np.fmax(np.fmax(np.fmin(t1[0], t2[0]), np.fmin(t1[1], t2[1])), np.fmin(t1[2], t2[2])))
+
+
+def winner_before_its_box(built, camera, px, py, hit):
+    """Is this hit record an fp32 ARTEFACT of the reference's triangle test: a t that lies BEFORE the distance at which the ray
+    enters the winning triangle's own padded AABB (Raytracing.compute:37-73 on a ray within a fraction of a degree of the
+    triangle's plane: det ~ 1e-4, the dot products cancel, t is noise; in double precision such a ray usually misses).  The
+    reference, which prunes nothing, reports such a t whenever the ray's line passes the triangle's box; a walker that skips boxes
+    entered beyond the best hit so far reports it only if it happens to visit that leaf before a genuine hit behind it.  This is
+    the ONLY way LBVH_TRACE_FAST / _FAST_EXACT can differ from the reference: t_fast > t_reference and this
+    predicate true for the reference's winner."""
+    if not float(hit["t"]) < float(L.MAX_FLOAT):
+        return False
+    o, d, inv = make_ray(camera, int(px), int(py))
+    box = built.triangle_aabb[int(hit["tri"])]
+    return bool(np.float32(hit["t"]) < box_entry(box["min"], box["max"], o, inv))
+
+
+def unexplained_mismatches(built, camera, reference_hits, fast_hits, origin=(0, 0), words=False):
+    """Pixels (y, x) where a fast-mode frame differs from the reference's (in t, or in any word with words=True) and the difference
+    is NOT the fp32 artefact above.  `origin` = (x0, y0) of the frames' top-left pixel.  Returns (unexplained, explained)."""
+    if words:
+        a = np.ascontiguousarray(reference_hits).view(np.uint32).reshape(reference_hits.shape + (4,))
+        b = np.ascontiguousarray(fast_hits).view(np.uint32).reshape(fast_hits.shape + (4,))
+        bad = np.argwhere((a != b).any(axis=-1))
+    else:
+        bad = np.argwhere(fast_hits["t"] != reference_hits["t"])
+    unexplained, explained = [], []
+    for y, x in bad:
+        r, f = reference_hits[y, x], fast_hits[y, x]
+        ok = float(f["t"]) > float(r["t"]) and winner_before_its_box(built, camera, x + origin[0], y + origin[1], r)
+        (explained if ok else unexplained).append((int(y), int(x)))
+    return unexplained, explained
+
+
 class Built:
     """All seven scene arrays of one Awake() build on the host."""
 
@@ -298,8 +344,11 @@ class Built:
         return s
 
 
-def trace_primary(built, camera, rect=None, step=(1, 1), threads=1):
-    """Returns (hits[h, w] of layouts.HIT, stats of layouts.TRACE_STATS) for the sampled grid."""
+def trace_primary(built, camera, rect=None, step=(1, 1), threads=1, fast_rule=False):
+    """Returns (hits[h, w] of layouts.HIT, stats of layouts.TRACE_STATS) for the sampled grid.  fast_rule: the reference's loop
+    with the accept rule of the library's fast modes (a computed t in front of its own triangle's box does not count):
+    what LBVH_TRACE_FAST_EXACT returns word for word and LBVH_TRACE_FAST in t — the reference's frame except where the
+    reference's winner is such a t (winner_before_its_box)."""
     cam = _camera(camera)
     x0, y0, x1, y1 = rect if rect is not None else (0, 0, cam.screen_width, cam.screen_height)
     sx, sy = step
@@ -308,7 +357,7 @@ def trace_primary(built, camera, rect=None, step=(1, 1), threads=1):
     hits = np.zeros((h, w), dtype=L.HIT)
     stats = np.zeros(1, dtype=L.TRACE_STATS)
     s = built.scene()
-    rc = _lib.orc_trace_primary(C.byref(cam), x0, y0, x1, y1, sx, sy, C.byref(s), _ptr(hits), _ptr(stats), threads)
+    rc = _lib.orc_trace_primary_rule(C.byref(cam), x0, y0, x1, y1, sx, sy, C.byref(s), _ptr(hits), _ptr(stats), threads, 1 if fast_rule else 0)
     if rc != 0:
         raise ValueError(f"orc_trace_primary rc={rc}")
     return hits, stats[0]

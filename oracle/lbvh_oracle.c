@@ -582,8 +582,8 @@ int orc_refit_mt(uint32_t n, const lbvh_internal_node* internal, const lbvh_leaf
 typedef struct { float origin[3], dir[3], inv_dir[3]; } ray_t;      /* :23-28 */
 
 /* RayBoxIntersection  :75-87.  HLSL min/max = fminf/fmaxf (non-NaN operand wins). */
-int orc_ray_box(const float bmin[3], const float bmax[3], const float origin[3],
-                const float inv_dir[3])
+static int ray_box_entry(const float bmin[3], const float bmax[3], const float origin[3],
+                         const float inv_dir[3], float* entry)
 {
     float tmin1[3], tmax1[3];
     for (int k = 0; k < 3; k++) {
@@ -594,7 +594,15 @@ int orc_ray_box(const float bmin[3], const float bmax[3], const float origin[3],
     }
     const float tmin = fmaxf(tmin1[0], fmaxf(tmin1[1], tmin1[2]));
     const float tmax = fminf(tmax1[0], fminf(tmax1[1], tmax1[2]));
+    *entry = tmin;                 /* the distance at which the slab test says the ray enters the box */
     return tmax > tmin && tmax > 0.0f;
+}
+
+int orc_ray_box(const float bmin[3], const float bmax[3], const float origin[3],
+                const float inv_dir[3])
+{
+    float entry;
+    return ray_box_entry(bmin, bmax, origin, inv_dir, &entry);
 }
 
 static inline void cross3(const float a[3], const float b[3], float o[3])
@@ -664,16 +672,23 @@ float orc_ray_triangle(const float orig[3], const float dir[3], const float a[3]
     return ray_triangle(orig, dir, a, b, c, &u, &v);
 }
 
+/* `fast_rule` (NOT the reference: the semantics of the library's LBVH_TRACE_FAST / _FAST_EXACT): a computed t that
+ * lies before the distance at which the ray enters the triangle's own box does not count.  The reference, which prunes nothing,
+ * reports such a t (fp32 noise of the triangle test on a ray almost inside the triangle's plane); a walk that skips boxes
+ * entered beyond its best hit can only be order-independent — and equal to a CPU restatement — without them.  With
+ * fast_rule = 0 this is CheckTriangle as written. */
 static void check_triangle(uint32_t triangle_index, const ray_t* ray, const lbvh_scene* s,
-                           lbvh_hit* result, lbvh_trace_stats* st)
+                           lbvh_hit* result, lbvh_trace_stats* st, int fast_rule)
 {
     st->leaf_tests++;
     const lbvh_aabb* b = &s->triangle_aabb[triangle_index];
-    if (orc_ray_box(b->min, b->max, ray->origin, ray->inv_dir)) {                      /* :91 */
+    float entry;
+    if (ray_box_entry(b->min, b->max, ray->origin, ray->inv_dir, &entry)) {           /* :91 */
         st->tri_tests++;
         const lbvh_triangle* t = &s->triangles[triangle_index];                       /* :93 */
         float u = 0.0f, v = 0.0f;
         const float dist = ray_triangle(ray->origin, ray->dir, t->a, t->b, t->c, &u, &v);
+        if (fast_rule && dist < entry) return;
         if (dist < result->t) {                                                        /* :95 strict */
             result->t = dist;
             result->tri = triangle_index;                                              /* :97 */
@@ -684,7 +699,7 @@ static void check_triangle(uint32_t triangle_index, const ray_t* ray, const lbvh
 }
 
 /* the traversal loop  :128-176 for one ray */
-static int trace_one(const lbvh_scene* s, const ray_t* ray, lbvh_hit* result, lbvh_trace_stats* st)
+static int trace_one(const lbvh_scene* s, const ray_t* ray, lbvh_hit* result, lbvh_trace_stats* st, int fast_rule)
 {
     result->t = LBVH_MAX_FLOAT;                 /* :129 */
     result->tri = 0;                            /* :130 */
@@ -708,14 +723,14 @@ static int trace_one(const lbvh_scene* s, const ray_t* ray, lbvh_hit* result, lb
             stack[sp++] = nd->leftNode;                                              /* :153-154 */
         } else {
             const uint32_t tri = s->sorted_indices[s->leaf_nodes[nd->leftNode].index]; /* :158 */
-            check_triangle(tri, ray, s, result, st);                                 /* :159 */
+            check_triangle(tri, ray, s, result, st, fast_rule);                                 /* :159 */
         }
         if (nd->rightNodeType == LBVH_INTERNAL_NODE) {                               /* :166 */
             if (sp >= 64) { overflow = 1; break; }
             stack[sp++] = nd->rightNode;                                             /* :168-169 */
         } else {
             const uint32_t tri = s->sorted_indices[s->leaf_nodes[nd->rightNode].index]; /* :173 */
-            check_triangle(tri, ray, s, result, st);                                 /* :174 */
+            check_triangle(tri, ray, s, result, st, fast_rule);                                 /* :174 */
         }
     }
     if (result->t < LBVH_MAX_FLOAT) st->hits++;                                      /* :184 alpha */
@@ -725,6 +740,16 @@ static int trace_one(const lbvh_scene* s, const ray_t* ray, lbvh_hit* result, lb
 int orc_trace_primary(const lbvh_camera* cam, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
                       int32_t x_step, int32_t y_step, const lbvh_scene* scene, lbvh_hit* hits,
                       lbvh_trace_stats* stats, int threads)
+{
+    return orc_trace_primary_rule(cam, x0, y0, x1, y1, x_step, y_step, scene, hits, stats, threads, 0);
+}
+
+/* fast_rule = 0: the reference.  fast_rule = 1: the reference's loop with the fast modes' accept rule (check_triangle) — what
+ * LBVH_TRACE_FAST_EXACT must return word for word and LBVH_TRACE_FAST in t; equal to the reference's frame wherever the
+ * reference's winner is not a t in front of its own triangle's box. */
+int orc_trace_primary_rule(const lbvh_camera* cam, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
+                           int32_t x_step, int32_t y_step, const lbvh_scene* scene, lbvh_hit* hits,
+                           lbvh_trace_stats* stats, int threads, int fast_rule)
 {
     (void)threads;
     if (x_step < 1 || y_step < 1 || x1 < x0 || y1 < y0) return -1;
@@ -747,7 +772,7 @@ int orc_trace_primary(const lbvh_camera* cam, int32_t x0, int32_t y0, int32_t x1
                 orc_make_ray(cam, (uint32_t)(x0 + i * x_step), (uint32_t)(y0 + j * y_step), ray.origin,
                              ray.dir, ray.inv_dir);
                 lbvh_trace_stats st = {0, 0, 0, 0, 0};
-                overflow |= trace_one(scene, &ray, &hits[j * w + i], &st);
+                overflow |= trace_one(scene, &ray, &hits[j * w + i], &st, fast_rule);
                 pops += st.pops; box_hits += st.box_hits; leaf_tests += st.leaf_tests;
                 tri_tests += st.tri_tests; nhits += st.hits;
             }
@@ -910,8 +935,8 @@ void orc_path_begin(const lbvh_camera* cam, lbvh_path_state* states)
 /* closest hit of arbitrary rays over the reference arrays (test infrastructure for the cfg5 extension, which has no reference
  * counterpart: include/lbvh.h lbvh_trace_rays).  Accept rule: t > t_min, strictly nearer — and among triangles hit at EXACTLY the
  * same t the lowest triangle index, whatever order the walk meets them in (the rule of LBVH_TRACE_FAST, which the GPU's per-ray
- * walkers share: a result that does not depend on the visit order).  The reference's own first-met rule lives in
- * orc_trace_primary. */
+ * walkers share: a result that does not depend on the visit order); and, for the same reason, a computed t in front of its own
+ * triangle's box does not count (check_triangle's fast_rule).  The reference's own first-met rule lives in orc_trace_primary. */
 int orc_trace_rays(const lbvh_path_state* states, size_t count, float t_min, const lbvh_scene* s, lbvh_hit* hits,
                    int threads)
 {
@@ -946,10 +971,12 @@ int orc_trace_rays(const lbvh_path_state* states, size_t count, float t_min, con
                 } else {
                     const uint32_t tri = s->sorted_indices[s->leaf_nodes[child[side]].index];
                     const lbvh_aabb* b = &s->triangle_aabb[tri];
-                    if (!orc_ray_box(b->min, b->max, ray.origin, ray.inv_dir)) continue;
+                    float entry;
+                    if (!ray_box_entry(b->min, b->max, ray.origin, ray.inv_dir, &entry)) continue;
                     const lbvh_triangle* t = &s->triangles[tri];
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_triangle(ray.origin, ray.dir, t->a, t->b, t->c, &u, &v);
+                    if (dist < entry) continue;          /* the fast modes' accept rule (check_triangle): not in front of its own box */
                     if (dist > t_min && (dist < result->t || (dist == result->t && tri < result->tri))) {
                         result->t = dist; result->tri = tri; result->u = u; result->v = v;
                     }

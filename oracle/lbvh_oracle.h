@@ -54,6 +54,11 @@ void orc_make_ray(const lbvh_camera* cam, uint32_t px, uint32_t py, float origin
 int orc_trace_primary(const lbvh_camera* cam, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
                       int32_t x_step, int32_t y_step, const lbvh_scene* scene, lbvh_hit* hits,
                       lbvh_trace_stats* stats, int threads);
+/* the same loop with the accept rule of the library's fast modes (fast_rule = 1): a computed t in front of its own triangle's box
+ * does not count (lbvh_oracle.c: check_triangle) */
+int orc_trace_primary_rule(const lbvh_camera* cam, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
+                           int32_t x_step, int32_t y_step, const lbvh_scene* scene, lbvh_hit* hits,
+                           lbvh_trace_stats* stats, int threads, int fast_rule);
 
 /* a-9 tail  Assets/_Shaders/Raytracing/Raytracing.compute:178-184 (see include/lbvh.h lbvh_shade) */
 void orc_shade(const lbvh_hit* hits, size_t count, const lbvh_triangle* tris, const uint8_t* tex, int32_t tex_w,

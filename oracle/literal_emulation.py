@@ -275,15 +275,24 @@ def _fmax(a, b):
     return b if a != a else (a if b != b else (a if a > b else b))
 
 
-def ray_box_intersection(bmin, bmax, origin, inv_dir):              # :75-87
+def _slabs(bmin, bmax, origin, inv_dir):                            # :77-84: tmin, tmax
     with np.errstate(invalid="ignore", over="ignore"):
         t1 = [(bmin[k] - origin[k]) * inv_dir[k] for k in range(3)]
         t2 = [(bmax[k] - origin[k]) * inv_dir[k] for k in range(3)]
     tmin1 = [_fmin(t1[k], t2[k]) for k in range(3)]
     tmax1 = [_fmax(t1[k], t2[k]) for k in range(3)]
-    tmin = _fmax(tmin1[0], _fmax(tmin1[1], tmin1[2]))
-    tmax = _fmin(tmax1[0], _fmin(tmax1[1], tmax1[2]))
+    return _fmax(tmin1[0], _fmax(tmin1[1], tmin1[2])), _fmin(tmax1[0], _fmin(tmax1[1], tmax1[2]))
+
+
+def ray_box_intersection(bmin, bmax, origin, inv_dir):              # :75-87
+    tmin, tmax = _slabs(bmin, bmax, origin, inv_dir)
     return bool(tmax > tmin and tmax > 0)
+
+
+def ray_box_entry(bmin, bmax, origin, inv_dir):
+    """tmin of the slab test: the distance at which it says the ray enters the box (not a reference function: the accept rule of
+    the library's fast modes compares a triangle's computed t with it)"""
+    return _slabs(bmin, bmax, origin, inv_dir)[0]
 
 
 def make_ray(cam, idx, idy):                                        # :108-126
@@ -317,18 +326,20 @@ class Scene:
         self.a, self.b, self.c = a, b, c
 
 
-def _check_triangle(s, tri, ray, result, counters):                 # :89-103
+def _check_triangle(s, tri, ray, result, counters, fast_rule=False):  # :89-103
     origin, direction, inv = ray
     counters[2] += 1
     if ray_box_intersection(s.tri_min[tri], s.tri_max[tri], origin, inv):
         counters[3] += 1
         dist, u, v = ray_triangle_intersection(origin, direction, tuple(s.a[tri]), tuple(s.b[tri]), tuple(s.c[tri]))
+        if fast_rule and dist < ray_box_entry(s.tri_min[tri], s.tri_max[tri], origin, inv):
+            return result                                            # NOT the reference: the fast modes' accept rule
         if dist < result[0]:
             return [dist, tri, u, v]
     return result
 
 
-def raytracing_thread(s, cam, idx, idy, counters):
+def raytracing_thread(s, cam, idx, idy, counters, fast_rule=False):
     """kernel Raytracing for dispatch thread (idx, idy) up to :176.  Returns [distance, triangleIndex, u, v];
     counters = [pops, boxes hit, leaf AABB tests, triangle tests] (SURVEY 8d's P, B, L, T)."""
     ray = make_ray(cam, idx, idy)
@@ -351,14 +362,14 @@ def raytracing_thread(s, cam, idx, idy, counters):
             current += 1
         else:
             tri = int(s.sorted_indices[int(s.leaf[left_index][1])])                  # :158
-            result = _check_triangle(s, tri, ray, result, counters)
+            result = _check_triangle(s, tri, ray, result, counters, fast_rule)
         right_index, right_type = int(s.internal[index][2]), int(s.internal[index][3])
         if right_type == INTERNAL_NODE:
             stack[current] = right_index
             current += 1
         else:
             tri = int(s.sorted_indices[int(s.leaf[right_index][1])])                 # :173
-            result = _check_triangle(s, tri, ray, result, counters)
+            result = _check_triangle(s, tri, ray, result, counters, fast_rule)
     return result
 
 

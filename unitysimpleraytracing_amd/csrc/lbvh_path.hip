@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(const lbvh_path_state* _
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_fast_triangle(ray, v0, v1, v2, u, v);
                     const uint32_t tri = __float_as_uint(v0.w);
-                    if (dist > t_min && (dist < best_t || (dist == best_t && tri < best_tri))) { best_t = dist; best_tri = tri; best_u = u; best_v = v; }
+                    if (dist > t_min && hit_counts(dist, side == 0 ? tl : tr) && (dist < best_t || (dist == best_t && tri < best_tri))) { best_t = dist; best_tri = tri; best_u = u; best_v = v; }
                 }
             }
             const bool go_l = hit_l && !(lref & 0x80000000u) && !(tl > best_t);
@@ -384,8 +384,9 @@ __global__ __launch_bounds__(64) void trace_rays_wide_kernel(const lbvh_path_sta
                 float u = 0.0f, v = 0.0f;
                 const float dist = ray_fast_triangle(ray, v0, v1, v2, u, v);
                 const uint32_t tri = __float_as_uint(v0.w);
+                const float entry = k == 0u ? t0 : (k == 1u ? t1 : (k == 2u ? t2 : t3));
                 // ties go to the lower triangle index, whatever order the leaves are met in (as in the packet walk)
-                if (dist > t_min && (dist < best_t || (dist == best_t && tri < best_tri))) { best_t = dist; best_tri = tri; best_u = u; best_v = v; }
+                if (dist > t_min && hit_counts(dist, entry) && (dist < best_t || (dist == best_t && tri < best_tri))) { best_t = dist; best_tri = tri; best_u = u; best_v = v; }
             }
             // nodes to enter, ordered by entry distance: the order key is the distance's bit pattern (non-negative floats
             // order like integers) with the slot number in its two lowest bits
@@ -489,6 +490,7 @@ __global__ __launch_bounds__(64) void trace_rays_wide_chain_kernel(const lbvh_pa
         if (!__any(active)) break;
         uint32_t leaves = 0u;
         uint4 leaf_ref = {};
+        float4 leaf_entry = {};
         bool fetch = active, done = false;
         if (active && have) {
             float t0, t1, t2, t3;
@@ -499,6 +501,7 @@ __global__ __launch_bounds__(64) void trace_rays_wide_chain_kernel(const lbvh_pa
             leaves = (h0 && (ref.x >> 31) ? 1u : 0u) | (h1 && (ref.y >> 31) ? 2u : 0u) | (h2 && (ref.z >> 31) ? 4u : 0u) |
                      (h3 && (ref.w >> 31) ? 8u : 0u);
             leaf_ref = ref;
+            leaf_entry = make_float4(t0, t1, t2, t3);
             // nodes to enter, ordered by entry distance: the order key is the distance's bit pattern (non-negative floats
             // order like integers) with the slot number in its two lowest bits
             constexpr uint32_t none = 0xFFFFFFFFu;
@@ -542,13 +545,15 @@ __global__ __launch_bounds__(64) void trace_rays_wide_chain_kernel(const lbvh_pa
             have = true;
         }
         while (leaves != 0u) {
+            const uint32_t slot = (uint32_t)__builtin_ctz(leaves);
+            const float entry = slot == 0u ? leaf_entry.x : (slot == 1u ? leaf_entry.y : (slot == 2u ? leaf_entry.z : leaf_entry.w));
             leaves &= leaves - 1u;
             if (STATS) n_tris++;
             float u = 0.0f, v = 0.0f;
             const float dist = ray_triangle_edges(ray, q0, q2.x, q2.y, q2.z, q1.w, q2.w, q3.w, u, v);
             const uint32_t tri = __float_as_uint(q0.w);
             // ties go to the lower triangle index, whatever order the leaves are met in (as in the packet walk)
-            if (dist > t_min && (dist < best_t || (dist == best_t && tri < best_tri))) { best_t = dist; best_tri = tri; best_u = u; best_v = v; }
+            if (dist > t_min && hit_counts(dist, entry) && (dist < best_t || (dist == best_t && tri < best_tri))) { best_t = dist; best_tri = tri; best_u = u; best_v = v; }
             if (leaves != 0u) {
                 const float4* line = reinterpret_cast<const float4*>(&lines[pick4(leaf_ref, (uint32_t)__builtin_ctz(leaves)) & 0x7FFFFFFFu]);
                 q0 = line[0]; q1 = line[1]; q2 = line[2]; q3 = line[3];

@@ -122,4 +122,19 @@ __device__ __forceinline__ float ray_fast_triangle(const ray_t& r, const float4 
     return ray_triangle_edges(r, t0, t1.x, t1.y, t1.z, t2.x, t2.y, t2.z, u_out, v_out);
 }
 
+// The second half of the fast walkers' accept rule (round 5): a computed t that lies BEFORE the distance at which
+// the ray enters the triangle's own padded box does not count.  Such a t is noise of the fp32 triangle test on a ray almost
+// inside the triangle's plane (det ~ 1e-4, the dot products cancel); the reference, which prunes nothing, reports it whenever
+// the ray's line passes that box — a walk that skips boxes entered beyond its best hit would report it or not depending on
+// the order in which it happens to meet the leaves (packet shape, shard count, dispatch history).  With this rule the
+// result is the nearest hit that is not in front of its own box, whatever the order: entry distances grow from a box to any
+// box inside it, so a candidate that counts satisfies t >= entry(leaf) >= entry(any ancestor), and a subtree skipped
+// because entry > best (strictly) cannot hold a candidate at or below best.  (entry = the slab test's tmin, the same six
+// fp32 products and minima / maxima as RayBoxIntersection; a NaN entry keeps the candidate, as the oracle's compare does.)
+#ifdef LBVH_AB_NO_ACCEPT_RULE      // tools/build_variant.sh: what the rule costs (A/B measurement only; never the product)
+__device__ __forceinline__ bool hit_counts(float, float) { return true; }
+#else
+__device__ __forceinline__ bool hit_counts(float t, float box_entry) { return !(t < box_entry); }
+#endif
+
 }  // namespace

@@ -590,11 +590,12 @@ __device__ __forceinline__ uint32_t walk_packet(const line_source& src, packet_r
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_fast_triangle(P.ray[r], v0, v1, v2, u, v);
                     const uint32_t id = EXACT ? __float_as_uint(nd.rmin.w) : __float_as_uint(v0.w);      // EXACT: the left leaf's position
-                    if (EXACT && dist == P.best_t[r] && dist != LBVH_MAX_FLOAT) {
+                    const bool counts = hit_counts(dist, tl[r]);
+                    if (EXACT && counts && dist == P.best_t[r] && dist != LBVH_MAX_FLOAT) {
                         tied = true;                                       // the candidate that does not stay in the running is listed now
                         list_tie(*sink->a, __ballot(true), sink->w, sink->px, sink->py, max(id, P.best_tri[r]), dist);
                     }
-                    if (closer(dist, id, P.best_t[r], P.best_tri[r])) { P.best_t[r] = dist; P.best_tri[r] = id; P.best_u[r] = u; P.best_v[r] = v; }
+                    if (counts && closer(dist, id, P.best_t[r], P.best_tri[r])) { P.best_t[r] = dist; P.best_tri[r] = id; P.best_u[r] = u; P.best_v[r] = v; }
                 }
                 hit_r[r] = hit_r[r] && !(tr[r] > P.best_t[r]);
                 any_r |= hit_r[r];
@@ -612,11 +613,12 @@ __device__ __forceinline__ uint32_t walk_packet(const line_source& src, packet_r
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_fast_triangle(P.ray[r], v0, v1, v2, u, v);
                     const uint32_t id = EXACT ? __float_as_uint(nd.rmax.w) : __float_as_uint(v0.w);      // EXACT: the right leaf's position
-                    if (EXACT && dist == P.best_t[r] && dist != LBVH_MAX_FLOAT) {
+                    const bool counts = hit_counts(dist, tr[r]);
+                    if (EXACT && counts && dist == P.best_t[r] && dist != LBVH_MAX_FLOAT) {
                         tied = true;
                         list_tie(*sink->a, __ballot(true), sink->w, sink->px, sink->py, max(id, P.best_tri[r]), dist);
                     }
-                    if (closer(dist, id, P.best_t[r], P.best_tri[r])) { P.best_t[r] = dist; P.best_tri[r] = id; P.best_u[r] = u; P.best_v[r] = v; }
+                    if (counts && closer(dist, id, P.best_t[r], P.best_tri[r])) { P.best_t[r] = dist; P.best_tri[r] = id; P.best_u[r] = u; P.best_v[r] = v; }
                 }
                 hit_l[r] = hit_l[r] && !(tl[r] > P.best_t[r]);
                 any_l |= hit_l[r];
@@ -784,7 +786,7 @@ __device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, pac
                 lean_tri T = uniform_tri(w_l, o_lane);
                 if (EXACT) T.index = (uint32_t)__builtin_amdgcn_readlane(w_node, 11);      // the left leaf's position
                 float t, u, v;            // every lane computes; the lanes that hit the leaf's box may keep the result
-                const bool cand = lean_triangle(r, T, t, u, v) && hit_l;
+                const bool cand = lean_triangle(r, T, t, u, v) && hit_l && hit_counts(t, tl);
                 if (EXACT) {
                     const uint64_t m = __builtin_amdgcn_ballot_w64(cand) & __builtin_amdgcn_ballot_w64(t == best_t);
                     if (m != 0) {         // (rare) the candidate that drops out of an exact tie is listed now
@@ -804,7 +806,7 @@ __device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, pac
                 lean_tri T = uniform_tri(w_r, o_lane);
                 if (EXACT) T.index = (uint32_t)__builtin_amdgcn_readlane(w_node, 15);      // the right leaf's position
                 float t, u, v;
-                const bool cand = lean_triangle(r, T, t, u, v) && hit_r;
+                const bool cand = lean_triangle(r, T, t, u, v) && hit_r && hit_counts(t, tr);
                 if (EXACT) {
                     const uint64_t m = __builtin_amdgcn_ballot_w64(cand) & __builtin_amdgcn_ballot_w64(t == best_t);
                     if (m != 0) {
@@ -1017,7 +1019,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                     if (STATS) C.tri++;
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_fast_triangle(P.ray[0], v0, v1, v2, u, v);
-                    if (dist <= best_t && dist != LBVH_MAX_FLOAT) {    // ties go to the atomic: (t, line index) orders them (see closer())
+                    if (dist <= best_t && dist != LBVH_MAX_FLOAT && hit_counts(dist, tl)) {    // ties go to the atomic: (t, line index) orders them (see closer())
                         best_t = dist;
                         const uint32_t id = EXACT ? (uint32_t)__builtin_amdgcn_readlane(w_node, 11) : (lref & 0x7FFFFFFFu);
                         const unsigned long long key = ((unsigned long long)ordered_key(dist) << 32) | id;
@@ -1038,7 +1040,7 @@ __device__ __forceinline__ void coop_tile(coop_shared& S, const trace_args& a, c
                     if (STATS) C.tri++;
                     float u = 0.0f, v = 0.0f;
                     const float dist = ray_fast_triangle(P.ray[0], v0, v1, v2, u, v);
-                    if (dist <= best_t && dist != LBVH_MAX_FLOAT) {    // ties go to the atomic: (t, line index) orders them (see closer())
+                    if (dist <= best_t && dist != LBVH_MAX_FLOAT && hit_counts(dist, tr)) {    // ties go to the atomic: (t, line index) orders them (see closer())
                         best_t = dist;
                         const uint32_t id = EXACT ? (uint32_t)__builtin_amdgcn_readlane(w_node, 15) : (rref & 0x7FFFFFFFu);
                         const unsigned long long key = ((unsigned long long)ordered_key(dist) << 32) | id;
