@@ -8,7 +8,7 @@ oracle's frames: reference mode against the reference's loop, the fast modes aga
 front of its own triangle's box does not count) — and the two oracle frames against each other: they may differ only
 where the reference's winner is such a t (counted and listed).  Also sorts random (key, value) arrays of random size and digit structure, and every eighth case
 animates and path-traces a small dynamic scene (1 .. 4 bounces) against the extension's own oracle.  Prints one line per case and a
-summary; exits non-zero on the first mismatch.   usage: python tools/fuzz_parity.py [seconds] [seed] [first_case]
+summary; exits non-zero on the first mismatch.   usage: python tools/fuzz_parity.py [seconds] [seed] [first_case]   (FUZZ_PATH_EVERY=1: a path-tracer-heavy stream)
 Every random draw of a case is made up front (draw_case), so `first_case` K replays the generator through cases 1 .. K-1 without
 running them and starts at case K: the way back to a failure that a long soak found (its message names the case's number)."""
 import ctypes as C, math, os, sys, time
@@ -21,6 +21,7 @@ from unitysimpleraytracing_amd.host import Context, DataBuffer, RaytracingMeshDr
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) & 0xFFFFFF
 first_case = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+path_every = int(os.environ.get("FUZZ_PATH_EVERY", "8"))       # 1: every case also path-traces a dynamic scene (a cfg5-heavy soak; another case stream)
 rng = np.random.default_rng(seed0)
 print("seed", seed0, "budget", budget, "s", "first case", first_case, flush=True)
 
@@ -114,7 +115,7 @@ def draw_case(case, skipped):
         x1, y1 = int(rng.integers(x0 + 1, w + 1)), int(rng.integers(y0 + 1, h + 1))
         q["rect"] = (x0, y0, x1, y1)
     q["cam2"] = random_camera(w, h)
-    if case % 8 == 0:
+    if case % path_every == 0:
         nu, nv, g = int(rng.integers(6, 28)), int(rng.integers(4, 18)), int(rng.integers(1, 4))
         sseed = int(rng.integers(1 << 30))
         sd, bounces, angle = int(rng.integers(1 << 20)), int(rng.integers(1, 5)), float(rng.uniform(0.0, 0.3))

@@ -786,7 +786,9 @@ __device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, pac
                 lean_tri T = uniform_tri(w_l, o_lane);
                 if (EXACT) T.index = (uint32_t)__builtin_amdgcn_readlane(w_node, 11);      // the left leaf's position
                 float t, u, v;            // every lane computes; the lanes that hit the leaf's box may keep the result
-                const bool cand = lean_triangle(r, T, t, u, v) && hit_l && hit_counts(t, tl);
+                // (the accept rule's second half, lbvh_rt.h hit_counts: EXACT needs it before the tie ballot; otherwise it sits behind
+                // `closer`, under the mask of the lanes that have a candidate at all: skipped with them)
+                const bool cand = lean_triangle(r, T, t, u, v) && hit_l && (!EXACT || hit_counts(t, tl));
                 if (EXACT) {
                     const uint64_t m = __builtin_amdgcn_ballot_w64(cand) & __builtin_amdgcn_ballot_w64(t == best_t);
                     if (m != 0) {         // (rare) the candidate that drops out of an exact tie is listed now
@@ -794,7 +796,7 @@ __device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, pac
                         if ((m >> lane) & 1ull) list_tie(*sink->a, m, sink->w, sink->px, sink->py, max(T.index, best_tri), t);
                     }
                 }
-                if (cand && closer(t, T.index, best_t, best_tri)) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
+                if (cand && closer(t, T.index, best_t, best_tri) && (EXACT || hit_counts(t, tl))) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
                 const bool still_r = !(tr > best_t);
                 hit_r = hit_r && still_r;
                 mr &= __builtin_amdgcn_ballot_w64(still_r);
@@ -806,7 +808,9 @@ __device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, pac
                 lean_tri T = uniform_tri(w_r, o_lane);
                 if (EXACT) T.index = (uint32_t)__builtin_amdgcn_readlane(w_node, 15);      // the right leaf's position
                 float t, u, v;
-                const bool cand = lean_triangle(r, T, t, u, v) && hit_r && hit_counts(t, tr);
+                // (the accept rule's second half, lbvh_rt.h hit_counts: EXACT needs it before the tie ballot; otherwise it sits behind
+                // `closer`, under the mask of the lanes that have a candidate at all: skipped with them)
+                const bool cand = lean_triangle(r, T, t, u, v) && hit_r && (!EXACT || hit_counts(t, tr));
                 if (EXACT) {
                     const uint64_t m = __builtin_amdgcn_ballot_w64(cand) & __builtin_amdgcn_ballot_w64(t == best_t);
                     if (m != 0) {
@@ -814,7 +818,7 @@ __device__ __forceinline__ uint32_t walk_packet_lean(const line_source& src, pac
                         if ((m >> lane) & 1ull) list_tie(*sink->a, m, sink->w, sink->px, sink->py, max(T.index, best_tri), t);
                     }
                 }
-                if (cand && closer(t, T.index, best_t, best_tri)) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
+                if (cand && closer(t, T.index, best_t, best_tri) && (EXACT || hit_counts(t, tr))) { best_t = t; best_tri = T.index; best_u = u; best_v = v; }
                 ml &= __builtin_amdgcn_ballot_w64(!(tl > best_t));
             }
             mr = 0;
