@@ -179,10 +179,11 @@ def test_sort_form_follows_the_last_sorts_largest_bucket():
         c.close()
 
 
-def test_sort_pairs_of_morton_codes_with_pads_finds_the_second_bucket_digit():
-    """lbvh_sort_pairs has no key_bits hint.  Morton codes below 2^30 plus 0xFFFFFFFF pads (the reference's own call sequence,
-    ComputeBufferSorter.Sort on the padded key buffer) fill only 64 top-byte buckets of 16 k and more: the four-pass sort measures
-    a second candidate digit (bits 22 .. 29) as well, and the next sort is two-level on that one.  Results are the oracle's."""
+def test_sort_pairs_of_morton_codes_with_pads_goes_two_level_without_a_hint():
+    """lbvh_sort_pairs has no key_bits hint: its fine bins are the keys' top 12 bits.  Morton codes below 2^30 plus 0xFFFFFFFF pads
+    (the reference's own call sequence, ComputeBufferSorter.Sort on the padded key buffer) fill a quarter of them and would fill 64
+    top-byte buckets of 16 k and more; the balanced buckets (ranges of fine bins of about count / 256 pairs) take them all the same:
+    the first sort measures, the next ones are two-level.  Results are the oracle's."""
     c = H().Context(0)
     try:
         rng = np.random.default_rng(5)

@@ -178,8 +178,8 @@ static lbvh_status create_impl(int32_t device_id, void* stream, bool own, lbvh_c
         return lbvh_set_error(nullptr, LBVH_ERR_OUT_OF_MEMORY, "lbvh_create", "no mapped host memory for the fault word");
     }
     memset(ctx->fault_host, 0, 256);
-    // words 16 .. 23: the largest bucket of the last sort for two candidate bucket digits (lbvh_sort.hip, the two-level form's hint); nothing known yet
-    for (int i = 16; i < 24; i++) ctx->fault_host[i] = 0xFFFFFFFFu;
+    // words 16 .. 19: the largest (balanced) bucket of the last sort, tagged with its fine shift (lbvh_sort.hip, the two-level form's hint); nothing known yet
+    for (int i = 16; i < 20; i++) ctx->fault_host[i] = 0xFFFFFFFFu;
     ctx->fault_host[24] = 0xFFFFFFFFu;        // word 24: the work estimate of the frame before last (lbvh_trace.hip, launch_packets); nothing known yet
     *out_ctx = ctx;
     return LBVH_OK;

@@ -110,7 +110,7 @@ struct lbvh_context {
     // lbvh_debug_switch (include/lbvh_debug.h): all 0 in the product
     uint32_t debug_switch[LBVH_DEBUG_SWITCHES] = {};
     // device-side protocol faults (a bounded spin gave up): one mapped host word, checked by lbvh_sync / download.  The same
-    // 256-byte mapped block carries, in words 16 .. 23, the largest bucket of the last sort of 2^15 .. 2^21 pairs for two candidate bucket digits, and in word 24 a work estimate of the last but one traced frame (written by the
+    // 256-byte mapped block carries, in words 16 .. 19, the largest (balanced) bucket of the last sort of 2^15 .. 2^21 pairs tagged with its fine shift, and in word 24 a work estimate of the last but one traced frame (written by the
     // first pass kernel, read without synchronisation by the next lbvh_launch_sort: which form to take — lbvh_sort.hip)
     uint32_t* fault_host = nullptr;
     uint32_t* fault_dev = nullptr;

@@ -36,15 +36,16 @@
 // alone, tools/ubench/tilecopy.hip: 2.9 -> 4.0 TB/s for unaligned 128-B runs).
 // Round 5 — the TWO-LEVEL form for latency-bound sizes (2^15 <= count < 2^21: the 1 M-triangle rebuild).  There a pass is not
 // bandwidth but the latency of ~250 dependent tiles (ticket, rank, two-level look-back, scatter: 15 us each, 62 us for four).
-// Two-level: ONE global onesweep pass on the most significant digit (stable partition into 256 buckets; digit =
-// min(key >> msd_shift, 255), msd_shift = key_bits - 8 from the caller's hint: 22 for Morton codes < 2^30, so that 0xFFFFFFFF
-// pads and anything else >= 2^30 land in the last bucket), then ONE kernel in which a workgroup sorts its whole bucket by the
-// remaining low bits — 3 stable 8-bit LSD passes (4 over the full key for the last bucket) with the pairs in registers and the
-// exchanges through LDS, no look-back, no global traffic between the passes.  Two launches and one look-back chain instead of
-// five and four.  The result is the same unique stable sort.  A bucket beyond one workgroup's registers (16 384 pairs) is
-// sorted by its workgroup chunk by chunk through global memory: correct for any input, slow — so the form is chosen per call
-// from the LAST sort's largest bucket (mapped host words the first pass kernel leaves behind; a hint one sort stale, like the
-// traversal's dispatch history: either form gives the same words).
+// Two-level: ONE global onesweep pass that partitions the pairs stably into 256 buckets — balanced ranges of the keys' 12-bit
+// prefix (build_bucket_map below; the prefix sits below the caller's key_bits hint: bits 18 .. 29 for Morton codes < 2^30, with
+// the 0xFFFFFFFF pads and anything else >= 2^30 in the last bin) — then ONE kernel in which a workgroup sorts its whole bucket by
+// key - (the bucket's first prefix) in as many stable 8-bit LSD passes as that difference has bytes (3 for Morton codes), with
+// the pairs in registers and the exchanges through LDS, no look-back, no global traffic between the passes.  Two launches and
+// one look-back chain instead of five and four.  The result is the same unique stable sort.  A bucket beyond one workgroup's
+// registers (16 384 pairs: more than ~12 K pairs with ONE 12-bit prefix) is sorted by its workgroup chunk by chunk through global
+// memory: correct for any input, slow — so the form is chosen per call from the LAST sort's largest bucket (mapped host words
+// the first pass kernel leaves behind; a hint one sort stale, like the traversal's dispatch history: either form gives the same
+// words).
 #include "lbvh_common.h"
 
 #include <algorithm>
@@ -61,23 +62,45 @@ constexpr uint32_t kValueMask = (1u << 30) - 1u;
 constexpr int kLook = 2;                   // group words inspected per look-back step
 constexpr int kLbGroup = 8;                // tiles per look-back group
 
-// the most significant digit of the two-level form: everything at or above 255 << msd_shift shares the last bucket
-__device__ __forceinline__ uint32_t msd_digit(uint32_t k, uint32_t msd_shift) { return min(k >> msd_shift, (uint32_t)kRadix - 1u); }
+// ---- the two-level form's buckets: BALANCED ranges of a 12-bit key prefix ---------------------------------------------------------
+// The bucket digit is not a fixed byte of the key (the top byte of cfg2's Morton codes: largest bucket 11 954 pairs, 3 x the
+// mean, and the bucket kernel's run time is its largest bucket's) but a monotone map from the key's 12-bit prefix
+// (fine bin = min(key >> fine_shift, 4095), fine_shift = key_bits - 12) to 256 buckets of about count / 256 pairs each:
+// bucket(bin) = floor(256 x (pairs in bins before it) / count), from a 4096-bin histogram the histogram kernel takes in the same
+// read of the keys.  Every tile of the MSD pass (and every bucket's workgroup) derives the map from those 16 KB by itself:
+// cheaper than a launch.  A bucket is then at most count / 256 + its largest bin; it covers the bins [first, last] and is
+// sorted by key - (first << fine_shift) in as many 8-bit passes as that difference has bytes (3 for Morton codes: 41 bins x 2^18).
+#ifndef LBVH_FINE_DEPTH
+#define LBVH_FINE_DEPTH 8
+#endif
+#ifndef LBVH_FINE_BLOCK_KEYS
+#define LBVH_FINE_BLOCK_KEYS 8192       // keys per block of the histogram kernel when it takes the fine bins (up to 4096 global atomics per block;
+                                        // 4 K x 4, 8 K x 4 / x 8 loads in flight, 16 K x 8: 8.5 / 8.6 / 8.4 / 10.5 us at 1 M keys)
+#endif
+constexpr int kFineBins = 4096;
+constexpr int kFineLog2 = 12;
+__device__ __forceinline__ uint32_t fine_bin(uint32_t k, uint32_t fine_shift) { return min(k >> fine_shift, (uint32_t)kFineBins - 1u); }
 
 // ---- all four digit histograms in one read of the keys ------------------------------------------
-// HIST_FOUR: ghist[p][256] for the four LSD passes; HIST_MSD: ghist[4][256] = the bucket sizes of the two-level form for the bucket
-// digit at msd_shift; HIST_MSD2: ghist[5][256] = the same for a second candidate digit at msd_shift2 (the four-pass form keeps
-// the statistics of BOTH candidates the next call's choice is made from)
-enum { HIST_FOUR = 1, HIST_MSD = 2, HIST_MSD2 = 4 };
+// HIST_FOUR: ghist[p][256] for the four LSD passes; HIST_FINE: gfine[4096] = the fine bins of the two-level form (the four-pass
+// form takes them too where the size allows the other form: the next call's choice is made from what they say)
+enum { HIST_FOUR = 1, HIST_FINE = 2 };
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t* __restrict__ keys,
-                                                                  uint32_t count, uint32_t* __restrict__ ghist, uint32_t msd_shift,
-                                                                  uint32_t msd_shift2)
+                                                                  uint32_t count, uint32_t* __restrict__ ghist, uint32_t* __restrict__ gfine,
+                                                                  uint32_t fine_shift)
 {
-    __shared__ uint32_t s_hist[kPasses + 2][kRadix];
+    __shared__ uint32_t s_hist[(MODE & HIST_FOUR) ? kPasses : 1][kRadix];
+    __shared__ uint32_t s_fine[(MODE & HIST_FINE) ? kFineBins : 1];
     const uint32_t t = threadIdx.x;
+    if (MODE & HIST_FOUR) {
 #pragma unroll
-    for (int p = 0; p < kPasses + 2; p++) s_hist[p][t] = 0;
+        for (int p = 0; p < kPasses; p++) s_hist[p][t] = 0;
+    }
+    if (MODE & HIST_FINE) {
+#pragma unroll
+        for (int i = 0; i < kFineBins / kThreads; i++) s_fine[i * kThreads + t] = 0;
+    }
     __syncthreads();
     // grid-stride over 16-B vectors (4 keys per lane per load), 2 loads in flight per thread
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -103,8 +126,7 @@ __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t
 #pragma unroll
                     for (int p = 0; p < kPasses; p++) atomicAdd(&s_hist[p][(k0 >> (8 * p)) & 255u], nactive);
                 }
-                if (MODE & HIST_MSD) atomicAdd(&s_hist[kPasses][msd_digit(k0, msd_shift)], nactive);
-                if (MODE & HIST_MSD2) atomicAdd(&s_hist[kPasses + 1][msd_digit(k0, msd_shift2)], nactive);
+                if (MODE & HIST_FINE) atomicAdd(&s_fine[fine_bin(k0, fine_shift)], nactive);
             }
             return;
         }
@@ -122,36 +144,30 @@ __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t
                 }
             }
         }
-        if (MODE & HIST_MSD) {
-            const uint32_t d = msd_digit(k, msd_shift), d0 = msd_digit(k0, msd_shift);
+        if (MODE & HIST_FINE) {
+            const uint32_t d = fine_bin(k, fine_shift), d0 = fine_bin(k0, fine_shift);
             if (__all(d == d0)) {
-                if (first) atomicAdd(&s_hist[kPasses][d0], nactive);
+                if (first) atomicAdd(&s_fine[d0], nactive);
             } else {
-                atomicAdd(&s_hist[kPasses][d], 1u);
-            }
-        }
-        if (MODE & HIST_MSD2) {
-            const uint32_t d = msd_digit(k, msd_shift2), d0 = msd_digit(k0, msd_shift2);
-            if (__all(d == d0)) {
-                if (first) atomicAdd(&s_hist[kPasses + 1][d0], nactive);
-            } else {
-                atomicAdd(&s_hist[kPasses + 1][d], 1u);
+                atomicAdd(&s_fine[d], 1u);
             }
         }
     };
-    for (uint32_t i0 = blockIdx.x * kThreads + t; i0 < nvec; i0 += stride * 4) {
-        // four 16-byte loads in flight per thread, read as streaming data (the passes read the keys again from memory
-        // anyway once they are beyond the L2): 0.092 -> 0.084 ms at 2^26 keys, 10.7 -> 9.7 us at 2^20
-        u32x4 v[4];
-        bool ok[4];
+    // loads in flight per thread: four 16-byte ones, read as streaming data (the passes read the keys again from memory anyway
+    // once they are beyond the L2): 0.092 -> 0.084 ms at 2^26 keys, 10.7 -> 9.7 us at 2^20; eight where the block takes the fine
+    // bins alone (fewer, larger blocks: each ends with up to 4096 global atomics)
+    constexpr int D = MODE == HIST_FINE ? LBVH_FINE_DEPTH : 4;
+    for (uint32_t i0 = blockIdx.x * kThreads + t; i0 < nvec; i0 += stride * D) {
+        u32x4 v[D];
+        bool ok[D];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < D; k++) {
             ok[k] = i0 + (uint32_t)k * stride < nvec;
             v[k] = u32x4{0u, 0u, 0u, 0u};
             if (ok[k]) v[k] = __builtin_nontemporal_load(&vkeys[i0 + (uint32_t)k * stride]);
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < D; k++)
             if (ok[k]) { add_key(v[k].x); add_key(v[k].y); add_key(v[k].z); add_key(v[k].w); }
     }
     if (blockIdx.x == 0 && t < 8u) {                   // at most 3 head + 3 tail keys
@@ -162,16 +178,131 @@ __global__ __launch_bounds__(kThreads) void sort_histogram_kernel(const uint32_t
 #pragma unroll
                 for (int p = 0; p < kPasses; p++) atomicAdd(&s_hist[p][(k >> (8 * p)) & 255u], 1u);
             }
-            if (MODE & HIST_MSD) atomicAdd(&s_hist[kPasses][msd_digit(k, msd_shift)], 1u);
-            if (MODE & HIST_MSD2) atomicAdd(&s_hist[kPasses + 1][msd_digit(k, msd_shift2)], 1u);
+            if (MODE & HIST_FINE) atomicAdd(&s_fine[fine_bin(k, fine_shift)], 1u);
         }
     }
     __syncthreads();
+    if (MODE & HIST_FOUR) {
 #pragma unroll
-    for (int p = 0; p < kPasses + 2; p++) {
-        if (p < kPasses ? !(MODE & HIST_FOUR) : (p == kPasses ? !(MODE & HIST_MSD) : !(MODE & HIST_MSD2))) continue;
-        const uint32_t c = s_hist[p][t];
-        if (c) atomicAdd(&ghist[p * kRadix + t], c);
+        for (int p = 0; p < kPasses; p++) {
+            const uint32_t c = s_hist[p][t];
+            if (c) atomicAdd(&ghist[p * kRadix + t], c);
+        }
+    }
+    if (MODE & HIST_FINE) {
+#pragma unroll
+        for (int i = 0; i < kFineBins / kThreads; i++) {
+            const uint32_t c = s_fine[i * kThreads + t];
+            if (c) atomicAdd(&gfine[i * kThreads + t], c);
+        }
+    }
+}
+
+// ---- the bucket map from the fine histogram, by one workgroup of 512 threads (8 bins each) ----------------------------------------
+// s_map[bin] = bucket of the bin (monotone); s_bsize / s_bfirst / s_blast[bucket] = its pairs and the first / last NON-EMPTY bin it
+// covers (first = 0xFFFFFFFF for a bucket without pairs).  `mul` = floor(2^40 / count): bucket = (pairs before the bin) x 256 / count
+// as one v_mul_hi (at most one short of the exact quotient: still monotone, still < 256).
+struct bucket_map_lds {
+    uint8_t map[kFineBins];
+    uint32_t bsize[kRadix], bfirst[kRadix], blast[kRadix];
+    uint32_t psize[kRadix];          // the plain map's bucket sizes (16 consecutive bins each)
+    uint32_t wsum[8], cost[2][4], plain;
+};
+template <bool ON> struct bucket_map_slot { bucket_map_lds v; };
+template <> struct bucket_map_slot<false> { uint32_t v; };
+
+// 8-bit LSD passes a bucket over the fine bins [first, last] takes: the bytes of its key span (the last bin holds everything from
+// 4095 << fine_shift up: 0xFFFFFFFF pads beside Morton codes)
+__device__ __forceinline__ uint32_t bucket_passes(uint32_t first_bin, uint32_t last_bin, uint32_t fine_shift, uint32_t& base)
+{
+    base = first_bin << fine_shift;
+    const uint32_t top = last_bin >= (uint32_t)kFineBins - 1u ? 0xFFFFFFFFu : ((last_bin + 1u) << fine_shift) - 1u;
+    const uint32_t span = top - base;
+    return span == 0u ? 1u : (39u - (uint32_t)__builtin_clz(span)) / 8u;      // 1 .. 4
+}
+
+// Two candidate maps, the cheaper one is kept (cost = the largest pairs x passes of any bucket: what the bucket kernel's run time
+// follows): the BALANCED one above, and the PLAIN one — bucket = bin >> 4, the top byte of the prefix — which wins where the keys
+// are spread evenly already: its buckets are aligned, 16 bins never span more than fine_shift + 4 bits, while a balanced bucket of
+// 17 bins of uniform 32-bit keys needs a fourth pass.  A pure function of the histogram: every workgroup reaches the same map.
+struct fine_bins8 { uint4 lo, hi; };      // thread t's 8 fine bins, requested early (their latency hides behind the tile's key loads)
+__device__ __forceinline__ fine_bins8 load_fine_bins(const uint32_t* __restrict__ gfine)
+{
+    fine_bins8 r;
+    r.lo = reinterpret_cast<const uint4*>(gfine)[2u * threadIdx.x];
+    r.hi = reinterpret_cast<const uint4*>(gfine)[2u * threadIdx.x + 1u];
+    return r;
+}
+__device__ __forceinline__ void build_bucket_map(const fine_bins8& fb, uint32_t mul, uint32_t fine_shift, bucket_map_lds& L)
+{
+    const uint32_t t = threadIdx.x, w = t >> 6, lane = lane_id();     // blockDim.x == 512
+    if (t < (uint32_t)kRadix) { L.bsize[t] = 0u; L.bfirst[t] = 0xFFFFFFFFu; L.blast[t] = 0u; L.psize[t] = 0u; }
+    const uint32_t f[8] = {fb.lo.x, fb.lo.y, fb.lo.z, fb.lo.w, fb.hi.x, fb.hi.y, fb.hi.z, fb.hi.w};
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) mine += f[j];
+    const uint32_t incl = wave_inclusive_sum(mine);
+    if (lane == 63) L.wsum[w] = incl;
+    __syncthreads();                                  // also: the tables' initial values are in place
+    uint32_t before = incl - mine;
+#pragma unroll
+    for (int i = 0; i < 8; i++) before += (uint32_t)i < w ? L.wsum[i] : 0u;
+    if (mine != 0) atomicAdd(&L.psize[t >> 1], mine);            // my 8 bins are half of plain bucket t / 2
+    // my 8 bins: runs of equal bucket go to the tables with one atomic each
+    uint32_t bytes[2] = {0u, 0u};
+    uint32_t cur = 0xFFFFFFFFu, acc = 0, lo = 0xFFFFFFFFu, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t bucket = min(__umulhi(before, mul), (uint32_t)kRadix - 1u);
+        bytes[j >> 2] |= bucket << (8 * (j & 3));
+        if (bucket != cur) {
+            if (acc != 0) { atomicAdd(&L.bsize[cur], acc); atomicMin(&L.bfirst[cur], lo); atomicMax(&L.blast[cur], hi); }
+            cur = bucket; acc = 0; lo = 0xFFFFFFFFu; hi = 0;
+        }
+        if (f[j] != 0) {
+            const uint32_t bin = 8u * t + (uint32_t)j;
+            acc += f[j];
+            lo = min(lo, bin);
+            hi = bin;
+        }
+        before += f[j];
+    }
+    if (acc != 0) { atomicAdd(&L.bsize[cur], acc); atomicMin(&L.bfirst[cur], lo); atomicMax(&L.blast[cur], hi); }
+    __syncthreads();
+    if (t < (uint32_t)kRadix) {                       // thread t = bucket t: the two maps' costs
+        uint32_t base;
+        uint32_t cb = L.bsize[t] != 0u ? L.bsize[t] * bucket_passes(L.bfirst[t], L.blast[t], fine_shift, base) : 0u;
+        uint32_t cp = L.psize[t] * bucket_passes(16u * t, 16u * t + 15u, fine_shift, base);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            cb = max(cb, (uint32_t)__shfl_xor((int)cb, d));
+            cp = max(cp, (uint32_t)__shfl_xor((int)cp, d));
+        }
+        if (lane == 0) { L.cost[0][w] = cb; L.cost[1][w] = cp; }
+    }
+    __syncthreads();
+    const uint32_t cost_b = max(max(L.cost[0][0], L.cost[0][1]), max(L.cost[0][2], L.cost[0][3]));
+    const uint32_t cost_p = max(max(L.cost[1][0], L.cost[1][1]), max(L.cost[1][2], L.cost[1][3]));
+    const bool plain = cost_p <= cost_b;              // uniform over the workgroup (and over the grid)
+    if (plain) {
+        bytes[0] = bytes[1] = (t >> 1) * 0x01010101u;
+        if (t < (uint32_t)kRadix) { L.bsize[t] = L.psize[t]; L.bfirst[t] = L.psize[t] != 0u ? 16u * t : 0xFFFFFFFFu; L.blast[t] = 16u * t + 15u; }
+    }
+    reinterpret_cast<uint32_t*>(L.map)[2u * t] = bytes[0];
+    reinterpret_cast<uint32_t*>(L.map)[2u * t + 1u] = bytes[1];
+    __syncthreads();
+}
+
+// the largest bucket of this input -> 4 mapped host words (one per wave of buckets; the host takes their maximum), each tagged
+// with the fine shift it belongs to: the NEXT sort's choice of form (lbvh_launch_sort)
+__device__ __forceinline__ void publish_bucket_stat(const bucket_map_lds& L, uint32_t* bucket_stat, uint32_t fine_shift)
+{
+    const uint32_t t = threadIdx.x, w = t >> 6, lane = lane_id();
+    if (t < (uint32_t)kRadix) {
+        uint32_t m = L.bsize[t];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+        if (lane == 0) __hip_atomic_store(bucket_stat + w, (fine_shift << 24) | min(m, 0xFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -183,16 +314,18 @@ __host__ __device__ __forceinline__ uint32_t ticket_tile(uint32_t k, uint32_t x,
 }
 
 // ---- one pass: rank + look-back + scatter ----------------------------------------------------------
-// MSD: the two-level form's one global pass — digit = msd_digit(key, shift) instead of a byte of the key
+// MSD: the two-level form's one global pass — digit = the key's bucket (build_bucket_map) instead of a byte of the key;
+// `shift` is then the fine shift
 template <int THREADS, int ITEMS, bool STREAM, bool MSD = false>
 __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t count, uint32_t shift,
-    const uint32_t* __restrict__ ghist,   // [256] digit totals of this pass
-    const uint32_t* __restrict__ msd_hist,// (nullable) [256] (+ [256] for a second candidate digit if stat_shifts names one) bucket sizes of the two-level
-                                          // form: tile 0 leaves their maxima ...
-    uint32_t* bucket_stat,                // ... in these 4 (+ 4) mapped host words, each (digit shift << 24 | largest bucket): the NEXT sort's choice of form
-    uint32_t stat_shifts,                 // the candidates' digit shifts: first | second << 8 (second 0xFF: none)
+    const uint32_t* __restrict__ ghist,   // [256] digit totals of this pass (MSD: unused — the bucket sizes come out of the map)
+    const uint32_t* __restrict__ gfine,   // (nullable; 512-thread x 8-item form only) [4096] fine bins: MSD derives its buckets from them;
+                                          // otherwise tile 0 derives them after its own work, for ...
+    uint32_t* bucket_stat,                // ... these 4 mapped host words, each (fine shift << 24 | largest bucket): the NEXT sort's choice of form
+    uint32_t fine_shift, uint32_t fine_mul,   // fine bin = min(key >> fine_shift, 4095); fine_mul = floor(2^40 / count)
+    uint32_t* __restrict__ gtable,        // MSD: [3][256] bucket sizes, first and last fine bin — tile 0 writes them for the bucket kernel
     uint32_t* status,                     // [tiles][256] tile words of this pass (zeroed per sort)
     uint32_t* gstatus,                    // [ceil(tiles / kLbGroup)][256] group words of this pass (zeroed per sort)
     uint32_t* tickets,                    // [8] per-XCD tile tickets of this pass (zeroed per sort)
@@ -215,10 +348,15 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     __shared__ uint32_t s_gofs[kRadix];          // global base of digit d minus its local start
     __shared__ uint32_t s_wsum[DWAVES + 1];
     __shared__ uint32_t s_tile;
+    constexpr bool kMapCapable = THREADS == 512 && ITEMS == 8 && !STREAM;      // the form used below 2^21 pairs
+    static_assert(kMapCapable || !MSD, "the MSD pass is the 512 x 8 form");
+    __shared__ bucket_map_slot<kMapCapable> s_bslot;                           // (4 bytes in the forms that never build a map)
 
     const uint32_t t = threadIdx.x;
     const uint32_t w = t >> 6;
     const uint32_t lane = lane_id();
+    fine_bins8 fine8 = {};
+    if constexpr (MSD) fine8 = load_fine_bins(gfine);      // 16 KB per tile from L2, in flight while the tile takes its ticket
     if (t == 0) {
         // when the home queue is drained take from the others.  grid == tiles and every workgroup takes exactly
         // one, so one is found.
@@ -238,34 +376,10 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     const uint32_t tile = s_tile;
     const uint32_t base = tile * (uint32_t)TILE;
     const uint32_t nvalid = min((uint32_t)TILE, count - base);
-    auto digit_of = [shift](uint32_t k) { return MSD ? msd_digit(k, shift) : (k >> shift) & (uint32_t)(kRadix - 1); };
-    if (msd_hist && tile == 0 && w < (uint32_t)DWAVES) {       // the largest bucket of this input (a hint for the next call)
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const uint32_t sh = (stat_shifts >> (8 * c)) & 0xFFu;
-            if (sh == 0xFFu) continue;
-            uint32_t m = msd_hist[c * kRadix + t];
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
-            // 4 words per candidate (one per wave of digits): the host takes their maximum and reads the shift they belong to
-            if (lane == 0) __hip_atomic_store(bucket_stat + 4 * c + w, (sh << 24) | min(m, 0xFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-
-    // exclusive scan of the pass's digit totals = first output index of each digit (every tile
-    // recomputes it from 1 KB of L2-resident counters: cheaper than a launch)
-    uint32_t digit_start = 0;
-    {
-        const uint32_t total = t < (uint32_t)kRadix ? ghist[t] : 0u;
-        const uint32_t incl = wave_inclusive_sum(total);
-        if (lane == 63 && w < (uint32_t)DWAVES) s_wsum[w] = incl;
-        __syncthreads();
-        uint32_t wave_prefix = 0;
-#pragma unroll
-        for (int i = 0; i < DWAVES; i++) wave_prefix += (uint32_t)i < w ? s_wsum[i] : 0u;
-        digit_start = incl - total + wave_prefix;
-    }
-
+    auto digit_of = [shift](uint32_t k) -> uint32_t {
+        if constexpr (MSD) return (uint32_t)s_bslot.v.map[fine_bin(k, shift)];
+        else return (k >> shift) & (uint32_t)(kRadix - 1);
+    };
     // wave-striped load: wave w owns keys [base + w*64*ITEMS, +64*ITEMS), item i = 64 consecutive
     // keys, so (item, lane) order is array order — what stability needs.
     // Register budget: 64 VGPRs = 8 waves per SIMD = 4 tiles per CU (the look-back and the loads are latency,
@@ -279,12 +393,46 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     // starts when its load lands instead of waiting for all sixteen.
     const __amdgpu_buffer_rsrc_t keys_in_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(keys_in), 0, (int)(count * 4u), 0x00020000);
+    auto load_keys = [&]() {
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const uint32_t idx = wave_base + (uint32_t)i * LBVH_WAVE + lane;
-        const uint32_t k = __builtin_amdgcn_raw_buffer_load_b32(keys_in_rsrc, idx * 4u, 0, kLoadPolicy);
-        key[i] = idx < count ? k : 0xFFFFFFFFu;
+        for (int i = 0; i < ITEMS; i++) {
+            const uint32_t idx = wave_base + (uint32_t)i * LBVH_WAVE + lane;
+            const uint32_t k = __builtin_amdgcn_raw_buffer_load_b32(keys_in_rsrc, idx * 4u, 0, kLoadPolicy);
+            key[i] = idx < count ? k : 0xFFFFFFFFu;
+        }
+    };
+    if constexpr (MSD) {
+        // every tile derives the bucket map from the 16 KB of fine bins by itself (cheaper than a launch), with its keys already
+        // requested; tile 0 leaves the bucket table to the bucket kernel and the largest bucket to the next call's choice of form
+        load_keys();
+        build_bucket_map(fine8, fine_mul, fine_shift, s_bslot.v);
+        if (tile == 0) {
+            if (t < (uint32_t)kRadix) {
+                gtable[t] = s_bslot.v.bsize[t];
+                gtable[kRadix + t] = s_bslot.v.bfirst[t];
+                gtable[2 * kRadix + t] = s_bslot.v.blast[t];
+            }
+            publish_bucket_stat(s_bslot.v, bucket_stat, fine_shift);
+        }
     }
+
+    // exclusive scan of the pass's digit totals = first output index of each digit (every tile
+    // recomputes it from 1 KB of L2-resident counters: cheaper than a launch)
+    uint32_t digit_start = 0;
+    {
+        uint32_t total = 0u;
+        if constexpr (MSD) total = t < (uint32_t)kRadix ? s_bslot.v.bsize[t] : 0u;
+        else total = t < (uint32_t)kRadix ? ghist[t] : 0u;
+        const uint32_t incl = wave_inclusive_sum(total);
+        if (lane == 63 && w < (uint32_t)DWAVES) s_wsum[w] = incl;
+        __syncthreads();
+        uint32_t wave_prefix = 0;
+#pragma unroll
+        for (int i = 0; i < DWAVES; i++) wave_prefix += (uint32_t)i < w ? s_wsum[i] : 0u;
+        digit_start = incl - total + wave_prefix;
+    }
+
+    if constexpr (!MSD) load_keys();
 
     // Ranking.  The wave's 64 keys of one item are matched on the whole 8-bit digit THROUGH LDS: every lane ORs its
     // lane bit into the 64-bit peer mask of cell (wave, digit) and reads the cell back — LDS executes a wave's
@@ -479,6 +627,15 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         if (pos < nvalid) __builtin_amdgcn_raw_buffer_store_b32(s_xchg[pos], vals_rsrc, dst * 4u, 0, 0);
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (kMapCapable && !MSD) {
+        // the four-pass form, first pass: what the two-level form's largest bucket WOULD be for this input (after this tile's own
+        // work: nobody waits for it)
+        if (gfine != nullptr && tile == 0) {
+            __syncthreads();
+            build_bucket_map(load_fine_bins(gfine), fine_mul, fine_shift, s_bslot.v);
+            publish_bucket_stat(s_bslot.v, bucket_stat, fine_shift);
+        }
+    }
 }
 
 #ifndef LBVH_RANK_GROUP
@@ -601,7 +758,8 @@ __device__ __forceinline__ void bucket_rank(const uint32_t (&key)[ITEMS], uint32
 template <int THREADS, int ITEMS>
 __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restrict__ keys_in, uint32_t* __restrict__ vals_in,
                                                               uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                              uint32_t msd_shift, const uint32_t* __restrict__ msd_hist)
+                                                              uint32_t fine_shift,
+                                                              const uint32_t* __restrict__ gtable)     // [3][256]: bucket sizes, first, last fine bin
 {
     constexpr int TILE = THREADS * ITEMS;
     constexpr int WAVES = THREADS / LBVH_WAVE, DWAVES = kRadix / LBVH_WAVE;
@@ -621,7 +779,7 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
     const uint32_t b = blockIdx.x;
     LBVH_BT(0);
     {   // where bucket b starts: exclusive scan of the 256 bucket sizes (1 KB of L2-resident counters, cheaper than a launch)
-        const uint32_t total = t < (uint32_t)kRadix ? msd_hist[t] : 0u;
+        const uint32_t total = t < (uint32_t)kRadix ? gtable[t] : 0u;
         const uint32_t incl = wave_inclusive_sum(total);
         if (lane == 63 && w < (uint32_t)DWAVES) s_wsum[w] = incl;
         __syncthreads();
@@ -639,8 +797,11 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
     if (threadIdx.x == 0) g_bucket_timing[blockIdx.x][39] = size;
 #endif
     if (size == 0) return;
-    // the remaining bits below the bucket digit; the last bucket holds everything from 255 << msd_shift up: the whole key
-    const uint32_t passes = b == (uint32_t)kRadix - 1u ? 4u : (msd_shift + 7u) / 8u;
+    // The bucket covers the fine bins [first, last]: its keys lie in [first << fine_shift, ((last + 1) << fine_shift) - 1] — the last
+    // bin holds everything from 4095 << fine_shift up (0xFFFFFFFF pads beside Morton codes).  Sorted by key - base, the bytes of
+    // that span are all the passes it takes; the keys travel as differences and get their base back on the way out.
+    uint32_t base;
+    const uint32_t passes = bucket_passes(gtable[kRadix + b], gtable[2 * kRadix + b], fine_shift, base);
     uint32_t key[ITEMS], lpos2[ITEMS / 2];
     uint32_t digit_total;
 
@@ -661,7 +822,7 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
             if ((uint32_t)i >= my_it) continue;
             const uint32_t idx = w * stripe + (uint32_t)i * LBVH_WAVE + lane;
             const uint32_t k = __builtin_amdgcn_raw_buffer_load_b32(k_rsrc, idx * 4u, 0, 0);
-            key[i] = idx < size ? k : 0xFFFFFFFFu;
+            key[i] = idx < size ? k - base : 0xFFFFFFFFu;
             val[i] = __builtin_amdgcn_raw_buffer_load_b32(v_rsrc, idx * 4u, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -680,7 +841,7 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
             if (p + 1 == passes) {
                 for (uint32_t pos = t; pos < size; pos += THREADS) {
                     const uint2 kv = s_pair[pos];
-                    keys_out[start + pos] = kv.x;
+                    keys_out[start + pos] = kv.x + base;
                     vals_out[start + pos] = kv.y;
                 }
                 LBVH_BT(30);
@@ -710,7 +871,7 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
         const uint32_t pshift = 8u * p;
         if (t < (uint32_t)kRadix) s_base[t] = 0;
         __syncthreads();
-        for (uint32_t idx = t; idx < size; idx += THREADS) atomicAdd(&s_base[(src_k[start + idx] >> pshift) & (kRadix - 1)], 1u);
+        for (uint32_t idx = t; idx < size; idx += THREADS) atomicAdd(&s_base[((src_k[start + idx] - base) >> pshift) & (kRadix - 1)], 1u);
         __syncthreads();
         {   // exclusive scan of the digit counts in place
             const uint32_t total = t < (uint32_t)kRadix ? s_base[t] : 0u;
@@ -730,7 +891,7 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
 #pragma unroll
             for (int i = 0; i < SI; i++) {
                 const uint32_t idx = w * (uint32_t)(LBVH_WAVE * SI) + (uint32_t)i * LBVH_WAVE + lane;
-                skey[i] = idx < nvalid ? src_k[start + c0 + idx] : 0xFFFFFFFFu;
+                skey[i] = idx < nvalid ? src_k[start + c0 + idx] - base : 0xFFFFFFFFu;
             }
             bucket_rank<THREADS, SI>(skey, (uint32_t)WAVES, (uint32_t)SI, pshift, s_xchg, &s_cnt[0][0], s_wcnt, s_dstart, s_wsum, slpos2, digit_total);
 #pragma unroll
@@ -740,7 +901,7 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
                 const uint32_t lpos = (i & 1) ? slpos2[i / 2] >> 16 : slpos2[i / 2] & 0xFFFFu;
                 if (idx < nvalid) {
                     const uint32_t dst = start + s_base[d] + (lpos - s_dstart[d]);        // its rank among the chunk's pairs of digit d
-                    dst_k[dst] = skey[i];
+                    dst_k[dst] = skey[i] + base;
                     dst_v[dst] = src_v[start + c0 + idx];
                 }
             }
@@ -769,13 +930,14 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
 template <int THREADS, int ITEMS, bool STREAM>
 void launch_passes(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t* alt_keys, uint32_t* alt_vals,
                    uint32_t count, uint32_t tiles, uint32_t* ghist, uint32_t* status, uint32_t* gstatus, uint32_t groups,
-                   uint32_t* tickets, uint32_t group, const uint32_t* msd_hist = nullptr, uint32_t* bucket_stat = nullptr,
-                   uint32_t stat_shifts = 0xFFFFu)
+                   uint32_t* tickets, uint32_t group, const uint32_t* gfine = nullptr, uint32_t* bucket_stat = nullptr,
+                   uint32_t fine_shift = 0u, uint32_t fine_mul = 0u)
 {
     uint32_t *ks = d_keys, *vs = d_values, *kd = alt_keys, *vd = alt_vals;
     for (uint32_t p = 0; p < (uint32_t)kPasses; p++) {   // ComputeBufferSorter.cs:102
         LBVH_LAUNCH(ctx, (sort_onesweep_kernel<THREADS, ITEMS, STREAM>), dim3(tiles), dim3(THREADS), ks, vs, kd, vd, count,
-                    8u * p, ghist + p * kRadix, p == 0 ? msd_hist : nullptr, bucket_stat, stat_shifts, status + (size_t)p * tiles * kRadix,
+                    8u * p, ghist + p * kRadix, p == 0 ? gfine : nullptr, bucket_stat, fine_shift, fine_mul, (uint32_t*)nullptr,
+                    status + (size_t)p * tiles * kRadix,
                     gstatus + (size_t)p * groups * kRadix, tickets + 8u * p, tiles, group, ctx->sort_queues, ctx->fault_dev);
         uint32_t* tmp;
         tmp = ks; ks = kd; kd = tmp;
@@ -803,9 +965,9 @@ static int sort_prepare(lbvh_context* ctx, uint32_t count, sort_plan* pl)
     const uint32_t tile = (uint32_t)threads * (uint32_t)items;
     const uint32_t tiles = (uint32_t)(((uint64_t)count + tile - 1) / tile);
     const size_t pair_bytes = (((size_t)count * 4) + 255) & ~(size_t)255;
-    // [ghist 4x256 + the two-level form's bucket sizes 256 | tickets (4 passes x 8 XCDs, padded to 256 B) | tile words 4 x tiles x 256 |
-    // group words] is zeroed per sort
-    const size_t head_bytes = (size_t)(kPasses + 2) * kRadix * 4 + 256;
+    // [ghist 4x256 | the two-level form's 4096 fine bins | its bucket table 3x256 | tickets (4 passes x 8 XCDs, padded to 256 B) |
+    // tile words 4 x tiles x 256 | group words] is zeroed per sort
+    const size_t head_bytes = (size_t)(kPasses * kRadix + kFineBins + 3 * kRadix) * 4 + 256;
     const uint32_t groups = (tiles + (uint32_t)kLbGroup - 1u) / (uint32_t)kLbGroup;
     const size_t status_bytes = (size_t)kPasses * ((size_t)tiles + groups) * kRadix * 4;
     int rc = lbvh_reserve(ctx, &ctx->sort_scratch, &ctx->sort_scratch_bytes, 2 * pair_bytes + head_bytes + status_bytes);
@@ -817,7 +979,7 @@ static int sort_prepare(lbvh_context* ctx, uint32_t count, sort_plan* pl)
     pl->alt_keys = (uint32_t*)p;
     pl->alt_vals = (uint32_t*)(p + pair_bytes);
     pl->ghist = (uint32_t*)(p + 2 * pair_bytes);
-    pl->tickets = pl->ghist + (kPasses + 2) * kRadix;
+    pl->tickets = pl->ghist + kPasses * kRadix + kFineBins + 3 * kRadix;
     pl->status = (uint32_t*)(p + 2 * pair_bytes + head_bytes);
     pl->gstatus = pl->status + (size_t)kPasses * tiles * kRadix;
     pl->zero_bytes = head_bytes + status_bytes;
@@ -863,51 +1025,39 @@ int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, ui
     if (hblocks > 256u * 8u) hblocks = 256u * 8u;
     // consecutive tiles per XCD: 16 when every XCD still gets several groups, fewer for small sorts
     const uint32_t group = tiles >= 1024u ? 16u : tiles >= 128u ? 8u : 1u;
-    // The form.  Two-level where a pass is latency (two_level_size) and the LAST sort of this context had no bucket beyond one
-    // workgroup's registers for the bucket digit in question — the first pass kernel of either form leaves the largest bucket of ITS
-    // input in mapped host words, each tagged with the digit's shift; read here without any synchronisation: a hint, one sort
-    // stale (a first sort, or one after a skewed input, takes the four passes; a skewed input after a uniform one is sorted
-    // correctly by the bucket kernel's slow path, once).  Candidates for the bucket digit: the 8 bits below the caller's key_bits
-    // (the rebuild: 30 -> bits 22 .. 29), for arbitrary keys the top byte and, second choice, bits 22 .. 29 (Morton codes with
-    // 0xFFFFFFFF pads sorted through lbvh_sort_pairs, the reference's own call sequence: the top byte would give 64 buckets of 16 k).
-    // The four-pass form measures both candidates; the two-level form the one it uses.
-    // lbvh_debug_switch(LBVH_DEBUG_SORT_FORM): 1 four passes always, 2 two-level (first candidate) wherever the size allows.
-    const bool hinted = key_bits >= 8u && key_bits < 32u;
-    const uint32_t cand[2] = {hinted ? key_bits - 8u : 24u, hinted ? 0xFFu : 22u};
-    uint32_t* msd_hist = ghist + kPasses * kRadix;
-    uint32_t* stat_dev = ctx->fault_dev + 16;                   // words 16 .. 23 of the mapped block (word 0: the fault word)
+    // The form.  Two-level where a pass is latency (two_level_size) and the LAST sort of this context, bucketed the same way, had
+    // no bucket beyond one workgroup's registers — the first pass kernel of either form leaves the largest (balanced) bucket of
+    // ITS input in four mapped host words, tagged with the fine shift; read here without any synchronisation: a hint, one sort
+    // stale (a first sort, or one after an input with more than ~16 K equal 12-bit prefixes, takes the four passes; such an input
+    // after a spread one is sorted correctly by the bucket kernel's slow path, once).  The fine bins are the 12 bits below the
+    // caller's key_bits (the rebuild: Morton codes < 2^30 -> bits 18 .. 29, pads in the last bin; lbvh_sort_pairs: the top 12).
+    // lbvh_debug_switch(LBVH_DEBUG_SORT_FORM): 1 four passes always, 2 two-level wherever the size allows.
+    const uint32_t fine_shift = (key_bits >= (uint32_t)kFineLog2 && key_bits <= 32u ? key_bits : 32u) - (uint32_t)kFineLog2;
+    const uint32_t fine_mul = (uint32_t)((1ull << 40) / count);
+    uint32_t* gfine = ghist + kPasses * kRadix;
+    uint32_t* gtable = gfine + kFineBins;
+    uint32_t* stat_dev = ctx->fault_dev + 16;                   // words 16 .. 19 of the mapped block (word 0: the fault word)
     bool two_level = false;
-    uint32_t msd_shift = cand[0];
     if (two_level_size(count)) {
         const volatile uint32_t* st = ctx->fault_host + 16;
-        // the largest bucket last seen for bucket digit `shift`, or "unknown"
-        auto largest_for = [&](uint32_t shift) -> uint32_t {
-            for (int c = 0; c < 2; c++) {
-                uint32_t m = 0;
-                bool ok = true;
-                for (int w = 0; w < 4; w++) {
-                    const uint32_t v = st[4 * c + w];
-                    ok = ok && (v >> 24) == shift && v != 0xFFFFFFFFu;
-                    m = std::max(m, v & 0xFFFFFFu);
-                }
-                if (ok) return m;
-            }
-            return 0xFFFFFFFFu;
-        };
-        const uint32_t form = ctx->debug_switch[LBVH_DEBUG_SORT_FORM];
-        if (form == 2u) {
-            two_level = true;
-        } else if (form == 0u) {
-            for (int c = 0; c < 2 && !two_level; c++)
-                if (cand[c] != 0xFFu && largest_for(cand[c]) <= (uint32_t)(kBucketThreads * kBucketItems)) { two_level = true; msd_shift = cand[c]; }
+        uint32_t largest = 0;
+        bool known = true;
+        for (int w = 0; w < 4; w++) {
+            const uint32_t v = st[w];
+            known = known && v != 0xFFFFFFFFu && (v >> 24) == fine_shift;
+            largest = std::max(largest, v & 0xFFFFFFu);
         }
+        const uint32_t form = ctx->debug_switch[LBVH_DEBUG_SORT_FORM];
+        two_level = form == 2u || (form == 0u && known && largest <= (uint32_t)(kBucketThreads * kBucketItems));
     }
     if (two_level) {
-        LBVH_LAUNCH(ctx, sort_histogram_kernel<HIST_MSD>, dim3(hblocks), dim3(kThreads), d_keys, count, ghist, msd_shift, 0u);
+        const uint32_t fblocks = std::max(1u, std::min(hblocks, (count + (uint32_t)LBVH_FINE_BLOCK_KEYS - 1u) / (uint32_t)LBVH_FINE_BLOCK_KEYS));
+        LBVH_LAUNCH(ctx, sort_histogram_kernel<HIST_FINE>, dim3(fblocks), dim3(kThreads), d_keys, count, ghist, gfine, fine_shift);
         LBVH_LAUNCH(ctx, (sort_onesweep_kernel<512, 8, false, true>), dim3(tiles), dim3(512), d_keys, d_values, alt_keys, alt_vals, count,
-                    msd_shift, msd_hist, msd_hist, stat_dev, msd_shift | 0xFF00u, status, gstatus, tickets, tiles, group, ctx->sort_queues, ctx->fault_dev);
+                    fine_shift, ghist, gfine, stat_dev, fine_shift, fine_mul, gtable, status, gstatus, tickets, tiles, group, ctx->sort_queues,
+                    ctx->fault_dev);
         LBVH_LAUNCH(ctx, (sort_bucket_kernel<kBucketThreads, kBucketItems>), dim3(kRadix), dim3(kBucketThreads), alt_keys, alt_vals, d_keys,
-                    d_values, msd_shift, msd_hist);
+                    d_values, fine_shift, gtable);
         LBVH_HIP_TRY(ctx, hipGetLastError());
 #ifdef LBVH_BUCKET_TIMING
         {
@@ -924,22 +1074,19 @@ int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, ui
 #endif
         return LBVH_OK;       // the buckets are back in d_keys / d_values
     }
-    const bool stat = two_level_size(count);
-    if (stat && cand[1] != 0xFFu)
-        LBVH_LAUNCH(ctx, (sort_histogram_kernel<HIST_FOUR | HIST_MSD | HIST_MSD2>), dim3(hblocks), dim3(kThreads), d_keys, count, ghist, cand[0], cand[1]);
-    else if (stat)
-        LBVH_LAUNCH(ctx, (sort_histogram_kernel<HIST_FOUR | HIST_MSD>), dim3(hblocks), dim3(kThreads), d_keys, count, ghist, cand[0], 0u);
+    const bool stat = two_level_size(count);      // (then items == 8: the 512 x 8 form, whose first tile can derive the buckets)
+    if (stat)
+        LBVH_LAUNCH(ctx, (sort_histogram_kernel<HIST_FOUR | HIST_FINE>), dim3(std::max(1u, std::min(hblocks, (count + (uint32_t)LBVH_FINE_BLOCK_KEYS - 1u) / (uint32_t)LBVH_FINE_BLOCK_KEYS))),
+                    dim3(kThreads), d_keys, count, ghist, gfine, fine_shift);
     else
-        LBVH_LAUNCH(ctx, sort_histogram_kernel<HIST_FOUR>, dim3(hblocks), dim3(kThreads), d_keys, count, ghist, 0u, 0u);
-    const uint32_t* stat_hist = stat ? msd_hist : nullptr;
-    const uint32_t stat_shifts = cand[0] | (cand[1] << 8);
+        LBVH_LAUNCH(ctx, sort_histogram_kernel<HIST_FOUR>, dim3(hblocks), dim3(kThreads), d_keys, count, ghist, gfine, fine_shift);
     if (items == 16 && count >= (1u << 23))
         launch_passes<512, 16, true>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     else if (items == 16)
         launch_passes<512, 16, false>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group);
     else
         launch_passes<512, 8, false>(ctx, d_keys, d_values, alt_keys, alt_vals, count, tiles, ghist, status, gstatus, groups, tickets, group,
-                                     stat_hist, stat_dev, stat_shifts);
+                                     stat ? gfine : nullptr, stat_dev, fine_shift, fine_mul);
     LBVH_HIP_TRY(ctx, hipGetLastError());
     return LBVH_OK;   // 4 passes: the result is back in d_keys / d_values
 }
