@@ -17,6 +17,8 @@ public static class LbvhNative
     public const int ABI_VERSION = 11;             // LBVH_ABI_VERSION of the include/lbvh.h this file was written against
     public const int TRACE_REFERENCE = 0, TRACE_FAST = 1;
     // TRACE_FAST + the reference's choice wherever two triangles are hit at exactly the same t: every record == TRACE_REFERENCE's
+    // (both fast modes: a computed t in front of its own triangle's box — fp32 noise on a grazing ray, which the un-pruned reference
+    // loop reports — does not count: include/lbvh.h at the traversal flavours, DESIGN 2.4)
     public const int TRACE_FAST_EXACT = 2;
     public const uint BUILD_FAST_SCENE = 1, BUILD_RESET_NODES = 2;      // lbvh_build_scene flags
 
