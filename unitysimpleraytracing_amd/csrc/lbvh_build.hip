@@ -1218,7 +1218,7 @@ __device__ __forceinline__ void aligned_keys_apply_body(uint32_t block, uint32_t
     __shared__ int32_t s_before[kAkThreads / LBVH_WAVE];
     if (block * kAkChunk >= n) {          // the extra workgroup
         __shared__ float s_box[6][kTopLdsSmall];
-        hier_top_levels<kAkThreads, kTopLdsSmall>(hier, n, s_box);
+        hier_top_levels<kAkThreads, kTopLdsSmall>(hier, n, s_box);      // (measured: 1.4 of this launch's 10.8 us)
         return;
     }
     int32_t carry;
