@@ -471,8 +471,12 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
 #pragma unroll
         for (int i = 0; i < WAVES; i++) total += s_xchg[(i * kRadix + t) * 4 + 2];
         ltotal = total;                                // including padding slots (they sit last)
-        // the padding slots of a partial last tile all landed on digit 255: they are not keys
-        if (t == kRadix - 1) total -= (uint32_t)TILE - nvalid;
+        // the padding slots of a partial last tile (key 0xFFFFFFFF) all landed on the LARGEST digit in use — 255, or in the MSD pass
+        // the bucket of the last fine bin (the map is monotone: no key has a larger one, so they still sit last in the tile) —:
+        // they are not keys
+        uint32_t pad_digit = (uint32_t)kRadix - 1u;
+        if constexpr (MSD) pad_digit = s_bslot.v.map[kFineBins - 1];
+        if (t == pad_digit) total -= (uint32_t)TILE - nvalid;
 
         // Two-level look-back.  A tile publishes its digit counts (tile words) and needs the counts of all
         // earlier tiles.  With single-level decoupled look-back the walk length is (tiles finishing per
