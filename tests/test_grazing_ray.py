@@ -130,3 +130,39 @@ def test_fast_modes_equal_the_fast_rule_frame_in_any_order_and_reference_mode_th
                 d.update(cam, rect=rect, mode=mode)
                 assert w32(d.hits()[y - rect[1], x - rect[0]]).tolist() == w32(of[y, x]).tolist(), (mode, rect)
         d.on_destroy()
+
+
+def test_entry_distances_grow_from_a_box_to_any_box_inside_it():
+    """The step of DESIGN 2.4's argument that carries the weight: with the slab test's own fp32 arithmetic ((plane - origin) * inv,
+    min / max) the entry distance of a box is never larger than that of a box inside it — subtraction and multiplication by one
+    factor are monotone under rounding — so `t >= entry(leaf)` implies `t >= entry(every ancestor)`.  200 000 random rays (any
+    signs, tiny and huge components, origins inside and outside) against random nested boxes; infinite inverse directions included
+    wherever they produce no NaN (0 * inf: there both restatements fall back to the non-NaN operand, and the library orders no
+    planes by sign)."""
+    rng = np.random.default_rng(11)
+    f = np.float32
+    n = 200000
+    lo_in = rng.uniform(-100, 100, (n, 3)).astype(f)
+    hi_in = lo_in + rng.uniform(0.001, 20, (n, 3)).astype(f)
+    lo_out = lo_in - rng.uniform(0, 30, (n, 3)).astype(f) * (rng.random((n, 3)) < 0.7)
+    hi_out = hi_in + rng.uniform(0, 30, (n, 3)).astype(f) * (rng.random((n, 3)) < 0.7)
+    lo_out, hi_out = lo_out.astype(f), hi_out.astype(f)
+    o = rng.uniform(-150, 150, (n, 3)).astype(f)
+    d = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-6, 0, (n, 3))
+    d[rng.random((n, 3)) < 0.02] = 0.0                         # exact zeros: inverse = inf
+    d = (d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)).astype(f)
+    with np.errstate(all="ignore"):
+        inv = (f(1) / d).astype(f)
+
+        def entry(lo, hi):
+            t1 = ((lo - o) * inv).astype(f)
+            t2 = ((hi - o) * inv).astype(f)
+            return np.fmax(np.fmax(np.fmin(t1[:, 0], t2[:, 0]), np.fmin(t1[:, 1], t2[:, 1])), np.fmin(t1[:, 2], t2[:, 2])), t1, t2
+        e_in, a1, a2 = entry(lo_in, hi_in)
+        e_out, b1, b2 = entry(lo_out, hi_out)
+    clean = ~(np.isnan(a1).any(axis=1) | np.isnan(a2).any(axis=1) | np.isnan(b1).any(axis=1) | np.isnan(b2).any(axis=1))
+    assert clean.sum() > 0.9 * n
+    assert (e_out[clean] <= e_in[clean]).all()
+    # and the oracle's scalar helper is that arithmetic
+    for k in np.nonzero(clean)[0][:200]:
+        assert O.box_entry(lo_in[k], hi_in[k], o[k], inv[k]) == e_in[k]
