@@ -134,6 +134,7 @@ def self_launch(n):
     worst = 0
     try:
         pending = list(procs)
+        deadline = None
         while pending:
             for p_ in list(pending):
                 rc = p_.poll()
@@ -142,8 +143,13 @@ def self_launch(n):
                 pending.remove(p_)
                 if rc != 0:
                     worst = worst or rc
-                    for q in pending:                  # one rank failed: the others would wait in a collective for ever
-                        q.terminate()
+                    # one rank failed: the others would wait in a collective for ever — but a rank that fails for a reason of its
+                    # own (no device for it) says so itself if it is given the time: ten seconds' grace, then they are ended
+                    deadline = deadline or time.time() + 10.0
+            if deadline is not None and time.time() > deadline:
+                for q in pending:
+                    q.terminate()
+                deadline = time.time() + 3600.0        # (terminated once; the loop ends when they are gone)
             time.sleep(0.05)
     finally:
         for p_ in procs:
