@@ -70,6 +70,10 @@ constexpr int kLbGroup = 8;                // tiles per look-back group
 // read of the keys.  Every tile of the MSD pass (and every bucket's workgroup) derives the map from those 16 KB by itself:
 // cheaper than a launch.  A bucket is then at most count / 256 + its largest bin; it covers the bins [first, last] and is
 // sorted by key - (first << fine_shift) in as many 8-bit passes as that difference has bytes (3 for Morton codes: 41 bins x 2^18).
+#ifndef LBVH_BUCKET_WAVE_PAIRS
+#define LBVH_BUCKET_WAVE_PAIRS 384     // pairs per active wave of the bucket kernel until all sixteen waves are in use
+                                       // (cfg2's balanced buckets of 3.9 .. 5.5 K pairs: 256 / 384 / 512 / 768 / 1024 -> 24.6 / 24.0 / 25.5 / 27.3 / 30.2 us)
+#endif
 #ifndef LBVH_FINE_DEPTH
 #define LBVH_FINE_DEPTH 8
 #endif
@@ -811,9 +815,9 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
 
     if (size <= (uint32_t)TILE) {
         // ---- the whole bucket in this workgroup's registers -------------------------------------------------------------------
-        // 512 pairs per active wave (8 items) until all sixteen waves are in use, then more items per wave
+        // LBVH_BUCKET_WAVE_PAIRS pairs per active wave (6 items) until all sixteen waves are in use, then more items per wave
         uint32_t val[ITEMS];
-        const uint32_t aw = min((size + 511u) / 512u, (uint32_t)WAVES);
+        const uint32_t aw = min((size + (uint32_t)LBVH_BUCKET_WAVE_PAIRS - 1u) / (uint32_t)LBVH_BUCKET_WAVE_PAIRS, (uint32_t)WAVES);
         const uint32_t it = (size + aw * LBVH_WAVE - 1u) / (aw * LBVH_WAVE);          // 1 .. ITEMS
         const uint32_t my_it = w < aw ? it : 0u;
         const uint32_t stripe = it * LBVH_WAVE;
