@@ -338,10 +338,11 @@ __device__ __forceinline__ int clz32(uint32_t v) { return v ? __builtin_clz(v) :
 // coalesced, so the dependent chain of a search (~30 probes for the widest node of a wave; a wave runs as long as
 // its widest node) costs LDS latency per probe instead of an L2 round trip; probes past the halo read global memory.
 constexpr int kTreeThreads = 256;
-constexpr int kTreeHalo = 256;
+constexpr int kTreeHalo = 256;            // (128 and 384 measured the same at 1 M nodes: 79.1 / 79.1 / 81.7 us)
 constexpr int kTreeWindow = kTreeThreads + 2 * kTreeHalo;
 
 typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+typedef unsigned long long u64;
 struct key_window {
     lds_u32* lds;                                   // an LDS pointer by TYPE (a generic one makes every probe a flat_load)
     int w0, w1;                                     // keys [w0, w1) are lds[0 .. w1 - w0)
@@ -383,17 +384,13 @@ __device__ __forceinline__ uint32_t last_true_64ary(uint32_t lo, uint32_t hi, Pr
     return lo;
 }
 
-// DetermineRange + FindSplit of node idx by the whole wave (uniform arguments and results)
-__device__ __forceinline__ void wide_node_search(const uint32_t* __restrict__ codes, int num, int idx, int& first, int& last,
-                                                 int& split)
+// DetermineRange + FindSplit of node idx by the whole wave (uniform arguments and results).  self, d, dmin: what the node's own
+// lane found in the LDS window (BVH.compute:36-38) — one round trip to memory less.
+__device__ __forceinline__ void wide_node_range(const uint32_t* __restrict__ codes, int num, int idx, uint32_t self, int d, int dmin,
+                                                int& first, int& last)
 {
     const uint32_t lane = lane_id();
-    const uint32_t self = codes[idx];
     auto dlt = [&](int y) -> int { return (y >= 0 && y <= num - 1) ? clz32(self ^ codes[y]) : -1; };      // :23-33
-    const int dl = dlt(idx - 1), dr = dlt(idx + 1);
-    const int diff = dr - dl;
-    const int d = (diff > 0) - (diff < 0);                                                 // :37
-    const int dmin = d > 0 ? dl : (d < 0 ? dr : clz32(0u));                                // :38
     // :39-41  lmax = 2; while (delta(idx + lmax d) > dmin) lmax *= 2: lane k tries 2 << k, the first failure ends it
     uint32_t lmax;
     {
@@ -407,15 +404,148 @@ __device__ __forceinline__ void wide_node_search(const uint32_t* __restrict__ co
     const int j = idx + (int)l * d;                                                        // :49
     first = min(idx, j);                                                                   // :50
     last = max(idx, j);
-    // FindSplit :54-92: the last position in [first, last) that shares more than the range's common prefix with `first`
-    const uint32_t first_code = codes[first], last_code = codes[last];
-    if (first_code == last_code) {
-        split = (first + last) >> 1;                                                       // :61-62
-    } else {
-        const int common_prefix = clz32(first_code ^ last_code);                           // :67
-        split = (int)last_true_64ary((uint32_t)first, (uint32_t)last,
-                                     [&](uint32_t q) { return clz32(first_code ^ codes[q]) > common_prefix; });
+}
+
+// FindSplit :54-92: the last position in [first, last) that shares more than the range's common prefix with `first`
+__device__ __forceinline__ int wide_node_split(const uint32_t* __restrict__ codes, int first, int last, uint32_t first_code,
+                                               uint32_t last_code)
+{
+    if (first_code == last_code) return (first + last) >> 1;                               // :61-62
+    const int common_prefix = clz32(first_code ^ last_code);                               // :67
+    return (int)last_true_64ary((uint32_t)first, (uint32_t)last,
+                                [&](uint32_t q) { return clz32(first_code ^ codes[q]) > common_prefix; });
+}
+
+// ---- search-free form: nearest-set-bit lookups in bitmaps of the adjacent-key prefix array ---------------------------------------
+// For sorted UNIQUE keys clz(k_i ^ k_j) = min_{i <= m < j} delta_m, delta_m = clz(k_m ^ k_{m+1}): the radix tree is the Cartesian
+// tree of the delta array.  Both searches of the reference (BVH.compute:39-47 and :74-89) return the LAST position at which a
+// predicate that is monotone along the sorted keys still holds, hence (exactly, whatever probe sequence finds it)
+//     dmin            = min(delta_{i-1}, delta_i)                         (delta_{-1} = delta_{n-1} = -1, BVH.compute:26-27)
+//     the other end j = the nearest m in direction d with delta_m <= dmin (j = m going right, m + 1 going left)
+//     split           = the first m >= first with delta_m <= clz(k_first ^ k_last)
+// The workgroup forms B[v] = { m in its key window : delta_m <= v }, v = 0 .. 31, once: lane p of a 32-lane half holds the row
+// 0xFFFFFFFF << delta_p (bit v set iff delta_p <= v) and a 32 x 32 bit transpose across the lanes (five ds_swizzle exchanges)
+// leaves lane v holding 32 positions of B[v] — ~20 instructions per 64 positions.  A node is then two lookups (word pair, shift,
+// count trailing / leading zeros) instead of two dependent probe loops of 9 (mean) .. 26 (a wave's widest node) LDS round trips at
+// 45 % lane utilisation (25 us each at 1 M nodes, HISTORY.md §4).  A lookup that finds nothing inside the window hands the node to
+// wide_node_search above, as a probe leaving the window did before.  tests/test_tree_bitmaps.py restates all of this on the CPU
+// against the oracle's literal searches.
+constexpr int kTreeWords = kTreeWindow / 32;          // 32-position words per B[v]
+constexpr int kBitStride = 33;                        // words of one position block for v = 0 .. 31 (+1: conflict-free columns)
+constexpr int kBitWords = (kTreeWords + 2) * kBitStride;      // one all-zero block in front and one behind: lookups read word pairs
+constexpr int kBitSums = 34;                          // per v: one bit per non-empty word; [32]: "equal neighbours seen" (see below)
+
+template <int J>
+__device__ __forceinline__ uint32_t swizzle_xor(uint32_t x)        // lane l <- lane l ^ J inside each half of the wave
+{
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, (J << 10) | 0x1F);
+}
+
+template <int S>
+__device__ __forceinline__ uint32_t transpose_step(uint32_t x, uint32_t lane)
+{
+    constexpr uint32_t J = 1u << S;
+    constexpr uint32_t M = S == 0 ? 0x55555555u : S == 1 ? 0x33333333u : S == 2 ? 0x0F0F0F0Fu : S == 3 ? 0x00FF00FFu : 0x0000FFFFu;
+    // lane ^ 1 and lane ^ 2 are quad permutes (DPP: the vector pipe); 4, 8, 16 go through ds_swizzle
+    const uint32_t y = S == 0   ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true)      // quad_perm:[1,0,3,2]
+                       : S == 1 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true)      // quad_perm:[2,3,0,1]
+                                : swizzle_xor<(int)J>(x);
+    const bool upper = (lane & J) != 0;
+    const uint32_t moved = upper ? (y >> J) : (y << J);
+    const uint32_t keep = upper ? ~M : M;
+    return (x & keep) | (moved & ~keep);
+}
+
+// lane v (of each 32-lane half) ends up with bit p = bit v of the row lane p came with
+__device__ __forceinline__ uint32_t transpose32_lanes(uint32_t x, uint32_t lane)
+{
+    x = transpose_step<0>(x, lane);
+    x = transpose_step<1>(x, lane);
+    x = transpose_step<2>(x, lane);
+    x = transpose_step<3>(x, lane);
+    x = transpose_step<4>(x, lane);
+    return x;
+}
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32_rw;
+struct delta_bitmaps {
+    lds_u32* bits;                                    // [kBitWords]: word q of B[v] at (q + 1) * kBitStride + v
+    lds_u32* sums;                                    // [kBitSums]
+    __device__ __forceinline__ uint32_t word(int q, int v) const { return bits[(q + 1) * kBitStride + v]; }
+    // window position of the first member of B[v] at or after position s (0 <= s < kTreeWindow)
+    __device__ __forceinline__ bool first_from(int v, int s, int& pos) const
+    {
+        const int q = s >> 5;
+        const u64 w = (((u64)word(q + 1, v) << 32) | word(q, v)) >> (s & 31);
+        if (w) { pos = s + __builtin_ctzll(w); return true; }
+        const uint32_t rest = sums[v] & ~((4u << q) - 1u);              // words past q + 1
+        if (!rest) return false;
+        const int c = __builtin_ctz(rest);
+        pos = c * 32 + __builtin_ctz(word(c, v));
+        return true;
     }
+    // ... of the last member at or before position e (e may be -1)
+    __device__ __forceinline__ bool last_upto(int v, int e, int& pos) const
+    {
+        if (e < 0) return false;
+        const int q = e >> 5;
+        const u64 w = (((u64)word(q, v) << 32) | word(q - 1, v)) << (31 - (e & 31));
+        if (w) { pos = e - __builtin_clzll(w); return true; }
+        const uint32_t rest = q >= 1 ? sums[v] & ((1u << (q - 1)) - 1u) : 0u;    // words before q - 1
+        if (!rest) return false;
+        const int c = 31 - __builtin_clz(rest);
+        pos = c * 32 + 31 - __builtin_clz(word(c, v));
+        return true;
+    }
+};
+
+// before the barrier that publishes the staged keys: the two all-zero blocks and the summary words
+__device__ __forceinline__ void clear_delta_bitmaps(uint32_t* s_bits, uint32_t* s_sums)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < (uint32_t)kBitStride) s_bits[t] = 0u;
+    else if (t < 2u * kBitStride) s_bits[(kTreeWords + 1) * kBitStride + (t - kBitStride)] = 0u;
+    else if (t < 2u * kBitStride + kBitSums) s_sums[t - 2u * kBitStride] = 0u;
+}
+
+// Stages the window's keys in LDS and forms the bitmaps on the way (one barrier must follow).  Wave w takes the 64-position
+// chunks w, w + 4, w + 8: lane p's delta needs the key of position p + 1 — lane p + 1's (DPP wave_shl:1), the last lane loads it.
+__device__ __forceinline__ void stage_keys_and_bitmaps(const uint32_t* __restrict__ codes, uint32_t* s_keys, uint32_t* s_bits,
+                                                       uint32_t* s_sums, const key_window& win)
+{
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    constexpr int kChunks = kTreeWindow / 64, kWaves = kTreeThreads / 64, kPer = kChunks / kWaves;
+    static_assert(kChunks % kWaves == 0, "every wave takes the same number of chunks");
+    uint32_t key[kPer], next[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+        const int m = win.w0 + ((int)wave + k * kWaves) * 64 + (int)lane;
+        key[k] = m < win.w1 ? codes[m] : 0u;
+        next[k] = 0u;
+        if (lane == 63u && m + 1 < win.w1) next[k] = codes[m + 1];
+    }
+    uint32_t some = 0u;                       // this lane's summary bits: lane (v, half) over the wave's chunks
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+        const int c = (int)wave + k * kWaves;
+        const int p = c * 64 + (int)lane, m = win.w0 + p;
+        if (m < win.w1) s_keys[p] = key[k];
+        const uint32_t from_next_lane = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key[k], 0x130, 0xf, 0xf, false);    // wave_shl:1
+        const uint32_t nxt = lane == 63u ? next[k] : from_next_lane;
+        uint32_t row = 0u;                    // no such position, or delta unknown (the key behind the window): member of no B[v]
+        if (m + 1 < win.w1) {
+            const uint32_t x = key[k] ^ nxt;
+            row = x ? 0xFFFFFFFFu << __builtin_clz(x) : 0u;
+            if (!x) s_sums[32] = 1u;          // equal neighbours (a caller's raw keys): this window takes the probe loops
+        } else if (m + 1 == win.num && m < win.w1) {
+            row = 0xFFFFFFFFu;                // delta_{n-1} = -1 (BVH.compute:26-27): below every value
+        }
+        const uint32_t x = transpose32_lanes(row, lane);
+        const int wd = 2 * c + (int)(lane >> 5);
+        s_bits[(wd + 1) * kBitStride + (int)(lane & 31u)] = x;
+        some |= x ? 1u << wd : 0u;
+    }
+    if (some) atomicOr(&s_sums[lane & 31u], some);
 }
 
 // ---- range hierarchy ------------------------------------------------------------------------------------------
@@ -452,8 +582,8 @@ __device__ __forceinline__ void store_corner(corner3* p, float x, float y, float
 
 // Unions of the leaf boxes a[q] .. b[q] (inclusive) for NQ ranges at once.  The walk over the levels needs no loaded
 // data (block indices come from a and b alone), so LV levels are resolved per round: all their block indices first,
-// then all loads back to back (a block that is not part of the range reads the NEUTRAL box kept at index 2 N2 - 1
-// instead of branching around the load), then the min / max — one memory latency per LV levels instead of one per
+// then all loads back to back (a block that is not part of the range is marked by the index of the NEUTRAL box, 2 N2 - 1, and
+// its load is masked off), then the min / max — one memory latency per LV levels instead of one per
 // block (the straightforward loop measured 17 us per query at 1 M nodes, all of it waiting).
 template <int NQ, int LV>
 __device__ __forceinline__ void range_boxes(const hier_t& h, const uint32_t a[NQ], const uint32_t b[NQ], float mn[NQ][3],
@@ -496,8 +626,16 @@ __device__ __forceinline__ void range_boxes(const hier_t& h, const uint32_t a[NQ
             for (int v = 0; v < LV; v++)
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
-                    lo[q][v][e] = load_corner(h.lo + idx[q][v][e]);
-                    hi[q][v][e] = load_corner(h.hi + idx[q][v][e]);
+                    // a block that is not part of the range: no load at all (exec-masked).  Round 2 read a NEUTRAL box there instead
+                    // of branching; but what a gather costs is the data its ACTIVE lanes return (768 B per full dwordx3 wave load
+                    // through a 64 B / clk path), and two thirds of these loads had nothing to fetch: 78.5 -> 74.3 us at 1 M nodes
+                    const f3 pinf = {INFINITY, INFINITY, INFINITY}, ninf = {-INFINITY, -INFINITY, -INFINITY};
+                    lo[q][v][e] = pinf;
+                    hi[q][v][e] = ninf;
+                    if (idx[q][v][e] != neutral) {
+                        lo[q][v][e] = load_corner(h.lo + idx[q][v][e]);
+                        hi[q][v][e] = load_corner(h.hi + idx[q][v][e]);
+                    }
                 }
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
@@ -515,6 +653,18 @@ __device__ __forceinline__ void range_boxes(const hier_t& h, const uint32_t a[NQ
     }
 }
 
+__device__ __forceinline__ void wave_union(float mn[3], float mx[3])
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], d));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d));
+        }
+    }
+}
+
 // hierarchy levels resolved per round of a range query: one range (the reference's boxes) / two ranges (the derived tree's child
 // boxes).  Round 5: 3 / 1 instead of round 2's 4 / 2 — fewer block indices and corners alive at once: 72 -> 60 - 62 registers, 7 -> 8
 // waves per SIMD, tree_pair_kernel 86.4 -> 81.8 us at 1 M triangles (4 / 1, 2 / 1, 1 / 1 within 0.5 us; 4 / 3: 89, 4 / 4: 94),
@@ -525,19 +675,44 @@ __device__ __forceinline__ void range_boxes(const hier_t& h, const uint32_t a[NQ
 #ifndef LBVH_RQ_LV2
 #define LBVH_RQ_LV2 1
 #endif
+__device__ __noinline__ void codes_sink(lbvh_internal_node* a, lbvh_fast_node* b)
+{
+    if (a) reinterpret_cast<uint32_t*>(a)[5] = 1u;
+    if (b) reinterpret_cast<uint32_t*>(b)[0] = 1u;
+}
+#ifdef LBVH_TREE_CLOCK
+__device__ unsigned long long g_tree_clock[2][16];       // [tree mode - 1][phase]: wave-cycles summed over all waves
+#define TREE_TICK(ph) do { const long long now_ = clock64(); if (lane_id() == 0 && MODE != TREE_TOPOLOGY) atomicAdd(&g_tree_clock[MODE - 1][ph], (unsigned long long)(now_ - tick_)); tick_ = now_; } while (0)
+#else
+#define TREE_TICK(ph) do { } while (0)
+#endif
 enum { TREE_TOPOLOGY = 0, TREE_REFERENCE = 1, TREE_FUSED = 2 };
+// measurement builds only (tools/build_variant.sh tree_eN -DLBVH_TREE_EXP=N): 1 = no node / leaf stores, 2 = no range queries,
+// 4 = no box / traversal-node output; LBVH_TREE_LOOPS: the probe loops instead of the bitmap lookups
+#ifndef LBVH_TREE_EXP
+#define LBVH_TREE_EXP 0
+#endif
+#ifdef LBVH_TREE_LOOPS
+constexpr bool kTreeLookups = false;
+#else
+constexpr bool kTreeLookups = true;
+#endif
 // TREE_TOPOLOGY   lbvh_build_tree: the reference's node arrays only
 // TREE_REFERENCE  + bvh[i] = box of the node's range (BVHData, BVH.compute:215)
 // TREE_FUSED      the derived traversal tree: nothing but the 64-byte traversal node (both child boxes + child references)
 // s_keys[kTreeWindow], s_out[kTreeThreads * kQuads of the mode]: the calling kernel's LDS (tree_pair_kernel runs two modes
 // in one launch on ONE set)
-template <int MODE>
-__device__ __forceinline__ void tree_body(uint32_t block, uint32_t* s_keys, float4* s_out, const uint32_t* __restrict__ codes,
+template <int MODE, bool LOOKUPS = kTreeLookups>
+__device__ __forceinline__ void tree_body(uint32_t block, uint32_t* s_keys, uint32_t* s_bits, uint32_t* s_sums, float4* s_out,
+                                          const uint32_t* __restrict__ codes,
                                           uint32_t n, lbvh_internal_node* __restrict__ internal, lbvh_leaf_node* __restrict__ leaf,
                                           uint32_t* __restrict__ zero_word, hier_t hier, lbvh_aabb* __restrict__ bvh,
                                           lbvh_fast_node* __restrict__ fused, uint32_t leaf_base,
                                           const uint32_t* __restrict__ sorted_indices)
 {
+#ifdef LBVH_TREE_CLOCK
+    long long tick_ = clock64();
+#endif
     const uint32_t thread_id = block * kTreeThreads + threadIdx.x;
     if (thread_id == 0 && zero_word) *zero_word = 0u;      // lbvh_build_tree + lbvh_refit: the refit's frontier counter
     key_window win;
@@ -545,8 +720,15 @@ __device__ __forceinline__ void tree_body(uint32_t block, uint32_t* s_keys, floa
     win.num = (int)n;
     win.w0 = max((int)(block * kTreeThreads) - kTreeHalo, 0);
     win.w1 = min((int)(block * kTreeThreads) + kTreeThreads + kTreeHalo, (int)n);
-    for (int k = win.w0 + (int)threadIdx.x; k < win.w1; k += kTreeThreads) s_keys[k - win.w0] = codes[k];
+    if (LOOKUPS) {
+        clear_delta_bitmaps(s_bits, s_sums);
+        __syncthreads();                                   // (nothing is in flight yet: the waves are here within cycles of each other)
+        stage_keys_and_bitmaps(codes, s_keys, s_bits, s_sums, win);
+    } else {
+        for (int k = win.w0 + (int)threadIdx.x; k < win.w1; k += kTreeThreads) s_keys[k - win.w0] = codes[k];
+    }
     __syncthreads();
+    TREE_TICK(0);
     // (no early return: the boxes leave through a workgroup-wide LDS transpose below)
     const bool in_range = thread_id < n - 1;                                               // :101
     const int idx = in_range ? (int)thread_id : win.w0;    // threads past the last node: a key INSIDE the window (results unused)
@@ -559,54 +741,104 @@ __device__ __forceinline__ void tree_body(uint32_t block, uint32_t* s_keys, floa
     const int diff = dr - dl;
     const int d = (diff > 0) - (diff < 0);                                                 // sign(), :37
     const int dmin = d > 0 ? dl : (d < 0 ? dr : clz32(0u));                                // :38
-    uint32_t lmax = 2;                                                                     // :39
-    while (in_range && win.delta(self, idx + (int)(lmax * (uint32_t)d), wide) > dmin) lmax *= 2;       // :40-41
-    int l = 0;
-    for (uint32_t t = lmax / 2; t >= 1 && in_range && !wide; t /= 2) {                     // :43
-        if (win.delta(self, idx + (int)(((uint32_t)l + t) * (uint32_t)d), wide) > dmin)
-            l += (int)t;                                                                   // :45-46
-    }
-    const int j = idx + l * d;                                                             // :49
-    int first = min(idx, j), last = max(idx, j);                                           // :50
-
-    // FindSplit :54-92
-    int split = first;
-    if (in_range && !wide) {
-        if (!win.inside(first) || !win.inside(last)) {
-            wide = true;
-        } else {
-            const uint32_t first_code = win.at(first);
-            const uint32_t last_code = win.at(last);
-            if (first_code == last_code) {
-                split = (first + last) >> 1;                                               // :61-62
+    int first, last, split;
+    // (equal neighbours somewhere in the window — possible only for a caller's raw keys, lbvh_build_tree — or d == 0: the loops)
+    const bool lookups = LOOKUPS && s_sums[32] == 0u;
+    if (LBVH_TREE_EXP & 32) {
+        first = idx; last = idx + (int)(self & 3u); split = idx;
+    } else if (lookups) {
+        // "search-free form" above: the other end of the range and the split by nearest-set-bit lookups
+        const delta_bitmaps bm = {(lds_u32*)s_bits, (lds_u32*)s_sums};
+        const int p0 = idx - win.w0;
+        int j = idx, pos = 0;
+        if (d > 0) {
+            if (dmin < 0) {                                      // the root: its range ends at delta_{n-1} = -1
+                if (win.w1 == win.num) j = win.num - 1; else wide = true;
+            } else if (bm.first_from(dmin, p0, pos)) {
+                j = win.w0 + pos;
             } else {
-                const int common_prefix = clz32(first_code ^ last_code);                   // :67
-                split = first;
-                int step = last - first;
-                do {                                   // (probes stay inside [first, last], hence inside the window)
-                    step = (step + 1) >> 1;                                                // :78
-                    const int new_split = split + step;
-                    if (new_split < last) {
-                        const int split_prefix = clz32(first_code ^ win.at(new_split));
-                        if (split_prefix > common_prefix) split = new_split;               // :85-86
-                    }
-                } while (step > 1);
+                wide = true;
+            }
+        } else if (d < 0) {
+            if (bm.last_upto(dmin, p0 - 1, pos)) j = win.w0 + pos + 1;
+            else if (win.w0 == 0) j = 0;                         // delta_{-1} = -1
+            else wide = true;
+        }
+        first = min(idx, j);                                                               // :50
+        last = max(idx, j);
+        split = first;
+        if (!wide) {                                             // FindSplit :54-92 (first and last are inside the window)
+            const uint32_t x = win.at(first) ^ win.at(last);
+            if (x == 0u) split = (first + last) >> 1;                                      // :61-62
+            else if (bm.first_from(__builtin_clz(x), first - win.w0, pos)) split = win.w0 + pos;
+            else wide = true;                                    // (unreachable for sorted unique keys)
+        }
+    } else {
+        uint32_t lmax = 2;                                                                 // :39
+        while (in_range && win.delta(self, idx + (int)(lmax * (uint32_t)d), wide) > dmin) lmax *= 2;       // :40-41
+        int l = 0;
+        for (uint32_t t = lmax / 2; t >= 1 && in_range && !wide; t /= 2) {                 // :43
+            if (win.delta(self, idx + (int)(((uint32_t)l + t) * (uint32_t)d), wide) > dmin)
+                l += (int)t;                                                               // :45-46
+        }
+        const int j = idx + l * d;                                                         // :49
+        first = min(idx, j);                                                               // :50
+        last = max(idx, j);
+
+        // FindSplit :54-92
+        split = first;
+        if (in_range && !wide) {
+            if (!win.inside(first) || !win.inside(last)) {
+                wide = true;
+            } else {
+                const uint32_t first_code = win.at(first);
+                const uint32_t last_code = win.at(last);
+                if (first_code == last_code) {
+                    split = (first + last) >> 1;                                           // :61-62
+                } else {
+                    const int common_prefix = clz32(first_code ^ last_code);               // :67
+                    split = first;
+                    int step = last - first;
+                    do {                                   // (probes stay inside [first, last], hence inside the window)
+                        step = (step + 1) >> 1;                                            // :78
+                        const int new_split = split + step;
+                        if (new_split < last) {
+                            const int split_prefix = clz32(first_code ^ win.at(new_split));
+                            if (split_prefix > common_prefix) split = new_split;           // :85-86
+                        }
+                    } while (step > 1);
+                }
             }
         }
     }
+    TREE_TICK(1);
     // the wave's wide nodes, one after the other, every lane probing
-    for (uint64_t todo = __ballot(in_range && wide); todo != 0; todo &= todo - 1) {
+    for (uint64_t todo = (LBVH_TREE_EXP & 8) ? 0ull : __ballot(in_range && wide); todo != 0; todo &= todo - 1) {
         const int src = __builtin_ctzll(todo);
         const int widx = __builtin_amdgcn_readlane(idx, src);
+        const uint32_t wself = (uint32_t)__builtin_amdgcn_readlane((int)self, src);
+        const int wd = __builtin_amdgcn_readlane(d, src), wdmin = __builtin_amdgcn_readlane(dmin, src);
         int f, la, sp;
-        wide_node_search(codes, (int)n, widx, f, la, sp);
+        wide_node_range(codes, (int)n, widx, wself, wd, wdmin, f, la);
+        const uint32_t other = codes[widx == f ? la : f];
+        const uint32_t fc = widx == f ? wself : other, lc = widx == f ? other : wself;
+        // the split from the window's bitmaps when the left child's range ends inside the window (it is the first member of
+        // B[delta_node] at or after `first`, wherever the range ends)
+        int pos = 0;
+        if (lookups && fc != lc && win.inside(f) &&
+            delta_bitmaps{(lds_u32*)s_bits, (lds_u32*)s_sums}.first_from(__builtin_clz(fc ^ lc), f - win.w0, pos) && win.w0 + pos < la)
+            sp = win.w0 + pos;
+        else
+            sp = wide_node_split(codes, f, la, fc, lc);
         if ((int)lane_id() == src) { first = f; last = la; split = sp; }
     }
+    TREE_TICK(2);
     const bool valid = in_range && !(split < 0 || (uint32_t)split + 1u >= n);   // invalid: only reachable with non-unique keys
 
     const bool left_leaf = split == first;                                                 // :114
     const bool right_leaf = split + 1 == last;                                             // :132
-    if (MODE != TREE_FUSED && valid) {
+    if ((LBVH_TREE_EXP & 1) && valid && (first ^ last ^ split) == 0x7FFFFFF1) codes_sink(internal, fused);
+    if (MODE != TREE_FUSED && valid && !(LBVH_TREE_EXP & 1)) {
         uint32_t* node = reinterpret_cast<uint32_t*>(&internal[thread_id]);
         // Inside lbvh_build_scene (TREE_REFERENCE) the reference's arrays are written as streaming data, here and below:
         // the frame that follows a rebuild walks the DERIVED scene, and 64 MB of node words and boxes written last would
@@ -631,13 +863,15 @@ __device__ __forceinline__ void tree_body(uint32_t block, uint32_t* s_keys, floa
         if (right_leaf) st2(&leaf[split + 1], thread_id, (uint32_t)split + 1u);
         else st1(&internal[split + 1].parent, thread_id);                                  // :144
     }
+    TREE_TICK(3);
     // The boxes: computed per node, written per LINE — every thread parks its record in LDS and the workgroup writes
     // the block's records as consecutive float4 (a wave's store covers 1 KB of whole records, not 64 quarter lines).
     constexpr int kQuads = MODE == TREE_FUSED ? 4 : 2;             // float4 per record: 64-byte traversal node / 32-byte AABB
     if (MODE == TREE_REFERENCE) {
         const uint32_t a[1] = {(uint32_t)first}, b[1] = {valid ? (uint32_t)last : (uint32_t)first};
         float mn[1][3], mx[1][3];
-        range_boxes<1, LBVH_RQ_LV1>(hier, a, b, mn, mx);
+        if (LBVH_TREE_EXP & 2) { for (int k = 0; k < 3; k++) { mn[0][k] = (float)first; mx[0][k] = (float)last; } }
+        else range_boxes<1, LBVH_RQ_LV1>(hier, a, b, mn, mx);
         s_out[threadIdx.x * 2 + 0] = make_float4(mn[0][0], mn[0][1], mn[0][2], 0.0f);      // :215
         s_out[threadIdx.x * 2 + 1] = make_float4(mx[0][0], mx[0][1], mx[0][2], 0.0f);
     }
@@ -645,7 +879,8 @@ __device__ __forceinline__ void tree_body(uint32_t block, uint32_t* s_keys, floa
         const uint32_t a[2] = {(uint32_t)first, (uint32_t)split + 1u};
         const uint32_t b[2] = {(uint32_t)split, valid ? (uint32_t)last : (uint32_t)split};
         float cmn[2][3], cmx[2][3];
-        range_boxes<2, LBVH_RQ_LV2>(hier, a, b, cmn, cmx);
+        if (LBVH_TREE_EXP & 2) { for (int k = 0; k < 3; k++) { cmn[0][k] = cmn[1][k] = (float)first; cmx[0][k] = cmx[1][k] = (float)last; } }
+        else range_boxes<2, LBVH_RQ_LV2>(hier, a, b, cmn, cmx);
         // child reference: a line index — node index, or LEAF | leaf_base + the triangle's ORIGINAL index (the triangle
         // lines stay in the caller's order: lbvh_common.h)
         uint32_t lref = (uint32_t)split, rref = (uint32_t)split + 1u;
@@ -657,20 +892,24 @@ __device__ __forceinline__ void tree_body(uint32_t block, uint32_t* s_keys, floa
         s_out[threadIdx.x * 4 + 2] = make_float4(cmn[1][0], cmn[1][1], cmn[1][2], __uint_as_float((uint32_t)split));
         s_out[threadIdx.x * 4 + 3] = make_float4(cmx[1][0], cmx[1][1], cmx[1][2], __uint_as_float((uint32_t)split + 1u));
     }
+    TREE_TICK(4);
     if (MODE != TREE_TOPOLOGY) {
         __syncthreads();
+        TREE_TICK(5);
         const uint32_t b0 = block * kTreeThreads;
         float4* out = MODE == TREE_FUSED ? reinterpret_cast<float4*>(fused + b0) : reinterpret_cast<float4*>(bvh + b0);
         const uint32_t live = n - 1 > b0 ? min(n - 1 - b0, (uint32_t)kTreeThreads) * kQuads : 0u;   // float4s of existing nodes
 #pragma unroll
         for (int k = 0; k < kQuads; k++) {
             const uint32_t q = (uint32_t)k * kTreeThreads + threadIdx.x;
+            if ((LBVH_TREE_EXP & 4) && s_out[q].x != 12345.678f) continue;
             if (q < live) {
                 if (MODE == TREE_REFERENCE) lbvh_nt_store(&out[q], s_out[q]);
                 else out[q] = s_out[q];
             }
         }
     }
+    TREE_TICK(6);
 }
 
 template <int MODE>
@@ -683,7 +922,9 @@ __global__ __launch_bounds__(kTreeThreads) void tree_kernel(const uint32_t* __re
 {
     __shared__ uint32_t s_keys[kTreeWindow];
     __shared__ float4 s_out[MODE == TREE_TOPOLOGY ? 1 : kTreeThreads * (MODE == TREE_FUSED ? 4 : 2)];
-    tree_body<MODE>(blockIdx.x, s_keys, s_out, codes, n, internal, leaf, zero_word, hier, bvh, fused, leaf_base, sorted_indices);
+    __shared__ uint32_t s_bits[kBitWords];
+    __shared__ uint32_t s_sums[kBitSums];
+    tree_body<MODE>(blockIdx.x, s_keys, s_bits, s_sums, s_out, codes, n, internal, leaf, zero_word, hier, bvh, fused, leaf_base, sorted_indices);
 }
 
 // lbvh_build_scene's two trees — the derived one over aligned keys, the reference's over the distributed keys — in ONE launch,
@@ -698,11 +939,13 @@ __global__ __launch_bounds__(kTreeThreads) void tree_pair_kernel(const uint32_t*
 {
     __shared__ uint32_t s_keys[kTreeWindow];
     __shared__ float4 s_out[kTreeThreads * 4];
+    __shared__ uint32_t s_bits[kBitWords];
+    __shared__ uint32_t s_sums[kBitSums];
     const uint32_t block = blockIdx.x >> 1;
     if (blockIdx.x & 1u)
-        tree_body<TREE_REFERENCE>(block, s_keys, s_out, codes, n, internal, leaf, nullptr, hier, bvh, nullptr, 0u, nullptr);
+        tree_body<TREE_REFERENCE>(block, s_keys, s_bits, s_sums, s_out, codes, n, internal, leaf, nullptr, hier, bvh, nullptr, 0u, nullptr);
     else
-        tree_body<TREE_FUSED>(block, s_keys, s_out, aligned_codes, n, nullptr, nullptr, nullptr, hier, nullptr, fused, leaf_base,
+        tree_body<TREE_FUSED>(block, s_keys, s_bits, s_sums, s_out, aligned_codes, n, nullptr, nullptr, nullptr, hier, nullptr, fused, leaf_base,
                               sorted_indices);
 }
 
@@ -733,7 +976,6 @@ __global__ __launch_bounds__(kTreeThreads) void tree_pair_kernel(const uint32_t*
 // (a left child).  A right child shares its parent's last leaf, a left child its parent's first; so the
 // unknown end is the index of the nearest ancestor of the OTHER kind (or 0 / n-1 above the root): a walk
 // over consecutive same-kind ancestors, 2 nodes on average, bounded by the tree depth.
-typedef unsigned long long u64;
 
 __device__ __forceinline__ void load_box_plain(const lbvh_aabb* p, float mn[3], float mx[3])
 {
@@ -748,18 +990,6 @@ __device__ __forceinline__ void store_box_plain(lbvh_aabb* p, const float mn[3],
     float4* q = reinterpret_cast<float4*>(p);
     q[0] = make_float4(mn[0], mn[1], mn[2], 0.0f);                                         // :215
     q[1] = make_float4(mx[0], mx[1], mx[2], 0.0f);
-}
-
-__device__ __forceinline__ void wave_union(float mn[3], float mx[3])
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            mn[k] = fminf(mn[k], __shfl_xor(mn[k], d));
-            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d));
-        }
-    }
 }
 
 constexpr int kRefitThreads = 1024;     // leaves per workgroup = range level 2
@@ -1535,6 +1765,15 @@ int lbvh_launch_refit(lbvh_context* ctx, uint32_t n, const lbvh_internal_node* d
     }
     return LBVH_OK;
 }
+
+#ifdef LBVH_TREE_CLOCK
+extern "C" int lbvh_debug_tree_clock(unsigned long long* out32, int reset)
+{
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_tree_clock), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tree_clock), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 extern "C" {
 
