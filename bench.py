@@ -82,6 +82,9 @@ def parse():
     # peer = traced straight into rank 0's memory (IPC-mapped, xGMI stores) + device-side completion flags;
     # packed = contiguous shares + one torch.distributed gather + lbvh_frame_unpack; auto = peer if its self-test passes
     ap.add_argument("--gather", choices=["auto", "peer", "packed"], default="auto")
+    # --gpus N from a plain launch: the parent ends every rank and exits 124 when the whole run takes longer than this (a
+    # collective library that never connects must not hold the caller until ITS timeout)
+    ap.add_argument("--launch-deadline", type=float, default=900.0, metavar="SECONDS")
     return ap.parse_args()
 
 
@@ -114,16 +117,25 @@ def yawed(cam, yaw_deg):
     return out
 
 
-def self_launch(n):
+def self_launch(n, deadline_s):
     """`python bench.py --gpus N` from a plain launch: start the N ranks as CHILD processes (one per GPU, the environment
     torch.distributed.run would give them) and exit with their worst return code.  Nothing in this parent has touched HIP
-    or torch at this point (no exec of a GPU-initialised process anywhere); rank 0's JSON line goes straight to stdout."""
+    or torch at this point (no exec of a GPU-initialised process anywhere); rank 0's JSON line goes straight to stdout.
+    The whole launch has a deadline (--launch-deadline, 900 s): ranks that hang in the rendezvous, in RCCL's set-up or in a
+    collective are ended — SIGTERM, five seconds later SIGKILL; children are fresh processes, nothing is exec'ed — and the parent
+    exits 124 having said which ranks were still running."""
     import subprocess
     import tempfile
     # rendezvous through a file the ranks share (torch.distributed's file:// store), not through a TCP port picked here and
     # released before rank 0 binds it (ADVICE r3: another process could take it in between)
     rdv_dir = tempfile.mkdtemp(prefix="lbvh_bench_rdv_")
     procs = []
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC — without it RCCL's own buffer sharing AND
+    # the peer-mapped frame gather fail with "hipIpcGetMemHandle: invalid argument" (the task environment exports it already; a
+    # caller's own value is never overridden).  Said once on stderr so that a first contact with N GPUs shows what was in force.
+    ipc_mode = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    print(f"[bench] launching {n} ranks; HSA_ENABLE_IPC_MODE_LEGACY={'0 (set here)' if ipc_mode is None else ipc_mode + ' (inherited)'}; "
+          f"overall deadline {deadline_s:.0f} s", file=sys.stderr, flush=True)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    LBVH_BENCH_RENDEZVOUS_FILE=os.path.join(rdv_dir, "store"))
@@ -132,9 +144,11 @@ def self_launch(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr))
     worst = 0
+    overall = time.time() + deadline_s
     try:
         pending = list(procs)
-        deadline = None
+        deadline = None          # set when a rank has failed: the others get ten seconds to say why themselves
+        kill_at = None           # set when the pending ranks have been sent SIGTERM
         while pending:
             for p_ in list(pending):
                 rc = p_.poll()
@@ -146,10 +160,21 @@ def self_launch(n):
                     # one rank failed: the others would wait in a collective for ever — but a rank that fails for a reason of its
                     # own (no device for it) says so itself if it is given the time: ten seconds' grace, then they are ended
                     deadline = deadline or time.time() + 10.0
-            if deadline is not None and time.time() > deadline:
+            now = time.time()
+            if pending and kill_at is None and now > overall:
+                print(f"[bench] the launch did not finish within {deadline_s:.0f} s: ending rank(s) "
+                      f"{[procs.index(q) for q in pending]} (hung in the rendezvous, the collective library's set-up or a collective)",
+                      file=sys.stderr, flush=True)
+                worst = 124
+                deadline = now - 1.0
+            if pending and kill_at is None and deadline is not None and now > deadline:
                 for q in pending:
                     q.terminate()
-                deadline = time.time() + 3600.0        # (terminated once; the loop ends when they are gone)
+                kill_at = now + 5.0
+            if pending and kill_at is not None and now > kill_at:
+                for q in pending:
+                    q.kill()
+                kill_at = now + 3600.0
             time.sleep(0.05)
     finally:
         for p_ in procs:
@@ -163,7 +188,13 @@ def self_launch(n):
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args.gpus)
+        self_launch(args.gpus, args.launch_deadline)
+    if os.environ.get("LBVH_BENCH_TEST_HANG") == "1" and "WORLD_SIZE" in os.environ:
+        # test hook (tests/test_sharding.py): a rank that never gets anywhere — before HIP, torch or a rendezvous is touched
+        import signal
+        signal.signal(signal.SIGTERM, signal.SIG_IGN if os.environ.get("RANK") == "1" else signal.SIG_DFL)
+        while True:
+            time.sleep(1.0)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -336,6 +367,41 @@ def main():
     # N > 1: trace_ms contains the records' way to rank 0 (on rank 0: the wait for every rank's share); the traversal alone:
     # (from behind the wait for rank 0's "frame read" word to the end of this rank's own kernel: no cross-rank skew in it)
     own_trace_ms_max = reduce_max(float(np.mean([ctx.elapsed_ms(e[3], e[2]) for e in events]))) if gather is not None else trace_ms_max
+
+    # ---- the arrays the timed steps left behind, word for word against an independent chain (untimed) ------
+    # The timed rebuild is ONE lbvh_build_scene call: two-level sort, three merged launches, the search-free tree kernel that
+    # takes its boxes from the range hierarchy, all replayed from a captured graph.  The check rebuilds the same triangles with
+    # the reference's stage calls one by one (MeshBufferContainer / ComputeBufferSorter / BVHConstructor mirrors: other kernels
+    # throughout — four 8-bit LSD passes forced, the three-kernel DistributeKeys, the topology-only tree kernel, the
+    # bottom-up refit climb) and refuses the line on any difference.
+    timed_path_check = None
+    if sorter is None:
+        c = drawer.container
+        n_ = c.triangles_length
+
+        def snapshot():
+            ctx.sync()
+            return (c.keys.get_data().copy(), c.triangle_index.get_data().copy(),
+                    c.bvh_internal_node.get_data().view(np.uint32).copy(), c.bvh_leaf_node.get_data().view(np.uint32).copy(),
+                    c.bvh_data.get_data()["min"][: n_ - 1].copy(), c.bvh_data.get_data()["max"][: n_ - 1].copy())
+        timed = snapshot()
+        for buf, word in ((c.keys, 0x0BADBEEF), (c.triangle_index, 0x0BADBEEF), (c.bvh_internal_node, 0x01357246),
+                          (c.bvh_leaf_node, 0x02468135), (c.bvh_data, 0x7FC00002)):
+            buf.fill_u32(word, mirror=False)
+        ctx.debug_switch(N.DEBUG_SWITCH_SORT_FORM, 1)
+        drawer.rebuild(fast=False, staged=True)
+        staged = snapshot()
+        ctx.debug_switch(N.DEBUG_SWITCH_SORT_FORM, 0)
+        names = ("keys", "sorted_indices", "internal_nodes", "leaf_nodes", "bvh_min", "bvh_max")
+        differing = {nm: int(np.count_nonzero(a != b)) for nm, a, b in zip(names, timed, staged)}
+        timed_path_check = {"arrays_equal_staged_four_pass_chain": not any(differing.values()), "differing_words": differing,
+                            "note": "container arrays after the K timed steps vs. a staged rebuild of the same triangles "
+                                    "(stage calls one by one, four-pass sort forced, separate tree + refit kernels)"}
+        if any(differing.values()):
+            raise SystemExit(f"[bench] rank {rank}: the timed rebuild path's arrays differ from the staged chain's: {differing}")
+        for _ in range(2):
+            rebuild()                   # the timed path's state again (and the sort's form hint), for the extras below
+        ctx.sync()
 
     # ---- N > 1: the assembled frame, word for word (untimed) ------------------------------------------
     frame_check = None
@@ -593,11 +659,20 @@ def main():
         # LBVH_TRACE_FAST_EXACT (not the timed mode): the packet walk + the reference's choice wherever two triangles are hit at
         # exactly the same t — every word of the frame equals LBVH_TRACE_REFERENCE's; what it costs, and the check itself
         exact_mode = None
+        t_mismatch = 0
         if mode == L.TRACE_FAST:
             N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s), L.TRACE_REFERENCE, full.device, None))
             ref_frame = full.get_data().view(np.uint32).copy()
             N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s), L.TRACE_FAST, full.device, None))
-            fast_differs = int((full.get_data().view(np.uint32) != ref_frame).reshape(-1, 4).any(axis=1).sum())
+            fast_frame = full.get_data().view(np.uint32).copy()
+            fast_differs = int((fast_frame != ref_frame).reshape(-1, 4).any(axis=1).sum())
+            # hit distances of the timed mode against LBVH_TRACE_REFERENCE on the timed frame, bit for bit: a pixel whose reference
+            # winner lies in front of its own triangle's box (the one case in which a pruned walk differs) would
+            # show up here; the line is refused if there is one
+            t_word = L.HIT.fields["t"][1] // 4
+            t_mismatch = int(np.count_nonzero(fast_frame.reshape(-1, 4)[:, t_word] != ref_frame.reshape(-1, 4)[:, t_word]))
+            if t_mismatch:
+                raise SystemExit(f"[bench] {t_mismatch} pixels of the timed frame differ in t between LBVH_TRACE_FAST and LBVH_TRACE_REFERENCE")
             for _ in range(3):
                 N.check(ctx.handle, N.lib.lbvh_trace_primary(ctx.handle, C.byref(ccam), 0, 0, W, H, C.byref(s), L.TRACE_FAST_EXACT, full.device, None))
             e0, e1 = ctx.event(), ctx.event()
@@ -762,6 +837,18 @@ def main():
             "value_without_gather": round(W * H / (own_trace_ms_max * 1e-3) / 1e6, 2),
             "trace_without_gather_ms": round(own_trace_ms_max, 4),
             "frame_gather": frame_check,
+            # N > 1: which way the shares reached rank 0 and how many ranks the collective library reported (flat: VERDICT r5 item 4)
+            "frame_gather_transport": gather.mode if gather is not None else None,
+            "rccl_ranks": (dist.get_world_size() if dist is not None and args.backend == "nccl" else None),
+            # parity guards of THIS run, flat (the line is not printed unless both hold): container arrays after the timed steps ==
+            # an independent staged rebuild, word for word; timed frame's t == LBVH_TRACE_REFERENCE's, bit for bit
+            "timed_path_arrays_equal_staged_chain": timed_path_check["arrays_equal_staged_four_pass_chain"] if timed_path_check else None,
+            "t_mismatch_vs_reference_mode": t_mismatch,
+            "timed_path_check": timed_path_check,
+            # methodology marker: 2 = rounds 5+: defaults --steps 100 --warmup 10; value / build_ms / trace_ms from an
+            # instrumented pass BEFORE the timed region, ms_per_step from the timed region (rounds 1-4: 20 / 3, one pass);
+            # 3 = round 6: + the two parity guards above
+            "bench_version": 3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "scaling_note": "strong scaling of ONE 1080p frame: `value` = rays of the whole frame / the slowest rank's trace part — for N > 1 "
                             "that part ends with the whole frame in rank 0's buffer (`frame_gather`; `value_without_gather`: the traversal "

@@ -213,6 +213,25 @@ def test_bench_rccl_launch_fails_cleanly_without_gpus():
     assert time.time() - t0 < 120
 
 
+def test_bench_launch_has_an_overall_deadline():
+    """if ALL ranks hang (rendezvous, RCCL's set-up, a collective) nobody fails and the ten seconds' grace never
+    starts — the parent of `bench.py --gpus N` must end them itself when --launch-deadline passes: SIGTERM, SIGKILL five seconds
+    later for a rank that ignores it (rank 1 of the hook does), exit status 124, no JSON line, the hung ranks named."""
+    import time
+    t0 = time.time()
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--launch-deadline", "3"], {"LBVH_BENCH_TEST_HANG": "1"}, timeout=120)
+    took = time.time() - t0
+    assert r.returncode == 124 and r.stdout.strip() == "" and "Traceback" not in r.stderr
+    assert "did not finish within 3 s" in r.stderr and "[0, 1]" in r.stderr
+    assert "HSA_ENABLE_IPC_MODE_LEGACY=" in r.stderr
+    assert 3.0 <= took < 40.0, took
+    # nothing of the launch is left behind
+    import subprocess
+    ps = subprocess.run(["ps", "-eo", "pid,args"], capture_output=True, text=True).stdout
+    left = [l for l in ps.splitlines() if "bench.py --gpus 2 --steps 1 --warmup 0 --launch-deadline 3" in l]
+    assert not left, left
+
+
 def test_centre_out_tile_order_is_a_permutation():
     """Frames without dispatch history take rows and columns (a share: its groups of 8 tiles) from the middle outwards
     (csrc/lbvh_trace.hip trace_packet_kernel, centre_out): the arithmetic, restated, is a bijection for every size — every tile
