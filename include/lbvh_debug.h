@@ -23,14 +23,18 @@ extern "C" {
  *                               always, 3 the two-stream form (plain), 4 the two-stream form as a graph
  *   LBVH_DEBUG_FRAME_WAIT_MS    wall-clock bound of lbvh_frame_wait's device-side wait in milliseconds (0: the default, 20 s)
  *   LBVH_DEBUG_SORT_FORM        1: the sort always runs the four 8-bit LSD passes, 2: the two-level form wherever the size allows
- *                               (0: chosen per call from the last sort's largest bucket) */
+ *                               (0: chosen per call from the last sorts' largest buckets)
+ *   LBVH_DEBUG_FAIL_RESERVE     k > 0: the k-th growth of a context-owned scratch buffer from now on fails as hipMalloc does when
+ *                               the device is full (LBVH_ERR_OUT_OF_MEMORY; the old block is gone, the pointer is null), then the
+ *                               switch is 0 again — the error paths of the sort / build / trace entry points on a healthy box */
 enum {
     LBVH_DEBUG_SORT_QUEUES = 0,
     LBVH_DEBUG_COLD_ORDER = 1,
     LBVH_DEBUG_BUILD_FORM = 2,
     LBVH_DEBUG_FRAME_WAIT_MS = 3,
     LBVH_DEBUG_SORT_FORM = 4,
-    LBVH_DEBUG_SWITCHES = 5
+    LBVH_DEBUG_FAIL_RESERVE = 5,
+    LBVH_DEBUG_SWITCHES = 6
 };
 lbvh_status lbvh_debug_switch(lbvh_context* ctx, uint32_t which, uint32_t value);
 

@@ -170,11 +170,15 @@ def test_sort_form_follows_the_last_sorts_largest_bucket():
         uniform = sort_inputs(300001, 1, "random")
         skewed = sort_inputs(300001, 2, "all_equal")
         forms = []
-        for keys, vals in (uniform, uniform, skewed, skewed, uniform, uniform):
+        seq = [uniform] * 4 + [skewed, skewed] + [uniform] * 4 + [skewed, uniform] * 4
+        for keys, vals in seq:
             prof = kernels(keys, vals)
             forms.append("two" if any("sort_bucket_kernel" in k for k in prof) else "four")
-        # first: nothing known -> four; then uniform -> two; the skewed input is still sorted two-level ONCE (slow path), then four
-        assert forms == ["four", "two", "two", "four", "four", "two"], forms
+        # round 6: THREE sorts in a row must have left a hint in order (lbvh_sort.hip kSortStreak).  First: nothing known -> four, and
+        # three more while the streak builds; then two.  The skewed input after a spread streak is still sorted two-level ONCE (the
+        # bucket kernel's slow path), then four; three spread sorts later two again; an input that ALTERNATES never leaves the
+        # four passes (it paid the slow path on every second sort)
+        assert forms == ["four"] * 3 + ["two"] + ["two", "four"] + ["four"] * 3 + ["two"] + ["two", "four"] + ["four"] * 6, forms
     finally:
         c.close()
 
@@ -183,7 +187,8 @@ def test_sort_pairs_of_morton_codes_with_pads_goes_two_level_without_a_hint():
     """lbvh_sort_pairs has no key_bits hint: its fine bins are the keys' top 12 bits.  Morton codes below 2^30 plus 0xFFFFFFFF pads
     (the reference's own call sequence, ComputeBufferSorter.Sort on the padded key buffer) fill a quarter of them and would fill 64
     top-byte buckets of 16 k and more; the balanced buckets (ranges of fine bins of about count / 256 pairs) take them all the same:
-    the first sort measures, the next ones are two-level.  Results are the oracle's."""
+    the first sorts measure (three in a row with every bucket inside one workgroup's registers), the next ones are two-level.
+    Results are the oracle's."""
     c = H().Context(0)
     try:
         rng = np.random.default_rng(5)
@@ -194,7 +199,7 @@ def test_sort_pairs_of_morton_codes_with_pads_goes_two_level_without_a_hint():
         vals = rng.permutation(n).astype(np.uint32)
         ok, ov = O.sort_pairs(keys, vals)
         forms = []
-        for _ in range(3):
+        for _ in range(5):
             kb, vb = up(c, keys, np.uint32), up(c, vals, np.uint32)
             c.profile_begin()
             N().check(c.handle, N().lib.lbvh_sort_pairs(c.handle, kb.device, vb.device, n))
@@ -203,7 +208,7 @@ def test_sort_pairs_of_morton_codes_with_pads_goes_two_level_without_a_hint():
             kb.dispose(); vb.dispose()
             assert (k == ok).all() and (v == ov).all()
             forms.append("two" if any("sort_bucket_kernel" in q for q in prof) else "four")
-        assert forms == ["four", "two", "two"], forms
+        assert forms == ["four"] * 3 + ["two"] * 2, forms
     finally:
         c.close()
 
@@ -1241,6 +1246,9 @@ def test_cfg2_timed_rebuild_path_word_for_word_at_its_own_size(ctx):
     b = O.Built(tris, capacity=c.capacity, threads=8)
     poison = ((c.keys, 0x0BADBEEF), (c.triangle_index, 0x0BADBEEF), (c.triangle_aabb, 0x7FC00001), (c.bvh_internal_node, 0x01357246),
               (c.bvh_leaf_node, 0x02468135), (c.bvh_data, 0x7FC00002))
+    for _ in range(4):      # (the sort takes its two-level form once three sorts in a row have left their hint in order)
+        d.rebuild()
+        ctx.sync()
     for k in range(3):
         for buf, word in poison:
             buf.fill_u32(word, mirror=False)

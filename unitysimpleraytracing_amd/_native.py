@@ -116,7 +116,7 @@ SIGNATURES = {
 }
 
 # include/lbvh_debug.h: not part of the drop-in boundary
-DEBUG_SWITCH_SORT_QUEUES, DEBUG_SWITCH_COLD_ORDER, DEBUG_SWITCH_BUILD_FORM, DEBUG_SWITCH_FRAME_WAIT_MS, DEBUG_SWITCH_SORT_FORM = range(5)
+DEBUG_SWITCH_SORT_QUEUES, DEBUG_SWITCH_COLD_ORDER, DEBUG_SWITCH_BUILD_FORM, DEBUG_SWITCH_FRAME_WAIT_MS, DEBUG_SWITCH_SORT_FORM, DEBUG_SWITCH_FAIL_RESERVE = range(6)
 DEBUG_SIGNATURES = {
     "lbvh_debug_switch": (_I32, [_P, _U32, _U32]),
     "lbvh_debug_sort_ticket_tile": (_U32, [_U32, _U32, _U32, _U32]),

@@ -26,8 +26,19 @@ int lbvh_reserve(lbvh_context* ctx, void** ptr, size_t* have, size_t bytes)
         *ptr = nullptr;
         *have = 0;
     }
+    // (from here to the end a failure leaves the slot EMPTY — null pointer, zero bytes: the next call of whatever owns it starts over)
+    *ptr = nullptr;
+    *have = 0;
     size_t want = bytes < 256 ? 256 : bytes;
-    LBVH_HIP_TRY(ctx, hipMalloc(ptr, want));
+    if (ctx->debug_switch[LBVH_DEBUG_FAIL_RESERVE] != 0 && --ctx->debug_switch[LBVH_DEBUG_FAIL_RESERVE] == 0)      // (test hook)
+        return lbvh_set_error(ctx, LBVH_ERR_OUT_OF_MEMORY, "lbvh_reserve", "hipMalloc failure injected by LBVH_DEBUG_FAIL_RESERVE");
+    void* fresh = nullptr;
+    const hipError_t e = hipMalloc(&fresh, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();              // (the runtime's sticky "last error": this one is reported through the status)
+        return lbvh_set_error(ctx, e == hipErrorOutOfMemory ? LBVH_ERR_OUT_OF_MEMORY : LBVH_ERR_HIP, "hipMalloc(scratch)", hipGetErrorString(e));
+    }
+    *ptr = fresh;
     *have = want;
     return LBVH_OK;
 }
@@ -250,7 +261,15 @@ lbvh_status lbvh_buffer_alloc(lbvh_context* ctx, size_t count, size_t stride, vo
     size_t bytes = count * stride;
     if (bytes == 0) bytes = stride;
     LBVH_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    LBVH_HIP_TRY(ctx, hipMalloc(out_d_ptr, bytes));
+    // (count * stride must not wrap: 2^44 elements of 2^20 bytes is not a small buffer)
+    if (count != 0 && bytes / count != stride)
+        return lbvh_set_error(ctx, LBVH_ERR_OUT_OF_MEMORY, "lbvh_buffer_alloc", "count * stride overflows size_t");
+    const hipError_t e = hipMalloc(out_d_ptr, bytes);
+    if (e != hipSuccess) {
+        *out_d_ptr = nullptr;
+        (void)hipGetLastError();
+        return lbvh_set_error(ctx, e == hipErrorOutOfMemory ? LBVH_ERR_OUT_OF_MEMORY : LBVH_ERR_HIP, "hipMalloc(buffer)", hipGetErrorString(e));
+    }
     return LBVH_OK;
 }
 

@@ -106,6 +106,7 @@ struct lbvh_context {
     // sort: 8 per-XCD ticket queues only on the layout they were designed for (all 256 CUs of an SPX device behind an
     // unmasked stream: workgroups dealt round-robin over the XCDs); anything else takes tiles in ticket order
     uint32_t sort_queues = 1;
+    uint32_t sort_hint_streak = 0;          // consecutive lbvh_launch_sort calls that found the two-level form's hint in order
     uint32_t sort_queues_detected = 1;      // what lbvh_create found (lbvh_debug_switch(LBVH_DEBUG_SORT_QUEUES, 0) goes back to it)
     // lbvh_debug_switch (include/lbvh_debug.h): all 0 in the product
     uint32_t debug_switch[LBVH_DEBUG_SWITCHES] = {};

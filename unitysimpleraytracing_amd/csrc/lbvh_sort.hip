@@ -43,7 +43,7 @@
 // the pairs in registers and the exchanges through LDS, no look-back, no global traffic between the passes.  Two launches and
 // one look-back chain instead of five and four.  The result is the same unique stable sort.  A bucket beyond one workgroup's
 // registers (16 384 pairs: more than ~12 K pairs with ONE 12-bit prefix) is sorted by its workgroup chunk by chunk through global
-// memory: correct for any input, slow — so the form is chosen per call from the LAST sort's largest bucket (mapped host words
+// memory: correct for any input, slow — so the form is chosen per call from the LAST sorts' largest buckets (mapped host words
 // the first pass kernel leaves behind; a hint one sort stale, like the traversal's dispatch history: either form gives the same
 // words).
 #include "lbvh_common.h"
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
     __shared__ uint32_t s_dstart[kRadix];
     __shared__ uint32_t s_wsum[DWAVES + 1];
     __shared__ uint32_t s_base[kRadix];          // big buckets: next output index of each digit, relative to the bucket
-    __shared__ uint32_t s_start, s_size;
+    __shared__ uint32_t s_start, s_size, s_same;
     uint2* s_pair = reinterpret_cast<uint2*>(s_xchg);
     const uint32_t t = threadIdx.x, w = t >> 6, lane = lane_id();
     const uint32_t b = blockIdx.x;
@@ -878,9 +878,36 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
     for (uint32_t p = 0; p < passes; p++) {
         const uint32_t pshift = 8u * p;
         if (t < (uint32_t)kRadix) s_base[t] = 0;
+        if (t == 0) s_same = 0u;
         __syncthreads();
-        for (uint32_t idx = t; idx < size; idx += THREADS) atomicAdd(&s_base[((src_k[start + idx] - base) >> pshift) & (kRadix - 1)], 1u);
+        {   // (runs of equal digits are added as one: a bucket of ONE key would otherwise put 2 M atomics on one LDS word per pass)
+            uint32_t run_digit = 0, run = 0;
+            for (uint32_t i0 = 0; i0 < size; i0 += 8u * THREADS) {      // eight loads in flight per thread
+                uint32_t k8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t idx = i0 + (uint32_t)u * THREADS + t;
+                    k8[u] = idx < size ? src_k[start + idx] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (i0 + (uint32_t)u * THREADS + t >= size) continue;
+                    const uint32_t dgt = ((k8[u] - base) >> pshift) & (kRadix - 1);
+                    if (dgt != run_digit && run != 0) { atomicAdd(&s_base[run_digit], run); run = 0; }
+                    run_digit = dgt;
+                    run++;
+                }
+            }
+            if (run != 0) atomicAdd(&s_base[run_digit], run);
+        }
         __syncthreads();
+        // every pair has the same digit: the pass is the identity (the whole bucket one key — ten thousand triangles in one Morton
+        // cell — costs its passes' counting walks, nothing else: 2^21 - 1 equal keys 5.4 -> 0.3 ms, profiles/r6/sort_cliff.txt)
+        if (t < (uint32_t)kRadix && s_base[t] == size) s_same = 1u;
+        __syncthreads();
+        const uint32_t same = s_same;
+        __syncthreads();                       // (the next pass clears the word)
+        if (same) continue;
         {   // exclusive scan of the digit counts in place
             const uint32_t total = t < (uint32_t)kRadix ? s_base[t] : 0u;
             const uint32_t incl = wave_inclusive_sum(total);
@@ -927,10 +954,19 @@ __global__ __launch_bounds__(THREADS) void sort_bucket_kernel(uint32_t* __restri
         tmp = src_k; src_k = dst_k; dst_k = tmp;
         tmp = src_v; src_v = dst_v; dst_v = tmp;
     }
-    if (src_k != keys_out) {          // an even number of passes (the last bucket's four) ends in the other buffer
-        for (uint32_t idx = t; idx < size; idx += THREADS) {
-            keys_out[start + idx] = src_k[start + idx];
-            vals_out[start + idx] = src_v[start + idx];
+    if (src_k != keys_out) {          // an even number of passes (the last bucket's four; none at all: one key) ends in the other buffer
+        for (uint32_t i0 = 0; i0 < size; i0 += 8u * THREADS) {          // (eight pairs in flight per thread)
+            uint32_t k8[8], v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t idx = i0 + (uint32_t)u * THREADS + t;
+                if (idx < size) { k8[u] = src_k[start + idx]; v8[u] = src_v[start + idx]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t idx = i0 + (uint32_t)u * THREADS + t;
+                if (idx < size) { keys_out[start + idx] = k8[u]; vals_out[start + idx] = v8[u]; }
+            }
         }
     }
 }
@@ -1012,6 +1048,7 @@ int lbvh_sort_scratch(lbvh_context* ctx, uint32_t count, uint32_t** d_zero, uint
 // there an MSD-first form was measured to gain nothing: profiles/r4/b_bucket_local_sort_passes.txt)
 static inline bool two_level_size(uint32_t count) { return count >= (1u << 15) && count < (1u << 21); }
 constexpr int kBucketThreads = 1024, kBucketItems = 16;        // a bucket of up to 16 384 pairs lives in one workgroup's registers
+constexpr uint32_t kSortStreak = 3;                            // sorts in a row whose largest bucket fitted, before the two-level form is taken
 
 int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, uint32_t count, bool scratch_cleared, uint32_t key_bits)
 {
@@ -1055,8 +1092,20 @@ int lbvh_launch_sort(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values, ui
             known = known && v != 0xFFFFFFFFu && (v >> 24) == fine_shift;
             largest = std::max(largest, v & 0xFFFFFFu);
         }
+        // ... and not on ONE such sort: kSortStreak calls in a row must have found the hint in order (round 6).  The bucket kernel
+        // sorts a bucket beyond its registers correctly but with ONE workgroup, chunk by chunk through memory — milliseconds for a
+        // bucket of a million pairs (profiles/r6/sort_cliff.txt) against ~60 us for the four passes.  With the streak an input that
+        // alternates between spread and degenerate (a scene collapsing into one Morton cell every other frame) stays in
+        // the four-pass form; what is left is one slow sort at the first degenerate input after at least kSortStreak spread ones.
+        const bool in_order = known && largest <= (uint32_t)(kBucketThreads * kBucketItems);
+        ctx->sort_hint_streak = in_order ? std::min(ctx->sort_hint_streak + 1u, 1u << 20) : 0u;
         const uint32_t form = ctx->debug_switch[LBVH_DEBUG_SORT_FORM];
-        two_level = form == 2u || (form == 0u && known && largest <= (uint32_t)(kBucketThreads * kBucketItems));
+        two_level = form == 2u || (form == 0u && ctx->sort_hint_streak >= kSortStreak);
+        // a chain being captured into a graph is replayed for inputs this call knows nothing about: a frozen hint is no hint
+        //  — captured sorts take the input-independent four passes
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (form != 2u && hipStreamIsCapturing(ctx->cur_stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)
+            two_level = false;
     }
     if (two_level) {
         const uint32_t fblocks = std::max(1u, std::min(hblocks, (count + (uint32_t)LBVH_FINE_BLOCK_KEYS - 1u) / (uint32_t)LBVH_FINE_BLOCK_KEYS));
