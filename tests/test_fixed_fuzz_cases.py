@@ -96,27 +96,39 @@ def test_oracle_frames_differ_only_where_the_winner_lies_before_its_box_cpu_subs
     assert artefacts == {19899: [(12, 210)]}, artefacts
 
 
+def _oracle_job(q):
+    """one case's oracle side in a worker process (no HIP in there): frames and artefact pixels"""
+    _, _, _, oh, of, explained = oracle_pair(q, 4)
+    return q["case"], oh, of, explained
+
+
 @pytest.mark.gpu
 def test_fixed_fuzz_cases_reference_frame_vs_rule_frame_and_the_three_modes(ctx):
+    """all 2 001 cases.  The oracle's two frames per case come from a pool of worker processes (spawned: they never touch HIP;
+    serial with 8 threads the CPU side alone took 20 minutes on the GPU box), the GPU's three modes are compared as they arrive."""
+    import concurrent.futures as cf
+    import multiprocessing as mp
     from unitysimpleraytracing_amd.host import RaytracingMeshDrawer
-    threads = O.num_threads()
     artefacts = {}
     pixels = 0
-    for q in CASES:
-        tris, cam, b, oh, of, explained = oracle_pair(q, threads)
-        if explained:
-            artefacts[q["case"]] = explained
-        pixels += oh.size
-        d = RaytracingMeshDrawer(ctx, tris).awake(fast=True)
-        what = (q["case"], q["kind"], len(tris), q["w"], q["h"])
-        d.update(cam, mode=L.TRACE_REFERENCE)
-        assert (words(d.hits()) == words(oh)).all(), what + ("reference mode",)
-        for frame in range(2):                     # the second frame runs the dispatch history of the first
-            d.update(cam, mode=L.TRACE_FAST)
-            assert (d.hits()["t"] == of["t"]).all(), what + ("fast mode", frame)
-        d.update(cam, mode=L.TRACE_FAST_EXACT)
-        assert (words(d.hits()) == words(of)).all(), what + ("exact mode",)
-        d.on_destroy()
+    workers = max(2, min(24, (os.cpu_count() or 8) // 4))
+    with cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as pool:
+        for q, (case, oh, of, explained) in zip(CASES, pool.map(_oracle_job, CASES, chunksize=8)):
+            assert case == q["case"]
+            if explained:
+                artefacts[case] = explained
+            pixels += oh.size
+            tris, cam = make_scene(q["kind"], q["n"], q["scene"]), camera_of(q)
+            d = RaytracingMeshDrawer(ctx, tris).awake(fast=True)
+            what = (q["case"], q["kind"], len(tris), q["w"], q["h"])
+            d.update(cam, mode=L.TRACE_REFERENCE)
+            assert (words(d.hits()) == words(oh)).all(), what + ("reference mode",)
+            for frame in range(2):                     # the second frame runs the dispatch history of the first
+                d.update(cam, mode=L.TRACE_FAST)
+                assert (d.hits()["t"] == of["t"]).all(), what + ("fast mode", frame)
+            d.update(cam, mode=L.TRACE_FAST_EXACT)
+            assert (words(d.hits()) == words(of)).all(), what + ("exact mode",)
+            d.on_destroy()
     print(f"\n{len(CASES)} fixed fuzz cases, {pixels} pixels: reference frame vs rule frame differ at {sum(map(len, artefacts.values()))} "
           f"pixel(s), every one a winner in front of its own triangle's box: {artefacts}")
     assert artefacts == {19899: [(12, 210)]}, artefacts
