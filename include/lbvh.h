@@ -117,13 +117,17 @@ typedef struct lbvh_camera {
 /* Traversal flavours of lbvh_trace_primary. */
 #define LBVH_TRACE_REFERENCE 0  /* the reference's visit order, no pruning, separate node arrays */
 #define LBVH_TRACE_FAST      1  /* 8x8 packets over fused 64-B nodes, near-first, t-pruned; same min-t (see the note below) */
-#define LBVH_TRACE_FAST_EXACT 2 /* LBVH_TRACE_FAST, and every record equals LBVH_TRACE_REFERENCE's word for word: a ray
-                                 * that meets two triangles at EXACTLY the same t (the one case in which the fast walk's
-                                 * order-independent choice — lowest triangle index — can differ from the triangle the
-                                 * reference's visit order meets first) is given to the triangle that order meets first:
-                                 * the order is read off the scene's internalNodes / leafNodes (parent words, child
-                                 * types; leaf j's `index` is j, as TreeConstructor writes it, BVH.compute:116-120).
-                                 * No d_stats with this mode. */
+#define LBVH_TRACE_FAST_EXACT 2 /* LBVH_TRACE_FAST with the reference's choice on exact ties: every record equals, word for
+                                 * word, the record of the reference's loop under the accept rule of the note below (the
+                                 * oracle's orc_trace_primary_rule with fast_rule = 1) — that is LBVH_TRACE_REFERENCE's record
+                                 * at every pixel whose reference winner is not a t in front of its own triangle's box
+                                 * (every pixel of every scene in the test suite but one, which is pinned:
+                                 * tests/golden/grazing_ray_case.json).  A ray that meets two triangles at EXACTLY the same t
+                                 * (the case in which the fast walk's order-independent choice — lowest triangle index — can
+                                 * differ from the triangle the reference's visit order meets first) is given to the triangle
+                                 * that order meets first: the order is read off the scene's internalNodes / leafNodes
+                                 * (parent words, child types; leaf j's `index` is j, as TreeConstructor writes it,
+                                 * BVH.compute:116-120).  No d_stats with this mode. */
 /* Where both fast modes differ from LBVH_TRACE_REFERENCE — by a rule, not by chance (tests/test_grazing_ray.py).
  * The reference prunes nothing, so its record is the minimum COMPUTED t over every triangle whose box the ray's line passes —
  * including, for a ray within ~0.01 degree of a triangle's plane, a t that is noise of the fp32 triangle test
@@ -518,7 +522,14 @@ lbvh_status lbvh_path_scatter(lbvh_context* ctx, const lbvh_scene* h_scene, cons
  * 0xFFFFFFFF, 0, 0} — still a miss to every reader; a later lbvh_path_bounce (bounce > 0) on the same buffers recognises
  * it and skips the finished path without reading its 64-byte state.  At bounce 0 every record is the caller's: one that
  * was pre-filled with 0xFFFFFFFF words and never traced is an ordinary miss (sky term, path ends), as in
- * lbvh_path_scatter.  States, radiance and image: the same as the two calls. */
+ * lbvh_path_scatter.  States, radiance and image: the same as the two calls.
+ * CROSS-CALL STATE: a call with bounce >= 1 — and the frame's last lbvh_path_scatter — visits only the paths the previous
+ * lbvh_path_bounce on the same d_states / d_hits listed as live (a list kept by the context).  Every library call that writes
+ * into those buffers drops the list (lbvh_path_begin, lbvh_trace_rays, a primary trace into any part of d_hits,
+ * lbvh_buffer_upload / _fill_u32 / _free), and so does lbvh_trace_forget; then every state is scanned again.  What the library
+ * cannot see is a write of the CALLER's own (a kernel or hipMemcpy that revives or ends paths, Russian roulette): between two
+ * consecutive bounces of a frame d_states and d_hits must not be written from outside the library — or lbvh_trace_forget must be
+ * called after such a write. */
 lbvh_status lbvh_path_bounce(lbvh_context* ctx, const lbvh_scene* h_scene, lbvh_path_state* d_states, lbvh_hit* d_hits,
                              size_t count, uint32_t bounce, uint32_t seed, float albedo, float t_min);
 
@@ -536,7 +547,8 @@ lbvh_status lbvh_path_resolve(lbvh_context* ctx, const lbvh_path_state* d_states
  * layout (a scheduling hint kept by the context; any order gives the same hits).  When the camera differs from that
  * trace's, a tile takes the count of the place it came from: the ray through its centre, at the distance of the scene
  * box's centre, projected with the previous camera (exact for a turn of the camera), widened by one tile.  This call
- * drops the history: the next trace runs as a first frame does (row-major).  For measuring cold frames. */
+ * drops the history: the next trace runs as a first frame does (row-major).  For measuring cold frames.  It also drops the path
+ * tracer's live-path list (lbvh_path_bounce): the next bounce scans every path state. */
 lbvh_status lbvh_trace_forget(lbvh_context* ctx);
 
 /* Multi-GPU frames (one context per GPU, each tracing its lbvh_trace_primary_shard share): the dispatch hint above comes

@@ -1844,8 +1844,12 @@ def test_light_whole_frames_take_the_eight_wave_cooperative_shape(ctx):
                 N().check(ctx.handle, N().lib.lbvh_trace_primary(ctx.handle, C.byref(cam), 0, 0, W, Ht, C.byref(s), mode, hb.device, None))
                 got = hb.get_data()
                 assert (got["t"].view(np.uint32) == ref["t"].view(np.uint32)).all(), (pos, mode, f)
-                if mode == L.TRACE_FAST_EXACT:
-                    assert (words(got) == words(ref)).all(), (pos, f)
+                if mode == L.TRACE_FAST_EXACT and not (words(got) == words(ref)).all():
+                    # word for word the reference mode's frame, except where the reference's winner lies in front of its own
+                    # triangle's box (include/lbvh.h): looked up in the oracle, not assumed away
+                    unexplained, _ = O.unexplained_mismatches(b, scenes.camera(W, Ht, pos), ref[: W * Ht].reshape(Ht, W),
+                                                              got[: W * Ht].reshape(Ht, W), words=True)
+                    assert not unexplained, (pos, f, unexplained[:4])
         assert (ref["t"] < 1e30).sum() > 1000
     hb.dispose()
     d.on_destroy()

@@ -57,8 +57,13 @@ def test_one_process_n_contexts_assemble_the_frame_on_the_owner(ranks):
             want = single.hits()
             assert (got.view(np.uint32) == want.view(np.uint32)).all(), (ranks, mode, f)
             if mode == L.TRACE_FAST_EXACT:
+                # the exact mode's frame is the reference mode's word for word — except where the reference's winner is a t in
+                # front of its own triangle's box (include/lbvh.h): such pixels are looked up in the oracle, not assumed away
                 single.update(cam, mode=L.TRACE_REFERENCE)
-                assert (got.view(np.uint32) == single.hits().view(np.uint32)).all(), (ranks, f)
+                ref = single.hits()
+                if not (got.view(np.uint32) == ref.view(np.uint32)).all():
+                    unexplained, _ = O.unexplained_mismatches(b, cam, ref, got, words=True)
+                    assert not unexplained, (ranks, f, unexplained[:4])
             if f in (0, 2):
                 oh, _ = O.trace_primary(b, cam, threads=8)
                 assert (got["t"].view(np.uint32) == oh["t"].view(np.uint32)).all()

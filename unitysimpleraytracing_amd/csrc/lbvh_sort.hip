@@ -354,7 +354,11 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
     __shared__ uint32_t s_tile;
     constexpr bool kMapCapable = THREADS == 512 && ITEMS == 8 && !STREAM;      // the form used below 2^21 pairs
     static_assert(kMapCapable || !MSD, "the MSD pass is the 512 x 8 form");
-    __shared__ bucket_map_slot<kMapCapable> s_bslot;                           // (4 bytes in the forms that never build a map)
+    // the MSD pass looks every key's bucket up in the map: its own 8.2 KB.  The LSD passes build a map only in tile 0 of the first
+    // pass, AFTER the tile's work (the next sort's hint): there it lives in the exchange buffer, which is free by then — the four
+    // passes' workgroups no longer carry 8.2 KB they never use
+    __shared__ bucket_map_slot<MSD> s_bslot;                                   // (4 bytes in the LSD passes)
+    static_assert(!kMapCapable || sizeof(bucket_map_lds) <= sizeof(uint32_t) * XCHG_WORDS, "the hint's map fits the exchange buffer");
 
     const uint32_t t = threadIdx.x;
     const uint32_t w = t >> 6;
@@ -639,9 +643,10 @@ __global__ __launch_bounds__(THREADS) void sort_onesweep_kernel(
         // the four-pass form, first pass: what the two-level form's largest bucket WOULD be for this input (after this tile's own
         // work: nobody waits for it)
         if (gfine != nullptr && tile == 0) {
-            __syncthreads();
-            build_bucket_map(load_fine_bins(gfine), fine_mul, fine_shift, s_bslot.v);
-            publish_bucket_stat(s_bslot.v, bucket_stat, fine_shift);
+            __syncthreads();                 // (every thread's last read of the exchange buffer is behind it)
+            bucket_map_lds& hint_map = *reinterpret_cast<bucket_map_lds*>(s_xchg);
+            build_bucket_map(load_fine_bins(gfine), fine_mul, fine_shift, hint_map);
+            publish_bucket_stat(hint_map, bucket_stat, fine_shift);
         }
     }
 }

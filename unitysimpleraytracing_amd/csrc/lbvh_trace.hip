@@ -1963,7 +1963,15 @@ static lbvh_status trace_impl(lbvh_context* ctx, const lbvh_camera* h_camera, in
     LBVH_REQUIRE(ctx, cam.screen_width > 0 && cam.screen_height > 0);
     LBVH_REQUIRE(ctx, x0 >= 0 && y0 >= 0 && x1 >= x0 && y1 >= y0);
     LBVH_REQUIRE(ctx, x1 <= cam.screen_width && y1 <= cam.screen_height);
-    if (d_hits == ctx->ray_list.hits) ctx->ray_list.valid = false;        // new primary hits in the path tracer's records: a new frame
+    // new primary hits anywhere inside the path tracer's records (the frame, a rectangle of it, a share written at an offset): a new
+    // frame for the live-path list of the last bounce (any overlap, not only the same base pointer)
+    if (d_hits && ctx->ray_list.valid) {
+        // (W x H records is an upper bound of every layout this call writes — frame, rectangle, packed share: dropping the list
+        // once too often costs one scan of the states, nothing else)
+        const uintptr_t w0 = (uintptr_t)d_hits, w1 = w0 + (size_t)cam.screen_width * (size_t)cam.screen_height * sizeof(lbvh_hit);
+        const uintptr_t l0 = (uintptr_t)ctx->ray_list.hits, l1 = l0 + ctx->ray_list.count * sizeof(lbvh_hit);
+        if (w0 < l1 && l0 < w1) ctx->ray_list.valid = false;
+    }
     LBVH_REQUIRE(ctx, s.n >= 2);
     if (x1 == x0 || y1 == y0) return LBVH_OK;
     LBVH_REQUIRE(ctx, d_hits != nullptr && ((uintptr_t)d_hits & 15) == 0);
@@ -2056,6 +2064,7 @@ lbvh_status lbvh_trace_forget(lbvh_context* ctx)
     if (!ctx) return LBVH_ERR_INVALID_ARG;
     ctx->trace_history = false;
     ctx->trace_frame_valid = false;
+    ctx->ray_list.valid = false;          // (and the path tracer's live-path list: the next bounce scans every state)
     return LBVH_OK;
 }
 

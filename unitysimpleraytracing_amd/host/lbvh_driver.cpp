@@ -93,6 +93,8 @@ static int multi_main(int argc, char** argv)
                 frames++;
                 equal += same ? 1 : 0;
                 if (mode == LBVH_TRACE_FAST_EXACT) {      // ... and the exact mode's frame is the reference mode's, word for word
+                    // (include/lbvh.h: except at a pixel whose reference winner lies in front of its own triangle's box — this
+                    // scene and these cameras have none; the general case is checked against the oracle by the Python suite)
                     single.Update(cam, LBVH_TRACE_REFERENCE);
                     single.Hits().GetData();
                     if (std::memcmp(multi.Hits().LocalBuffer().data(), single.Hits().LocalBuffer().data(), (size_t)w * h * sizeof(lbvh_hit)) != 0)
