@@ -68,14 +68,32 @@ def run(ctx, frames=20, warmup=3, bounces=4, w=1920, h=1080, profile=True, live=
             if per_launch:            # mean per launch of either walker x the frame's four launches
                 traffic = {k: (round(v * bounces) if isinstance(v, (int, float)) else v) for k, v in per_launch.items()}
                 traffic["basis"] = "mean per launch of trace_rays_wide_kernel / trace_rays_wide_chain_kernel x %d launches per frame" % bounces
-        out["roofline"] = {"kernel": "trace_rays_wide_kernel + trace_rays_wide_chain_kernel (the %d bounces of a frame)" % bounces,
-                           "kernel_ms": round(walk_ms, 4), "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes": round(alg),
+        # roofline_version 5 (round 6): the walk's OWN line bytes exceed what reaches HBM several times over —
+        # the lines of divergent rays come from L2 / Infinity Cache, and a ray waits for its dependent line fetches:
+        # the kernel is latency-bound and says so; `achieved` / `frac` are the HBM-side bytes of the counters over the kernels'
+        # time when the counters ran (else the own-line rate), the own-line rate stands beside them under its own name
+        hbm_bytes = None
+        if traffic and isinstance(traffic.get("bytes"), (int, float)):
+            hbm_bytes = float(traffic["bytes"])            # FETCH_SIZE (x 2 on gfx950) + WRITE_SIZE, x the frame's launches
+        hbm_rate = hbm_bytes / (walk_ms * 1e-3) / 1e9 if hbm_bytes is not None else None
+        out["roofline"] = {"roofline_version": 5,
+                           "kernel": "trace_rays_wide_kernel + trace_rays_wide_chain_kernel (the %d bounces of a frame)" % bounces,
+                           "kernel_ms": round(walk_ms, 4), "bound": "latency", "roofline_of": "hbm",
+                           "achieved": round(hbm_rate if hbm_rate is not None else achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round((hbm_rate if hbm_rate is not None else achieved) / HBM_PEAK_GBS, 4),
+                           "achieved_basis": "HBM-side bytes of the PMC passes (FETCH_SIZE + WRITE_SIZE, corrected) / the kernels' time"
+                                             if hbm_rate is not None else "own line bytes (no counter pass in this run)",
+                           "own_line_GBs": round(achieved, 1), "own_line_frac_of_hbm_peak": round(achieved / HBM_PEAK_GBS, 4),
+                           "own_line_bytes": round(alg), "algorithmic_bytes": round(alg),
+                           "own_over_hbm_bytes": round(alg / hbm_bytes, 2) if hbm_bytes else None,
                            "rays": int(st["rays"]), "node_fetches_per_ray": round(float(st["node_fetches"]) / max(float(st["rays"]), 1.0), 1),
                            "triangle_tests_per_ray": round(float(st["triangle_tests"]) / max(float(st["rays"]), 1.0), 2),
-                           "bytes_basis": "128 B per four-wide node line + 64 B per triangle line + 64 B path state + 16 B hit record per ray, "
-                                          "this frame's counters (lbvh_ray_stats_target); divergent per-ray fetches: the lines come mostly from L2, "
-                                          "`traffic` is what reached HBM",
+                           "bytes_basis": "own lines: 128 B per four-wide node line + 64 B per triangle line + 64 B path state + 16 B hit record "
+                                          "per ray, this frame's counters (lbvh_ray_stats_target).  Divergent per-ray fetches are served by L2 / "
+                                          "Infinity Cache: own bytes > HBM bytes, the walk waits for dependent line fetches — a latency-bound "
+                                          "kernel reported against the bandwidth roofline SURVEY 8(d) asks for",
+                           "wide_node_decision": "8-wide nodes on a node-local 8-bit grid would fetch 33.5 % fewer node lines per secondary ray "
+                                                 "(tools/treelab `wide`, profiles/r6/cfg5_wide_collapse_lab.txt): below the 35 % bar, not built",
                            "traffic": traffic}
     img = pt.image()
     out["alpha_fraction"] = round(float((img[..., 3] > 0).mean()), 4)

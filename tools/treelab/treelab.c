@@ -818,6 +818,139 @@ static void evaluate(const char* name, const tree_t* t, double build_s)
     free(g_cnt);
 }
 
+// ---- k-wide collapses of a binary tree for the per-ray walk (round 6, VERDICT r5 item 7: decide cfg5's 8-wide node HERE) -------------------
+// A wide node = a binary node with its children opened by surface — the internal child with the largest box area is replaced by its
+// two children — until it has k children or only leaves are left.  k = 4 is the product's four-wide form (lbvh_path.hip: up to four
+// child boxes per 128-byte line).  k = 8 fits one 128-byte line only with boxes on a node-local 8-bit grid (origin + extent of the
+// node: 24 B, 8 x 6 B of quantised corners, 8 x 4 B of references = 104 B): `quant` rounds every child box OUTWARD onto that grid,
+// as such a node would have to.  Counted per diffuse bounce ray: node lines fetched (one per wide node visited) and triangle lines.
+typedef struct { uint32_t n; uint32_t child[8]; box_t box[8]; } wnode_t;
+typedef struct { wnode_t* nd; uint32_t count; } wtree_t;
+
+static box_t quantise_outward(box_t b, box_t frame)
+{
+    box_t q;
+    for (int k = 0; k < 3; k++) {
+        const float ext = frame.mx[k] - frame.mn[k], step = ext > 0.0f ? ext / 255.0f : 1.0f;
+        float lo = floorf((b.mn[k] - frame.mn[k]) / step), hi = ceilf((b.mx[k] - frame.mn[k]) / step);
+        lo = fminf(fmaxf(lo, 0.0f), 255.0f); hi = fminf(fmaxf(hi, 0.0f), 255.0f);
+        q.mn[k] = frame.mn[k] + lo * step; q.mx[k] = frame.mn[k] + hi * step;
+        if (q.mn[k] > b.mn[k]) q.mn[k] = b.mn[k];          // (rounding of the products: never inward)
+        if (q.mx[k] < b.mx[k]) q.mx[k] = b.mx[k];
+    }
+    return q;
+}
+
+static uint32_t collapse_node(const tree_t* t, wtree_t* w, uint32_t bin, uint32_t k, int quant)
+{
+    const uint32_t me = w->count++;
+    uint32_t ch[8]; box_t bx[8]; uint32_t cn = 2;
+    ch[0] = t->nd[bin].l; bx[0] = t->nd[bin].lb; ch[1] = t->nd[bin].r; bx[1] = t->nd[bin].rb;
+    while (cn < k) {
+        int pick = -1; float area = -1.0f;
+        for (uint32_t i = 0; i < cn; i++) if (!(ch[i] & LEAF) && box_area(bx[i]) > area) { area = box_area(bx[i]); pick = (int)i; }
+        if (pick < 0) break;
+        const node_t* c = &t->nd[ch[pick]];
+        ch[pick] = c->l; bx[pick] = c->lb;
+        ch[cn] = c->r; bx[cn] = c->rb; cn++;
+    }
+    box_t frame = box_empty();
+    for (uint32_t i = 0; i < cn; i++) frame = box_union(frame, bx[i]);
+    wnode_t nd; nd.n = cn;
+    for (uint32_t i = 0; i < cn; i++) {
+        nd.box[i] = quant ? quantise_outward(bx[i], frame) : bx[i];
+        nd.child[i] = (ch[i] & LEAF) ? ch[i] : collapse_node(t, w, ch[i], k, quant);
+    }
+    w->nd[me] = nd;
+    return me;
+}
+
+// near-first per-ray walk over wide nodes: node lines fetched; *tris = triangle lines fetched (own-box test passed)
+static uint32_t walk_wide(const wtree_t* w, const ray_t* r, float t_min, float* best_out, uint32_t* leaf_out, uint32_t* tris)
+{
+    struct { uint32_t node; float t; } stack[512];
+    uint32_t sp = 0, visits = 0, node = 0;
+    float best = MAXF; uint32_t best_leaf = 0xFFFFFFFFu;
+    for (;;) {
+        const wnode_t* nd = &w->nd[node];
+        visits++;
+        uint32_t hit_i[8]; float hit_t[8]; uint32_t hn = 0;
+        for (uint32_t i = 0; i < nd->n; i++) {
+            float te;
+            if (!slab(&nd->box[i], r, &te) || te > best) continue;
+            if (nd->child[i] & LEAF) {
+                float tt;
+                (*tris)++;
+                if (tri_test(r, sidx[nd->child[i] & ~LEAF], &tt) && tt > t_min && tt < best) { best = tt; best_leaf = nd->child[i] & ~LEAF; }
+            } else { hit_i[hn] = nd->child[i]; hit_t[hn] = te; hn++; }
+        }
+        // far to near onto the stack, the nearest is walked next (entries beyond the best hit by now are dropped when popped)
+        for (uint32_t a = 1; a < hn; a++)
+            for (uint32_t b = a; b > 0 && hit_t[b] > hit_t[b - 1]; b--) {
+                const float tf = hit_t[b]; hit_t[b] = hit_t[b - 1]; hit_t[b - 1] = tf;
+                const uint32_t ti = hit_i[b]; hit_i[b] = hit_i[b - 1]; hit_i[b - 1] = ti;
+            }
+        for (uint32_t a = 0; a < hn; a++) if (!(hit_t[a] > best)) { stack[sp].node = hit_i[a]; stack[sp].t = hit_t[a]; sp++; }
+        for (;;) {
+            if (!sp) { *best_out = best; *leaf_out = best_leaf; return visits; }
+            sp--;
+            if (!(stack[sp].t > best)) { node = stack[sp].node; break; }
+        }
+    }
+}
+
+static int g_wide = 0;
+// diffuse bounce rays (the primary hits of every 4th pixel of cfg2's camera, two bounces) over the binary tree and its collapses
+static void evaluate_wide(const tree_t* t)
+{
+    const struct { uint32_t k; int quant; const char* name; } forms[] = {
+        {2, 0, "binary (2 child boxes per 64-byte line)"}, {4, 0, "4-wide, fp32 boxes (the product's walkers: one 128-byte line)"},
+        {8, 0, "8-wide, fp32 boxes (would be two lines: 224 B)"}, {8, 1, "8-wide, node-local 8-bit grid (one 128-byte line)"},
+        {6, 0, "6-wide, fp32 boxes (would be 168 B)"}, {6, 1, "6-wide, node-local 8-bit grid"}, {4, 1, "4-wide, node-local 8-bit grid (64-byte line)"}};
+    camera_t c = {1920, 1080, tanf(30.0f * (float)M_PI / 180.0f), 0.3f, {0.0f, 0.0f, 250.0f}};
+    printf("   per-ray walks over collapses of this tree: rays = primary hits of every 4th pixel + two diffuse bounces (as evaluate())\n");
+    for (size_t f = 0; f < sizeof forms / sizeof forms[0]; f++) {
+        wtree_t w; w.nd = malloc((size_t)(n - 1) * sizeof(wnode_t)); w.count = 0;
+        collapse_node(t, &w, 0, forms[f].k, forms[f].quant);
+        uint64_t pv = 0, pt = 0, bv[2] = {0, 0}, bt_[2] = {0, 0}, rays[2] = {0, 0}, mism = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : pv, pt, bv[:2], bt_[:2], rays[:2], mism)
+        for (int py = 0; py < c.h; py += 4)
+            for (int px = 0; px < c.w; px += 4) {
+                ray_t r = camera_ray(&c, px, py);
+                float bt; uint32_t bl, tl = 0;
+                pv += walk_wide(&w, &r, 0.0f, &bt, &bl, &tl); pt += tl;
+                { float b2; uint32_t l2; walk_ray(t, &r, 0.0f, &b2, &l2); if (b2 != bt) mism++; }
+                uint32_t seed = (uint32_t)(py * c.w + px) * 9781u + 1u;
+                for (int bounce = 0; bounce < 2 && bl != 0xFFFFFFFFu; bounce++) {
+                    const float* v = tri[sidx[bl]];
+                    const float e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+                    float nrm[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                    float len = sqrtf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+                    if (!(len > 0.0f)) break;
+                    float side = nrm[0] * r.d[0] + nrm[1] * r.d[1] + nrm[2] * r.d[2];
+                    for (int k = 0; k < 3; k++) nrm[k] = (side > 0.0f ? -nrm[k] : nrm[k]) / len;
+                    const float z = 1.0f - 2.0f * ((float)(pcg(&seed) >> 8) / 16777216.0f), ph = 6.2831853f * ((float)(pcg(&seed) >> 8) / 16777216.0f);
+                    const float s_ = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+                    float d[3] = {nrm[0] + s_ * cosf(ph), nrm[1] + s_ * sinf(ph), nrm[2] + z};
+                    len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                    if (!(len > 1e-6f)) break;
+                    ray_t q;
+                    for (int k = 0; k < 3; k++) { q.o[k] = r.o[k] + r.d[k] * bt; q.d[k] = d[k] / len; q.inv[k] = 1.0f / q.d[k]; }
+                    tl = 0;
+                    bv[bounce] += walk_wide(&w, &q, 1e-3f, &bt, &bl, &tl); bt_[bounce] += tl; rays[bounce]++;
+                    { float b2; uint32_t l2; walk_ray(t, &q, 1e-3f, &b2, &l2); if (b2 != bt) mism++; }
+                    r = q;
+                }
+            }
+        const double all_rays = (double)(c.w / 4) * (c.h / 4) + (double)rays[0] + (double)rays[1];
+        printf("   %-66s nodes %8u | node lines per ray: primary %5.1f  bounce 1 %5.1f  bounce 2 %5.1f  all %5.1f | triangle lines per ray %4.2f | t differs from the binary walk: %llu\n",
+               forms[f].name, w.count, (double)pv / ((double)(c.w / 4) * (c.h / 4)), (double)bv[0] / (double)rays[0], (double)bv[1] / (double)rays[1],
+               (double)(pv + bv[0] + bv[1]) / all_rays, (double)(pt + bt_[0] + bt_[1]) / all_rays, (unsigned long long)mism);
+        free(w.nd);
+    }
+    fflush(stdout);
+}
+
 static tree_t new_tree(void) { tree_t t; t.nd = malloc((size_t)(n - 1) * sizeof(node_t)); t.count = 0; return t; }
 
 static void run_range(const char* name, const uint32_t* keys, int top, int bottom, uint32_t threshold)
@@ -827,7 +960,8 @@ static void run_range(const char* name, const uint32_t* keys, int top, int botto
     const double t0 = omp_get_wtime();
     box_t root;
     build_range(&t, 0, n - 1, &root);
-    evaluate(name, &t, omp_get_wtime() - t0);
+    if (g_wide) evaluate_wide(&t);
+    else evaluate(name, &t, omp_get_wtime() - t0);
     free(t.nd);
 }
 
@@ -846,6 +980,7 @@ int main(int argc, char** argv)
         else if (!strcmp(w, "cull")) g_cull = 1;
         else if (!strcmp(w, "predict")) g_predict = 1;
         else if (!strcmp(w, "steal")) g_steal = 1;
+        else if (!strcmp(w, "wide")) g_wide = 1;          // the following trees: per-ray walks over their 2 / 4 / 6 / 8-wide collapses only
         else if (!strcmp(w, "popnearest")) g_pop_nearest = 1;
         else if (!strncmp(w, "tile", 4)) { sscanf(w + 4, "%dx%d", &g_tw, &g_th); printf("tile %dx%d\n", g_tw, g_th); }
         else if (!strncmp(w, "near", 4)) { g_near_rule = atoi(w + 4); printf("near rule %d\n", g_near_rule); }
