@@ -21,5 +21,5 @@ python tools/fuzz_parity.py 300 44 > gpurun_out/r5w/fuzz.txt 2>&1; tail -3 gpuru
 # cfg4 (configs[3] on one GPU): the bench line and the rocprofv3 summary + FETCH / WRITE passes of the same command
 python bench.py --workload cfg4 --no-dynamic --no-cpu-baseline --no-live-counters > gpurun_out/r5w/bench_cfg4.json 2> gpurun_out/r5w/bench_cfg4.err; tail -1 gpurun_out/r5w/bench_cfg4.err
 bash tools/prof.sh n5cfg4 --workload cfg4 --no-dynamic --no-sort-bench > gpurun_out/r5w/prof_cfg4.txt 2>&1; tail -30 gpurun_out/r5w/prof_cfg4.txt
-python tools/bucket_sort_probe.py > gpurun_out/r5w/bucket_sort_probe.txt 2>&1; cat gpurun_out/r5w/bucket_sort_probe.txt
+
 python tools/whole_frame_probe.py --cfg4 > gpurun_out/r5w/whole_frames.txt 2>&1; cat gpurun_out/r5w/whole_frames.txt
