@@ -338,7 +338,10 @@ __device__ __forceinline__ int clz32(uint32_t v) { return v ? __builtin_clz(v) :
 // coalesced, so the dependent chain of a search (~30 probes for the widest node of a wave; a wave runs as long as
 // its widest node) costs LDS latency per probe instead of an L2 round trip; probes past the halo read global memory.
 constexpr int kTreeThreads = 256;
-constexpr int kTreeHalo = 256;            // (128 and 384 measured the same at 1 M nodes: 79.1 / 79.1 / 81.7 us)
+#ifndef LBVH_TREE_HALO
+#define LBVH_TREE_HALO 256               // (measurement builds: 128 and 384 run the same at 1 M nodes, 79.1 / 79.1 / 81.7 us)
+#endif
+constexpr int kTreeHalo = LBVH_TREE_HALO;
 constexpr int kTreeWindow = kTreeThreads + 2 * kTreeHalo;
 
 typedef __attribute__((address_space(3))) const uint32_t lds_u32;
@@ -441,29 +444,44 @@ __device__ __forceinline__ uint32_t swizzle_xor(uint32_t x)        // lane l <- 
     return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, (J << 10) | 0x1F);
 }
 
+// one exchange step of the transpose: lanes l and l ^ J swap the half-blocks that belong to each other.  `keep` = the bits a lane
+// keeps (M in the lower lane of a pair, ~M in the upper), `amt` = the right-rotation that moves the partner's bits into place
+// (32 - J: a left shift by J for the lower lane, J for the upper — under ~keep the rotation IS the shift): exchange, v_alignbit,
+// v_bfi — three instructions per step (the kernel is bound by its instruction count: ~1 200 per wave)
 template <int S>
-__device__ __forceinline__ uint32_t transpose_step(uint32_t x, uint32_t lane)
+__device__ __forceinline__ uint32_t transpose_step(uint32_t x, uint32_t keep, uint32_t amt)
 {
     constexpr uint32_t J = 1u << S;
-    constexpr uint32_t M = S == 0 ? 0x55555555u : S == 1 ? 0x33333333u : S == 2 ? 0x0F0F0F0Fu : S == 3 ? 0x00FF00FFu : 0x0000FFFFu;
     // lane ^ 1 and lane ^ 2 are quad permutes (DPP: the vector pipe); 4, 8, 16 go through ds_swizzle
     const uint32_t y = S == 0   ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true)      // quad_perm:[1,0,3,2]
                        : S == 1 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true)      // quad_perm:[2,3,0,1]
                                 : swizzle_xor<(int)J>(x);
-    const bool upper = (lane & J) != 0;
-    const uint32_t moved = upper ? (y >> J) : (y << J);
-    const uint32_t keep = upper ? ~M : M;
+    const uint32_t moved = __builtin_amdgcn_alignbit(y, y, amt);
     return (x & keep) | (moved & ~keep);
 }
 
-// lane v (of each 32-lane half) ends up with bit p = bit v of the row lane p came with
-__device__ __forceinline__ uint32_t transpose32_lanes(uint32_t x, uint32_t lane)
+struct transpose_consts { uint32_t keep[5], amt[5]; };
+__device__ __forceinline__ transpose_consts make_transpose_consts(uint32_t lane)
 {
-    x = transpose_step<0>(x, lane);
-    x = transpose_step<1>(x, lane);
-    x = transpose_step<2>(x, lane);
-    x = transpose_step<3>(x, lane);
-    x = transpose_step<4>(x, lane);
+    transpose_consts c;
+    const uint32_t M[5] = {0x55555555u, 0x33333333u, 0x0F0F0F0Fu, 0x00FF00FFu, 0x0000FFFFu};
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        const bool upper = (lane >> s) & 1u;
+        c.keep[s] = upper ? ~M[s] : M[s];
+        c.amt[s] = upper ? (1u << s) : 32u - (1u << s);
+    }
+    return c;
+}
+
+// lane v (of each 32-lane half) ends up with bit p = bit v of the row lane p came with
+__device__ __forceinline__ uint32_t transpose32_lanes(uint32_t x, const transpose_consts& c)
+{
+    x = transpose_step<0>(x, c.keep[0], c.amt[0]);
+    x = transpose_step<1>(x, c.keep[1], c.amt[1]);
+    x = transpose_step<2>(x, c.keep[2], c.amt[2]);
+    x = transpose_step<3>(x, c.keep[3], c.amt[3]);
+    x = transpose_step<4>(x, c.keep[4], c.amt[4]);
     return x;
 }
 
@@ -524,6 +542,7 @@ __device__ __forceinline__ void stage_keys_and_bitmaps(const uint32_t* __restric
         next[k] = 0u;
         if (lane == 63u && m + 1 < win.w1) next[k] = codes[m + 1];
     }
+    const transpose_consts tc = make_transpose_consts(lane);
     uint32_t some = 0u;                       // this lane's summary bits: lane (v, half) over the wave's chunks
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
@@ -540,7 +559,7 @@ __device__ __forceinline__ void stage_keys_and_bitmaps(const uint32_t* __restric
         } else if (m + 1 == win.num && m < win.w1) {
             row = 0xFFFFFFFFu;                // delta_{n-1} = -1 (BVH.compute:26-27): below every value
         }
-        const uint32_t x = transpose32_lanes(row, lane);
+        const uint32_t x = transpose32_lanes(row, tc);
         const int wd = 2 * c + (int)(lane >> 5);
         s_bits[(wd + 1) * kBitStride + (int)(lane & 31u)] = x;
         some |= x ? 1u << wd : 0u;
@@ -585,13 +604,38 @@ __device__ __forceinline__ void store_corner(corner3* p, float x, float y, float
 // then all loads back to back (a block that is not part of the range is marked by the index of the NEUTRAL box, 2 N2 - 1, and
 // its load is masked off), then the min / max — one memory latency per LV levels instead of one per
 // block (the straightforward loop measured 17 us per query at 1 M nodes, all of it waiting).
-template <int NQ, int LV>
-__device__ __forceinline__ void range_boxes(const hier_t& h, const uint32_t a[NQ], const uint32_t b[NQ], float mn[NQ][3],
-                                            float mx[NQ][3])
+__device__ __forceinline__ void wave_union(float mn[3], float mx[3])
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], d));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d));
+        }
+    }
+}
+
+typedef uint32_t u3v __attribute__((ext_vector_type(3)));
+// BUF: the corners are fetched through buffer descriptors with 32-bit byte offsets (v_mul_u32_u24 + buffer_load_dwordx3) instead
+// of 64-bit flat addresses (one v_mad_u64_u32 per load: the kernel is bound by its instruction count, and that one is a slow
+// instruction) — whenever the hierarchy's 12 n2x2 bytes fit 32 bits (up to 178 M leaves)
+template <int NQ, int LV, bool BUF>
+__device__ __forceinline__ void range_boxes_impl(const hier_t& h, const uint32_t a[NQ], const uint32_t b[NQ], float mn[NQ][3],
+                                                 float mx[NQ][3])
 {
     const uint32_t neutral = h.n2x2 - 1u;
+    __amdgpu_buffer_rsrc_t lo_rsrc, hi_rsrc;
+    if (BUF) {
+        lo_rsrc = __builtin_amdgcn_make_buffer_rsrc(h.lo, 0, (int)(h.n2x2 * 12u), 0x00020000);
+        hi_rsrc = __builtin_amdgcn_make_buffer_rsrc(h.hi, 0, (int)(h.n2x2 * 12u), 0x00020000);
+    }
     uint32_t l[NQ], r[NQ];
     bool more = false;
+    // the corners of a round's blocks.  Set to the neutral element ONCE: a load is masked off where a block is not part of the
+    // range, and what such a register then still holds is a block of an EARLIER round of the same range — taking it again changes
+    // nothing (min / max are idempotent), so the rounds need no re-initialisation (36 v_mov per round of the reference's query)
+    f3 lo[NQ][LV][2], hi[NQ][LV][2];
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
         l[q] = a[q];
@@ -599,6 +643,14 @@ __device__ __forceinline__ void range_boxes(const hier_t& h, const uint32_t a[NQ
         more = more || l[q] < r[q];
 #pragma unroll
         for (int d = 0; d < 3; d++) { mn[q][d] = INFINITY; mx[q][d] = -INFINITY; }
+#pragma unroll
+        for (int v = 0; v < LV; v++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const f3 pinf = {INFINITY, INFINITY, INFINITY}, ninf = {-INFINITY, -INFINITY, -INFINITY};
+                lo[q][v][e] = pinf;
+                hi[q][v][e] = ninf;
+            }
     }
     for (uint32_t k = 0; more; k += LV) {
         uint32_t idx[NQ][LV][2];
@@ -619,7 +671,6 @@ __device__ __forceinline__ void range_boxes(const hier_t& h, const uint32_t a[NQ
                 r[q] >>= 1;
             }
         }
-        f3 lo[NQ][LV][2], hi[NQ][LV][2];
 #pragma unroll
         for (int q = 0; q < NQ; q++)
 #pragma unroll
@@ -629,12 +680,16 @@ __device__ __forceinline__ void range_boxes(const hier_t& h, const uint32_t a[NQ
                     // a block that is not part of the range: no load at all (exec-masked).  Round 2 read a NEUTRAL box there instead
                     // of branching; but what a gather costs is the data its ACTIVE lanes return (768 B per full dwordx3 wave load
                     // through a 64 B / clk path), and two thirds of these loads had nothing to fetch: 78.5 -> 74.3 us at 1 M nodes
-                    const f3 pinf = {INFINITY, INFINITY, INFINITY}, ninf = {-INFINITY, -INFINITY, -INFINITY};
-                    lo[q][v][e] = pinf;
-                    hi[q][v][e] = ninf;
                     if (idx[q][v][e] != neutral) {
-                        lo[q][v][e] = load_corner(h.lo + idx[q][v][e]);
-                        hi[q][v][e] = load_corner(h.hi + idx[q][v][e]);
+                        if (BUF) {
+                            const u3v x = __builtin_amdgcn_raw_buffer_load_b96(lo_rsrc, idx[q][v][e] * 12u, 0, 0);
+                            const u3v y = __builtin_amdgcn_raw_buffer_load_b96(hi_rsrc, idx[q][v][e] * 12u, 0, 0);
+                            lo[q][v][e].x = __uint_as_float(x.x); lo[q][v][e].y = __uint_as_float(x.y); lo[q][v][e].z = __uint_as_float(x.z);
+                            hi[q][v][e].x = __uint_as_float(y.x); hi[q][v][e].y = __uint_as_float(y.y); hi[q][v][e].z = __uint_as_float(y.z);
+                        } else {
+                            lo[q][v][e] = load_corner(h.lo + idx[q][v][e]);
+                            hi[q][v][e] = load_corner(h.hi + idx[q][v][e]);
+                        }
                     }
                 }
 #pragma unroll
@@ -653,16 +708,12 @@ __device__ __forceinline__ void range_boxes(const hier_t& h, const uint32_t a[NQ
     }
 }
 
-__device__ __forceinline__ void wave_union(float mn[3], float mx[3])
+template <int NQ, int LV>
+__device__ __forceinline__ void range_boxes(const hier_t& h, const uint32_t a[NQ], const uint32_t b[NQ], float mn[NQ][3],
+                                            float mx[NQ][3])
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            mn[k] = fminf(mn[k], __shfl_xor(mn[k], d));
-            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d));
-        }
-    }
+    if (h.n2x2 <= 0x15555555u) range_boxes_impl<NQ, LV, true>(h, a, b, mn, mx);        // 12 n2x2 < 2^32
+    else range_boxes_impl<NQ, LV, false>(h, a, b, mn, mx);
 }
 
 // hierarchy levels resolved per round of a range query: one range (the reference's boxes) / two ranges (the derived tree's child
