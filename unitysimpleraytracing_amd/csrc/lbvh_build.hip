@@ -719,12 +719,13 @@ __device__ __forceinline__ void range_boxes(const hier_t& h, const uint32_t a[NQ
 // hierarchy levels resolved per round of a range query: one range (the reference's boxes) / two ranges (the derived tree's child
 // boxes).  Round 5: 3 / 1 instead of round 2's 4 / 2 — fewer block indices and corners alive at once: 72 -> 60 - 62 registers, 7 -> 8
 // waves per SIMD, tree_pair_kernel 86.4 -> 81.8 us at 1 M triangles (4 / 1, 2 / 1, 1 / 1 within 0.5 us; 4 / 3: 89, 4 / 4: 94),
-// the 16 M-triangle build unchanged
+// the 16 M-triangle build unchanged.  Round 6: the derived tree's two ranges are queried one after the other (tree_body), each
+// LBVH_RQ_LV2 = 3 levels per round: 73.6 -> 72.0 us (2: 74.2, 4: 81.7, 5: 93.8)
 #ifndef LBVH_RQ_LV1
 #define LBVH_RQ_LV1 3
 #endif
 #ifndef LBVH_RQ_LV2
-#define LBVH_RQ_LV2 1
+#define LBVH_RQ_LV2 3
 #endif
 __device__ __noinline__ void codes_sink(lbvh_internal_node* a, lbvh_fast_node* b)
 {
@@ -931,7 +932,14 @@ __device__ __forceinline__ void tree_body(uint32_t block, uint32_t* s_keys, uint
         const uint32_t b[2] = {(uint32_t)split, valid ? (uint32_t)last : (uint32_t)split};
         float cmn[2][3], cmx[2][3];
         if (LBVH_TREE_EXP & 2) { for (int k = 0; k < 3; k++) { cmn[0][k] = cmn[1][k] = (float)first; cmx[0][k] = cmx[1][k] = (float)last; } }
-        else range_boxes<2, LBVH_RQ_LV2>(hier, a, b, cmn, cmx);
+        else {
+            // the two child ranges one after the other, LBVH_RQ_LV2 levels per round each (round 6: 3) — not both at once with one
+            // level per round (rounds 2 - 5): a round is a full memory latency, the waves wait 64 % of their cycles
+            // (profiles/r6/tree_pair_counters.txt), and two queries of three levels keep as many corners in registers as the
+            // reference's one (four levels per round: 62 -> 70 registers, one wave per SIMD less, 72 -> 82 us)
+            range_boxes<1, LBVH_RQ_LV2>(hier, &a[0], &b[0], &cmn[0], &cmx[0]);
+            range_boxes<1, LBVH_RQ_LV2>(hier, &a[1], &b[1], &cmn[1], &cmx[1]);
+        }
         // child reference: a line index — node index, or LEAF | leaf_base + the triangle's ORIGINAL index (the triangle
         // lines stay in the caller's order: lbvh_common.h)
         uint32_t lref = (uint32_t)split, rref = (uint32_t)split + 1u;
