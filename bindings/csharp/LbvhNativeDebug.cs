@@ -10,7 +10,7 @@ public static class LbvhNativeDebug
     const string Lib = "lbvh";
 
     // lbvh_debug_switch: per-context switches that were environment variables until round 4 (all 0 in the product)
-    public const uint SWITCH_SORT_QUEUES = 0, SWITCH_COLD_ORDER = 1, SWITCH_BUILD_FORM = 2, SWITCH_FRAME_WAIT_MS = 3, SWITCH_SORT_FORM = 4;
+    public const uint SWITCH_SORT_QUEUES = 0, SWITCH_COLD_ORDER = 1, SWITCH_BUILD_FORM = 2, SWITCH_FRAME_WAIT_MS = 3, SWITCH_SORT_FORM = 4, SWITCH_FAIL_RESERVE = 5;
     [DllImport(Lib)] public static extern int lbvh_debug_switch(IntPtr ctx, uint which, uint value);
     // host-side model of the sort's tile hand-out order (no GPU involved)
     [DllImport(Lib)] public static extern uint lbvh_debug_sort_ticket_tile(uint k, uint x, uint group, uint queues);
