@@ -333,13 +333,14 @@ __global__ __launch_bounds__(kDistThreads) void distribute_apply_kernel(
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }   // :18-21
 
-// The searches of a node probe keys at idx +- 1, 2, 4, ... and inside its range: for > 95 % of the nodes all of that
-// lies within a few hundred keys of idx.  The workgroup's keys plus a halo on each side are staged in LDS once,
-// coalesced, so the dependent chain of a search (~30 probes for the widest node of a wave; a wave runs as long as
-// its widest node) costs LDS latency per probe instead of an L2 round trip; probes past the halo read global memory.
+// A node's range and split depend on the keys around it: for > 99 % of the nodes on nothing further than a few hundred keys from
+// idx.  The workgroup's keys plus a halo on each side are staged in LDS once, coalesced; what a node needs from them is answered
+// there — by nearest-set-bit lookups in bitmaps of the adjacent-key prefix array ("search-free form" below; rounds 1 - 5: by the
+// reference's probe loops, which remain for windows with equal neighbours) — and a node whose answer lies outside the window is
+// handed to its wave ("wide nodes").
 constexpr int kTreeThreads = 256;
 #ifndef LBVH_TREE_HALO
-#define LBVH_TREE_HALO 256               // (measurement builds: 128 and 384 run the same at 1 M nodes, 79.1 / 79.1 / 81.7 us)
+#define LBVH_TREE_HALO 256               // (measurement builds: 128 / 256 / 384 run 74.5 / 73.4 / 77.8 us at 1 M nodes, round 6)
 #endif
 constexpr int kTreeHalo = LBVH_TREE_HALO;
 constexpr int kTreeWindow = kTreeThreads + 2 * kTreeHalo;
