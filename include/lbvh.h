@@ -222,7 +222,14 @@ lbvh_status lbvh_morton_aabb(lbvh_context* ctx, const lbvh_triangle* d_triangles
  * Sh/Sorting/GlobalRadixSort.compute:20-40): sorts `count` (key,value) pairs in place, ascending
  * by key, STABLE (equal keys keep their input order) — the unique result of the reference's
  * 4-pass LSD radix sort.  The reference always sorts its whole padded capacity; pass the capacity
- * as `count` to reproduce that (0xFFFFFFFF pads end up last).  Any count >= 0 is accepted. */
+ * as `count` to reproduce that (0xFFFFFFFF pads end up last).  Any count >= 0 is accepted.
+ * LATENCY (the result never depends on it): for 2^15 <= count < 2^21 a context whose last THREE sorts of this size class had
+ * their keys spread over the 12-bit key prefixes (no more than ~12 K pairs under one prefix) takes a two-level form — 49 us
+ * instead of 62 at 1 M pairs — whose one weak case is the FIRST input after such a streak that puts more than 16 384 pairs
+ * under one prefix: that one call is sorted by a single workgroup per oversized bucket (2 M pairs under one prefix: 13 ms
+ * against 0.12 ms; all keys equal: 1.2 ms; profiles/r6/n_sort_cliff.txt), the following calls take the four passes again.
+ * An input that alternates between the two kinds never leaves the four passes; a sort captured into a hipGraph (the build
+ * chain of lbvh_build_scene when it is replayed) always takes them. */
 lbvh_status lbvh_sort_pairs(lbvh_context* ctx, uint32_t* d_keys, uint32_t* d_values,
                             uint32_t count);
 
