@@ -389,6 +389,59 @@ def test_build_tree_wide_nodes_bit_exact(ctx, shape, n):
         b.dispose()
 
 
+def _bitmap_key_sets():
+    import importlib
+    tb = importlib.import_module("test_tree_bitmaps")
+    sets = [(name, np.sort(k)) for name, k in tb.key_sets()]
+    rng = np.random.default_rng(77)
+    # raw keys with EQUAL neighbours in some windows only (lbvh_build_tree on a caller's keys): those workgroups take the probe
+    # loops, the others the lookups; a run of equal keys across a window border; all keys equal
+    mixed = np.sort(rng.integers(0, 1 << 22, 9000, dtype=np.uint32))
+    mixed[3000:3400] = mixed[3000]
+    mixed[700:703] = mixed[700]
+    sets.append(("equal_runs_in_some_windows", np.sort(mixed)))
+    sets.append(("all_equal", np.full(2000, 12345, dtype=np.uint32)))
+    big = np.unique(rng.integers(0, 1 << 30, 400000, dtype=np.uint32))
+    sets.append(("random_400k", big))
+    return sets
+
+
+@pytest.mark.parametrize("name", [n for n, _ in _bitmap_key_sets()])
+def test_build_tree_search_free_form_on_adversarial_key_sets(ctx, name):
+    """The key sets of tests/test_tree_bitmaps.py (the CPU model of the tree kernel's bitmap lookups) through lbvh_build_tree on the
+    GPU, plus raw keys with equal neighbours — in some windows only, across a window border, everywhere: such windows fall back to
+    the reference's probe loops (tree_body) — every node and leaf word against the oracle (BVH.compute:35-149)."""
+    keys = dict(_bitmap_key_sets())[name]
+    n = len(keys)
+    cap = n + 7
+    kb, ib, lb = gpu_tree(ctx, keys, n, cap)
+    oi, ol = O.build_tree(keys, n, capacity=cap, threads=8)
+    gi, gl = ib.get_data().copy(), lb.get_data().copy()
+    if len(np.unique(keys)) == n:
+        assert (words(gi) == words(oi)).all(), name
+        assert (words(gl) == words(ol)).all(), name
+    else:
+        # Equal keys make TreeConstructor write a malformed tree (the reason DistributeKeys exists, MeshBufferContainer.cs:154-169):
+        # several nodes name the same child, and whose `parent` word survives is the reference's own race (BVH.compute:126,144 — the
+        # oracle runs the nodes in index order, the GPU in any).  Every word a node writes about ITSELF, every leaf word, and the
+        # parent word of every child that exactly one node names are compared.
+        own = [0, 1, 2, 3, 5]
+        assert (words(gi).reshape(-1, 6)[:, own] == words(oi).reshape(-1, 6)[:, own]).all(), name
+        inner = oi[: n - 1]
+        named = np.concatenate([inner["leftNode"][inner["leftNodeType"] == L.INTERNAL], inner["rightNode"][inner["rightNodeType"] == L.INTERNAL]])
+        named = named[named < n - 1]
+        once = np.nonzero(np.bincount(named, minlength=cap) == 1)[0]
+        assert (gi["parent"][once] == oi["parent"][once]).all(), name
+        never = np.nonzero(np.bincount(named, minlength=cap) == 0)[0]
+        assert (gi["parent"][never] == oi["parent"][never]).all(), name          # (untouched: the fill value)
+        leaf_named = np.concatenate([inner["leftNode"][inner["leftNodeType"] == L.LEAF], inner["rightNode"][inner["rightNodeType"] == L.LEAF]])
+        leaf_named = leaf_named[leaf_named < n]
+        lonce = np.nonzero(np.bincount(leaf_named, minlength=cap) <= 1)[0]
+        assert (words(gl).reshape(-1, 2)[lonce] == words(ol).reshape(-1, 2)[lonce]).all(), name
+    for b in (kb, ib, lb):
+        b.dispose()
+
+
 def test_build_tree_known_answer(ctx):
     keys = np.array([0, 1, 3, 4, 18, 23, 24, 29], dtype=np.uint32)
     kb, ib, lb = gpu_tree(ctx, keys, 8, 8)
